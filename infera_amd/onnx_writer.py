@@ -1,0 +1,256 @@
+"""Minimal ONNX protobuf writer (no `onnx` package in this image).
+
+Emits ModelProto files for the benchmark / parity configurations of BASELINE.md section 4:
+a dynamic-batch twin of the reference's ``linear.onnx`` fixture, the C2/C3 MLP
+(Gemm+Relu chain), the C4 logistic-regression + Softmax model and the C5 ResNet-18 topology.
+All models carry a symbolic batch dimension ``N`` so a whole DuckDB vector (<=2048 rows) or
+a super-batch goes through in one call (the reference's fixture has a fixed batch of 1,
+/root/reference test/models/README.md:5).
+
+Wire format follows onnx.proto3 field numbers (ModelProto.graph=7, GraphProto.node=1 ...).
+Weights are written as ``raw_data`` (little-endian f32) unless ``float_data=True`` which
+reproduces the encoding of the reference fixture (packed field 4).
+"""
+from __future__ import annotations
+
+import math
+import struct
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from .synth import uniform_pm1
+
+FLOAT = 1
+INT64 = 7
+
+
+def _varint(v: int) -> bytes:
+    if v < 0:
+        v += 1 << 64
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _tag(field: int, wt: int) -> bytes:
+    return _varint((field << 3) | wt)
+
+
+def _ld(field: int, payload: bytes) -> bytes:
+    return _tag(field, 2) + _varint(len(payload)) + payload
+
+
+def _vi(field: int, v: int) -> bytes:
+    return _tag(field, 0) + _varint(v)
+
+
+def _s(field: int, s: str) -> bytes:
+    return _ld(field, s.encode())
+
+
+def tensor(name: str, arr: np.ndarray, float_data: bool = False) -> bytes:
+    """TensorProto: dims=1, data_type=2, float_data=4, int64_data=7, name=8, raw_data=9."""
+    out = b"".join(_vi(1, int(d)) for d in arr.shape)
+    if arr.dtype == np.float32:
+        out += _vi(2, FLOAT)
+        if float_data:
+            out += _ld(4, arr.astype("<f4").tobytes())
+        else:
+            out += _ld(9, arr.astype("<f4").tobytes())
+    elif arr.dtype == np.int64:
+        out += _vi(2, INT64)
+        out += _ld(9, arr.astype("<i8").tobytes())
+    else:
+        raise TypeError(arr.dtype)
+    return out + _s(8, name)
+
+
+def attr_i(name: str, v: int) -> bytes:
+    return _s(1, name) + _vi(3, v) + _vi(20, 2)
+
+
+def attr_f(name: str, v: float) -> bytes:
+    return _s(1, name) + _tag(2, 5) + struct.pack("<f", v) + _vi(20, 1)
+
+
+def attr_ints(name: str, vs: Iterable[int]) -> bytes:
+    return _s(1, name) + b"".join(_vi(8, int(v)) for v in vs) + _vi(20, 7)
+
+
+def attr_s(name: str, v: str) -> bytes:
+    return _s(1, name) + _ld(4, v.encode()) + _vi(20, 3)
+
+
+def node(op: str, inputs: Sequence[str], outputs: Sequence[str], attrs: Sequence[bytes] = (), name: str = "") -> bytes:
+    out = b"".join(_s(1, i) for i in inputs) + b"".join(_s(2, o) for o in outputs)
+    if name:
+        out += _s(3, name)
+    out += _s(4, op)
+    out += b"".join(_ld(5, a) for a in attrs)
+    return out
+
+
+def value_info(name: str, dims: Sequence[int | str], elem_type: int = FLOAT) -> bytes:
+    shape = b""
+    for d in dims:
+        dim = _s(2, d) if isinstance(d, str) else _vi(1, int(d))
+        shape += _ld(1, dim)
+    ttype = _vi(1, elem_type) + _ld(2, shape)
+    return _s(1, name) + _ld(2, _ld(1, ttype))
+
+
+def model(graph_name: str, nodes: Sequence[bytes], inits: Sequence[bytes], inputs: Sequence[bytes],
+          outputs: Sequence[bytes], opset: int = 13, ir_version: int = 8, producer: str = "infera_amd") -> bytes:
+    g = b"".join(_ld(1, n) for n in nodes) + _s(2, graph_name)
+    g += b"".join(_ld(5, t) for t in inits)
+    g += b"".join(_ld(11, i) for i in inputs) + b"".join(_ld(12, o) for o in outputs)
+    opset_import = _s(1, "") + _vi(2, opset)
+    return _vi(1, ir_version) + _s(2, producer) + _ld(7, g) + _ld(8, opset_import)
+
+
+# ------------------------------------------------------------------------------------------
+# deterministic weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in)), seed 1234
+# ------------------------------------------------------------------------------------------
+
+class _WeightStream:
+    def __init__(self, seed: int = 1234):
+        self.seed = seed
+        self.counter = 0
+
+    def take(self, shape: Sequence[int], fan_in: int) -> np.ndarray:
+        n = int(np.prod(shape))
+        idx = np.arange(self.counter, self.counter + n, dtype=np.uint64)
+        self.counter += n
+        u = uniform_pm1(self.seed, idx).astype(np.float64)
+        return (u / math.sqrt(fan_in)).astype(np.float32).reshape(shape)
+
+
+def linear_dyn() -> bytes:
+    """Dynamic-batch twin of the reference fixture test/models/linear.onnx: Y = X.W + B with
+    W=(2,-1,0.5), B=0.25 -> (1,2,3) -> 1.75 (test/sql/test_core_functionality.test:48-56)."""
+    w = np.array([[2.0], [-1.0], [0.5]], np.float32)
+    b = np.array([0.25], np.float32)
+    nodes = [node("MatMul", ["X", "W"], ["Z"]), node("Add", ["Z", "B"], ["Y"])]
+    return model("LinearModelDyn", nodes, [tensor("W", w, float_data=True), tensor("B", b, float_data=True)],
+                 [value_info("X", ["N", 3])], [value_info("Y", ["N", 1])])
+
+
+def mlp(dims: Sequence[int] = (128, 256, 64, 1), acts: Sequence[str] | None = None, final_softmax: bool = False,
+        seed: int = 1234, use_matmul_add: bool = False, trans_b: bool = False, opset: int = 13,
+        batch: int | str = "N") -> bytes:
+    """Gemm chain `dims[0] -> dims[1] -> ...` with an activation after every layer but the last
+    (default Relu; names from {"Relu","Sigmoid","Tanh","LeakyRelu",""}).  C2/C3 = defaults."""
+    nl = len(dims) - 1
+    if acts is None:
+        acts = ["Relu"] * (nl - 1) + [""]
+    assert len(acts) == nl
+    ws = _WeightStream(seed)
+    nodes, inits = [], []
+    cur = "X"
+    for l in range(nl):
+        k, m = dims[l], dims[l + 1]
+        w = ws.take((k, m), k)
+        b = ws.take((m,), k)
+        out = f"H{l}" if (l < nl - 1 or acts[l] or final_softmax) else "Y"
+        if use_matmul_add:
+            inits += [tensor(f"W{l}", w), tensor(f"B{l}", b)]
+            nodes += [node("MatMul", [cur, f"W{l}"], [f"Z{l}"]), node("Add", [f"Z{l}", f"B{l}"], [out])]
+        elif trans_b:
+            inits += [tensor(f"W{l}", np.ascontiguousarray(w.T)), tensor(f"B{l}", b)]
+            nodes += [node("Gemm", [cur, f"W{l}", f"B{l}"], [out], [attr_i("transB", 1)])]
+        else:
+            inits += [tensor(f"W{l}", w), tensor(f"B{l}", b)]
+            nodes += [node("Gemm", [cur, f"W{l}", f"B{l}"], [out])]
+        cur = out
+        if acts[l]:
+            last = l == nl - 1 and not final_softmax
+            out = "Y" if last else f"A{l}"
+            attrs = [attr_f("alpha", 0.1)] if acts[l] == "LeakyRelu" else []
+            nodes.append(node(acts[l], [cur], [out], attrs))
+            cur = out
+    if final_softmax:
+        nodes.append(node("Softmax", [cur], ["Y"], [attr_i("axis", 1)]))
+    return model("mlp_" + "x".join(map(str, dims)), nodes, inits, [value_info("X", [batch, dims[0]])],
+                 [value_info("Y", [batch, dims[-1]])], opset=opset)
+
+
+def logreg_softmax(features: int = 128, classes: int = 10, seed: int = 1234) -> bytes:
+    """C4: Gemm(features -> classes) + Softmax(axis=1)."""
+    return mlp((features, classes), acts=[""], final_softmax=True, seed=seed)
+
+
+def identity(cols: int = 4, batch: int | str = "N") -> bytes:
+    return model("identity_dyn", [node("Identity", ["X"], ["Y"])], [], [value_info("X", [batch, cols])],
+                 [value_info("Y", [batch, cols])], opset=13)
+
+
+def resnet18(classes: int = 1000, seed: int = 1234, in_hw: int = 224, width: int = 64) -> bytes:
+    """C5: ResNet-18 topology (conv7x7/2 + BN + Relu + maxpool3x3/2, 4 stages x 2 BasicBlocks,
+    global-avgpool, Flatten, Gemm -> classes), random weights, BatchNormalization kept as
+    separate nodes so the loader's BN-fold is exercised.  Input [N,3,in_hw,in_hw]."""
+    ws = _WeightStream(seed)
+    nodes, inits = [], []
+    uid = [0]
+
+    def fresh(p: str) -> str:
+        uid[0] += 1
+        return f"{p}{uid[0]}"
+
+    def conv_bn(x: str, cin: int, cout: int, k: int, stride: int, pad: int, relu: bool) -> str:
+        w = ws.take((cout, cin, k, k), cin * k * k)
+        wn, y = fresh("w"), fresh("c")
+        inits.append(tensor(wn, w))
+        nodes.append(node("Conv", [x, wn], [y], [attr_ints("kernel_shape", [k, k]), attr_ints("strides", [stride, stride]),
+                                                 attr_ints("pads", [pad] * 4)]))
+        scale = (1.0 + 0.1 * ws.take((cout,), 1)).astype(np.float32)
+        beta = (0.1 * ws.take((cout,), 1)).astype(np.float32)
+        mean = (0.1 * ws.take((cout,), 1)).astype(np.float32)
+        var = (1.0 + 0.5 * np.abs(ws.take((cout,), 1))).astype(np.float32)
+        names = [fresh("bn_s"), fresh("bn_b"), fresh("bn_m"), fresh("bn_v")]
+        for nme, arr in zip(names, (scale, beta, mean, var)):
+            inits.append(tensor(nme, arr))
+        z = fresh("b")
+        nodes.append(node("BatchNormalization", [y] + names, [z], [attr_f("epsilon", 1e-5)]))
+        if relu:
+            r = fresh("r")
+            nodes.append(node("Relu", [z], [r]))
+            return r
+        return z
+
+    x = conv_bn("X", 3, width, 7, 2, 3, True)
+    p = fresh("p")
+    nodes.append(node("MaxPool", [x], [p], [attr_ints("kernel_shape", [3, 3]), attr_ints("strides", [2, 2]), attr_ints("pads", [1, 1, 1, 1])]))
+    x, cin = p, width
+    for stage, cout in enumerate([width, width * 2, width * 4, width * 8]):
+        for blk in range(2):
+            stride = 2 if (stage > 0 and blk == 0) else 1
+            y = conv_bn(x, cin, cout, 3, stride, 1, True)
+            y = conv_bn(y, cout, cout, 3, 1, 1, False)
+            sc = x
+            if stride != 1 or cin != cout:
+                sc = conv_bn(x, cin, cout, 1, stride, 0, False)
+            s, r = fresh("s"), fresh("r")
+            nodes.append(node("Add", [y, sc], [s]))
+            nodes.append(node("Relu", [s], [r]))
+            x, cin = r, cout
+    g, f = fresh("g"), fresh("f")
+    nodes.append(node("GlobalAveragePool", [x], [g]))
+    nodes.append(node("Flatten", [g], [f], [attr_i("axis", 1)]))
+    w = ws.take((cin, classes), cin)
+    b = ws.take((classes,), cin)
+    inits += [tensor("fc_w", w), tensor("fc_b", b)]
+    nodes.append(node("Gemm", [f, "fc_w", "fc_b"], ["Y"]))
+    return model("resnet18", nodes, inits, [value_info("X", ["N", 3, in_hw, in_hw])], [value_info("Y", ["N", classes])], opset=13)
+
+
+def write(path: str, blob: bytes) -> str:
+    with open(path, "wb") as fh:
+        fh.write(blob)
+    return path
