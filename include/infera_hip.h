@@ -1,0 +1,102 @@
+/*
+ * infera_hip.h -- ADDITIVE entry points of the MI355X backend (same library, libinfera.so).
+ *
+ * Nothing here exists in the reference (its roadmap lists "GPU support", "zero-copy" and
+ * "BLOB columns in a single FFI call" as not done, /root/reference ROADMAP.md:43-46); the 13
+ * reference symbols in infera.h keep their exact signatures.  Everything is plain C: pointers,
+ * sizes, status codes (0 ok / -1 error + infera_last_error()).
+ */
+#ifndef INFERA_HIP_H
+#define INFERA_HIP_H
+
+#include "infera.h"
+
+#ifdef __cplusplus
+namespace infera {
+extern "C" {
+#endif
+
+/* ---- device discovery -------------------------------------------------------------------- */
+
+/* Number of GPUs the backend will use (INFERA_DEVICES, default all visible).  0 = none: models
+ * still load (metadata, validation) but every predict fails with "ONNX error: HIP backend
+ * unavailable: ...".  There is no CPU execution path in this library. */
+int32_t infera_hip_device_count(void);
+/* HIP ordinal of the i-th selected device, or -1. */
+int32_t infera_hip_device_ordinal(int32_t i);
+/* JSON: {"devices":[{"ordinal":0,"arch":"gfx950:...","cus":256},..],"reason":".."}.  infera_free. */
+char *infera_hip_get_devices(void);
+/* JSON description of the lowered plan of a loaded model (steps, fusion decisions, kernel names,
+ * flop/row).  infera_free. */
+char *infera_hip_get_plan(const char *model_name);
+
+/* ---- device-resident scan (the path bench.py measures) ------------------------------------ */
+
+/* d_in: row-major [rows x cols] f32 in the HBM of HIP device `device`; d_out: caller-allocated
+ * [rows x out_cols] f32 on the same device, out_capacity in elements.  Same validation and error
+ * strings as infera_predict (engine.rs:111-164).  The kernels are ENQUEUED on the calling thread's
+ * stream for that device; call infera_hip_sync before reading d_out.  out_rows/out_cols receive
+ * shape_rows_cols of the output (may be NULL). */
+int32_t infera_hip_predict_device(const char *model_name, int32_t device, const float *d_in, uint64_t rows,
+                                  uint64_t cols, float *d_out, uint64_t out_capacity, uint64_t *out_rows,
+                                  uint64_t *out_cols);
+int32_t infera_hip_sync(int32_t device);
+
+/* Times `iters` back-to-back infera_hip_predict_device passes with HIP events recorded on the
+ * stream the kernels are launched on (the calling thread's stream); writes the elapsed
+ * milliseconds of all iters to *elapsed_ms.  Used for roofline.achieved in bench.py. */
+int32_t infera_hip_time_predict_device(const char *model_name, int32_t device, const float *d_in, uint64_t rows,
+                                       uint64_t cols, float *d_out, uint64_t out_capacity, int32_t iters,
+                                       float *elapsed_ms);
+
+/* Device-memory helpers so a harness (ctypes, cgo, JNI) needs no second HIP binding. */
+void *infera_hip_malloc(int32_t device, uint64_t bytes);
+int32_t infera_hip_free(int32_t device, void *ptr);
+int32_t infera_hip_memcpy_h2d(int32_t device, void *dst, const void *src, uint64_t bytes);
+int32_t infera_hip_memcpy_d2h(int32_t device, void *dst, const void *src, uint64_t bytes);
+/* Fills d_dst[rows x cols] with the synthetic table of SURVEY.md 8d / BASELINE.md 4:
+ * u = splitmix64(seed ^ (row*cols + col)); x = ((u >> 40) * 2^-24) * 2 - 1, rows starting at row0. */
+int32_t infera_hip_synth_fill(int32_t device, float *d_dst, uint64_t seed, uint64_t row0, uint64_t rows,
+                              uint64_t cols);
+
+/* ---- host-side fast paths above the reference ABI ------------------------------------------ */
+
+/* infera_predict into a caller-owned buffer (no result allocation/free pair per DataChunk). */
+int32_t infera_predict_into(const char *model_name, const float *data, uint64_t rows, uint64_t cols, float *out,
+                            uint64_t out_capacity, uint64_t *out_rows, uint64_t *out_cols);
+
+/* Columnar gather: replaces the per-cell Vector::GetValue loop of ExtractFeatures
+ * (infera_extension.cpp:199-227).  Each column is a flat typed vector as DuckDB holds it
+ * (UnifiedVectorFormat data pointer + validity bitmask, bit set = valid, NULL mask = all valid).
+ * Casts follow the reference: DOUBLE/INTEGER/BIGINT -> static_cast<float>.  A NULL cell fails with
+ * "Feature values cannot be NULL" (infera_extension.cpp:207-209). */
+typedef enum InferaColumnType {
+  INFERA_COL_FLOAT = 0,
+  INFERA_COL_DOUBLE = 1,
+  INFERA_COL_INTEGER = 2,
+  INFERA_COL_BIGINT = 3
+} InferaColumnType;
+
+typedef struct InferaColumn {
+  const void *data;         /* rows elements of the column's type (or 1 element if is_constant) */
+  const uint64_t *validity; /* may be NULL */
+  int32_t type;             /* InferaColumnType */
+  int32_t is_constant;      /* CONSTANT_VECTOR: element 0 applies to every row */
+} InferaColumn;
+
+struct InferaInferenceResult infera_predict_columns(const char *model_name, const InferaColumn *columns,
+                                                    uintptr_t ncols, uintptr_t rows);
+
+/* One call for a whole chunk of BLOBs (the reference makes one FFI call and one batch-1 run per
+ * row, infera_extension.cpp:303-326).  Every blob must hold exactly one sample
+ * (prod(input_shape[1:]) f32); NULL entries are not allowed here (the binding filters them).
+ * Result: rows = n, cols = per-sample output size. */
+struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_name, const uint8_t *const *blobs,
+                                                            const uintptr_t *lens, uintptr_t n);
+
+#ifdef __cplusplus
+} /* extern "C" */
+} /* namespace infera */
+#endif
+
+#endif /* INFERA_HIP_H */

@@ -1,0 +1,448 @@
+#include "backend.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <sstream>
+
+#include "../host/common.hpp"
+
+namespace infera_hip {
+
+namespace {
+
+[[noreturn]] void hip_fail(hipError_t e, const char *what) {
+  throw InferaError::onnx(std::string("HIP: ") + what + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                               \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) hip_fail(_e, #expr);      \
+  } while (0)
+
+constexpr size_t kHostPassBytes = 64ull << 20;     // pinned staging per direction per thread
+constexpr size_t kScratchBudgetBytes = 8ull << 30; // activation scratch per thread for unfused plans
+
+// ---------------------------------------------------------------------------------------------
+// per-thread, per-device execution context (stream + staging + scratch)
+// ---------------------------------------------------------------------------------------------
+struct ThreadCtx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  float *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr, *scratch = nullptr;
+  size_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0, scratch_cap = 0;  // bytes
+
+  void ensure_pinned(float *&p, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) HIP_TRY(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), bytes, hipHostMallocDefault));
+    cap = bytes;
+  }
+  void ensure_dev(float *&p, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipFree(p));
+    }
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+    cap = bytes;
+  }
+};
+
+// Contexts are owned by a process-lifetime pool (never destroyed: tearing HIP objects down from
+// thread-exit / atexit handlers races the runtime's own shutdown).  A thread returns its contexts
+// to the pool when it exits so short-lived threads do not grow it.
+std::mutex g_pool_mu;
+std::vector<std::vector<ThreadCtx *>> g_pool;  // [device slot] -> free contexts
+
+struct ThreadHolder {
+  std::vector<ThreadCtx *> by_slot;
+  int home_slot = -1;
+  ~ThreadHolder() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t s = 0; s < by_slot.size(); s++)
+      if (by_slot[s]) g_pool[s].push_back(by_slot[s]);
+  }
+};
+thread_local ThreadHolder t_holder;
+std::atomic<unsigned> g_next_home{0};
+
+int slot_of_ordinal(int ordinal) {
+  const auto &ds = devices();
+  for (size_t i = 0; i < ds.ids.size(); i++)
+    if (ds.ids[i] == ordinal) return int(i);
+  throw InferaError::onnx("HIP device " + std::to_string(ordinal) + " is not among the selected devices");
+}
+
+ThreadCtx &ctx_for_slot(int slot) {
+  const auto &ds = devices();
+  if (t_holder.by_slot.size() < ds.ids.size()) t_holder.by_slot.resize(ds.ids.size(), nullptr);
+  ThreadCtx *&c = t_holder.by_slot[size_t(slot)];
+  HIP_TRY(hipSetDevice(ds.ids[size_t(slot)]));
+  if (!c) {
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      if (g_pool.size() < ds.ids.size()) g_pool.resize(ds.ids.size());
+      if (!g_pool[size_t(slot)].empty()) {
+        c = g_pool[size_t(slot)].back();
+        g_pool[size_t(slot)].pop_back();
+      }
+    }
+    if (!c) {
+      auto *n = new ThreadCtx();
+      n->device = ds.ids[size_t(slot)];
+      hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
+      if (e != hipSuccess) {
+        delete n;
+        hip_fail(e, "hipStreamCreateWithFlags");
+      }
+      c = n;
+    }
+  }
+  return *c;
+}
+
+int home_slot() {
+  if (t_holder.home_slot < 0) t_holder.home_slot = int(g_next_home.fetch_add(1) % unsigned(devices().ids.size()));
+  return t_holder.home_slot;
+}
+
+kern::ActParam act_of(const Step &s) { return kern::ActParam{int(s.act), s.act_a, s.act_b}; }
+
+float *upload(const std::vector<float> &v) {
+  if (v.empty()) return nullptr;
+  float *d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), v.size() * sizeof(float)));
+  hipError_t e = hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    hip_fail(e, "hipMemcpy(weights)");
+  }
+  return d;
+}
+
+// Which buffers an executed step reads / writes once fusion decisions are applied.
+struct EffStep {
+  int idx;
+  std::vector<int> reads;
+  int writes;
+};
+
+std::vector<EffStep> effective_steps(const LoadedModel &m) {
+  std::vector<EffStep> out;
+  const auto &st = m.plan.steps;
+  for (size_t i = 0; i < st.size(); i++) {
+    switch (m.exec[i]) {
+      case ExecKind::Skipped: break;
+      case ExecKind::Mlp3Head: out.push_back({int(i), {st[i].in0}, st[i + 2].out}); break;
+      case ExecKind::DenseSoftmax: out.push_back({int(i), {st[i].in0}, st[i + 1].out}); break;
+      default: {
+        EffStep e{int(i), {st[i].in0}, st[i].out};
+        if (st[i].in1 >= 0) e.reads.push_back(st[i].in1);
+        out.push_back(e);
+      }
+    }
+  }
+  return out;
+}
+
+void schedule(LoadedModel &m) {
+  const auto &st = m.plan.steps;
+  const size_t n = st.size();
+  m.exec.assign(n, ExecKind::Normal);
+  std::vector<int> uses(m.plan.buf_per_row.size(), 0);
+  for (const auto &s : st) {
+    if (s.in0 >= 0) uses[size_t(s.in0)]++;
+    if (s.in1 >= 0) uses[size_t(s.in1)]++;
+  }
+  uses[size_t(m.plan.out_buf)]++;
+  const Config &cfg = Config::get();
+  bool have_mlp3 = false;
+  for (size_t i = 0; i < n; i++) {
+    if (m.exec[i] != ExecKind::Normal) continue;
+    // Dense -> Dense -> Dense with private intermediates: whole-chain fused kernel
+    if (cfg.fused_mlp && !have_mlp3 && i + 2 < n && st[i].kind == StepKind::Dense && st[i + 1].kind == StepKind::Dense &&
+        st[i + 2].kind == StepKind::Dense && st[i + 1].in0 == st[i].out && st[i + 2].in0 == st[i + 1].out &&
+        uses[size_t(st[i].out)] == 1 && uses[size_t(st[i + 1].out)] == 1) {
+      kern::Mlp3Shape sh{int(st[i].K), int(st[i].M), int(st[i + 1].M), int(st[i + 2].M), int(st[i].act), int(st[i + 1].act),
+                         int(st[i + 2].act)};
+      if (kern::mlp3_supported(sh)) {
+        m.exec[i] = ExecKind::Mlp3Head;
+        m.exec[i + 1] = m.exec[i + 2] = ExecKind::Skipped;
+        m.mlp3_shape = sh;
+        have_mlp3 = true;
+        i += 2;
+        continue;
+      }
+    }
+    // Dense + row Softmax over exactly its M outputs: softmax in the GEMM epilogue
+    if (i + 1 < n && st[i].kind == StepKind::Dense && st[i + 1].kind == StepKind::Softmax && st[i + 1].in0 == st[i].out &&
+        uses[size_t(st[i].out)] == 1 && st[i + 1].sm_outer == 1 && st[i + 1].sm_inner == 1 && st[i + 1].sm_len == st[i].M &&
+        st[i].M <= 64) {
+      m.exec[i] = ExecKind::DenseSoftmax;
+      m.exec[i + 1] = ExecKind::Skipped;
+      i += 1;
+    }
+  }
+  // scratch slots by liveness: a slot is reused once its buffer has been read for the last time
+  auto eff = effective_steps(m);
+  const size_t nb = m.plan.buf_per_row.size();
+  std::vector<int> last_read(nb, -1);
+  for (size_t e = 0; e < eff.size(); e++)
+    for (int b : eff[e].reads) last_read[size_t(b)] = int(e);
+  m.slot_of_buf.assign(nb, -1);
+  m.slot_per_row.clear();
+  std::vector<int> slot_free_after;  // per slot: effective-step index after which it is free (-2 = free now)
+  for (size_t e = 0; e < eff.size(); e++) {
+    const int b = eff[e].writes;
+    if (b == m.plan.out_buf || b == 0) continue;
+    int chosen = -1;
+    for (size_t s = 0; s < slot_free_after.size(); s++)
+      if (slot_free_after[s] < int(e)) {  // strictly before this step: in-place reuse is not allowed
+        chosen = int(s);
+        break;
+      }
+    if (chosen < 0) {
+      chosen = int(slot_free_after.size());
+      slot_free_after.push_back(0);
+      m.slot_per_row.push_back(0);
+    }
+    m.slot_of_buf[size_t(b)] = chosen;
+    m.slot_per_row[size_t(chosen)] = std::max(m.slot_per_row[size_t(chosen)], m.plan.buf_per_row[size_t(b)]);
+    slot_free_after[size_t(chosen)] = last_read[size_t(b)] < 0 ? int(e) : last_read[size_t(b)];
+  }
+  m.scratch_per_row = 0;
+  for (auto v : m.slot_per_row) m.scratch_per_row += v;
+}
+
+void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
+  HIP_TRY(hipSetDevice(dm.device));
+  const auto &st = m.plan.steps;
+  dm.steps.resize(st.size());
+  for (size_t i = 0; i < st.size(); i++) {
+    if (m.exec[i] == ExecKind::Skipped) continue;
+    const Step &s = st[i];
+    DeviceStep &d = dm.steps[i];
+    if (m.exec[i] == ExecKind::Mlp3Head) {
+      std::vector<float> packed(kern::mlp3_packed_floats(m.mlp3_shape));
+      const Step &s1 = st[i], &s2 = st[i + 1], &s3 = st[i + 2];
+      kern::mlp3_pack(m.mlp3_shape, s1.W.data(), s1.bias.empty() ? nullptr : s1.bias.data(), s2.W.data(),
+                      s2.bias.empty() ? nullptr : s2.bias.data(), s3.W.data(), s3.bias.empty() ? nullptr : s3.bias.data(),
+                      packed.data());
+      dm.mlp3_packed = upload(packed);
+      continue;
+    }
+    d.W = upload(s.W);
+    d.bias = upload(s.bias);
+    d.cst = upload(s.cst);
+    d.scale = upload(s.scale);
+    d.shift = upload(s.shift);
+  }
+}
+
+void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, const float *d_in, float *d_out, int64_t rows) {
+  const Plan &p = m.plan;
+  if (rows <= 0) return;
+  hipStream_t s = ctx.stream;
+  if (p.out_buf == 0) {  // pure alias / Identity graph
+    HIP_TRY(hipMemcpyAsync(d_out, d_in, size_t(rows) * size_t(p.in_per_row()) * 4, hipMemcpyDeviceToDevice, s));
+    return;
+  }
+  int64_t rows_pass = rows;
+  if (m.scratch_per_row > 0) {
+    int64_t by_budget = int64_t(kScratchBudgetBytes / (size_t(m.scratch_per_row) * 4));
+    rows_pass = std::min<int64_t>(rows, std::max<int64_t>(1, std::min<int64_t>(by_budget, int64_t(Config::get().max_rows_per_pass))));
+    ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass) * size_t(m.scratch_per_row) * 4);
+  }
+  std::vector<int64_t> slot_base(m.slot_per_row.size(), 0);
+  {
+    int64_t off = 0;
+    for (size_t i = 0; i < m.slot_per_row.size(); i++) {
+      slot_base[i] = off;
+      off += m.slot_per_row[i] * rows_pass;
+    }
+  }
+  const auto &st = p.steps;
+  for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
+    const int64_t nr = std::min(rows_pass, rows - r0);
+    auto buf = [&](int b) -> float * {
+      if (b == 0) return const_cast<float *>(d_in) + r0 * p.in_per_row();
+      if (b == p.out_buf) return d_out + r0 * p.out_per_row();
+      return ctx.scratch + slot_base[size_t(m.slot_of_buf[size_t(b)])];
+    };
+    for (size_t i = 0; i < st.size(); i++) {
+      const Step &x = st[i];
+      const DeviceStep &d = dm.steps[i];
+      switch (m.exec[i]) {
+        case ExecKind::Skipped: continue;
+        case ExecKind::Mlp3Head:
+          kern::mlp3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_packed, buf(st[i + 2].out), nr, dm.num_cus);
+          continue;
+        case ExecKind::DenseSoftmax:
+          kern::dense(s, buf(x.in0), d.W, d.bias, buf(st[i + 1].out), nr, int(x.K), int(x.M), act_of(x),
+                      st[i + 1].log_softmax ? 2 : 1);
+          continue;
+        default: break;
+      }
+      switch (x.kind) {
+        case StepKind::Dense: kern::dense(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, int(x.K), int(x.M), act_of(x), 0); break;
+        case StepKind::Unary: kern::unary(s, buf(x.in0), buf(x.out), nr * p.buf_per_row[size_t(x.out)], act_of(x)); break;
+        case StepKind::AffineChannel:
+          kern::affine_channel(s, buf(x.in0), d.scale, d.shift, buf(x.out), nr, x.C, x.S, act_of(x));
+          break;
+        case StepKind::BinaryConst:
+          kern::binary_const(s, buf(x.in0), d.cst, buf(x.out), nr, p.buf_per_row[size_t(x.out)], x.bop, x.const_left, act_of(x));
+          break;
+        case StepKind::BinaryAct:
+          kern::binary_act(s, buf(x.in0), buf(x.in1), buf(x.out), nr * p.buf_per_row[size_t(x.out)], x.bop, act_of(x));
+          break;
+        case StepKind::Softmax: kern::softmax(s, buf(x.in0), buf(x.out), nr, x.sm_outer, x.sm_len, x.sm_inner, x.log_softmax); break;
+        case StepKind::Conv2d: {
+          kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
+                           int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
+          kern::conv2d(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x));
+          break;
+        }
+        case StepKind::Pool2d:
+          kern::pool2d(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.H), int(x.Wd), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
+                       int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), x.is_max, x.count_pad);
+          break;
+        case StepKind::GlobalAvgPool: kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S)); break;
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+}
+
+const DeviceModel &device_model(const LoadedModel &m, int slot) {
+  if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
+  return *m.dev[size_t(slot)];
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+
+const DeviceSet &devices() {
+  static const DeviceSet ds = [] {
+    DeviceSet d;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      d.why = std::string("no HIP device visible (hipGetDeviceCount: ") + (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")";
+      (void)hipGetLastError();
+      return d;
+    }
+    std::vector<int> want = Config::get().devices;
+    if (want.empty())
+      for (int i = 0; i < n; i++) want.push_back(i);
+    for (int id : want) {
+      if (id < 0 || id >= n) continue;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, id) != hipSuccess) continue;
+      d.ids.push_back(id);
+      d.cus.push_back(prop.multiProcessorCount);
+      d.arch.push_back(prop.gcnArchName);
+    }
+    if (d.ids.empty()) d.why = "INFERA_DEVICES selects no usable HIP device";
+    return d;
+  }();
+  return ds;
+}
+
+DeviceModel::~DeviceModel() {
+  if (device < 0) return;
+  if (hipSetDevice(device) != hipSuccess) return;
+  (void)hipDeviceSynchronize();
+  for (auto &d : steps) {
+    for (float *p : {d.W, d.bias, d.cst, d.scale, d.shift})
+      if (p) (void)hipFree(p);
+  }
+  if (mlp3_packed) (void)hipFree(mlp3_packed);
+}
+
+std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::string &path) {
+  auto m = std::make_shared<LoadedModel>();
+  m->name = name;
+  onnx::Model om = onnx::parse_file(path);
+  m->plan = lower_model(om);
+  schedule(*m);
+  const DeviceSet &ds = devices();
+  if (ds.ids.empty()) {
+    // No GPU: the model is registered (metadata, shape validation and the error paths above the
+    // compute call keep working) but cannot execute; see run_host/run_device.
+    m->device_error = ds.why;
+    log_msg(1, "model '" + name + "' loaded without a GPU: " + ds.why + "; predictions will fail");
+    return m;
+  }
+  for (size_t i = 0; i < ds.ids.size(); i++) {
+    auto dm = std::make_unique<DeviceModel>();
+    dm->device = ds.ids[i];
+    dm->num_cus = ds.cus[i];
+    upload_to_device(*m, *dm);
+    m->dev.push_back(std::move(dm));
+  }
+  return m;
+}
+
+void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows) {
+  if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
+  if (rows <= 0) return;
+  const int slot = home_slot();
+  ThreadCtx &ctx = ctx_for_slot(slot);
+  const DeviceModel &dm = device_model(m, slot);
+  const size_t in_row = size_t(m.plan.in_per_row()) * 4, out_row = size_t(m.plan.out_per_row()) * 4;
+  const size_t widest = std::max(in_row, out_row);
+  int64_t rows_pass = std::max<int64_t>(1, int64_t(kHostPassBytes / widest));
+  rows_pass = std::min(rows_pass, rows);
+  ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, size_t(rows_pass) * in_row);
+  ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows_pass) * out_row);
+  ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, size_t(rows_pass) * in_row);
+  ctx.ensure_dev(ctx.dev_out, ctx.dev_out_cap, size_t(rows_pass) * out_row);
+  for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
+    const int64_t nr = std::min(rows_pass, rows - r0);
+    // The caller's buffer is only borrowed for the call (SURVEY.md 8b "Ownership"): stage it.
+    std::memcpy(ctx.pin_in, h_in + size_t(r0) * (in_row / 4), size_t(nr) * in_row);
+    HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+    exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr);
+    HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    std::memcpy(h_out + size_t(r0) * (out_row / 4), ctx.pin_out, size_t(nr) * out_row);
+  }
+}
+
+void run_device(const LoadedModel &m, int device_ordinal, const float *d_in, float *d_out, int64_t rows) {
+  if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
+  const int slot = slot_of_ordinal(device_ordinal);
+  ThreadCtx &ctx = ctx_for_slot(slot);
+  exec_plan(m, device_model(m, slot), ctx, d_in, d_out, rows);
+}
+
+void sync_device(int device_ordinal) {
+  ThreadCtx &ctx = ctx_for_slot(slot_of_ordinal(device_ordinal));
+  HIP_TRY(hipStreamSynchronize(ctx.stream));
+}
+
+hipStream_t thread_stream(int device_ordinal) { return ctx_for_slot(slot_of_ordinal(device_ordinal)).stream; }
+
+std::string LoadedModel::describe_json() const {
+  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax"};
+  std::ostringstream o;
+  o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
+  for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";
+  o << "],\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
+  for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
+  o << "]";
+  for (size_t i = 0; i < exec.size(); i++)
+    if (exec[i] == ExecKind::Mlp3Head) o << ",\"fused_kernel\":" << json_str(kern::mlp3_kernel_name(mlp3_shape));
+  if (!device_error.empty()) o << ",\"device_error\":" << json_str(device_error);
+  o << "}";
+  return o.str();
+}
+
+}  // namespace infera_hip

@@ -1,0 +1,79 @@
+// backend.hpp -- MI355X execution backend: device discovery, per-model HBM residency, per-thread
+// streams / pinned staging, and the plan executor.
+//
+// This replaces the half of engine.rs that talks to Tract (engine.rs:49-55 load, :139-154 run).
+// Threading model mirrors the reference's contract (SURVEY.md section 8b "Threading"): any number
+// of caller threads run inferences concurrently; each thread owns a stream, pinned staging and
+// scratch on "its" GPU (threads are dealt round-robin over the selected devices, which is how a
+// DuckDB scan spreads its DataChunks over the 8 GPUs of a node with no collective).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../host/plan.hpp"
+#include "kernels.hpp"
+
+namespace infera_hip {
+
+// Device discovery (cached).  count==0 -> `why` says what hipGetDeviceCount reported.
+struct DeviceSet {
+  std::vector<int> ids;  // HIP ordinals selected by INFERA_DEVICES (default: all)
+  std::vector<int> cus;  // multiprocessor count per selected device
+  std::vector<std::string> arch;
+  std::string why;
+};
+const DeviceSet &devices();
+
+// Constants of one plan step resident in one GPU's HBM.
+struct DeviceStep {
+  float *W = nullptr, *bias = nullptr, *cst = nullptr, *scale = nullptr, *shift = nullptr;
+};
+
+// How the executor runs a step.
+enum class ExecKind : int { Normal = 0, Skipped = 1, Mlp3Head = 2, DenseSoftmax = 3 };
+
+struct DeviceModel {
+  int device = -1;  // HIP ordinal
+  int num_cus = 0;
+  std::vector<DeviceStep> steps;
+  float *mlp3_packed = nullptr;
+  ~DeviceModel();
+};
+
+class LoadedModel {
+ public:
+  std::string name;
+  Plan plan;
+  // execution schedule (device independent)
+  std::vector<ExecKind> exec;
+  kern::Mlp3Shape mlp3_shape{};
+  std::vector<int> slot_of_buf;        // scratch slot per activation buffer (-1: external in/out)
+  std::vector<int64_t> slot_per_row;   // floats per row of each scratch slot
+  int64_t scratch_per_row = 0;         // sum over slots
+  // per selected device residency; empty when no GPU is visible (then `device_error` says why and
+  // every predict fails loudly -- there is no CPU execution path in this library).
+  std::vector<std::unique_ptr<DeviceModel>> dev;
+  std::string device_error;
+
+  std::string describe_json() const;
+};
+
+// Parse + lower + upload.  Throws InferaError.
+std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::string &path);
+
+// Host-memory inference (infera_predict / infera_predict_from_blob): `h_in` is rows x in_per_row
+// f32 in pageable host memory; result written to `h_out` (rows x out_per_row).  Blocks until done.
+void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows);
+
+// Device-resident inference: d_in / d_out live on HIP device `device_ordinal`.  Enqueues on the
+// calling thread's stream for that device and returns without synchronising.
+void run_device(const LoadedModel &m, int device_ordinal, const float *d_in, float *d_out, int64_t rows);
+// Blocks until the calling thread's stream on that device is idle.
+void sync_device(int device_ordinal);
+hipStream_t thread_stream(int device_ordinal);
+
+}  // namespace infera_hip

@@ -1,0 +1,174 @@
+// eltwise.hip -- HBM-bound elementwise kernels, row softmax and the synthetic-table fill.
+//
+// All of these stream each byte once: grid-stride loops, 16 B per lane where the layout allows,
+// grid capped at 256 CUs x 8 blocks (cdna_hip_programming.md Guideline 11).
+#include "device_common.hpp"
+
+namespace infera_hip::kern {
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(int64_t work_items) {
+  int64_t g = (work_items + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return int(g);
+}
+
+__global__ __launch_bounds__(kBlock) void unary_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n,
+                                                      ActParam act) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+  f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = x4[i];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = apply_act(v[j], act);
+    y4[i] = v;
+  }
+  for (int64_t i = (n4 << 2) + int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) y[i] = apply_act(x[i], act);
+}
+
+__global__ __launch_bounds__(kBlock) void binary_const_kernel(const float *__restrict__ x, const float *__restrict__ c,
+                                                             float *__restrict__ y, int64_t n, int64_t per_row, char op,
+                                                             bool const_left, ActParam act) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    y[i] = apply_act(apply_bop(x[i], c[i % per_row], op, const_left), act);
+}
+
+__global__ __launch_bounds__(kBlock) void binary_act_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                           float *__restrict__ y, int64_t n, char op, ActParam act) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a);
+  const f32x4 *b4 = reinterpret_cast<const f32x4 *>(b);
+  f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += stride) {
+    f32x4 u = a4[i], v = b4[i], r;
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = apply_act(apply_bop(u[j], v[j], op, false), act);
+    y4[i] = r;
+  }
+  for (int64_t i = (n4 << 2) + int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    y[i] = apply_act(apply_bop(a[i], b[i], op, false), act);
+}
+
+__global__ __launch_bounds__(kBlock) void affine_channel_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                               const float *__restrict__ shift, float *__restrict__ y,
+                                                               int64_t n, int64_t C, int64_t S, ActParam act) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t c = (i / S) % C;
+    y[i] = apply_act(x[i] * scale[c] + shift[c], act);
+  }
+}
+
+// One lane per softmax vector when the vector is short (the common case here: 10 classes); the
+// vector's `len` elements are `inner` floats apart.  max / exp / sum / divide in the oracle's order.
+__global__ __launch_bounds__(kBlock) void softmax_small_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                              int64_t nvec, int64_t len, int64_t inner, bool logsm) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t v = int64_t(blockIdx.x) * kBlock + threadIdx.x; v < nvec; v += stride) {
+    const int64_t ou = v / inner, in = v % inner;
+    const float *src = x + ou * len * inner + in;
+    float *dst = y + ou * len * inner + in;
+    float mx = -INFINITY;
+    for (int64_t j = 0; j < len; j++) mx = fmaxf(mx, src[j * inner]);
+    float sum = 0.f;
+    for (int64_t j = 0; j < len; j++) sum += expf(src[j * inner] - mx);
+    if (logsm) {
+      const float ls = logf(sum);
+      for (int64_t j = 0; j < len; j++) dst[j * inner] = (src[j * inner] - mx) - ls;
+    } else {
+      for (int64_t j = 0; j < len; j++) dst[j * inner] = expf(src[j * inner] - mx) / sum;
+    }
+  }
+}
+
+// One wave per vector for long contiguous vectors (inner == 1): lanes stride the vector, the
+// reductions are wave shuffles over 64 lanes.  The sum is therefore tree-ordered, not sequential.
+__global__ __launch_bounds__(kBlock) void softmax_wave_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                             int64_t nvec, int64_t len, bool logsm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+  const int64_t nwaves = (int64_t(gridDim.x) * kBlock) >> 6;
+  for (int64_t v = wave; v < nvec; v += nwaves) {
+    const float *src = x + v * len;
+    float *dst = y + v * len;
+    float mx = -INFINITY;
+    for (int64_t j = lane; j < len; j += 64) mx = fmaxf(mx, src[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int64_t j = lane; j < len; j += 64) sum += expf(src[j] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float ls = logf(sum);
+    for (int64_t j = lane; j < len; j += 64) dst[j] = logsm ? (src[j] - mx) - ls : expf(src[j] - mx) / sum;
+  }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(kBlock) void synth_fill_kernel(float *__restrict__ dst, uint64_t seed, uint64_t base,
+                                                           uint64_t n) {
+  const uint64_t stride = uint64_t(gridDim.x) * kBlock;
+  for (uint64_t i = uint64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const uint64_t u = splitmix64(seed ^ (base + i));
+    dst[i] = float(u >> 40) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+  }
+}
+
+}  // namespace
+
+void unary(hipStream_t s, const float *x, float *y, int64_t n, ActParam act) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(unary_kernel, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, s, x, y, n, act);
+}
+
+void binary_const(hipStream_t s, const float *x, const float *c, float *y, int64_t rows, int64_t per_row, char op,
+                  bool const_left, ActParam act) {
+  const int64_t n = rows * per_row;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(binary_const_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, c, y, n, per_row, op, const_left, act);
+}
+
+void binary_act(hipStream_t s, const float *a, const float *b, float *y, int64_t n, char op, ActParam act) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(binary_act_kernel, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, s, a, b, y, n, op, act);
+}
+
+void affine_channel(hipStream_t s, const float *x, const float *scale, const float *shift, float *y, int64_t rows,
+                    int64_t C, int64_t S, ActParam act) {
+  const int64_t n = rows * C * S;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(affine_channel_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, scale, shift, y, n, C, S, act);
+}
+
+void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner,
+             bool log_softmax) {
+  const int64_t nvec = rows * outer * inner;
+  if (nvec <= 0 || len <= 0) return;
+  if (inner == 1 && len >= 256) {
+    hipLaunchKernelGGL(softmax_wave_kernel, dim3(grid_for(nvec * 64)), dim3(kBlock), 0, s, x, y, nvec, len, log_softmax);
+  } else {
+    // vectors index as (row*outer + ou, in): flatten (row,outer) into the `ou` coordinate
+    hipLaunchKernelGGL(softmax_small_kernel, dim3(grid_for(nvec)), dim3(kBlock), 0, s, x, y, nvec, len, inner, log_softmax);
+  }
+}
+
+void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_t rows, uint64_t ncols) {
+  const uint64_t n = rows * ncols;
+  if (n == 0) return;
+  hipLaunchKernelGGL(synth_fill_kernel, dim3(grid_for(int64_t(n))), dim3(kBlock), 0, s, dst, seed, row0 * ncols, n);
+}
+
+}  // namespace infera_hip::kern

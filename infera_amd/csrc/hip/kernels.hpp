@@ -1,0 +1,64 @@
+// kernels.hpp -- host-callable launchers for the gfx950 kernels.  Every launcher enqueues on the
+// given stream and returns immediately; errors surface through hipGetLastError at the call site.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace infera_hip::kern {
+
+// Activation codes shared with plan.hpp (Act enum values).
+struct ActParam {
+  int kind = 0;  // 0 none, 1 relu, 2 sigmoid, 3 tanh, 4 leaky-relu(a), 5 clip(a,b)
+  float a = 0.f, b = 0.f;
+};
+
+// ---- elementwise / reductions (eltwise.hip) --------------------------------------------------
+void unary(hipStream_t s, const float *x, float *y, int64_t n, ActParam act);
+// y[r, i] = act(x[r, i] (op) c[i])   (const_left: c (op) x)
+void binary_const(hipStream_t s, const float *x, const float *c, float *y, int64_t rows, int64_t per_row, char op,
+                  bool const_left, ActParam act);
+void binary_act(hipStream_t s, const float *a, const float *b, float *y, int64_t n, char op, ActParam act);
+// y[r, c, i] = act(x * scale[c] + shift[c])
+void affine_channel(hipStream_t s, const float *x, const float *scale, const float *shift, float *y, int64_t rows,
+                    int64_t C, int64_t S, ActParam act);
+// softmax over `len` with element stride `inner`, repeated rows*outer*inner times
+void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner,
+             bool log_softmax);
+// synthetic table fill (SURVEY.md 8d generator), row-major [rows, ncols]
+void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_t rows, uint64_t ncols);
+
+// ---- dense layer, fp32 MFMA (dense.hip) -------------------------------------------------------
+// Y[rows, M] = act(X[rows, K] . W[K, M] + bias[M]); W row-major, bias may be null.
+// softmax_fused: apply a row softmax over the M outputs in the epilogue (requires M <= 256).
+void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
+           ActParam act, int softmax_mode /*0 none,1 softmax,2 log-softmax*/);
+bool dense_can_fuse_softmax(int M);
+
+// ---- whole-chain fused MLP (mlp_fused.hip) -----------------------------------------------------
+// A chain D0 -> D1 -> D2 -> D3 evaluated in one persistent kernel; activations never leave
+// registers.  `packed` holds the fragment-major weights produced by mlp3_pack().
+struct Mlp3Shape {
+  int d0, d1, d2, d3;
+  int act1, act2, act3;  // only None/Relu chains are instantiated ahead of time
+};
+bool mlp3_supported(const Mlp3Shape &sh);
+// Size in floats of the packed weight blob and host-side packing (fragment-major order, see mlp_fused.hip).
+size_t mlp3_packed_floats(const Mlp3Shape &sh);
+void mlp3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+               const float *b3, float *packed);
+void mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus);
+const char *mlp3_kernel_name(const Mlp3Shape &sh);
+
+// ---- convolution / pooling (conv.hip) ----------------------------------------------------------
+struct ConvGeom {
+  int C, H, W, M, OH, OW, kh, kw, sh, sw, pt, pl, dh, dw, groups;
+};
+void conv2d(hipStream_t s, const float *X, const float *Wt, const float *bias, const float *residual, float *Y,
+            int64_t rows, const ConvGeom &g, ActParam act);
+void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
+            int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad);
+void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S);
+
+}  // namespace infera_hip::kern

@@ -1,0 +1,470 @@
+// capi.cpp -- the C ABI (include/infera.h + include/infera_hip.h).
+//
+// Each wrapper follows the shape of the reference's FFI functions in lib.rs: null checks ->
+// UTF-8 check -> delegate -> map failure to (status | -1) + thread-local last error
+// (lib.rs:38-64, 81-102, 127-149, 174-195, 215-233, 245-260, 275-285, 299-308, 326-366, 388-425).
+#include <dirent.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../../include/infera_hip.h"
+#include "../hip/backend.hpp"
+#include "common.hpp"
+#include "engine.hpp"
+
+using namespace infera_hip;
+
+namespace {
+
+char *dup_cstr(const std::string &s) {
+  char *p = static_cast<char *>(std::malloc(s.size() + 1));
+  if (!p) return nullptr;
+  std::memcpy(p, s.c_str(), s.size() + 1);
+  return p;
+}
+
+infera::InferaInferenceResult error_result() {  // ffi_utils.rs:28-36
+  infera::InferaInferenceResult r;
+  r.data = nullptr;
+  r.len = r.rows = r.cols = 0;
+  r.status = -1;
+  return r;
+}
+
+std::string checked_str(const char *p) {
+  if (!p) throw InferaError::null_pointer();
+  if (!is_valid_utf8(p)) throw InferaError::utf8();
+  return std::string(p);
+}
+
+// Runs fn, converting any exception into the last-error slot; returns true on success.
+template <typename F>
+bool guarded(F &&fn, std::string *err_text = nullptr) {
+  try {
+    fn();
+    return true;
+  } catch (const InferaError &e) {
+    set_last_error(e.what());
+    if (err_text) *err_text = e.what();
+  } catch (const std::bad_alloc &) {
+    set_last_error(InferaError::memory().what());
+    if (err_text) *err_text = InferaError::memory().what();
+  } catch (const std::exception &e) {
+    std::string t = InferaError::onnx(e.what()).what();
+    set_last_error(t);
+    if (err_text) *err_text = t;
+  }
+  return false;
+}
+
+float *alloc_out(uint64_t len) {
+  float *p = static_cast<float *>(std::malloc(len ? len * sizeof(float) : 1));
+  if (!p) throw InferaError::memory();
+  return p;
+}
+
+std::string error_json(const std::string &msg) { return "{\"error\":" + json_str(msg) + "}"; }
+
+bool ends_with(const std::string &s, const std::string &suf) {
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+bool is_regular_file(const std::string &p) {
+  struct stat st;
+  return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+}  // namespace
+
+namespace infera {
+extern "C" {
+
+int32_t infera_load_model(const char *name, const char *path) {
+  return guarded([&] {
+           if (!name || !path) throw InferaError::null_pointer();
+           std::string n = checked_str(name), p = checked_str(path);
+           if (p.rfind("http", 0) == 0)  // lib.rs:47-48 would download; no network stack in this build
+             throw InferaError::http("remote model fetch is not available in the MI355X build (no network): " + p);
+           engine::load_model(n, p);
+         })
+             ? 0
+             : -1;
+}
+
+int32_t infera_unload_model(const char *name) {
+  return guarded([&] {
+           std::string n = checked_str(name);
+           if (!engine::unload_model(n)) throw InferaError::model_not_found(n);
+         })
+             ? 0
+             : -1;
+}
+
+struct InferaInferenceResult infera_predict(const char *model_name, const float *data, uintptr_t rows, uintptr_t cols) {
+  InferaInferenceResult res = error_result();
+  guarded([&] {
+    if (!model_name || !data) throw InferaError::null_pointer();
+    auto m = engine::find(checked_str(model_name));
+    OutShape o = engine::validate_predict(*m, rows, cols);
+    float *out = alloc_out(o.len);
+    try {
+      run_host(*m, data, out, int64_t(rows));
+    } catch (...) {
+      std::free(out);
+      throw;
+    }
+    res.data = out;
+    res.len = o.len;
+    res.rows = o.rows;
+    res.cols = o.cols;
+    res.status = 0;
+  });
+  return res;
+}
+
+struct InferaInferenceResult infera_predict_from_blob(const char *model_name, const uint8_t *blob_data, uintptr_t blob_len) {
+  InferaInferenceResult res = error_result();
+  guarded([&] {
+    if (!model_name || !blob_data) throw InferaError::null_pointer();
+    auto m = engine::find(checked_str(model_name));
+    const uint64_t rows = engine::validate_blob(*m, blob_len);
+    OutShape o = engine::out_shape_for_rows(*m, rows);
+    float *out = alloc_out(o.len);
+    try {
+      // native-endian bytes ARE the f32 row-major tensor (engine.rs:212-220); may be unaligned
+      run_host(*m, reinterpret_cast<const float *>(blob_data), out, int64_t(rows));
+    } catch (...) {
+      std::free(out);
+      throw;
+    }
+    res.data = out;
+    res.len = o.len;
+    res.rows = o.rows;
+    res.cols = o.cols;
+    res.status = 0;
+  });
+  return res;
+}
+
+char *infera_get_model_info(const char *model_name) {
+  std::string json, err;
+  if (guarded([&] { json = engine::model_metadata_json(checked_str(model_name)); }, &err)) return dup_cstr(json);
+  return dup_cstr(error_json(err));  // lib.rs:225-232
+}
+
+char *infera_get_loaded_models(void) { return dup_cstr(json_str_array(engine::loaded_names())); }
+
+char *infera_get_version(void) {
+  // lib.rs:278-282; keys sorted as serde_json would emit them
+  return dup_cstr("{\"model_cache_dir\":" + json_str(Config::get().cache_dir) +
+                  ",\"onnx_backend\":\"hip-gfx950\",\"version\":\"0.4.0-mi355x\"}");
+}
+
+int32_t infera_clear_cache(void) {
+  // http.rs clear_cache: remove the cache directory's contents; a missing directory is fine
+  return guarded([&] {
+           const std::string &dir = Config::get().cache_dir;
+           DIR *d = ::opendir(dir.c_str());
+           if (!d) return;
+           while (dirent *e = ::readdir(d)) {
+             std::string n = e->d_name;
+             if (n == "." || n == "..") continue;
+             std::string full = dir + "/" + n;
+             if (is_regular_file(full) && ::unlink(full.c_str()) != 0) {
+               ::closedir(d);
+               throw InferaError::io("cannot remove " + full);
+             }
+           }
+           ::closedir(d);
+         })
+             ? 0
+             : -1;
+}
+
+char *infera_get_cache_info(void) {
+  const Config &cfg = Config::get();
+  uint64_t total = 0, count = 0;
+  if (DIR *d = ::opendir(cfg.cache_dir.c_str())) {
+    while (dirent *e = ::readdir(d)) {
+      std::string full = cfg.cache_dir + "/" + e->d_name;
+      struct stat st;
+      if (ends_with(full, ".onnx") && ::stat(full.c_str(), &st) == 0 && S_ISREG(st.st_mode)) {
+        total += uint64_t(st.st_size);
+        count++;
+      }
+    }
+    ::closedir(d);
+  }
+  // lib.rs:353-358, keys sorted
+  return dup_cstr("{\"cache_dir\":" + json_str(cfg.cache_dir) + ",\"file_count\":" + std::to_string(count) +
+                  ",\"size_limit_bytes\":" + std::to_string(cfg.cache_size_limit) + ",\"total_size_bytes\":" + std::to_string(total) + "}");
+}
+
+char *infera_set_autoload_dir(const char *path) {
+  std::string err, json;
+  bool ok = guarded(
+      [&] {
+        std::string dir = checked_str(path);
+        DIR *d = ::opendir(dir.c_str());
+        if (!d) throw InferaError::io(std::string(std::strerror(errno)) + " (" + dir + ")");
+        std::vector<std::string> loaded;
+        std::string errors;
+        while (dirent *e = ::readdir(d)) {
+          std::string fname = e->d_name;
+          std::string full = dir + "/" + fname;
+          if (!ends_with(fname, ".onnx") || !is_regular_file(full)) continue;
+          std::string stem = fname.substr(0, fname.size() - 5);
+          try {
+            engine::load_model(stem, full);  // lib.rs:405-413 calls load_model_impl directly
+            loaded.push_back(stem);
+          } catch (const std::exception &ex) {
+            if (!errors.empty()) errors += ",";
+            errors += "{\"error\":" + json_str(ex.what()) + ",\"file\":" + json_str(full) + "}";
+          }
+        }
+        ::closedir(d);
+        json = "{\"errors\":[" + errors + "],\"loaded\":" + json_str_array(loaded) + "}";
+      },
+      &err);
+  return dup_cstr(ok ? json : error_json(err));
+}
+
+const char *infera_last_error(void) { return last_error_cstr(); }
+
+void infera_free(char *ptr) {
+  if (ptr) std::free(ptr);
+}
+
+void infera_free_result(struct InferaInferenceResult res) {
+  if (res.data) std::free(res.data);
+}
+
+// ================================ additive MI355X entry points ================================
+
+int32_t infera_hip_device_count(void) { return int32_t(devices().ids.size()); }
+
+int32_t infera_hip_device_ordinal(int32_t i) {
+  const auto &ds = devices();
+  return (i >= 0 && size_t(i) < ds.ids.size()) ? ds.ids[size_t(i)] : -1;
+}
+
+char *infera_hip_get_devices(void) {
+  const auto &ds = devices();
+  std::string o = "{\"devices\":[";
+  for (size_t i = 0; i < ds.ids.size(); i++) {
+    if (i) o += ",";
+    o += "{\"arch\":" + json_str(ds.arch[i]) + ",\"cus\":" + std::to_string(ds.cus[i]) + ",\"ordinal\":" + std::to_string(ds.ids[i]) + "}";
+  }
+  o += "],\"reason\":" + json_str(ds.why) + "}";
+  return dup_cstr(o);
+}
+
+char *infera_hip_get_plan(const char *model_name) {
+  std::string json, err;
+  if (guarded([&] { json = engine::find(checked_str(model_name))->describe_json(); }, &err)) return dup_cstr(json);
+  return dup_cstr(error_json(err));
+}
+
+int32_t infera_hip_predict_device(const char *model_name, int32_t device, const float *d_in, uint64_t rows, uint64_t cols,
+                                  float *d_out, uint64_t out_capacity, uint64_t *out_rows, uint64_t *out_cols) {
+  return guarded([&] {
+           if (!model_name || !d_in || !d_out) throw InferaError::null_pointer();
+           auto m = engine::find(checked_str(model_name));
+           OutShape o = engine::validate_predict(*m, rows, cols);
+           if (o.len > out_capacity)
+             throw InferaError::onnx("output buffer too small: need " + std::to_string(o.len) + " elements, have " + std::to_string(out_capacity));
+           run_device(*m, device, d_in, d_out, int64_t(rows));
+           if (out_rows) *out_rows = o.rows;
+           if (out_cols) *out_cols = o.cols;
+         })
+             ? 0
+             : -1;
+}
+
+int32_t infera_hip_sync(int32_t device) { return guarded([&] { sync_device(device); }) ? 0 : -1; }
+
+int32_t infera_hip_time_predict_device(const char *model_name, int32_t device, const float *d_in, uint64_t rows,
+                                       uint64_t cols, float *d_out, uint64_t out_capacity, int32_t iters, float *elapsed_ms) {
+  return guarded([&] {
+           if (!model_name || !d_in || !d_out || !elapsed_ms) throw InferaError::null_pointer();
+           auto m = engine::find(checked_str(model_name));
+           OutShape o = engine::validate_predict(*m, rows, cols);
+           if (o.len > out_capacity) throw InferaError::onnx("output buffer too small");
+           hipStream_t s = thread_stream(device);
+           hipEvent_t e0, e1;
+           if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) throw InferaError::onnx("HIP: hipEventCreate failed");
+           (void)hipEventRecord(e0, s);
+           for (int i = 0; i < iters; i++) run_device(*m, device, d_in, d_out, int64_t(rows));
+           (void)hipEventRecord(e1, s);
+           hipError_t e = hipEventSynchronize(e1);
+           float ms = 0.f;
+           if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+           (void)hipEventDestroy(e0);
+           (void)hipEventDestroy(e1);
+           if (e != hipSuccess) throw InferaError::onnx(std::string("HIP: event timing failed: ") + hipGetErrorString(e));
+           *elapsed_ms = ms;
+         })
+             ? 0
+             : -1;
+}
+
+void *infera_hip_malloc(int32_t device, uint64_t bytes) {
+  void *p = nullptr;
+  guarded([&] {
+    if (hipSetDevice(device) != hipSuccess) throw InferaError::onnx("HIP: hipSetDevice failed");
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      p = nullptr;
+      throw InferaError::onnx(std::string("HIP: hipMalloc: ") + hipGetErrorString(e));
+    }
+  });
+  return p;
+}
+
+int32_t infera_hip_free(int32_t device, void *ptr) {
+  return guarded([&] {
+           if (!ptr) return;
+           if (hipSetDevice(device) != hipSuccess || hipFree(ptr) != hipSuccess) throw InferaError::onnx("HIP: hipFree failed");
+         })
+             ? 0
+             : -1;
+}
+
+int32_t infera_hip_memcpy_h2d(int32_t device, void *dst, const void *src, uint64_t bytes) {
+  return guarded([&] {
+           if (!dst || !src) throw InferaError::null_pointer();
+           hipError_t e = hipSetDevice(device);
+           if (e == hipSuccess) e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+           if (e != hipSuccess) throw InferaError::onnx(std::string("HIP: hipMemcpy H2D: ") + hipGetErrorString(e));
+         })
+             ? 0
+             : -1;
+}
+
+int32_t infera_hip_memcpy_d2h(int32_t device, void *dst, const void *src, uint64_t bytes) {
+  return guarded([&] {
+           if (!dst || !src) throw InferaError::null_pointer();
+           hipError_t e = hipSetDevice(device);
+           if (e == hipSuccess) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+           if (e != hipSuccess) throw InferaError::onnx(std::string("HIP: hipMemcpy D2H: ") + hipGetErrorString(e));
+         })
+             ? 0
+             : -1;
+}
+
+int32_t infera_hip_synth_fill(int32_t device, float *d_dst, uint64_t seed, uint64_t row0, uint64_t rows, uint64_t cols) {
+  return guarded([&] {
+           if (!d_dst) throw InferaError::null_pointer();
+           hipStream_t s = thread_stream(device);
+           kern::synth_fill(s, d_dst, seed, row0, rows, cols);
+           hipError_t e = hipGetLastError();
+           if (e == hipSuccess) e = hipStreamSynchronize(s);
+           if (e != hipSuccess) throw InferaError::onnx(std::string("HIP: synth_fill: ") + hipGetErrorString(e));
+         })
+             ? 0
+             : -1;
+}
+
+int32_t infera_predict_into(const char *model_name, const float *data, uint64_t rows, uint64_t cols, float *out,
+                            uint64_t out_capacity, uint64_t *out_rows, uint64_t *out_cols) {
+  return guarded([&] {
+           if (!model_name || !data || !out) throw InferaError::null_pointer();
+           auto m = engine::find(checked_str(model_name));
+           OutShape o = engine::validate_predict(*m, rows, cols);
+           if (o.len > out_capacity)
+             throw InferaError::onnx("output buffer too small: need " + std::to_string(o.len) + " elements, have " + std::to_string(out_capacity));
+           run_host(*m, data, out, int64_t(rows));
+           if (out_rows) *out_rows = o.rows;
+           if (out_cols) *out_cols = o.cols;
+         })
+             ? 0
+             : -1;
+}
+
+struct InferaInferenceResult infera_predict_columns(const char *model_name, const InferaColumn *columns, uintptr_t ncols,
+                                                    uintptr_t rows) {
+  InferaInferenceResult res = error_result();
+  guarded([&] {
+    if (!model_name || !columns) throw InferaError::null_pointer();
+    auto m = engine::find(checked_str(model_name));
+    // gather first (a NULL cell must fail before any model-level error, as ExtractFeatures runs
+    // before the FFI call in the reference: infera_extension.cpp:267-270)
+    std::vector<float> feat(size_t(rows) * size_t(ncols));
+    for (uintptr_t c = 0; c < ncols; c++) {
+      const InferaColumn &col = columns[c];
+      if (!col.data) throw InferaError::null_pointer();
+      const bool cst = col.is_constant != 0;
+      if (col.validity) {
+        for (uintptr_t r = 0; r < (cst ? (rows ? 1 : 0) : rows); r++)
+          if (!((col.validity[r >> 6] >> (r & 63)) & 1)) throw InferaError(ErrKind::Onnx, "Feature values cannot be NULL");
+      }
+      float *dst = feat.data() + c;
+      auto gather = [&](auto *src) {
+        for (uintptr_t r = 0; r < rows; r++) dst[size_t(r) * ncols] = static_cast<float>(src[cst ? 0 : r]);
+      };
+      switch (col.type) {
+        case INFERA_COL_FLOAT: gather(static_cast<const float *>(col.data)); break;
+        case INFERA_COL_DOUBLE: gather(static_cast<const double *>(col.data)); break;
+        case INFERA_COL_INTEGER: gather(static_cast<const int32_t *>(col.data)); break;
+        case INFERA_COL_BIGINT: gather(static_cast<const int64_t *>(col.data)); break;
+        default: throw InferaError(ErrKind::Onnx, "Unsupported feature type: " + std::to_string(col.type));
+      }
+    }
+    OutShape o = engine::validate_predict(*m, rows, ncols);
+    float *out = alloc_out(o.len);
+    try {
+      run_host(*m, feat.data(), out, int64_t(rows));
+    } catch (...) {
+      std::free(out);
+      throw;
+    }
+    res.data = out;
+    res.len = o.len;
+    res.rows = o.rows;
+    res.cols = o.cols;
+    res.status = 0;
+  });
+  return res;
+}
+
+struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_name, const uint8_t *const *blobs,
+                                                            const uintptr_t *lens, uintptr_t n) {
+  InferaInferenceResult res = error_result();
+  guarded([&] {
+    if (!model_name || !blobs || !lens) throw InferaError::null_pointer();
+    auto m = engine::find(checked_str(model_name));
+    const auto &in = m->plan.input_shape;
+    uint64_t per_sample = 1;
+    for (size_t i = 1; i < in.size(); i++) per_sample *= uint64_t(in[i]);
+    if (in.empty() || in[0] != -1)
+      throw InferaError::onnx("batched BLOB inference needs a model with a symbolic leading (batch) dimension");
+    std::vector<float> stage(size_t(n) * size_t(per_sample));
+    for (uintptr_t i = 0; i < n; i++) {
+      if (!blobs[i]) throw InferaError::null_pointer();
+      if (lens[i] % 4 != 0) throw InferaError::invalid_blob_size();
+      if (lens[i] / 4 != per_sample) throw InferaError::blob_shape_mismatch(size_t(per_sample), size_t(lens[i] / 4));
+      std::memcpy(stage.data() + size_t(i) * per_sample, blobs[i], lens[i]);
+    }
+    OutShape o = engine::out_shape_for_rows(*m, n);
+    float *out = alloc_out(o.len);
+    try {
+      run_host(*m, stage.data(), out, int64_t(n));
+    } catch (...) {
+      std::free(out);
+      throw;
+    }
+    res.data = out;
+    res.len = o.len;
+    res.rows = o.rows;
+    res.cols = o.cols;
+    res.status = 0;
+  });
+  return res;
+}
+
+}  // extern "C"
+}  // namespace infera

@@ -1,0 +1,110 @@
+// common.hpp -- error type, thread-local last-error slot, env configuration, JSON helpers.
+//
+// Mirrors (behaviour, not code) the reference's error plumbing and config singleton:
+//   error.rs:9-62   InferaError variants and their Display strings (asserted verbatim by the
+//                   reference's SQL tests)
+//   error.rs:70-102 thread-local LAST_ERROR / infera_last_error
+//   config.rs:101-176 INFERA_* environment variables read once
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace infera_hip {
+
+enum class ErrKind {
+  ModelNotFound,
+  InvalidInputShape,
+  Onnx,
+  Memory,
+  Utf8,
+  NullPointer,
+  Io,
+  Json,
+  FeatureNotEnabled,
+  HttpRequest,
+  CacheDir,
+  InvalidBlobSize,
+  BlobShapeMismatch,
+};
+
+// An error carrying the exact text the reference's `thiserror` Display would print.
+class InferaError : public std::runtime_error {
+ public:
+  InferaError(ErrKind k, const std::string &text) : std::runtime_error(text), kind(k) {}
+  ErrKind kind;
+
+  static InferaError model_not_found(const std::string &name) {
+    return {ErrKind::ModelNotFound, "Model not found: " + name};  // error.rs:13-14
+  }
+  static InferaError invalid_input_shape(const std::string &expected, const std::string &actual) {
+    return {ErrKind::InvalidInputShape, "Invalid input shape: expected " + expected + ", got " + actual};  // :16-22
+  }
+  static InferaError onnx(const std::string &msg) { return {ErrKind::Onnx, "ONNX error: " + msg}; }  // :24-25
+  static InferaError memory() { return {ErrKind::Memory, "Memory allocation error"}; }                // :27-28
+  static InferaError utf8() { return {ErrKind::Utf8, "Invalid UTF-8 string"}; }                       // :30-31
+  static InferaError null_pointer() { return {ErrKind::NullPointer, "Null pointer passed"}; }         // :33-34
+  static InferaError io(const std::string &msg) { return {ErrKind::Io, "IO error: " + msg}; }         // :36-37
+  static InferaError json(const std::string &msg) { return {ErrKind::Json, "JSON serialization error: " + msg}; }
+  static InferaError feature_not_enabled(const std::string &msg) {
+    return {ErrKind::FeatureNotEnabled, "Feature not enabled: " + msg};  // :42-43
+  }
+  static InferaError http(const std::string &msg) { return {ErrKind::HttpRequest, "HTTP request failed: " + msg}; }
+  static InferaError cache_dir(const std::string &msg) {
+    return {ErrKind::CacheDir, "Failed to create cache directory: " + msg};
+  }
+  static InferaError invalid_blob_size() {
+    return {ErrKind::InvalidBlobSize, "Invalid BLOB size: length must be a multiple of 4"};  // :51-52
+  }
+  static InferaError blob_shape_mismatch(size_t expected, size_t actual) {  // :54-61
+    return {ErrKind::BlobShapeMismatch, "BLOB data does not match model's expected input shape. Expected " +
+                                            std::to_string(expected) + " elements, but BLOB contained " +
+                                            std::to_string(actual) + "."};
+  }
+};
+
+// error.rs:78-84 / :96-102.  The slot is per thread, survives later successes, and the returned
+// pointer stays valid until the next error on the same thread.
+void set_last_error(const std::string &text);
+const char *last_error_cstr();
+
+// Valid UTF-8 check (CStr::to_str in lib.rs:44-45, :136).
+bool is_valid_utf8(const char *s);
+
+// ---------------------------------------------------------------------------------------------
+// Configuration (config.rs:101-176 pattern: env vars read once, invalid values fall back)
+// ---------------------------------------------------------------------------------------------
+struct Config {
+  std::string cache_dir;              // INFERA_CACHE_DIR        (default $TMPDIR/infera_cache)
+  uint64_t cache_size_limit;          // INFERA_CACHE_SIZE_LIMIT (default 1 GiB)
+  int log_level;                      // INFERA_LOG_LEVEL        ERROR=0 WARN=1 INFO=2 DEBUG=3 (default WARN)
+  // MI355X backend knobs (new; same style)
+  std::vector<int> devices;           // INFERA_DEVICES="0,1,.."  (default: all visible)
+  bool use_hipgraph;                  // INFERA_HIPGRAPH=0|1      per-(model,rows) hipGraph for host-path chunks
+  bool fused_mlp;                     // INFERA_FUSED_MLP=0|1     whole-chain fused kernel when the plan allows
+  uint64_t max_rows_per_pass;         // INFERA_MAX_ROWS_PER_PASS scratch bound for unfused plans
+  static const Config &get();
+};
+
+void log_msg(int level, const std::string &msg);  // config.rs:200-207 `log!`
+
+// ---------------------------------------------------------------------------------------------
+// JSON emitters (serde_json compact form: no spaces, keys of json!{} objects sorted)
+// ---------------------------------------------------------------------------------------------
+std::string json_escape(const std::string &s);
+inline std::string json_str(const std::string &s) { return "\"" + json_escape(s) + "\""; }
+template <typename T>
+std::string json_int_array(const std::vector<T> &v) {
+  std::ostringstream o;
+  o << "[";
+  for (size_t i = 0; i < v.size(); i++) o << (i ? "," : "") << v[i];
+  o << "]";
+  return o.str();
+}
+std::string json_str_array(const std::vector<std::string> &v);
+
+}  // namespace infera_hip

@@ -1,0 +1,605 @@
+// lowering.cpp -- ONNX graph -> Plan (shape inference with a symbolic row axis + peephole fusion).
+//
+// Fusions performed while walking the (topologically sorted) node list:
+//   MatMul + Add(const [M])            -> Dense with bias
+//   Gemm(transB, alpha, beta)          -> Dense (constants folded into W / bias)
+//   Dense|Conv|Binary|Affine + act     -> trailing activation fused into the producing step
+//   Conv + BatchNormalization          -> BN folded into conv weights/bias
+//   Identity/Dropout/Flatten/Reshape/Squeeze/Unsqueeze -> buffer alias (no kernel)
+// Dense chains are kept as consecutive Dense steps; the device executor decides whether a chain
+// runs as one whole-chain fused kernel or layer by layer.
+#include <cmath>
+#include <functional>
+#include <map>
+#include <numeric>
+#include <sstream>
+
+#include "common.hpp"
+#include "plan.hpp"
+
+namespace infera_hip {
+
+namespace {
+
+using onnx::NodeDef;
+using onnx::TensorData;
+
+struct Val {
+  bool is_const = false;
+  std::shared_ptr<TensorData> c;
+  int buf = -1;
+  std::vector<int64_t> shape;  // activations: dim0 = -1 (symbolic rows) or fixed batch
+};
+
+int64_t prod(const std::vector<int64_t> &v, size_t from = 0, size_t to = SIZE_MAX) {
+  int64_t p = 1;
+  for (size_t i = from; i < std::min(to, v.size()); i++) p *= v[i];
+  return p;
+}
+
+std::string shape_str(const std::vector<int64_t> &s) {
+  std::string o = "[";
+  for (size_t i = 0; i < s.size(); i++) o += (i ? "," : "") + std::to_string(s[i]);
+  return o + "]";
+}
+
+[[noreturn]] void unsupported(const NodeDef &n, const std::string &why) {
+  throw InferaError::onnx("node '" + (n.name.empty() ? n.op : n.name) + "' (" + n.op + "): " + why);
+}
+
+struct Lowerer {
+  const onnx::Model &m;
+  Plan plan;
+  std::map<std::string, Val> vals;
+  std::map<std::string, int> uses;
+  std::map<int, int> producer;  // buffer id -> index of the step that wrote it
+  std::map<int, std::vector<std::string>> buf_names;  // value names that denote each buffer
+  std::map<int, int> alias_edges;  // nodes folded away whose input AND output denote the buffer
+
+  explicit Lowerer(const onnx::Model &model) : m(model) {}
+
+  int new_buf(const std::vector<int64_t> &shape) {
+    plan.buf_shape.push_back(shape);
+    plan.buf_per_row.push_back(prod(shape, 1));
+    return int(plan.buf_shape.size()) - 1;
+  }
+
+  const Val &get(const NodeDef &n, size_t i) {
+    if (i >= n.inputs.size() || n.inputs[i].empty()) unsupported(n, "missing input " + std::to_string(i));
+    auto it = vals.find(n.inputs[i]);
+    if (it != vals.end()) return it->second;
+    auto ci = m.initializers.find(n.inputs[i]);
+    if (ci != m.initializers.end()) {
+      Val v;
+      v.is_const = true;
+      v.c = ci->second;
+      v.shape = ci->second->dims;
+      return vals[n.inputs[i]] = v;
+    }
+    unsupported(n, "input '" + n.inputs[i] + "' is not produced by any earlier node");
+  }
+  bool has_input(const NodeDef &n, size_t i) const { return i < n.inputs.size() && !n.inputs[i].empty(); }
+
+  const std::vector<float> &cf32(const NodeDef &n, const Val &v) {
+    if (!v.is_const || v.c->dtype != onnx::kFloat) unsupported(n, "expected a constant f32 tensor");
+    return v.c->f32;
+  }
+
+  // Binds the node's first output to `buf`.  `folded` = the node itself emitted no step (alias or
+  // fused into its producer), i.e. it is an edge inside the buffer rather than a consumer of it.
+  void set_act(const NodeDef &n, int buf, const std::vector<int64_t> &shape, bool folded = false) {
+    Val v;
+    v.buf = buf;
+    v.shape = shape;
+    vals[n.outputs[0]] = v;
+    buf_names[buf].push_back(n.outputs[0]);
+    if (folded) alias_edges[buf]++;
+  }
+
+  // Number of not-yet-folded consumers (incl. graph outputs) of a buffer across all its names.
+  int live_uses(int buf) {
+    int total = 0;
+    for (const auto &nm : buf_names[buf]) total += uses[nm];
+    return total - alias_edges[buf];
+  }
+
+  // The step that produced `v` if it can still absorb a trailing op: sole consumer is this node.
+  Step *fusable_producer(const NodeDef &n, size_t in_idx) {
+    const Val &v = get(n, in_idx);
+    if (v.is_const || v.buf <= 0) return nullptr;
+    if (live_uses(v.buf) != 1) return nullptr;
+    auto it = producer.find(v.buf);
+    if (it == producer.end()) return nullptr;
+    return &plan.steps[size_t(it->second)];
+  }
+
+  Step &emit(Step s, const NodeDef &n, const std::vector<int64_t> &out_shape) {
+    s.out = new_buf(out_shape);
+    s.origin = n.op + (n.name.empty() ? "" : ":" + n.name);
+    plan.steps.push_back(std::move(s));
+    producer[plan.steps.back().out] = int(plan.steps.size()) - 1;
+    set_act(n, plan.steps.back().out, out_shape);
+    return plan.steps.back();
+  }
+
+  // ------------------------------------------------------------------------------------------
+  void dense(const NodeDef &n, bool gemm) {
+    const Val &a = get(n, 0);
+    const Val &b = get(n, 1);
+    if (a.is_const) unsupported(n, "constant left operand is not supported");
+    if (!b.is_const) unsupported(n, "right operand must be a constant weight matrix");
+    if (a.shape.size() != 2 || b.shape.size() != 2) unsupported(n, "only [rows,K] x [K,M] is supported, got " + shape_str(a.shape) + " x " + shape_str(b.shape));
+    bool tA = gemm && n.attr_i("transA", 0) != 0, tB = gemm && n.attr_i("transB", 0) != 0;
+    if (tA) unsupported(n, "transA=1 mixes table rows and is not supported");
+    float alpha = gemm ? n.attr_f("alpha", 1.f) : 1.f, beta = gemm ? n.attr_f("beta", 1.f) : 1.f;
+    const auto &w = cf32(n, b);
+    int64_t K = tB ? b.shape[1] : b.shape[0], M = tB ? b.shape[0] : b.shape[1];
+    if (a.shape[1] != K) unsupported(n, "inner dimensions differ: " + shape_str(a.shape) + " x " + shape_str(b.shape));
+    Step s;
+    s.kind = StepKind::Dense;
+    s.in0 = a.buf;
+    s.K = K;
+    s.M = M;
+    s.W.resize(size_t(K * M));
+    for (int64_t k = 0; k < K; k++)
+      for (int64_t j = 0; j < M; j++) {
+        float v = tB ? w[size_t(j * K + k)] : w[size_t(k * M + j)];
+        s.W[size_t(k * M + j)] = alpha == 1.f ? v : alpha * v;
+      }
+    if (gemm && has_input(n, 2)) {
+      const Val &c = get(n, 2);
+      const auto &cv = cf32(n, c);
+      if (int64_t(cv.size()) != M && cv.size() != 1) unsupported(n, "bias C must have M or 1 elements (row-independent)");
+      s.bias.resize(size_t(M));
+      for (int64_t j = 0; j < M; j++) {
+        float v = cv.size() == 1 ? cv[0] : cv[size_t(j)];
+        s.bias[size_t(j)] = beta == 1.f ? v : beta * v;
+      }
+    }
+    emit(std::move(s), n, {a.shape[0], M});
+  }
+
+  // Broadcast a constant against an activation's per-row shape; returns per_row floats.
+  std::vector<float> broadcast_const(const NodeDef &n, const Val &c, const std::vector<int64_t> &act_shape) {
+    const auto &cv = cf32(n, c);
+    std::vector<int64_t> cs = c.shape;
+    if (cs.size() > act_shape.size()) unsupported(n, "constant operand has higher rank than the activation");
+    while (cs.size() < act_shape.size()) cs.insert(cs.begin(), 1);
+    if (cs[0] != 1) unsupported(n, "constant operand varies along the row axis");
+    for (size_t i = 1; i < cs.size(); i++)
+      if (cs[i] != 1 && cs[i] != act_shape[i]) unsupported(n, "constant operand " + shape_str(c.shape) + " does not broadcast to " + shape_str(act_shape));
+    int64_t per_row = prod(act_shape, 1);
+    std::vector<float> out(size_t(per_row), 0.f);
+    size_t r = act_shape.size();
+    for (int64_t flat = 0; flat < per_row; flat++) {
+      int64_t rem = flat, idx = 0, stride = 1;
+      for (size_t i = r; i-- > 1;) {
+        int64_t coord = rem % act_shape[i];
+        rem /= act_shape[i];
+        if (cs[i] != 1) idx += coord * stride;
+        stride *= cs[i];
+      }
+      out[size_t(flat)] = cv[size_t(idx)];
+    }
+    return out;
+  }
+
+  void binary(const NodeDef &n, char op) {
+    const Val &a = get(n, 0);
+    const Val &b = get(n, 1);
+    if (a.is_const && b.is_const) {  // fold
+      const auto &x = cf32(n, a), &y = cf32(n, b);
+      if (a.shape != b.shape && x.size() != 1 && y.size() != 1) unsupported(n, "constant folding needs equal shapes or a scalar");
+      auto t = std::make_shared<TensorData>();
+      t->dtype = onnx::kFloat;
+      t->dims = x.size() >= y.size() ? a.shape : b.shape;
+      size_t cnt = std::max(x.size(), y.size());
+      t->f32.resize(cnt);
+      for (size_t i = 0; i < cnt; i++) {
+        float u = x[x.size() == 1 ? 0 : i], v = y[y.size() == 1 ? 0 : i];
+        t->f32[i] = op == '+' ? u + v : op == '-' ? u - v : op == '*' ? u * v : u / v;
+      }
+      Val v;
+      v.is_const = true;
+      v.c = t;
+      v.shape = t->dims;
+      vals[n.outputs[0]] = v;
+      return;
+    }
+    if (!a.is_const && !b.is_const) {
+      if (a.shape != b.shape) unsupported(n, "activation operands must have equal shapes, got " + shape_str(a.shape) + " and " + shape_str(b.shape));
+      Step s;
+      s.kind = StepKind::BinaryAct;
+      s.in0 = a.buf;
+      s.in1 = b.buf;
+      s.bop = op;
+      emit(std::move(s), n, a.shape);
+      return;
+    }
+    const bool const_left = a.is_const;
+    const Val &act = const_left ? b : a;
+    const Val &cst = const_left ? a : b;
+    std::vector<int64_t> act_shape = act.shape;
+    // MatMul + Add(const over M) -> Dense bias
+    if (op == '+') {
+      Step *p = fusable_producer(n, const_left ? 1 : 0);
+      const auto &cv = cf32(n, cst);
+      bool over_m = p && p->kind == StepKind::Dense && p->bias.empty() && p->act == Act::None && int64_t(cv.size()) == p->M &&
+                    (cst.shape.size() == 1 || (cst.shape.size() == 2 && cst.shape[0] == 1));
+      if (over_m) {
+        p->bias = cv;
+        p->origin += "+Add";
+        set_act(n, act.buf, act_shape, true);
+        return;
+      }
+    }
+    Step s;
+    s.kind = StepKind::BinaryConst;
+    s.in0 = act.buf;
+    s.bop = op;
+    s.const_left = const_left;
+    s.cst = broadcast_const(n, cst, act_shape);
+    emit(std::move(s), n, act_shape);
+  }
+
+  void unary(const NodeDef &n) {
+    Act act;
+    float pa = 0.f, pb = 0.f;
+    if (n.op == "Relu") act = Act::Relu;
+    else if (n.op == "Sigmoid") act = Act::Sigmoid;
+    else if (n.op == "Tanh") act = Act::Tanh;
+    else if (n.op == "LeakyRelu") { act = Act::LeakyRelu; pa = n.attr_f("alpha", 0.01f); }
+    else {  // Clip
+      act = Act::Clip;
+      pa = -INFINITY;
+      pb = INFINITY;
+      if (auto *a = n.attr("min")) pa = a->f;
+      if (auto *a = n.attr("max")) pb = a->f;
+      if (has_input(n, 1)) { const Val &v = get(n, 1); if (cf32(n, v).size() == 1) pa = v.c->f32[0]; }
+      if (has_input(n, 2)) { const Val &v = get(n, 2); if (cf32(n, v).size() == 1) pb = v.c->f32[0]; }
+    }
+    const Val &a = get(n, 0);
+    if (a.is_const) unsupported(n, "activation of a constant");
+    std::vector<int64_t> shape = a.shape;
+    if (Step *p = fusable_producer(n, 0)) {
+      if (p->act == Act::None && p->kind != StepKind::Softmax && p->kind != StepKind::Pool2d && p->kind != StepKind::GlobalAvgPool) {
+        p->act = act;
+        p->act_a = pa;
+        p->act_b = pb;
+        p->origin += "+" + n.op;
+        set_act(n, a.buf, shape, true);
+        return;
+      }
+    }
+    Step s;
+    s.kind = StepKind::Unary;
+    s.in0 = a.buf;
+    s.act = act;
+    s.act_a = pa;
+    s.act_b = pb;
+    emit(std::move(s), n, shape);
+  }
+
+  void alias(const NodeDef &n, const std::vector<int64_t> &new_shape) {
+    const Val &a = get(n, 0);
+    if (prod(new_shape, 1) != prod(a.shape, 1) || new_shape.empty() || new_shape[0] != a.shape[0])
+      unsupported(n, "reshape " + shape_str(a.shape) + " -> " + shape_str(new_shape) + " does not preserve the row axis");
+    int buf = a.buf;
+    set_act(n, buf, new_shape, true);
+  }
+
+  void reshape_like(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    if (a.is_const) {
+      if (n.op == "Identity") { vals[n.outputs[0]] = a; return; }
+      unsupported(n, "reshaping constants is not supported");
+    }
+    std::vector<int64_t> out;
+    const int64_t rank = int64_t(a.shape.size());
+    if (n.op == "Identity" || n.op == "Dropout") {
+      out = a.shape;
+    } else if (n.op == "Flatten") {
+      int64_t axis = n.attr_i("axis", 1);
+      if (axis < 0) axis += rank;
+      if (axis != 1) unsupported(n, "only axis=1 keeps the row axis");
+      out = {a.shape[0], prod(a.shape, 1)};
+    } else if (n.op == "Reshape") {
+      std::vector<int64_t> tgt;
+      if (has_input(n, 1)) {
+        const Val &s = get(n, 1);
+        if (!s.is_const || s.c->dtype != onnx::kInt64) unsupported(n, "shape must be a constant int64 tensor");
+        tgt = s.c->i64;
+      } else if (auto *p = n.attr_ints("shape")) tgt = *p;
+      else unsupported(n, "missing shape");
+      if (tgt.empty()) unsupported(n, "empty target shape");
+      int64_t per_row = prod(a.shape, 1);
+      // leading entry must denote the row axis: 0 (copy), the fixed batch, or -1 with the rest complete
+      int64_t rest = 1;
+      int neg = -1;
+      for (size_t i = 1; i < tgt.size(); i++) {
+        int64_t d = tgt[i];
+        if (d == 0) { if (i >= a.shape.size()) unsupported(n, "0 entry out of range"); d = a.shape[i]; tgt[i] = d; }
+        if (d == -1) { if (neg >= 0) unsupported(n, "more than one -1"); neg = int(i); continue; }
+        rest *= d;
+      }
+      bool lead_ok = tgt[0] == 0 || (tgt[0] == a.shape[0] && a.shape[0] > 0) || (tgt[0] == -1 && neg < 0 && rest == per_row);
+      if (!lead_ok) unsupported(n, "target shape " + shape_str(tgt) + " does not keep the row axis of " + shape_str(a.shape));
+      if (neg >= 0) {
+        if (rest == 0 || per_row % rest) unsupported(n, "cannot infer -1");
+        tgt[size_t(neg)] = per_row / rest;
+      }
+      tgt[0] = a.shape[0];
+      out = tgt;
+    } else {  // Squeeze / Unsqueeze
+      std::vector<int64_t> axes;
+      if (has_input(n, 1)) {
+        const Val &s = get(n, 1);
+        if (!s.is_const || s.c->dtype != onnx::kInt64) unsupported(n, "axes must be constant");
+        axes = s.c->i64;
+      } else if (auto *p = n.attr_ints("axes")) axes = *p;
+      if (n.op == "Squeeze") {
+        for (int64_t i = 0; i < rank; i++) {
+          bool drop = axes.empty() ? (a.shape[size_t(i)] == 1 && i != 0) : false;
+          for (auto ax : axes) if ((ax < 0 ? ax + rank : ax) == i) drop = true;
+          if (drop && i == 0) unsupported(n, "cannot squeeze the row axis");
+          if (!drop) out.push_back(a.shape[size_t(i)]);
+        }
+      } else {
+        int64_t nr = rank + int64_t(axes.size());
+        size_t src = 0;
+        for (int64_t i = 0; i < nr; i++) {
+          bool ins = false;
+          for (auto ax : axes) if ((ax < 0 ? ax + nr : ax) == i) ins = true;
+          if (ins && i == 0) unsupported(n, "cannot insert an axis before the row axis");
+          out.push_back(ins ? 1 : a.shape[src++]);
+        }
+      }
+    }
+    alias(n, out);
+  }
+
+  void softmax(const NodeDef &n, bool logsm) {
+    const Val &a = get(n, 0);
+    if (a.is_const) unsupported(n, "softmax of a constant");
+    const int64_t rank = int64_t(a.shape.size());
+    int64_t axis = n.attr_i("axis", m.opset >= 13 ? -1 : 1);
+    if (axis < 0) axis += rank;
+    if (axis < 1 || axis >= rank) unsupported(n, "axis must address a non-row axis");
+    Step s;
+    s.kind = StepKind::Softmax;
+    s.in0 = a.buf;
+    s.log_softmax = logsm;
+    s.sm_outer = prod(a.shape, 1, size_t(axis));
+    if (m.opset >= 13) {
+      s.sm_len = a.shape[size_t(axis)];
+      s.sm_inner = prod(a.shape, size_t(axis) + 1);
+    } else {
+      s.sm_len = prod(a.shape, size_t(axis));
+      s.sm_inner = 1;
+    }
+    std::vector<int64_t> shape = a.shape;
+    emit(std::move(s), n, shape);
+  }
+
+  void spatial(const NodeDef &n, Step &s, int64_t H, int64_t W) {
+    s.sh = s.sw = s.dh = s.dw = 1;
+    s.pt = s.pl = s.pb = s.pr = 0;
+    if (auto *p = n.attr_ints("strides")) { if (p->size() != 2) unsupported(n, "only 2-D"); s.sh = (*p)[0]; s.sw = (*p)[1]; }
+    if (auto *p = n.attr_ints("dilations")) { if (p->size() != 2) unsupported(n, "only 2-D"); s.dh = (*p)[0]; s.dw = (*p)[1]; }
+    if (auto *p = n.attr_ints("pads")) { if (p->size() != 4) unsupported(n, "only 2-D"); s.pt = (*p)[0]; s.pl = (*p)[1]; s.pb = (*p)[2]; s.pr = (*p)[3]; }
+    std::string ap = n.attr_s("auto_pad", "NOTSET");
+    if (ap == "VALID") s.pt = s.pl = s.pb = s.pr = 0;
+    else if (ap == "SAME_UPPER" || ap == "SAME_LOWER") {
+      int64_t oh = (H + s.sh - 1) / s.sh, ow = (W + s.sw - 1) / s.sw;
+      int64_t ph = std::max<int64_t>(0, (oh - 1) * s.sh + (s.kh - 1) * s.dh + 1 - H);
+      int64_t pw = std::max<int64_t>(0, (ow - 1) * s.sw + (s.kw - 1) * s.dw + 1 - W);
+      bool up = ap == "SAME_UPPER";
+      s.pt = up ? ph / 2 : ph - ph / 2; s.pb = ph - s.pt;
+      s.pl = up ? pw / 2 : pw - pw / 2; s.pr = pw - s.pl;
+    } else if (ap != "NOTSET") unsupported(n, "auto_pad " + ap);
+    if (n.attr_i("ceil_mode", 0) != 0) unsupported(n, "ceil_mode=1");
+    s.OH = (H + s.pt + s.pb - (s.dh * (s.kh - 1) + 1)) / s.sh + 1;
+    s.OW = (W + s.pl + s.pr - (s.dw * (s.kw - 1) + 1)) / s.sw + 1;
+    if (s.OH <= 0 || s.OW <= 0) unsupported(n, "empty spatial output");
+  }
+
+  void conv(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    const Val &w = get(n, 1);
+    if (a.is_const || a.shape.size() != 4) unsupported(n, "only 2-D NCHW activations");
+    if (!w.is_const || w.shape.size() != 4) unsupported(n, "weights must be a constant [M,C/g,kh,kw]");
+    Step s;
+    s.kind = StepKind::Conv2d;
+    s.in0 = a.buf;
+    s.C = a.shape[1]; s.H = a.shape[2]; s.Wd = a.shape[3];
+    s.Mo = w.shape[0]; s.kh = w.shape[2]; s.kw = w.shape[3];
+    s.groups = n.attr_i("group", 1);
+    if (s.groups < 1 || s.C != w.shape[1] * s.groups || s.Mo % s.groups) unsupported(n, "channel/group mismatch");
+    spatial(n, s, s.H, s.Wd);
+    s.W = cf32(n, w);
+    if (has_input(n, 2)) {
+      s.bias = cf32(n, get(n, 2));
+      if (int64_t(s.bias.size()) != s.Mo) unsupported(n, "bias size mismatch");
+    }
+    s.K = (s.C / s.groups) * s.kh * s.kw;
+    s.M = s.Mo;
+    std::vector<int64_t> shape = {a.shape[0], s.Mo, s.OH, s.OW};
+    emit(std::move(s), n, shape);
+  }
+
+  void batchnorm(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    if (a.is_const || a.shape.size() < 2) unsupported(n, "bad input");
+    const auto &sc = cf32(n, get(n, 1)), &bi = cf32(n, get(n, 2)), &mu = cf32(n, get(n, 3)), &var = cf32(n, get(n, 4));
+    const int64_t C = a.shape[1];
+    if (int64_t(sc.size()) != C || int64_t(bi.size()) != C || int64_t(mu.size()) != C || int64_t(var.size()) != C)
+      unsupported(n, "parameter size mismatch");
+    float eps = n.attr_f("epsilon", 1e-5f);
+    std::vector<float> scale((size_t)C), shift((size_t)C);
+    for (int64_t c = 0; c < C; c++) {
+      float inv = 1.0f / std::sqrt(var[size_t(c)] + eps);
+      scale[size_t(c)] = sc[size_t(c)] * inv;
+      shift[size_t(c)] = bi[size_t(c)] - mu[size_t(c)] * scale[size_t(c)];
+    }
+    std::vector<int64_t> shape = a.shape;
+    if (Step *p = fusable_producer(n, 0)) {
+      if (p->kind == StepKind::Conv2d && p->act == Act::None) {  // fold into conv
+        const int64_t per_m = p->K;
+        for (int64_t mo = 0; mo < p->Mo; mo++)
+          for (int64_t k = 0; k < per_m; k++) p->W[size_t(mo * per_m + k)] *= scale[size_t(mo)];
+        if (p->bias.empty()) p->bias.assign(size_t(p->Mo), 0.f);
+        for (int64_t mo = 0; mo < p->Mo; mo++) p->bias[size_t(mo)] = p->bias[size_t(mo)] * scale[size_t(mo)] + shift[size_t(mo)];
+        p->origin += "+BatchNormalization";
+        set_act(n, a.buf, shape, true);
+        return;
+      }
+    }
+    Step s;
+    s.kind = StepKind::AffineChannel;
+    s.in0 = a.buf;
+    s.C = C;
+    s.S = prod(a.shape, 2);
+    s.scale = std::move(scale);
+    s.shift = std::move(shift);
+    emit(std::move(s), n, shape);
+  }
+
+  void pool(const NodeDef &n, bool is_max) {
+    const Val &a = get(n, 0);
+    if (a.is_const || a.shape.size() != 4) unsupported(n, "only 2-D NCHW activations");
+    auto *ks = n.attr_ints("kernel_shape");
+    if (!ks || ks->size() != 2) unsupported(n, "kernel_shape must have 2 entries");
+    Step s;
+    s.kind = StepKind::Pool2d;
+    s.in0 = a.buf;
+    s.is_max = is_max;
+    s.count_pad = n.attr_i("count_include_pad", 0) != 0;
+    s.C = a.shape[1]; s.H = a.shape[2]; s.Wd = a.shape[3];
+    s.kh = (*ks)[0]; s.kw = (*ks)[1];
+    spatial(n, s, s.H, s.Wd);
+    std::vector<int64_t> shape = {a.shape[0], s.C, s.OH, s.OW};
+    emit(std::move(s), n, shape);
+  }
+
+  void global_avgpool(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    if (a.is_const || a.shape.size() < 3) unsupported(n, "bad input");
+    Step s;
+    s.kind = StepKind::GlobalAvgPool;
+    s.in0 = a.buf;
+    s.C = a.shape[1];
+    s.S = prod(a.shape, 2);
+    std::vector<int64_t> shape = a.shape;
+    for (size_t i = 2; i < shape.size(); i++) shape[i] = 1;
+    emit(std::move(s), n, shape);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  Plan run() {
+    plan.opset = m.opset;
+    const onnx::ValueDef &in = m.inputs[0];
+    if (!in.has_shape) throw InferaError::onnx("input '" + in.name + "' has no declared shape");
+    if (in.elem_type != 0 && in.elem_type != onnx::kFloat) throw InferaError::onnx("input '" + in.name + "' is not f32");
+    if (in.dims.size() < 2) throw InferaError::onnx("input rank " + std::to_string(in.dims.size()) + " has no row axis + feature axis; rank >= 2 is required");
+    for (size_t i = 1; i < in.dims.size(); i++)
+      if (in.dims[i] <= 0) throw InferaError::onnx("only the leading (row/batch) dimension of the input may be symbolic, got " + shape_str(in.dims));
+    plan.input_shape = in.dims;
+    if (in.dims[0] > 0) plan.fixed_batch = in.dims[0];
+    else plan.input_shape[0] = -1;
+    {
+      Val v;
+      v.buf = new_buf(plan.input_shape);
+      v.shape = plan.input_shape;
+      vals[in.name] = v;
+      buf_names[v.buf].push_back(in.name);
+    }
+    for (const auto &n : m.nodes)
+      for (const auto &i : n.inputs) uses[i]++;
+    for (const auto &o : m.outputs) uses[o.name]++;
+
+    for (const auto &n : m.nodes) {
+      if (n.outputs.empty()) throw InferaError::onnx("node " + n.op + " has no outputs");
+      if (!n.domain.empty() && n.domain != "ai.onnx") unsupported(n, "operator domain '" + n.domain + "'");
+      const std::string &op = n.op;
+      if (op == "MatMul") dense(n, false);
+      else if (op == "Gemm") dense(n, true);
+      else if (op == "Add") binary(n, '+');
+      else if (op == "Sub") binary(n, '-');
+      else if (op == "Mul") binary(n, '*');
+      else if (op == "Div") binary(n, '/');
+      else if (op == "Relu" || op == "Sigmoid" || op == "Tanh" || op == "LeakyRelu" || op == "Clip") unary(n);
+      else if (op == "Identity" || op == "Dropout" || op == "Flatten" || op == "Reshape" || op == "Squeeze" || op == "Unsqueeze") reshape_like(n);
+      else if (op == "Softmax") softmax(n, false);
+      else if (op == "LogSoftmax") softmax(n, true);
+      else if (op == "Conv") conv(n);
+      else if (op == "BatchNormalization") batchnorm(n);
+      else if (op == "MaxPool") pool(n, true);
+      else if (op == "AveragePool") pool(n, false);
+      else if (op == "GlobalAveragePool") global_avgpool(n);
+      else if (op == "Constant") {
+        auto *a = n.attr("value");
+        if (!a || !a->t) unsupported(n, "only the tensor `value` form is supported");
+        Val v;
+        v.is_const = true;
+        v.c = a->t;
+        v.shape = a->t->dims;
+        vals[n.outputs[0]] = v;
+      } else {
+        unsupported(n, "unsupported operator");
+      }
+    }
+    // first output only (engine.rs:146-149)
+    const onnx::ValueDef &out = m.outputs[0];
+    auto it = vals.find(out.name);
+    if (it == vals.end()) throw InferaError::onnx("output '" + out.name + "' is never produced");
+    if (it->second.is_const) throw InferaError::onnx("output '" + out.name + "' is a constant; nothing to run");
+    if (out.elem_type != 0 && out.elem_type != onnx::kFloat) throw InferaError::onnx("output '" + out.name + "' is not f32");
+    plan.out_buf = it->second.buf;
+    plan.output_shape = it->second.shape;
+    if (plan.fixed_batch < 0) plan.output_shape[0] = -1;
+    // declared output dims must agree where both are known
+    if (out.has_shape) {
+      if (out.dims.size() != plan.output_shape.size())
+        throw InferaError::onnx("declared output rank " + std::to_string(out.dims.size()) + " differs from inferred " + shape_str(plan.output_shape));
+      for (size_t i = 0; i < out.dims.size(); i++)
+        if (out.dims[i] > 0 && plan.output_shape[i] > 0 && out.dims[i] != plan.output_shape[i])
+          throw InferaError::onnx("declared output shape " + shape_str(out.dims) + " conflicts with inferred " + shape_str(plan.output_shape));
+    }
+    return std::move(plan);
+  }
+};
+
+}  // namespace
+
+Plan lower_model(const onnx::Model &m) { return Lowerer(m).run(); }
+
+double Plan::flops_per_row() const {
+  double f = 0;
+  for (const auto &s : steps) {
+    if (s.kind == StepKind::Dense) f += 2.0 * double(s.K) * double(s.M);
+    else if (s.kind == StepKind::Conv2d) f += 2.0 * double(s.K) * double(s.Mo) * double(s.OH) * double(s.OW);
+  }
+  return f;
+}
+
+std::string Plan::describe_json() const {
+  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool"};
+  static const char *acts[] = {"", "Relu", "Sigmoid", "Tanh", "LeakyRelu", "Clip"};
+  std::ostringstream o;
+  o << "{\"input_shape\":" << json_int_array(input_shape) << ",\"output_shape\":" << json_int_array(output_shape)
+    << ",\"flops_per_row\":" << (long long)flops_per_row() << ",\"steps\":[";
+  for (size_t i = 0; i < steps.size(); i++) {
+    const Step &s = steps[i];
+    if (i) o << ",";
+    o << "{\"kind\":\"" << kinds[int(s.kind)] << "\",\"in\":" << s.in0 << ",\"out\":" << s.out;
+    if (s.in1 >= 0) o << ",\"in1\":" << s.in1;
+    if (s.kind == StepKind::Dense) o << ",\"K\":" << s.K << ",\"M\":" << s.M << ",\"bias\":" << (s.bias.empty() ? "false" : "true");
+    if (s.kind == StepKind::Conv2d) o << ",\"C\":" << s.C << ",\"M\":" << s.Mo << ",\"k\":[" << s.kh << "," << s.kw << "],\"out_hw\":[" << s.OH << "," << s.OW << "]";
+    if (s.act != Act::None) o << ",\"act\":\"" << acts[int(s.act)] << "\"";
+    o << ",\"origin\":" << json_str(s.origin) << "}";
+  }
+  o << "]}";
+  return o.str();
+}
+
+}  // namespace infera_hip

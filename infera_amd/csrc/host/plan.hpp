@@ -1,0 +1,75 @@
+// plan.hpp -- the lowered, device-independent execution plan of one model.
+//
+// infera_load_model turns the ONNX graph into this at load time (the reference does the analogous
+// work with Tract's into_optimized()/into_runnable(), engine.rs:52-55).  Every activation is a
+// row-major [rows, per_row] f32 matrix whose leading axis is the table-row (batch) axis, so all
+// steps are row-independent and a scan shards by row range with no exchange.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "onnx_model.hpp"
+
+namespace infera_hip {
+
+enum class Act : int { None = 0, Relu = 1, Sigmoid = 2, Tanh = 3, LeakyRelu = 4, Clip = 5 };
+
+enum class StepKind : int {
+  Dense = 0,        // Y[rows,M] = act(X[rows,K] . W[K,M] + bias[M])       (MatMul / Gemm [+Add] [+act])
+  Unary = 1,        // elementwise activation
+  AffineChannel = 2,// y = x*scale[c] + shift[c]  per channel              (unfused BatchNormalization)
+  BinaryConst = 3,  // y = x (op) cst[per_row]  (constant pre-broadcast to one row)
+  BinaryAct = 4,    // y = a (op) b             (residual adds)
+  Softmax = 5,      // softmax / log-softmax over `sm_len` with (outer, len, inner) strides inside a row
+  Conv2d = 6,       // NCHW convolution as implicit GEMM (BatchNormalization folded when adjacent)
+  Pool2d = 7,       // MaxPool / AveragePool
+  GlobalAvgPool = 8,
+};
+
+struct Step {
+  StepKind kind = StepKind::Unary;
+  int in0 = -1, in1 = -1, out = -1;  // activation buffer ids; 0 is the model input
+  Act act = Act::None;               // fused trailing activation
+  float act_a = 0.f, act_b = 0.f;    // LeakyRelu alpha / Clip lo,hi
+  // Dense
+  int64_t K = 0, M = 0;
+  std::vector<float> W;     // [K, M] row-major (Gemm transB / alpha already folded)
+  std::vector<float> bias;  // [M] or empty (Gemm beta folded)
+  // AffineChannel: scale/shift per channel, S = elements per channel
+  std::vector<float> scale, shift;
+  int64_t S = 1;
+  // BinaryConst / BinaryAct
+  char bop = '+';
+  bool const_left = false;
+  std::vector<float> cst;  // per_row elements
+  // Softmax
+  int64_t sm_outer = 1, sm_len = 1, sm_inner = 1;
+  bool log_softmax = false;
+  // Conv2d / Pool2d / GlobalAvgPool geometry (per sample)
+  int64_t C = 0, H = 0, Wd = 0, Mo = 0, OH = 0, OW = 0;
+  int64_t kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0, dh = 1, dw = 1, groups = 1;
+  bool is_max = false, count_pad = false;
+  std::string origin;  // ONNX node names/ops this step came from (diagnostics)
+};
+
+struct Plan {
+  std::vector<int64_t> input_shape, output_shape;  // -1 = symbolic (engine.rs:64-73)
+  std::vector<std::vector<int64_t>> buf_shape;     // per activation buffer, dim0 = -1 or the fixed batch
+  std::vector<int64_t> buf_per_row;                // elements per row of each buffer
+  std::vector<Step> steps;
+  int out_buf = 0;
+  int64_t fixed_batch = -1;  // > 0 when the model's leading dim is a constant (e.g. linear.onnx [1,3])
+  int64_t opset = 1;
+
+  int64_t in_per_row() const { return buf_per_row[0]; }
+  int64_t out_per_row() const { return buf_per_row[out_buf]; }
+  double flops_per_row() const;  // 2*MACs of Dense/Conv steps (bias/activation excluded)
+  std::string describe_json() const;
+};
+
+// Throws InferaError::onnx on unsupported graphs.
+Plan lower_model(const onnx::Model &m);
+
+}  // namespace infera_hip

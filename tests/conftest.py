@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build libinfera.so + the oracle once per session (no-ops when up to date)."""
+    import __graft_entry__ as g
+
+    g.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def models(tmp_path_factory, built):
+    """Benchmark/parity ONNX models written by infera_amd.onnx_writer (deterministic, seed 1234)."""
+    from infera_amd import onnx_writer as W
+
+    d = tmp_path_factory.mktemp("models")
+    out = {
+        "linear": os.path.join(ROOT, "tests", "golden", "linear.onnx"),
+        "multi_output": os.path.join(ROOT, "tests", "golden", "multi_output.onnx"),
+        "linear_dyn": W.write(str(d / "linear_dyn.onnx"), W.linear_dyn()),
+        "mlp": W.write(str(d / "mlp.onnx"), W.mlp((128, 256, 64, 1))),
+        "logreg": W.write(str(d / "logreg.onnx"), W.logreg_softmax(128, 10)),
+        "identity_dyn": W.write(str(d / "identity_dyn.onnx"), W.identity(4)),
+    }
+    return out
