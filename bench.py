@@ -73,7 +73,7 @@ def main():
     torch.cuda.set_device(local_rank)
     torch.cuda.init()
 
-    from infera_amd import capi, onnx_writer
+    from infera_amd import capi, onnx_writer, shard
 
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: " + capi.get_devices()["reason"])
@@ -93,7 +93,8 @@ def main():
 
     d_in = capi.DeviceBuffer(dev, rows * cols * 4)
     d_out = capi.DeviceBuffer(dev, rows * out_cols * 4)
-    capi.synth_fill(d_in, 42, rank * rows, rows, cols)  # this rank's row range of the global table
+    row0, _ = shard.row_range(rank, world, rows)
+    capi.synth_fill(d_in, 42, row0, rows, cols)  # this rank's row range of the global table
 
     def step():
         capi.predict_device("bench", d_in, rows, cols, d_out, sync=False)
@@ -102,10 +103,7 @@ def main():
         step()
     capi.sync(dev)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
+    barrier = shard.barrier
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -115,10 +113,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed)
 
     # roofline of the dominant kernel: HIP events on the launching stream around back-to-back launches
     iters = max(3, min(args.steps, 10))

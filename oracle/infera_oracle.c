@@ -1318,11 +1318,13 @@ typedef struct {
   union { float f; double d; int32_t i32; int64_t i64; } v;
 } BoxedValue;
 
-static __attribute__((noinline)) BoxedValue *box_get_value(const float *column, size_t row) {
-  BoxedValue *b = (BoxedValue *)malloc(sizeof *b); /* Value construction allocates for some types */
-  b->type_id = 1;
-  b->is_null = 0;
-  b->v.f = column[row];
+/* Returned by value through a non-inlined call: the cost class of Vector::GetValue for a FLOAT
+ * cell (a tagged Value is materialised per cell; numeric Values do not heap-allocate). */
+static __attribute__((noinline)) BoxedValue box_get_value(const float *column, size_t row) {
+  BoxedValue b;
+  b.type_id = 1;
+  b.is_null = 0;
+  b.v.f = column[row];
   return b;
 }
 
@@ -1355,16 +1357,15 @@ static void *scan_worker(void *p) {
       size_t k = 0;
       for (size_t r = 0; r < nr; r++)
         for (size_t j = 0; j < F; j++) {
-          BoxedValue *b = box_get_value(cols + j * CH, r);
-          if (b->is_null) { a->failed = 1; }
+          BoxedValue b = box_get_value(cols + j * CH, r);
+          if (b.is_null) { a->failed = 1; }
           float v;
-          switch (b->type_id) {
-            case 1: v = b->v.f; break;
-            case 2: v = (float)b->v.d; break;
-            case 3: v = (float)b->v.i32; break;
-            default: v = (float)b->v.i64; break;
+          switch (b.type_id) {
+            case 1: v = b.v.f; break;
+            case 2: v = (float)b.v.d; break;
+            case 3: v = (float)b.v.i32; break;
+            default: v = (float)b.v.i64; break;
           }
-          free(b);
           feat[k++] = v;
         }
     } else {

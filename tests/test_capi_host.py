@@ -1,0 +1,226 @@
+"""CPU tests of the C-ABI library (no compute calls: this box has no GPU).
+
+Re-states the reference's Rust unit tests of the FFI layer (infera/src/lib.rs:427-657,
+ffi_utils.rs:79-112) against libinfera.so, plus registry / lowering behaviour.
+"""
+import ctypes as C
+import json
+import os
+import re
+import shutil
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def api(built):
+    from infera_amd import capi
+
+    capi.load_library()
+    return capi
+
+
+def test_library_exports_every_declared_symbol(api):
+    declared = set()
+    for hdr in ("infera.h", "infera_hip.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(infera_\w+)\s*\(", text))
+    assert set(api.REFERENCE_SYMBOLS) <= declared and len(api.REFERENCE_SYMBOLS) == 13
+    assert declared == set(api.REFERENCE_SYMBOLS) | set(api.EXTENSION_SYMBOLS)
+    lib = api.load_library()
+    for sym in sorted(declared):
+        assert getattr(lib, sym) is not None
+
+
+def test_result_struct_layout(api):
+    # rust.h:28-49: 40 bytes on LP64, status at offset 32
+    assert C.sizeof(api.InferaInferenceResult) == 40
+    assert api.InferaInferenceResult.status.offset == 32
+
+
+def test_ffi_null_pointers(api):
+    """lib.rs:500-577 test_ffi_null_pointers."""
+    L = api.load_library()
+    name, path = b"test", b"path"
+    assert L.infera_load_model(None, path) == -1 and "Null pointer passed" in api.last_error()
+    assert L.infera_load_model(name, None) == -1 and "Null pointer passed" in api.last_error()
+    assert L.infera_unload_model(None) == -1 and "Null pointer passed" in api.last_error()
+    data = (C.c_float * 1)(0.0)
+    r = L.infera_predict(None, data, 1, 1)
+    assert r.status == -1 and not r.data and r.len == r.rows == r.cols == 0 and "Null pointer passed" in api.last_error()
+    L.infera_free_result(r)  # callers free even failed results
+    r = L.infera_predict(name, None, 1, 1)
+    assert r.status == -1 and "Null pointer passed" in api.last_error()
+    blob = (C.c_uint8 * 4)()
+    assert L.infera_predict_from_blob(None, blob, 4).status == -1 and "Null pointer passed" in api.last_error()
+    assert L.infera_predict_from_blob(name, None, 4).status == -1 and "Null pointer passed" in api.last_error()
+    for fn in (L.infera_get_model_info, L.infera_set_autoload_dir, L.infera_hip_get_plan):
+        p = fn(None)
+        js = json.loads(C.string_at(p).decode())
+        L.infera_free(p)
+        assert "Null pointer passed" in js["error"]
+    L.infera_free(None)  # NULL is a no-op (ffi_utils.rs:49-54)
+    L.infera_free_result(api.InferaInferenceResult())  # NULL data is a no-op (ffi_utils.rs:69-77)
+
+
+def test_invalid_utf8(api):
+    L = api.load_library()
+    assert L.infera_unload_model(b"\xff\xfe") == -1 and api.last_error() == "Invalid UTF-8 string"
+
+
+def test_last_error_is_thread_local_and_sticky(api):
+    L = api.load_library()
+    assert L.infera_unload_model(b"__nope__") == -1
+    assert api.last_error() == "Model not found: __nope__"
+    assert api.get_version()["onnx_backend"] == "hip-gfx950"  # a success does not clear the slot
+    assert api.last_error() == "Model not found: __nope__"
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(api.last_error()))
+    t.start()
+    t.join()
+    assert seen == [None]  # a thread that never failed sees NULL (error.rs:96-102)
+
+
+def test_predict_from_blob_invalid_size(api):
+    """lib.rs:579-601."""
+    api.load_model("test_model", os.path.join(GOLD, "linear.onnx"))
+    with pytest.raises(api.InferaError, match="Invalid BLOB size: length must be a multiple of 4"):
+        api.predict_from_blob("test_model", b"\0" * 5)
+    with pytest.raises(api.InferaError, match=r"Expected 3 elements, but BLOB contained 4\."):
+        api.predict_from_blob("test_model", b"\0" * 16)  # test_edge_cases.test:33-36
+    api.unload_model("test_model")
+
+
+def test_predict_invalid_shape(api):
+    """lib.rs:603-630."""
+    api.load_model("shape_check", os.path.join(GOLD, "linear.onnx"))
+    with pytest.raises(api.InferaError, match=r"^Invalid input shape: expected batch x \[3\], got 1 x 2$"):
+        api.predict("shape_check", np.zeros((1, 2), np.float32))
+    with pytest.raises(api.InferaError, match=r"^ONNX error: input shape mismatch at axis 0: model expects 1, got 2$"):
+        api.predict("shape_check", np.zeros((2, 3), np.float32))
+    api.unload_model("shape_check")
+
+
+def test_model_not_found_and_info_error_json(api):
+    with pytest.raises(api.InferaError, match="^Model not found: linear_x$"):  # test_edge_cases.test:54-57
+        api.predict("linear_x", np.zeros((1, 3), np.float32))
+    info = api.get_model_info("__missing_model__")  # lib.rs:632-644
+    assert info == {"error": "Model not found: __missing_model__"}
+
+
+def test_version_and_cache_info(api):
+    v = api.get_version()  # lib.rs:434-444
+    assert all(isinstance(v[k], str) for k in ("version", "onnx_backend", "model_cache_dir"))
+    ci = api.get_cache_info()  # lib.rs:646-656
+    assert ci["size_limit_bytes"] == int(os.environ.get("INFERA_CACHE_SIZE_LIMIT", 1024 ** 3))
+    assert set(ci) == {"cache_dir", "total_size_bytes", "file_count", "size_limit_bytes"}
+    api.clear_cache()
+
+
+def test_model_info_json_and_registry(api):
+    api.load_model("linear", os.path.join(GOLD, "linear.onnx"))
+    api.load_model("linear_b", os.path.join(GOLD, "linear.onnx"))  # test_edge_cases.test:13-24
+    raw = C.string_at(api.load_library().infera_get_model_info(b"linear")).decode()
+    assert '"input_shape":[1,3]' in raw and '"output_shape":[1,1]' in raw  # test_core_functionality.test:41-44
+    assert json.loads(raw) == {"input_shape": [1, 3], "loaded": True, "name": "linear", "output_shape": [1, 1]}
+    assert {"linear", "linear_b"} <= set(api.get_loaded_models())
+    api.load_model("linear", os.path.join(GOLD, "multi_output.onnx"))  # same name silently replaces (engine.rs:74-80)
+    assert api.get_model_info("linear")["output_shape"] == [1, 4]  # test_multi_output.test:17-20
+    api.unload_model("linear")
+    api.unload_model("linear_b")
+    with pytest.raises(api.InferaError, match="^Model not found: linear$"):
+        api.unload_model("linear")
+    assert "linear" not in api.get_loaded_models()
+
+
+def test_load_errors(api, tmp_path):
+    with pytest.raises(api.InferaError, match="^ONNX error: "):
+        api.load_model("x", str(tmp_path / "does_not_exist.onnx"))
+    bad = tmp_path / "bad.onnx"
+    bad.write_text("invalid onnx data")
+    with pytest.raises(api.InferaError, match="^ONNX error: "):
+        api.load_model("x", str(bad))
+    with pytest.raises(api.InferaError, match="^HTTP request failed: "):
+        api.load_model("x", "https://example.invalid/model.onnx")
+    assert "x" not in api.get_loaded_models()
+
+
+def test_set_autoload_dir(api, tmp_path):
+    """lib.rs:447-498."""
+    good = tmp_path / "good"
+    good.mkdir()
+    shutil.copy(os.path.join(GOLD, "linear.onnx"), good / "linear.onnx")
+    res = api.set_autoload_dir(str(good))
+    assert res == {"loaded": ["linear"], "errors": []}
+    api.unload_model("linear")
+    res = api.set_autoload_dir(str(tmp_path / "non_existent"))
+    assert isinstance(res["error"], str) and res["error"].startswith("IO error: ")
+    badd = tmp_path / "bad"
+    badd.mkdir()
+    (badd / "invalid.onnx").write_text("invalid onnx data")
+    res = api.set_autoload_dir(str(badd))
+    assert res["loaded"] == [] and len(res["errors"]) == 1 and res["errors"][0]["file"] == str(badd / "invalid.onnx")
+
+
+def test_registry_concurrency_without_compute(api):
+    """Shape of test/concurrency/test_concurrency.py:25-50 minus the predict (needs a GPU; the full
+    version is tests/test_parity_gpu.py::test_concurrency_like_reference)."""
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(10):
+                n = f"lin_{t}_{i}"
+                api.load_model(n, os.path.join(GOLD, "linear.onnx"))
+                assert api.get_model_info(n)["input_shape"] == [1, 3]
+                api.unload_model(n)
+            assert api.load_library().infera_unload_model(b"non_existent_again") == -1
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors and [m for m in api.get_loaded_models() if m.startswith("lin_")] == []
+
+
+def test_lowering_decisions(api, models, tmp_path):
+    from infera_amd import onnx_writer as W
+
+    api.load_model("p_mlp", models["mlp"])
+    p = api.get_plan("p_mlp")
+    assert p["exec"] == ["mlp3_fused", "skipped", "skipped"] and p["plan"]["flops_per_row"] == 98432
+    assert [s["origin"] for s in p["plan"]["steps"]] == ["Gemm+Relu", "Gemm+Relu", "Gemm"]
+    api.load_model("p_lr", models["logreg"])
+    assert api.get_plan("p_lr")["exec"] == ["dense_softmax", "skipped"]
+    api.load_model("p_ma", W.write(str(tmp_path / "ma.onnx"), W.mlp((8, 4), acts=[""], use_matmul_add=True)))
+    assert api.get_plan("p_ma")["plan"]["steps"][0]["origin"] == "MatMul+Add"
+    api.load_model("p_id", models["identity_dyn"])
+    assert api.get_plan("p_id")["plan"]["steps"] == [] and api.get_model_info("p_id")["output_shape"] == [-1, 4]
+    api.load_model("p_rn", W.write(str(tmp_path / "rn.onnx"), W.resnet18(classes=10, in_hw=32, width=8)))
+    p = api.get_plan("p_rn")
+    kinds = [s["kind"] for s in p["plan"]["steps"]]
+    assert kinds.count("Conv2d") == 20 and kinds.count("BinaryAct") == 8 and "AffineChannel" not in kinds  # BN folded
+    assert api.get_model_info("p_rn")["input_shape"] == [-1, 3, 32, 32]
+    with pytest.raises(api.InferaError, match=r"^ONNX error: input rank mismatch: model expects rank 4, got rank 2$"):
+        api.predict("p_rn", np.zeros((1, 3 * 32 * 32), np.float32))
+    bad = W.model("bad", [W.node("Erf", ["X"], ["Y"])], [], [W.value_info("X", ["N", 4])], [W.value_info("Y", ["N", 4])])
+    with pytest.raises(api.InferaError, match=r"^ONNX error: .*Erf.*unsupported operator"):
+        api.load_model("p_bad", W.write(str(tmp_path / "bad.onnx"), bad))
+    for n in ("p_mlp", "p_lr", "p_ma", "p_id", "p_rn"):
+        api.unload_model(n)
+
+
+def test_predict_without_gpu_fails_loudly(api):
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    api.load_model("nogpu", os.path.join(GOLD, "linear.onnx"))
+    with pytest.raises(api.InferaError, match="^ONNX error: HIP backend unavailable: "):
+        api.predict("nogpu", np.array([[1, 2, 3]], np.float32))
+    api.unload_model("nogpu")
