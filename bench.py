@@ -124,6 +124,17 @@ def main():
     else:
         achieved, peak, unit = bytes_row * rows / kernel_s / 1e9, HBM_PEAK_GBS, "GB/s"
 
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; they are collected by
+    # tools/profile_bench.sh (separate rocprofv3 --pmc passes of this same command) and committed as
+    # profiles/traffic_<workload>.json.  Reported only when that file matches this workload and row count.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("rows") == rows:
+            traffic = {"bytes": tj["traffic_bytes_per_launch"], "algorithmic_bytes": bytes_row * rows,
+                       "source": f"profiles/{os.path.basename(tpath)} (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, {tj.get('round', '')})"}
+
     # a cheap end-of-run sanity check so a silently wrong kernel cannot post a number
     y = d_out.download((4, out_cols))
     assert all(map(lambda v: v == v, y.ravel().tolist())), "NaN in output"
@@ -147,7 +158,7 @@ def main():
                        "entry": "infera_hip_predict_device (inputs resident in HBM)",
                        "kernel": plan.get("fused_kernel", ",".join(plan["exec"]))},
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                         "traffic": None, "kernel_ms": kernel_s * 1e3,
+                         "traffic": traffic, "kernel_ms": kernel_s * 1e3,
                          "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -131,6 +131,7 @@ typedef struct {
   size_t n;
   float *f;     /* dtype FLOAT */
   int64_t *i64; /* dtype INT64 */
+  int arena;    /* payload lives in the thread's bump arena (not freed individually) */
 } Tensor;
 
 typedef struct {
@@ -180,10 +181,25 @@ struct OrcModel {
   int64_t in_shape[MAXRANK], out_shape[MAXRANK];
 };
 
+/* Optional per-thread bump arena for intermediate tensors.  The multi-threaded scan baseline turns
+ * it on so that hundreds of threads do not serialise on mmap/munmap of MB-sized per-chunk tensors
+ * (an allocator artefact, not part of the algorithm); everything else uses plain malloc. */
+static __thread struct { char *base; size_t cap, off; int active; } t_arena;
+
+static void *arena_alloc(size_t n) {
+  n = (n + 63) & ~(size_t)63;
+  if (t_arena.off + n > t_arena.cap) return NULL;
+  void *p = t_arena.base + t_arena.off;
+  t_arena.off += n;
+  return p;
+}
+
 static void tensor_free_payload(Tensor *t) {
   free(t->name);
-  free(t->f);
-  free(t->i64);
+  if (!t->arena) {
+    free(t->f);
+    free(t->i64);
+  }
 }
 
 static size_t dims_count(const int64_t *d, int rank) {
@@ -533,8 +549,10 @@ static Tensor *env_new(Env *e, const char *name, int dtype, int rank, const int6
   t->rank = rank;
   memcpy(t->dims, dims, sizeof(int64_t) * (size_t)rank);
   t->n = dims_count(dims, rank);
-  if (dtype == DT_FLOAT) t->f = (float *)xmalloc(t->n * 4);
-  else t->i64 = (int64_t *)xmalloc(t->n * 8);
+  void *mem = t_arena.active ? arena_alloc(t->n * (dtype == DT_FLOAT ? 4 : 8)) : NULL;
+  t->arena = mem != NULL;
+  if (dtype == DT_FLOAT) t->f = mem ? (float *)mem : (float *)xmalloc(t->n * 4);
+  else t->i64 = mem ? (int64_t *)mem : (int64_t *)xmalloc(t->n * 8);
   return t;
 }
 static void env_free(Env *e) {
@@ -1344,6 +1362,9 @@ static void *scan_worker(void *p) {
   float *feat = (float *)xmalloc(F * CH * 4);  /* row-major gather target */
   float *resv = (float *)xmalloc(CH * 64 * 4); /* result vector */
   uint64_t nchunks = (a->rows + CH - 1) / CH;
+  t_arena.cap = (size_t)256 << 20;
+  t_arena.base = (char *)xmalloc(t_arena.cap);
+  t_arena.active = 1;
   for (;;) {
     uint64_t c = __atomic_fetch_add(a->next_chunk, 1, __ATOMIC_RELAXED);
     if (c >= nchunks) break;
@@ -1374,11 +1395,14 @@ static void *scan_worker(void *p) {
     }
     OrcResult res;
     char err[256];
+    t_arena.off = 0;
     if (orc_predict(a->m, feat, nr, F, &res, err, sizeof err)) { a->failed = 1; break; }
     size_t take = res.len < CH * 64 ? res.len : CH * 64;
     for (size_t i = 0; i < take; i++) { resv[i] = res.data[i]; a->checksum += (double)res.data[i]; }
     orc_free_result(&res);
   }
+  t_arena.active = 0;
+  free(t_arena.base);
   free(cols);
   free(feat);
   free(resv);

@@ -117,7 +117,7 @@ def test_committed_golden_vectors_on_gpu(api, tmp_path):
 
 
 @pytest.mark.parametrize("dims,acts", [((3, 1), [""]), ((5, 7, 2), ["Relu", ""]), ((130, 33, 70, 9), ["Sigmoid", "Tanh", "LeakyRelu"]),
-                                       ((64, 300), ["Relu"]), ((128, 256, 64, 3), ["Relu", "Relu", ""]), ((17, 64, 64, 64, 5), ["Relu"] * 3 + [""])])
+                                       ((64, 300), ["Relu"]), ((128, 256, 64, 3), ["Relu", "Relu", ""]), ((128, 256, 64, 10), ["Relu", "Relu", ""]), ((17, 64, 64, 64, 5), ["Relu"] * 3 + [""])])
 @pytest.mark.parametrize("rows", [1, 129, 1000])
 def test_generic_dense_shapes_vs_oracle(api, tmp_path, dims, acts, rows):
     """Ragged K / M (not multiples of 4, 8 or 32), every activation, chains that do not match the
