@@ -1,0 +1,435 @@
+// sql_surface.cpp -- see sql_surface.h.  Each function cites the reference function it mirrors.
+#include "sql_surface.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/infera_hip.h"
+
+namespace {
+
+using namespace infera;
+
+// DuckDB reports InvalidInputException as "Invalid Input Error: <msg>" (the prefix the reference's
+// sqllogictests assert, e.g. test/sql/test_edge_cases.test:27-30).
+struct InvalidInput : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+struct Chunk {
+  const InferaSqlVector *v;
+  size_t ncols, rows;
+  size_t size() const { return rows; }
+  size_t ColumnCount() const { return ncols; }
+};
+
+bool is_null(const InferaSqlVector &v, size_t row) {
+  if (!v.validity) return false;
+  const size_t r = v.is_constant ? 0 : row;
+  return !((v.validity[r >> 6] >> (r & 63)) & 1);
+}
+
+std::string get_string(const InferaSqlVector &v, size_t row) {
+  const size_t r = v.is_constant ? 0 : row;
+  auto ptrs = static_cast<const uint8_t *const *>(v.data);
+  const size_t len = v.lens ? size_t(v.lens[r]) : std::strlen(reinterpret_cast<const char *>(ptrs[r]));
+  return std::string(reinterpret_cast<const char *>(ptrs[r]), len);
+}
+
+const char *type_name(int t) {
+  static const char *n[] = {"VARCHAR", "FLOAT", "DOUBLE", "INTEGER", "BIGINT", "BLOB", "BOOLEAN", "FLOAT[]"};
+  return (t >= 0 && t < 8) ? n[t] : "UNKNOWN";
+}
+
+std::string last_error() {  // GetInferaError, infera_extension.cpp:52-55
+  const char *e = infera_last_error();
+  return e ? std::string(e) : std::string("unknown error");
+}
+
+void set_constant_bool(InferaSqlResult *out, bool v) {
+  out->type = INFERA_SQL_BOOLEAN;
+  out->is_constant = 1;
+  out->boolean = static_cast<uint8_t *>(std::malloc(1));
+  out->boolean[0] = v;
+}
+
+void set_constant_string(InferaSqlResult *out, const std::string &s) {
+  out->type = INFERA_SQL_VARCHAR;
+  out->is_constant = 1;
+  out->strings = static_cast<char **>(std::malloc(sizeof(char *)));
+  out->strings[0] = strdup(s.c_str());
+}
+
+void set_constant_null(InferaSqlResult *out, int type) {
+  out->type = type;
+  out->is_constant = 1;
+  out->validity = static_cast<uint64_t *>(std::calloc(1, sizeof(uint64_t)));
+}
+
+// ValidateAndGetModelName, infera_extension.cpp:239-248 (name from row 0 only)
+std::string validate_and_get_model_name(const Chunk &args, const std::string &func) {
+  if (args.ColumnCount() < 2) throw InvalidInput(func + "(model_name, feature1, ...) requires at least 2 arguments");
+  if (is_null(args.v[0], 0)) throw InvalidInput("Model name cannot be NULL");
+  return get_string(args.v[0], 0);
+}
+
+// ExtractFeatures (infera_extension.cpp:199-227) without the per-cell boxing: validity masks are
+// scanned per column, the typed flat pointers go to infera_predict_columns, which gathers them into
+// the row-major f32 buffer with static_cast<float> per type.
+InferaInferenceResult predict_chunk(const Chunk &args, const std::string &model) {
+  const size_t F = args.ColumnCount() - 1, rows = args.size();
+  std::vector<InferaColumn> cols(F);
+  for (size_t c = 0; c < F; c++) {
+    const InferaSqlVector &v = args.v[c + 1];
+    for (size_t r = 0; r < (v.is_constant ? 1 : rows); r++)
+      if (is_null(v, r)) throw InvalidInput("Feature values cannot be NULL");  // :207-209
+    switch (v.type) {
+      case INFERA_SQL_FLOAT: cols[c].type = INFERA_COL_FLOAT; break;
+      case INFERA_SQL_DOUBLE: cols[c].type = INFERA_COL_DOUBLE; break;
+      case INFERA_SQL_INTEGER: cols[c].type = INFERA_COL_INTEGER; break;
+      case INFERA_SQL_BIGINT: cols[c].type = INFERA_COL_BIGINT; break;
+      default: throw InvalidInput(std::string("Unsupported feature type: ") + type_name(v.type));  // :222
+    }
+    cols[c].data = v.data;
+    cols[c].validity = nullptr;
+    cols[c].is_constant = v.is_constant;
+  }
+  InferaInferenceResult res = infera_predict_columns(model.c_str(), cols.data(), F, rows);
+  if (res.status != 0) {  // :271-274
+    infera_free_result(res);
+    throw InvalidInput("Inference failed for model '" + model + "': " + last_error());
+  }
+  return res;
+}
+
+std::string fmt_shape_mismatch(size_t batch, size_t r, size_t c) {  // StringUtil::Format, :276
+  char buf[160];
+  std::snprintf(buf, sizeof buf, "Model output shape mismatch. Expected (%d, 1), but got (%d, %d).", int(batch), int(r), int(c));
+  return buf;
+}
+std::string fmt_row_mismatch(size_t batch, size_t r) {  // :398, :446
+  char buf[160];
+  std::snprintf(buf, sizeof buf, "Model output row count mismatch. Expected %d, but got %d.", int(batch), int(r));
+  return buf;
+}
+
+// Predict, infera_extension.cpp:260-286
+void Predict(const Chunk &args, InferaSqlResult *out) {
+  out->type = INFERA_SQL_FLOAT;
+  if (args.size() == 0) return;
+  const std::string model = validate_and_get_model_name(args, "infera_predict");
+  const size_t batch = args.size();
+  InferaInferenceResult res = predict_chunk(args, model);
+  if (res.rows != batch || res.cols != 1) {
+    std::string msg = fmt_shape_mismatch(batch, res.rows, res.cols);
+    infera_free_result(res);
+    throw InvalidInput(msg);
+  }
+  out->f32 = static_cast<float *>(std::malloc(batch * sizeof(float)));
+  std::memcpy(out->f32, res.data, batch * sizeof(float));  // :280-284
+  infera_free_result(res);
+}
+
+// PredictMulti, infera_extension.cpp:382-418 -- "[a,b,c]" via ostream << float (%g, 6 digits)
+void PredictMulti(const Chunk &args, InferaSqlResult *out) {
+  out->type = INFERA_SQL_VARCHAR;
+  if (args.size() == 0) return;
+  const std::string model = validate_and_get_model_name(args, "infera_predict_multi");
+  const size_t batch = args.size();
+  InferaInferenceResult res = predict_chunk(args, model);
+  if (res.rows != batch) {
+    std::string msg = fmt_row_mismatch(batch, res.rows);
+    infera_free_result(res);
+    throw InvalidInput(msg);
+  }
+  out->strings = static_cast<char **>(std::calloc(batch, sizeof(char *)));
+  for (size_t r = 0; r < batch; r++) {
+    std::ostringstream oss;
+    oss << "[";
+    for (size_t c = 0; c < res.cols; c++) {
+      if (c) oss << ",";
+      oss << res.data[r * res.cols + c];
+    }
+    oss << "]";
+    out->strings[r] = strdup(oss.str().c_str());
+  }
+  infera_free_result(res);
+}
+
+// PredictMultiList, infera_extension.cpp:430-462 -- list children written in one block
+void PredictMultiList(const Chunk &args, InferaSqlResult *out, const char *fname) {
+  out->type = INFERA_SQL_LIST_FLOAT;
+  if (args.size() == 0) return;
+  const std::string model = validate_and_get_model_name(args, fname);
+  const size_t batch = args.size();
+  InferaInferenceResult res = predict_chunk(args, model);
+  if (res.rows != batch) {
+    std::string msg = fmt_row_mismatch(batch, res.rows);
+    infera_free_result(res);
+    throw InvalidInput(msg);
+  }
+  out->list_offsets = static_cast<uint64_t *>(std::malloc((batch + 1) * sizeof(uint64_t)));
+  for (size_t r = 0; r <= batch; r++) out->list_offsets[r] = r * res.cols;
+  out->list_values = static_cast<float *>(std::malloc(std::max<size_t>(res.len, 1) * sizeof(float)));
+  std::memcpy(out->list_values, res.data, res.len * sizeof(float));
+  infera_free_result(res);
+}
+
+// PredictFromBlob, infera_extension.cpp:297-328
+void PredictFromBlob(const Chunk &args, InferaSqlResult *out) {
+  out->type = INFERA_SQL_LIST_FLOAT;
+  if (args.ColumnCount() != 2) throw InvalidInput("infera_predict_from_blob(model_name, input_blob) requires 2 arguments");
+  const size_t n = args.size();
+  if (n == 0) return;
+  std::vector<std::vector<float>> lists(n);
+  std::vector<bool> valid(n, false);
+  std::vector<size_t> live;
+  for (size_t i = 0; i < n; i++)
+    if (!is_null(args.v[0], i) && !is_null(args.v[1], i)) live.push_back(i);  // :306-309 NULL in -> NULL out
+  auto blob_ptr = [&](size_t i) { return static_cast<const uint8_t *const *>(args.v[1].data)[args.v[1].is_constant ? 0 : i]; };
+  auto blob_len = [&](size_t i) { return size_t(args.v[1].lens[args.v[1].is_constant ? 0 : i]); };
+  // One batched FFI call when the whole chunk uses one model and every blob holds one sample
+  // (ROADMAP.md:43 "single FFI call"); anything else takes the reference's per-row route, which
+  // also reproduces its per-row error texts.
+  bool batched = false;
+  if (live.size() > 1) {
+    const std::string first = get_string(args.v[0], live[0]);
+    bool same = true;
+    for (size_t i : live) same = same && get_string(args.v[0], i) == first;
+    if (same) {
+      std::vector<const uint8_t *> ptrs;
+      std::vector<uintptr_t> lens;
+      for (size_t i : live) {
+        ptrs.push_back(blob_ptr(i));
+        lens.push_back(blob_len(i));
+      }
+      InferaInferenceResult res = infera_predict_from_blob_batch(first.c_str(), ptrs.data(), lens.data(), live.size());
+      if (res.status == 0 && res.rows == live.size()) {
+        for (size_t k = 0; k < live.size(); k++) {
+          lists[live[k]].assign(res.data + k * res.cols, res.data + (k + 1) * res.cols);
+          valid[live[k]] = true;
+        }
+        batched = true;
+      }
+      infera_free_result(res);
+    }
+  }
+  if (!batched) {
+    for (size_t i : live) {
+      const std::string model = get_string(args.v[0], i);
+      InferaInferenceResult res = infera_predict_from_blob(model.c_str(), blob_ptr(i), blob_len(i));
+      if (res.status != 0) {
+        infera_free_result(res);
+        throw InvalidInput("Inference failed for model '" + model + "': " + last_error());  // :315-318
+      }
+      lists[i].assign(res.data, res.data + res.len);  // all res.len elements (:319-325)
+      valid[i] = true;
+      infera_free_result(res);
+    }
+  }
+  out->list_offsets = static_cast<uint64_t *>(std::malloc((n + 1) * sizeof(uint64_t)));
+  size_t total = 0;
+  for (size_t i = 0; i < n; i++) {
+    out->list_offsets[i] = total;
+    total += lists[i].size();
+  }
+  out->list_offsets[n] = total;
+  out->list_values = static_cast<float *>(std::malloc(std::max<size_t>(total, 1) * sizeof(float)));
+  for (size_t i = 0; i < n; i++)
+    if (!lists[i].empty()) std::memcpy(out->list_values + out->list_offsets[i], lists[i].data(), lists[i].size() * sizeof(float));
+  if (live.size() != n) {
+    out->validity = static_cast<uint64_t *>(std::calloc((n + 63) / 64, sizeof(uint64_t)));
+    for (size_t i = 0; i < n; i++)
+      if (valid[i]) out->validity[i >> 6] |= uint64_t(1) << (i & 63);
+  }
+}
+
+// LoadModel, infera_extension.cpp:133-156
+void LoadModel(const Chunk &args, InferaSqlResult *out) {
+  if (args.ColumnCount() != 2) throw InvalidInput("infera_load_model(model_name, path) expects exactly 2 arguments");
+  out->type = INFERA_SQL_BOOLEAN;
+  if (args.size() == 0) return;
+  if (is_null(args.v[0], 0) || is_null(args.v[1], 0)) throw InvalidInput("Model name and path cannot be NULL");
+  const std::string name = get_string(args.v[0], 0), path = get_string(args.v[1], 0);
+  if (name.empty()) throw InvalidInput("Model name cannot be empty");
+  if (infera_load_model(name.c_str(), path.c_str()) != 0) throw InvalidInput("Failed to load model '" + name + "': " + last_error());
+  set_constant_bool(out, true);
+}
+
+// UnloadModel, infera_extension.cpp:167-188 (model-not-found is a benign idempotent success)
+void UnloadModel(const Chunk &args, InferaSqlResult *out) {
+  if (args.ColumnCount() != 1) throw InvalidInput("infera_unload_model(model_name) expects exactly 1 argument");
+  out->type = INFERA_SQL_BOOLEAN;
+  if (args.size() == 0) return;
+  if (is_null(args.v[0], 0)) throw InvalidInput("Model name cannot be NULL");
+  const std::string name = get_string(args.v[0], 0);
+  if (infera_unload_model(name.c_str()) != 0) {
+    std::string err = last_error();
+    if (err.rfind("Model not found:", 0) != 0) throw InvalidInput("Failed to unload model '" + name + "': " + err);
+  }
+  set_constant_bool(out, true);
+}
+
+std::string take(char *p, const char *dflt = "") {
+  std::string s = p ? std::string(p) : std::string(dflt);
+  infera_free(p);
+  return s;
+}
+
+// GetModelInfo, infera_extension.cpp:473-497
+void GetModelInfo(const Chunk &args, InferaSqlResult *out) {
+  if (args.ColumnCount() != 1) throw InvalidInput("infera_get_model_info(model_name) expects exactly 1 argument");
+  out->type = INFERA_SQL_VARCHAR;
+  if (args.size() == 0) return;
+  if (is_null(args.v[0], 0)) throw InvalidInput("Model name cannot be NULL");
+  const std::string name = get_string(args.v[0], 0);
+  const std::string js = take(infera_get_model_info(name.c_str()));
+  if (js.empty() || js.find("\"error\"") != std::string::npos) throw InvalidInput("Failed to get info for model '" + name + "'");
+  set_constant_string(out, js);
+}
+
+// IsModelLoaded, infera_extension.cpp:349-370 (substring search for the quoted name)
+void IsModelLoaded(const Chunk &args, InferaSqlResult *out) {
+  if (args.ColumnCount() != 1) throw InvalidInput("infera_is_model_loaded(model_name) expects exactly 1 argument");
+  out->type = INFERA_SQL_BOOLEAN;
+  if (args.size() == 0) return;
+  if (is_null(args.v[0], 0)) throw InvalidInput("Model name cannot be NULL");
+  const std::string js = take(infera_get_loaded_models());
+  set_constant_bool(out, js.find("\"" + get_string(args.v[0], 0) + "\"") != std::string::npos);
+}
+
+// SetAutoloadDir, infera_extension.cpp:88-104
+void SetAutoloadDir(const Chunk &args, InferaSqlResult *out) {
+  if (args.ColumnCount() != 1) throw InvalidInput("infera_set_autoload_dir(path) expects exactly 1 argument");
+  out->type = INFERA_SQL_VARCHAR;
+  if (args.size() == 0) return;
+  if (is_null(args.v[0], 0)) throw InvalidInput("Path cannot be NULL");
+  set_constant_string(out, take(infera_set_autoload_dir(get_string(args.v[0], 0).c_str())));
+}
+
+struct FnInfo {
+  const char *name;
+  int min_args, max_args;
+  const char *returns;
+  bool is_volatile;
+  bool default_null_handling;  // constant-NULL argument -> NULL result without calling
+};
+
+// LoadInternal, infera_extension.cpp:546-592 (+ infera_predict_array, + feature cap raised)
+const FnInfo kFunctions[] = {
+    {"infera_load_model", 2, 2, "BOOLEAN", true, true},
+    {"infera_unload_model", 1, 1, "BOOLEAN", true, true},
+    {"infera_predict", 2, 1 + INFERA_SQL_MAX_FEATURES, "FLOAT", true, true},
+    {"infera_predict_multi", 2, 1 + INFERA_SQL_MAX_FEATURES, "VARCHAR", true, true},
+    {"infera_predict_multi_list", 2, 1 + INFERA_SQL_MAX_FEATURES, "FLOAT[]", true, true},
+    {"infera_predict_array", 2, 1 + INFERA_SQL_MAX_FEATURES, "FLOAT[]", true, true},
+    {"infera_predict_from_blob", 2, 2, "FLOAT[]", true, true},
+    {"infera_get_loaded_models", 0, 0, "VARCHAR", true, true},
+    {"infera_get_model_info", 1, 1, "VARCHAR", true, true},
+    {"infera_get_version", 0, 0, "VARCHAR", false, true},
+    {"infera_set_autoload_dir", 1, 1, "VARCHAR", true, true},
+    {"infera_is_model_loaded", 1, 1, "BOOLEAN", true, true},
+    {"infera_clear_cache", 0, 0, "BOOLEAN", true, true},
+    {"infera_get_cache_info", 0, 0, "VARCHAR", true, true},
+};
+
+int result_type_of(const std::string &r) {
+  if (r == "FLOAT") return INFERA_SQL_FLOAT;
+  if (r == "BOOLEAN") return INFERA_SQL_BOOLEAN;
+  if (r == "VARCHAR") return INFERA_SQL_VARCHAR;
+  return INFERA_SQL_LIST_FLOAT;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t infera_sql_call(const char *function, const InferaSqlVector *argv, uintptr_t nargs, uintptr_t rows, InferaSqlResult *out) {
+  std::memset(out, 0, sizeof *out);
+  out->rows = rows;
+  try {
+    if (!function) throw InvalidInput("function name is NULL");
+    const std::string fn = function;
+    const FnInfo *info = nullptr;
+    for (const auto &f : kFunctions)
+      if (fn == f.name) info = &f;
+    if (!info) throw std::runtime_error("Catalog Error: Scalar Function with name " + fn + " does not exist!");
+    if (int(nargs) < info->min_args || int(nargs) > info->max_args)
+      throw std::runtime_error("Binder Error: No function matches the given name and argument types '" + fn + "' with " +
+                               std::to_string(nargs) + " arguments");
+    if (rows > INFERA_SQL_VECTOR_SIZE) throw InvalidInput("chunk larger than STANDARD_VECTOR_SIZE");
+    Chunk args{argv, size_t(nargs), size_t(rows)};
+    // DuckDB's default NULL handling: a constant NULL argument short-circuits to a constant NULL
+    // result; the function body is never entered (test/sql/test_edge_cases.test:38-42).
+    if (info->default_null_handling && rows > 0)
+      for (size_t c = 0; c < nargs; c++)
+        if (argv[c].is_constant && is_null(argv[c], 0)) {
+          set_constant_null(out, result_type_of(info->returns));
+          return 0;
+        }
+    if (fn == "infera_predict") Predict(args, out);
+    else if (fn == "infera_predict_multi") PredictMulti(args, out);
+    else if (fn == "infera_predict_multi_list" || fn == "infera_predict_array") PredictMultiList(args, out, function);
+    else if (fn == "infera_predict_from_blob") PredictFromBlob(args, out);
+    else if (fn == "infera_load_model") LoadModel(args, out);
+    else if (fn == "infera_unload_model") UnloadModel(args, out);
+    else if (fn == "infera_get_model_info") GetModelInfo(args, out);
+    else if (fn == "infera_is_model_loaded") IsModelLoaded(args, out);
+    else if (fn == "infera_set_autoload_dir") SetAutoloadDir(args, out);
+    else if (fn == "infera_get_loaded_models") set_constant_string(out, take(infera_get_loaded_models(), "[]"));  // :339-347
+    else if (fn == "infera_get_version") set_constant_string(out, take(infera_get_version()));                    // :115-121
+    else if (fn == "infera_get_cache_info") set_constant_string(out, take(infera_get_cache_info()));              // :530-536
+    else if (fn == "infera_clear_cache") {                                                                         // :508-518
+      if (infera_clear_cache() != 0) throw InvalidInput("Failed to clear cache: " + last_error());
+      set_constant_bool(out, true);
+    }
+    return 0;
+  } catch (const InvalidInput &e) {
+    infera_sql_free_result(out);
+    out->status = -1;
+    out->error = strdup((std::string("Invalid Input Error: ") + e.what()).c_str());
+  } catch (const std::exception &e) {
+    infera_sql_free_result(out);
+    out->status = -1;
+    out->error = strdup(e.what());
+  }
+  return -1;
+}
+
+void infera_sql_free_result(InferaSqlResult *r) {
+  if (!r) return;
+  std::free(r->error);
+  std::free(r->f32);
+  std::free(r->boolean);
+  if (r->strings) {
+    const uint64_t n = r->is_constant ? 1 : r->rows;
+    for (uint64_t i = 0; i < n; i++) std::free(r->strings[i]);
+    std::free(r->strings);
+  }
+  std::free(r->list_offsets);
+  std::free(r->list_values);
+  std::free(r->validity);
+  const uint64_t rows = r->rows;
+  std::memset(r, 0, sizeof *r);
+  r->rows = rows;
+}
+
+char *infera_sql_list_functions(void) {
+  std::string o = "[";
+  bool first = true;
+  for (const auto &f : kFunctions) {
+    if (!first) o += ",";
+    first = false;
+    o += std::string("{\"name\":\"") + f.name + "\",\"min_args\":" + std::to_string(f.min_args) + ",\"max_args\":" +
+         std::to_string(f.max_args) + ",\"returns\":\"" + f.returns + "\",\"volatile\":" + (f.is_volatile ? "true" : "false") + "}";
+  }
+  o += "]";
+  return strdup(o.c_str());
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+/*
+ * sql_surface.h -- the SQL scalar-function layer of the Infera extension over a MOCK columnar chunk.
+ *
+ * In production this layer is infera/bindings/infera_extension.cpp inside DuckDB (SURVEY.md section 8a
+ * rows 1-8).  DuckDB's headers are not available in the build image (external/duckdb is an empty
+ * submodule), so the same functions -- same names, argument checks, NULL behaviour, error strings
+ * and output formatting -- are implemented here over a minimal stand-in for DataChunk/Vector
+ * (flat or constant typed vectors + validity bitmask, <= 2048 rows per call), so that gather/scatter
+ * is testable and benchmarkable without DuckDB.  It calls the engine ONLY through the C ABI of
+ * include/infera.h / include/infera_hip.h, exactly like the real binding would.
+ *
+ * Differences from the reference binding, on purpose (SURVEY.md section 8b "Extensions"):
+ *   - ExtractFeatures reads columns through flat pointers + validity masks and hands them to
+ *     infera_predict_columns (no per-cell Value boxing; infera_extension.cpp:204-225);
+ *   - feature overloads up to INFERA_SQL_MAX_FEATURES (reference: 127, infera_extension.cpp:550);
+ *   - infera_predict_array = alias of infera_predict_multi_list;
+ *   - PredictFromBlob makes one batched FFI call per chunk when every blob holds one sample.
+ */
+#ifndef INFERA_SQL_SURFACE_H
+#define INFERA_SQL_SURFACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INFERA_SQL_MAX_FEATURES 1024
+#define INFERA_SQL_VECTOR_SIZE 2048 /* DuckDB STANDARD_VECTOR_SIZE */
+
+typedef enum InferaSqlType {
+  INFERA_SQL_VARCHAR = 0,
+  INFERA_SQL_FLOAT = 1,
+  INFERA_SQL_DOUBLE = 2,
+  INFERA_SQL_INTEGER = 3,
+  INFERA_SQL_BIGINT = 4,
+  INFERA_SQL_BLOB = 5,
+  INFERA_SQL_BOOLEAN = 6,
+  INFERA_SQL_LIST_FLOAT = 7
+} InferaSqlType;
+
+/* One argument vector of the chunk (non-owning view, like a DuckDB Vector over its buffer). */
+typedef struct InferaSqlVector {
+  int32_t type;             /* InferaSqlType */
+  int32_t is_constant;      /* CONSTANT_VECTOR: entry 0 applies to every row */
+  const void *data;         /* numeric: typed array; VARCHAR/BLOB: const uint8_t *const * (one pointer per row) */
+  const uint64_t *lens;     /* VARCHAR/BLOB byte lengths per row */
+  const uint64_t *validity; /* bit set = valid; NULL = all valid */
+} InferaSqlVector;
+
+/* Result vector (owning).  Exactly one payload is filled according to `type`. */
+typedef struct InferaSqlResult {
+  int32_t status;         /* 0 ok; -1: `error` holds "Invalid Input Error: ..." as DuckDB would report it */
+  char *error;
+  int32_t type;           /* InferaSqlType of the result */
+  int32_t is_constant;    /* CONSTANT_VECTOR result (entry 0) */
+  uint64_t rows;
+  float *f32;             /* FLOAT */
+  uint8_t *boolean;       /* BOOLEAN */
+  char **strings;         /* VARCHAR (rows entries, or 1 if constant) */
+  uint64_t *list_offsets; /* LIST<FLOAT>: rows+1 offsets into list_values */
+  float *list_values;
+  uint64_t *validity;     /* result NULL mask, NULL = all valid */
+} InferaSqlResult;
+
+/* Executes SQL scalar function `function` on one chunk.  Returns out->status. */
+int32_t infera_sql_call(const char *function, const InferaSqlVector *args, uintptr_t nargs, uintptr_t rows,
+                        InferaSqlResult *out);
+void infera_sql_free_result(InferaSqlResult *res);
+/* JSON list of the registered functions {"name","min_args","max_args","returns","volatile"}; free() it. */
+char *infera_sql_list_functions(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,191 @@
+"""ctypes driver for libinfera_sqlmock.so -- the SQL scalar-function layer over a mock DataChunk
+(infera_amd/csrc/binding/sql_surface.{h,cpp}).  Lets the tests read like the reference's
+sqllogictests (/root/reference test/sql/*.test): `sql("infera_predict", "linear", 1.0, 2.0, 3.0)`.
+
+Argument conventions (one call = one DataChunk of <= 2048 rows):
+  * Python str / bytes / float / int / None  -> CONSTANT_VECTOR (None = SQL NULL)
+  * numpy array (float32/float64/int32/int64) -> FLAT_VECTOR; numpy.ma masked entries = NULL
+  * list of str / bytes / None                -> FLAT VARCHAR / BLOB vector
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Any
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinfera_sqlmock.so")
+
+VARCHAR, FLOAT, DOUBLE, INTEGER, BIGINT, BLOB, BOOLEAN, LIST_FLOAT = range(8)
+_NP = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE, np.dtype(np.int32): INTEGER, np.dtype(np.int64): BIGINT}
+
+
+class SqlError(RuntimeError):
+    """Carries the message exactly as DuckDB would print it ("Invalid Input Error: ...")."""
+
+
+class _Vector(C.Structure):
+    _fields_ = [("type", C.c_int32), ("is_constant", C.c_int32), ("data", C.c_void_p), ("lens", C.POINTER(C.c_uint64)),
+                ("validity", C.POINTER(C.c_uint64))]
+
+
+class _Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("error", C.c_char_p), ("type", C.c_int32), ("is_constant", C.c_int32),
+                ("rows", C.c_uint64), ("f32", C.POINTER(C.c_float)), ("boolean", C.POINTER(C.c_uint8)),
+                ("strings", C.POINTER(C.c_char_p)), ("list_offsets", C.POINTER(C.c_uint64)),
+                ("list_values", C.POINTER(C.c_float)), ("validity", C.POINTER(C.c_uint64))]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        capi.load_library()  # libinfera.so first (same instance the mock links against)
+        if not os.path.exists(LIB_PATH):
+            raise capi.InferaError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.infera_sql_call.argtypes = [C.c_char_p, C.POINTER(_Vector), C.c_size_t, C.c_size_t, C.POINTER(_Result)]
+        L.infera_sql_call.restype = C.c_int32
+        L.infera_sql_free_result.argtypes = [C.POINTER(_Result)]
+        L.infera_sql_list_functions.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+def list_functions() -> list[dict]:
+    p = lib().infera_sql_list_functions()
+    s = C.string_at(p).decode()
+    C.CDLL(None).free(C.c_void_p(p))
+    return json.loads(s)
+
+
+def _validity_words(mask_valid: np.ndarray) -> np.ndarray:
+    n = len(mask_valid)
+    words = np.zeros((n + 63) // 64, np.uint64)
+    for i in np.nonzero(mask_valid)[0]:
+        words[i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    return words
+
+
+def _make_vector(arg: Any, keep: list) -> tuple[_Vector, int | None]:
+    """Returns (vector, row count or None for constants)."""
+    v = _Vector()
+    if arg is None or isinstance(arg, (str, bytes, float, int)):
+        v.is_constant = 1
+        if arg is None:
+            v.type = VARCHAR
+            words = np.zeros(1, np.uint64)
+            buf = C.create_string_buffer(b"", 1)
+            ptrs = (C.c_void_p * 1)(C.addressof(buf))
+            lens = np.zeros(1, np.uint64)
+            keep += [words, buf, ptrs, lens]
+            v.data = C.addressof(ptrs)
+            v.lens = lens.ctypes.data_as(C.POINTER(C.c_uint64))
+            v.validity = words.ctypes.data_as(C.POINTER(C.c_uint64))
+        elif isinstance(arg, (str, bytes)):
+            raw = arg.encode() if isinstance(arg, str) else arg
+            v.type = VARCHAR if isinstance(arg, str) else BLOB
+            buf = C.create_string_buffer(raw, max(len(raw), 1))
+            ptrs = (C.c_void_p * 1)(C.addressof(buf))
+            lens = np.array([len(raw)], np.uint64)
+            keep += [buf, ptrs, lens]
+            v.data = C.addressof(ptrs)
+            v.lens = lens.ctypes.data_as(C.POINTER(C.c_uint64))
+        else:
+            a = np.array([arg], np.float64 if isinstance(arg, float) else np.int32)
+            keep.append(a)
+            v.type = _NP[a.dtype]
+            v.data = a.ctypes.data
+        return v, None
+    if isinstance(arg, (list, tuple)):
+        n = len(arg)
+        is_blob = any(isinstance(x, bytes) for x in arg)
+        v.type = BLOB if is_blob else VARCHAR
+        bufs, valid = [], np.ones(n, bool)
+        for i, x in enumerate(arg):
+            if x is None:
+                valid[i] = False
+                x = b""
+            raw = x.encode() if isinstance(x, str) else x
+            bufs.append((C.create_string_buffer(raw, max(len(raw), 1)), len(raw)))
+        ptrs = (C.c_void_p * max(n, 1))(*[C.addressof(b) for b, _ in bufs])
+        lens = np.array([ln for _, ln in bufs] or [0], np.uint64)
+        keep += [bufs, ptrs, lens]
+        v.data = C.addressof(ptrs)
+        v.lens = lens.ctypes.data_as(C.POINTER(C.c_uint64))
+        if not valid.all():
+            words = _validity_words(valid)
+            keep.append(words)
+            v.validity = words.ctypes.data_as(C.POINTER(C.c_uint64))
+        return v, n
+    a = arg
+    mask = None
+    if isinstance(a, np.ma.MaskedArray):
+        mask = ~np.ma.getmaskarray(a)
+        a = a.filled(0)
+    a = np.ascontiguousarray(a)
+    if a.dtype not in _NP:
+        raise TypeError(f"unsupported column dtype {a.dtype}")
+    keep.append(a)
+    v.type = _NP[a.dtype]
+    v.data = a.ctypes.data
+    if mask is not None and not mask.all():
+        words = _validity_words(mask)
+        keep.append(words)
+        v.validity = words.ctypes.data_as(C.POINTER(C.c_uint64))
+    return v, len(a)
+
+
+def sql(function: str, *args: Any, rows: int | None = None):
+    """Executes one SQL scalar function call on one chunk and returns Python values:
+    FLOAT -> np.ndarray[rows]; VARCHAR -> list[str] (or str if constant); BOOLEAN -> bool;
+    LIST<FLOAT> -> list[np.ndarray | None]; a constant NULL result -> None."""
+    keep: list = []
+    vecs = (_Vector * max(len(args), 1))()
+    counts = []
+    for i, a in enumerate(args):
+        vecs[i], n = _make_vector(a, keep)
+        if n is not None:
+            counts.append(n)
+    if rows is None:
+        rows = counts[0] if counts else 1
+    assert all(c == rows for c in counts), "all flat vectors of a chunk must have the same row count"
+    res = _Result()
+    rc = lib().infera_sql_call(function.encode(), vecs, len(args), rows, C.byref(res))
+    try:
+        if rc != 0:
+            raise SqlError(res.error.decode() if res.error else "unknown error")
+
+        def is_valid(i):
+            if not res.validity:
+                return True
+            return bool((res.validity[i >> 6] >> (i & 63)) & 1)
+
+        if res.is_constant and not is_valid(0):
+            return None
+        if res.type == FLOAT:
+            return np.ctypeslib.as_array(res.f32, shape=(rows,)).copy() if rows else np.zeros(0, np.float32)
+        if res.type == BOOLEAN:
+            return bool(res.boolean[0]) if res.boolean else None
+        if res.type == VARCHAR:
+            if res.is_constant:
+                return res.strings[0].decode()
+            return [res.strings[i].decode() for i in range(rows)] if res.strings else []
+        out = []
+        for i in range(rows if res.list_offsets else 0):
+            if not is_valid(i):
+                out.append(None)
+                continue
+            a, b = res.list_offsets[i], res.list_offsets[i + 1]
+            out.append(np.array([res.list_values[j] for j in range(a, b)], np.float32) if b - a < 64 else
+                       np.ctypeslib.as_array(res.list_values, shape=(res.list_offsets[rows],))[a:b].copy())
+        return out
+    finally:
+        lib().infera_sql_free_result(C.byref(res))

@@ -1,0 +1,191 @@
+"""The SQL scalar-function layer over the mock DataChunk (csrc/binding/sql_surface.cpp), driven the
+way the reference's sqllogictests drive the DuckDB extension (/root/reference test/sql/*.test).
+The CPU half covers everything that does not reach a kernel; the GPU half (marked) replays the
+value-producing statements of those test files."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINEAR = os.path.join(ROOT, "tests", "golden", "linear.onnx")
+MULTI = os.path.join(ROOT, "tests", "golden", "multi_output.onnx")
+
+
+@pytest.fixture(scope="module")
+def S(built):
+    from infera_amd import sqlmock
+
+    sqlmock.lib()
+    return sqlmock
+
+
+# ---------------------------------------------------------------- CPU: registration / management / errors
+
+def test_registered_functions(S):
+    fns = {f["name"]: f for f in S.list_functions()}
+    # docs/README.md:5-19 surface (13 functions) + infera_predict_array (north_star)
+    for name in ["infera_load_model", "infera_unload_model", "infera_predict", "infera_predict_multi", "infera_predict_multi_list",
+                 "infera_predict_from_blob", "infera_get_loaded_models", "infera_get_model_info", "infera_get_version",
+                 "infera_set_autoload_dir", "infera_is_model_loaded", "infera_clear_cache", "infera_get_cache_info", "infera_predict_array"]:
+        assert name in fns
+    # reference caps at 127 features (infera_extension.cpp:550); BASELINE C2 needs 128
+    assert fns["infera_predict"]["max_args"] - 1 >= 128
+    assert all(fns[n]["volatile"] for n in ("infera_predict", "infera_predict_multi", "infera_predict_multi_list", "infera_predict_from_blob"))
+    with pytest.raises(S.SqlError, match="does not exist"):
+        S.sql("infera_nope")
+    with pytest.raises(S.SqlError, match="No function matches"):
+        S.sql("infera_predict", "m")  # the 1-argument overload is not registered
+
+
+def test_core_management_flow(S):
+    """test_core_functionality.test:14-44, 61-75; test_is_model_loaded.test."""
+    assert S.sql("infera_get_version") is not None
+    for m in S.capi.get_loaded_models():
+        S.sql("infera_unload_model", m)
+    assert S.sql("infera_get_loaded_models") == "[]"
+    assert S.sql("infera_is_model_loaded", "linear") is False
+    assert S.sql("infera_load_model", "linear", LINEAR) is True
+    assert "linear" in S.sql("infera_get_loaded_models")
+    assert S.sql("infera_is_model_loaded", "linear") is True
+    assert '"input_shape":[1,3]' in S.sql("infera_get_model_info", "linear")
+    assert S.sql("infera_unload_model", "linear") is True
+    assert S.sql("infera_get_loaded_models") == "[]"
+    res = S.sql("infera_set_autoload_dir", os.path.join(ROOT, "tests", "golden"))
+    assert "linear" in res and "linear" in S.sql("infera_get_loaded_models")
+    S.sql("infera_unload_model", "linear")
+    S.sql("infera_unload_model", "multi_output")
+
+
+def test_unload_idempotent_and_info_error(S):
+    """test_edge_cases_more.test:22-38, test_integration_and_errors.test:14-22, test_get_model_info_error.slt."""
+    assert S.sql("infera_unload_model", "nonexistent_model") is True
+    S.sql("infera_load_model", "linear", LINEAR)
+    assert S.sql("infera_unload_model", "linear") is True
+    assert S.sql("infera_unload_model", "linear") is True
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Failed to get info for model 'linear'$"):
+        S.sql("infera_get_model_info", "linear")
+
+
+def test_load_model_argument_errors(S):
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Model name cannot be empty$"):  # test_edge_cases.test:45-48
+        S.sql("infera_load_model", "", LINEAR)
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Failed to load model 'x': ONNX error: "):
+        S.sql("infera_load_model", "x", "/nonexistent/model.onnx")
+    assert S.sql("infera_load_model", None, LINEAR) is None  # constant NULL argument -> NULL, body not entered
+
+
+def test_null_handling_and_feature_errors(S):
+    """test_edge_cases.test:38-42 (constant NULL -> NULL), test_integration_and_errors.test:48-57
+    (NULL inside a column -> error), unsupported feature type."""
+    S.sql("infera_load_model", "linear", LINEAR)
+    assert S.sql("infera_predict", None, 1.0, 2.0, 3.0) is None
+    assert S.sql("infera_predict", "linear", 1.0, None, 3.0) is None
+    f3 = np.ma.masked_array(np.array([3.0], np.float32), mask=[True])
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Feature values cannot be NULL$"):
+        S.sql("infera_predict", "linear", np.array([1.0], np.float32), np.array([2.0], np.float32), f3)
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Unsupported feature type: VARCHAR$"):
+        S.sql("infera_predict", "linear", 1.0, "two", 3.0)
+    assert S.sql("infera_predict_from_blob", "linear", None) is None  # test_edge_cases_more.test:17-20
+    got = S.sql("infera_predict_from_blob", ["linear", None], [None, b"\0" * 12])  # per-row NULLs -> NULL rows
+    assert got == [None, None]
+    S.sql("infera_unload_model", "linear")
+
+
+def test_blob_and_missing_model_errors(S):
+    """test_edge_cases.test:26-36, 50-57 -- exact strings."""
+    S.sql("infera_load_model", "linear", LINEAR)
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Inference failed for model 'linear': Invalid BLOB size: length must be a multiple of 4$"):
+        S.sql("infera_predict_from_blob", "linear", b"\0" * 5)
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Inference failed for model 'linear': BLOB data does not match model's expected input shape. Expected 3 elements, but BLOB contained 4\.$"):
+        S.sql("infera_predict_from_blob", "linear", b"\0" * 16)
+    S.sql("infera_unload_model", "linear")
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Inference failed for model 'linear': Model not found: linear$"):
+        S.sql("infera_predict", "linear", 1.0, 2.0, 3.0)
+
+
+def test_cache_functions(S):
+    """test_cache_management.test / test_volatile_and_null_safety.test:76-101."""
+    info = S.sql("infera_get_cache_info")
+    assert "cache_dir" in info and "total_size_bytes" in info
+    assert S.sql("infera_clear_cache") is True
+
+
+def test_empty_chunk(S):
+    assert len(S.sql("infera_predict", "linear", np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32), rows=0)) == 0
+
+
+# ---------------------------------------------------------------- GPU: the value-producing statements
+
+@pytest.mark.gpu
+def test_sql_predict_values(S):
+    """test_core_functionality.test:46-58, test_predict_multi_list.test:20-33, test_multi_output.test:22-32,
+    test_decimal_features.test:19-22, test_volatile_and_null_safety.test:40-59."""
+    S.sql("infera_load_model", "linear", LINEAR)
+    S.sql("infera_load_model", "multi_output", MULTI)
+    assert S.sql("infera_predict", "linear", 1.0, 2.0, 3.0).tolist() == [1.75]
+    assert "1.75" in S.sql("infera_predict_multi", "linear", 1.0, 2.0, 3.0)[0]
+    assert S.sql("infera_predict_multi", "multi_output", 1.0, 2.0, 3.0, 4.0) == ["[1,2,3,4]"]
+    assert S.sql("infera_predict_multi_list", "multi_output", 1.0, 2.0, 3.0, 4.0)[0].tolist() == [1.0, 2.0, 3.0, 4.0]
+    assert S.sql("infera_predict_multi_list", "linear", 1.0, 2.0, 3.0)[0].tolist() == [1.75]
+    assert S.sql("infera_predict_array", "linear", 1.0, 2.0, 3.0)[0].tolist() == [1.75]
+    with pytest.raises(S.SqlError, match=r"^Invalid Input Error: Model output shape mismatch. Expected \(1, 1\), but got \(1, 4\)\.$"):
+        S.sql("infera_predict", "multi_output", 1.0, 2.0, 3.0, 4.0)
+    # DECIMAL literals reach the function as DOUBLE (the DOUBLE overloads, infera_extension.cpp:564-576)
+    assert abs(S.sql("infera_predict", "linear", np.array([1.0]), np.array([2.0]), np.array([3.0]))[0] - 1.75) < 1e-5
+    # INTEGER / BIGINT columns (ExtractFeatures casts, :213-214)
+    assert S.sql("infera_predict", "linear", np.array([1], np.int32), np.array([2], np.int64), np.array([3.0], np.float32)).tolist() == [1.75]
+    assert len(S.sql("infera_predict_from_blob", "linear", b"\0" * 12)[0]) >= 0
+    assert S.sql("infera_predict_from_blob", "linear", b"\0" * 12)[0].tolist() == [0.25]
+    # table scan + avg (test_integration_and_errors.test:25-45)
+    pred = S.sql("infera_predict", "linear", np.array([1.0], np.float32), np.array([2.0], np.float32), np.array([3.0], np.float32))
+    assert abs(float(pred.mean()) - 1.75) < 1e-5 and len(pred) == 1
+    S.sql("infera_unload_model", "linear")
+    S.sql("infera_unload_model", "multi_output")
+
+
+@pytest.mark.gpu
+def test_sql_wide_table_chunk(S, models):
+    """BASELINE C2 through the SQL surface: 128 FLOAT feature columns x 2048 rows per chunk."""
+    from infera_amd import synth
+    from oracle import oracle
+
+    S.sql("infera_load_model", "mlp", models["mlp"])
+    S.sql("infera_load_model", "logreg", models["logreg"])
+    x = synth.table(42, 0, 2048, 128)
+    cols = [np.ascontiguousarray(x[:, j]) for j in range(128)]
+    want = oracle.Model(models["mlp"]).predict(x).ravel()
+    got = S.sql("infera_predict", "mlp", *cols)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+    # mixed column types, same values
+    cols2 = [c.astype(np.float64) if j % 2 else c for j, c in enumerate(cols)]
+    np.testing.assert_array_equal(S.sql("infera_predict", "mlp", *cols2), got)
+    # multi-output forms against the oracle + its formatting restatement
+    p = oracle.Model(models["logreg"]).predict(x)
+    lists = S.sql("infera_predict_array", "logreg", *cols)
+    np.testing.assert_allclose(np.stack(lists), p, rtol=1e-4, atol=1e-6)
+    js = S.sql("infera_predict_multi", "logreg", *cols)
+    assert js[0].startswith("[") and js[0].count(",") == 9
+    parsed = np.array([[float(t) for t in s[1:-1].split(",")] for s in js])
+    np.testing.assert_allclose(parsed, p, rtol=2e-5, atol=1e-6)  # %g keeps 6 significant digits
+    assert js[:8] == oracle.predict_multi_json(np.stack(lists))[:8]
+    S.sql("infera_unload_model", "mlp")
+    S.sql("infera_unload_model", "logreg")
+
+
+@pytest.mark.gpu
+def test_sql_blob_chunk_batched(S, tmp_path):
+    from infera_amd import onnx_writer as W, synth
+    from oracle import oracle
+
+    path = W.write(str(tmp_path / "rn.onnx"), W.resnet18(classes=10, in_hw=32, width=8))
+    S.sql("infera_load_model", "rn", path)
+    imgs = synth.table(3, 0, 6, 3 * 32 * 32)
+    blobs = [imgs[i].tobytes() for i in range(6)]
+    blobs[2] = None
+    got = S.sql("infera_predict_from_blob", "rn", blobs)
+    want = oracle.Model(path).predict_blob(imgs.tobytes())
+    assert got[2] is None
+    for i in (0, 1, 3, 4, 5):
+        np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=1e-6)
+    S.sql("infera_unload_model", "rn")
