@@ -87,6 +87,11 @@ typedef struct InferaColumn {
 struct InferaInferenceResult infera_predict_columns(const char *model_name, const InferaColumn *columns,
                                                     uintptr_t ncols, uintptr_t rows);
 
+/* The gather step alone (host only, no GPU): rows [row0, row0+nrows) of the chunk -> dst[nrows x ncols]
+ * row-major f32.  For bindings that keep calling infera_predict with their own buffer but want the
+ * vectorised ExtractFeatures.  Validity masks are checked ("Feature values cannot be NULL"). 0 / -1. */
+int32_t infera_gather_columns(const InferaColumn *columns, uintptr_t ncols, uintptr_t row0, uintptr_t nrows, float *dst);
+
 /* One call for a whole chunk of BLOBs (the reference makes one FFI call and one batch-1 run per
  * row, infera_extension.cpp:303-326).  Every blob must hold exactly one sample
  * (prod(input_shape[1:]) f32); NULL entries are not allowed here (the binding filters them).

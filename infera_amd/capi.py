@@ -27,7 +27,7 @@ EXTENSION_SYMBOLS = [
     "infera_hip_device_count", "infera_hip_device_ordinal", "infera_hip_get_devices", "infera_hip_get_plan",
     "infera_hip_predict_device", "infera_hip_sync", "infera_hip_time_predict_device", "infera_hip_malloc",
     "infera_hip_free", "infera_hip_memcpy_h2d", "infera_hip_memcpy_d2h", "infera_hip_synth_fill",
-    "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch",
+    "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch", "infera_gather_columns",
 ]
 
 
@@ -112,6 +112,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.infera_predict_into.restype = C.c_int32
     L.infera_predict_columns.argtypes = [C.c_char_p, C.POINTER(InferaColumn), C.c_size_t, C.c_size_t]
     L.infera_predict_columns.restype = InferaInferenceResult
+    L.infera_gather_columns.argtypes = [C.POINTER(InferaColumn), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.infera_gather_columns.restype = C.c_int32
     L.infera_predict_from_blob_batch.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t]
     L.infera_predict_from_blob_batch.restype = InferaInferenceResult
     _lib = L
@@ -296,10 +298,7 @@ def predict_into(name: str, x: np.ndarray, out: np.ndarray) -> tuple[int, int]:
     return r.value, c.value
 
 
-def predict_columns(name: str, columns: Sequence[np.ndarray], rows: int | None = None,
-                    validity: Sequence[np.ndarray | None] | None = None) -> np.ndarray:
-    """Columnar gather path: each column a flat typed vector (float32/float64/int32/int64);
-    a length-1 column is a CONSTANT_VECTOR."""
+def _make_columns(columns, rows, validity):
     n = len(columns)
     cols = (InferaColumn * max(n, 1))()
     keep = []
@@ -316,8 +315,27 @@ def predict_columns(name: str, columns: Sequence[np.ndarray], rows: int | None =
             v = np.ascontiguousarray(v, dtype=np.uint64)
             keep.append(v)
             cols[i].validity = v.ctypes.data_as(C.POINTER(C.c_uint64))
+    return cols, n, rows, keep
+
+
+def predict_columns(name: str, columns: Sequence[np.ndarray], rows: int | None = None,
+                    validity: Sequence[np.ndarray | None] | None = None) -> np.ndarray:
+    """Columnar gather path: each column a flat typed vector (float32/float64/int32/int64);
+    a length-1 column is a CONSTANT_VECTOR."""
+    cols, n, rows, _keep = _make_columns(columns, rows, validity)
     res = load_library().infera_predict_columns(_enc(name), cols, n, rows)
     return _take_result(res, "infera_predict_columns")
+
+
+def gather_columns(columns: Sequence[np.ndarray], rows: int | None = None, row0: int = 0, nrows: int | None = None,
+                   validity: Sequence[np.ndarray | None] | None = None) -> np.ndarray:
+    """The gather step alone (CPU): typed columns -> row-major f32 [nrows, ncols]."""
+    cols, n, rows, _keep = _make_columns(columns, rows, validity)
+    nrows = rows - row0 if nrows is None else nrows
+    out = np.empty((nrows, n), np.float32)
+    if load_library().infera_gather_columns(cols, n, row0, nrows, out.ctypes.data) != 0:
+        raise InferaError(last_error())
+    return out
 
 
 def predict_from_blob_batch(name: str, blobs: Sequence[bytes]) -> np.ndarray:

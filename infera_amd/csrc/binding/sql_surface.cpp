@@ -1,7 +1,11 @@
 // sql_surface.cpp -- see sql_surface.h.  Each function cites the reference function it mirrors.
 #include "sql_surface.h"
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -430,6 +434,90 @@ char *infera_sql_list_functions(void) {
   }
   o += "]";
   return strdup(o.c_str());
+}
+
+namespace {
+uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+}  // namespace
+
+double infera_sql_bench_scan(const char *function, const char *model, uint64_t rows, uint32_t ncols, int32_t threads,
+                             int32_t pool_chunks, uint64_t seed, double *checksum, char *err, uint64_t errlen) {
+  if (threads < 1) threads = 1;
+  if (pool_chunks < 1) pool_chunks = 1;
+  const size_t CH = INFERA_SQL_VECTOR_SIZE;
+  const uint64_t nchunks = (rows + CH - 1) / CH;
+  std::atomic<uint64_t> next{0};
+  std::mutex mu;
+  std::string first_error;
+  double total = 0.0;
+  std::vector<std::vector<float>> pools((size_t)threads);  // [thread] -> pool_chunks x ncols x CH, column-major per chunk
+  for (int t = 0; t < threads; t++) {
+    pools[size_t(t)].resize(size_t(pool_chunks) * ncols * CH);
+    for (int p = 0; p < pool_chunks; p++)
+      for (uint32_t c = 0; c < ncols; c++)
+        for (size_t r = 0; r < CH; r++) {
+          const uint64_t row = (uint64_t(t) * uint64_t(pool_chunks) + uint64_t(p)) * CH + r;
+          const uint64_t u = splitmix64(seed ^ (row * ncols + c));
+          pools[size_t(t)][(size_t(p) * ncols + c) * CH + r] = float(u >> 40) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+        }
+  }
+  const std::string fn = function ? function : "infera_predict";
+  auto worker = [&](int t) {
+    std::vector<InferaSqlVector> args(ncols + 1);
+    const uint8_t *name_ptr = reinterpret_cast<const uint8_t *>(model);
+    uint64_t name_len = std::strlen(model);
+    args[0].type = INFERA_SQL_VARCHAR;
+    args[0].is_constant = 1;
+    args[0].data = &name_ptr;
+    args[0].lens = &name_len;
+    args[0].validity = nullptr;
+    double local = 0.0;
+    uint64_t k = 0;
+    for (;;) {
+      const uint64_t c = next.fetch_add(1, std::memory_order_relaxed);
+      if (c >= nchunks) break;
+      const size_t nr = size_t(std::min<uint64_t>(CH, rows - c * CH));
+      const float *base = pools[size_t(t)].data() + size_t(k++ % uint64_t(pool_chunks)) * ncols * CH;
+      for (uint32_t j = 0; j < ncols; j++) {
+        args[j + 1].type = INFERA_SQL_FLOAT;
+        args[j + 1].is_constant = 0;
+        args[j + 1].data = base + size_t(j) * CH;
+        args[j + 1].lens = nullptr;
+        args[j + 1].validity = nullptr;
+      }
+      InferaSqlResult res;
+      if (infera_sql_call(fn.c_str(), args.data(), ncols + 1, nr, &res) != 0) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (first_error.empty()) first_error = res.error ? res.error : "unknown error";
+        infera_sql_free_result(&res);
+        next.store(nchunks);
+        break;
+      }
+      if (res.f32)
+        for (size_t i = 0; i < nr; i++) local += double(res.f32[i]);
+      else if (res.list_offsets)
+        for (uint64_t i = 0; i < res.list_offsets[nr]; i++) local += double(res.list_values[i]);
+      infera_sql_free_result(&res);
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    total += local;
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; t++) th.emplace_back(worker, t);
+  for (auto &x : th) x.join();
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (checksum) *checksum = total;
+  if (!first_error.empty()) {
+    if (err && errlen) std::snprintf(err, size_t(errlen), "%s", first_error.c_str());
+    return -1.0;
+  }
+  return sec;
 }
 
 }  // extern "C"

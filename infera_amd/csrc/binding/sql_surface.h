@@ -70,6 +70,16 @@ void infera_sql_free_result(InferaSqlResult *res);
 /* JSON list of the registered functions {"name","min_args","max_args","returns","volatile"}; free() it. */
 char *infera_sql_list_functions(void);
 
+/* Table-scan driver: `threads` worker threads (DuckDB pipeline workers) pull 2048-row chunks of a
+ * synthetic columnar table (ncols FLOAT columns, generator of SURVEY.md 8d) from a shared counter and
+ * run `SELECT function(model, c1..cN)` on each through infera_sql_call -- i.e. gather -> C ABI ->
+ * H2D -> kernels -> D2H -> result vector, everything the SQL path does per chunk.  Chunk columns are
+ * drawn from a per-thread pool of `pool_chunks` pre-generated chunks (table generation is not part of
+ * the path).  Returns wall seconds for `rows` rows (<0 on error, message in err); checksum (optional)
+ * receives the f64 sum of every output element. */
+double infera_sql_bench_scan(const char *function, const char *model, uint64_t rows, uint32_t ncols, int32_t threads,
+                             int32_t pool_chunks, uint64_t seed, double *checksum, char *err, uint64_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

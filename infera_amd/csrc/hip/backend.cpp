@@ -32,9 +32,25 @@ struct ThreadCtx {
   hipStream_t stream = nullptr;
   float *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr, *scratch = nullptr;
   size_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0, scratch_cap = 0;  // bytes
+  // hipGraph per (model uid, rows): {H2D memcpy, kernels, D2H memcpy} captured once on this context's
+  // stream and buffers, replayed for every later DataChunk of that shape (one API call per chunk
+  // instead of one per node).  Any reallocation of the buffers the graph points at drops the cache.
+  struct GraphEntry {
+    uint64_t uid;
+    int64_t rows;
+    hipGraphExec_t exec;
+    uint64_t last_use;
+  };
+  std::vector<GraphEntry> graphs;
+  uint64_t graph_clock = 0;
+  void drop_graphs() {
+    for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
+    graphs.clear();
+  }
 
   void ensure_pinned(float *&p, size_t &cap, size_t bytes) {
     if (bytes <= cap) return;
+    drop_graphs();
     if (p) HIP_TRY(hipHostFree(p));
     p = nullptr;
     cap = 0;
@@ -43,6 +59,7 @@ struct ThreadCtx {
   }
   void ensure_dev(float *&p, size_t &cap, size_t bytes) {
     if (bytes <= cap) return;
+    drop_graphs();
     if (p) {
       HIP_TRY(hipStreamSynchronize(stream));
       HIP_TRY(hipFree(p));
@@ -114,11 +131,15 @@ int home_slot() {
 
 kern::ActParam act_of(const Step &s) { return kern::ActParam{int(s.act), s.act_a, s.act_b}; }
 
-float *upload(const std::vector<float> &v) {
+// Weight upload on an explicit (non-blocking) stream: a legacy-stream hipMemcpy would try to
+// synchronise with every blocking stream of the device, which is illegal while another thread is
+// capturing a hipGraph ("would make the legacy stream depend on a capturing blocking stream").
+float *upload(const std::vector<float> &v, hipStream_t stream) {
   if (v.empty()) return nullptr;
   float *d = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), v.size() * sizeof(float)));
-  hipError_t e = hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+  hipError_t e = hipMemcpyAsync(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e != hipSuccess) {
     (void)hipFree(d);
     hip_fail(e, "hipMemcpy(weights)");
@@ -221,7 +242,7 @@ void schedule(LoadedModel &m) {
 }
 
 void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
-  HIP_TRY(hipSetDevice(dm.device));
+  hipStream_t us = ctx_for_slot(slot_of_ordinal(dm.device)).stream;  // also does hipSetDevice
   const auto &st = m.plan.steps;
   dm.steps.resize(st.size());
   for (size_t i = 0; i < st.size(); i++) {
@@ -234,15 +255,25 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       kern::mlp3_pack(m.mlp3_shape, s1.W.data(), s1.bias.empty() ? nullptr : s1.bias.data(), s2.W.data(),
                       s2.bias.empty() ? nullptr : s2.bias.data(), s3.W.data(), s3.bias.empty() ? nullptr : s3.bias.data(),
                       packed.data());
-      dm.mlp3_packed = upload(packed);
+      dm.mlp3_packed = upload(packed, us);
       continue;
     }
-    d.W = upload(s.W);
-    d.bias = upload(s.bias);
-    d.cst = upload(s.cst);
-    d.scale = upload(s.scale);
-    d.shift = upload(s.shift);
+    d.W = upload(s.W, us);
+    d.bias = upload(s.bias, us);
+    d.cst = upload(s.cst, us);
+    d.scale = upload(s.scale, us);
+    d.shift = upload(s.shift, us);
   }
+}
+
+// Rows per device pass for plans that need activation scratch; also grows the scratch (never inside a
+// stream capture: callers that capture call this first).
+int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
+  if (m.scratch_per_row <= 0 || m.plan.out_buf == 0) return rows;
+  int64_t by_budget = int64_t(kScratchBudgetBytes / (size_t(m.scratch_per_row) * 4));
+  int64_t rows_pass = std::min<int64_t>(rows, std::max<int64_t>(1, std::min<int64_t>(by_budget, int64_t(Config::get().max_rows_per_pass))));
+  ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass) * size_t(m.scratch_per_row) * 4);
+  return rows_pass;
 }
 
 void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, const float *d_in, float *d_out, int64_t rows) {
@@ -253,12 +284,7 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
     HIP_TRY(hipMemcpyAsync(d_out, d_in, size_t(rows) * size_t(p.in_per_row()) * 4, hipMemcpyDeviceToDevice, s));
     return;
   }
-  int64_t rows_pass = rows;
-  if (m.scratch_per_row > 0) {
-    int64_t by_budget = int64_t(kScratchBudgetBytes / (size_t(m.scratch_per_row) * 4));
-    rows_pass = std::min<int64_t>(rows, std::max<int64_t>(1, std::min<int64_t>(by_budget, int64_t(Config::get().max_rows_per_pass))));
-    ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass) * size_t(m.scratch_per_row) * 4);
-  }
+  const int64_t rows_pass = prepare_scratch(m, ctx, rows);
   std::vector<int64_t> slot_base(m.slot_per_row.size(), 0);
   {
     int64_t off = 0;
@@ -367,7 +393,9 @@ DeviceModel::~DeviceModel() {
 }
 
 std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::string &path) {
+  static std::atomic<uint64_t> next_uid{1};
   auto m = std::make_shared<LoadedModel>();
+  m->uid = next_uid.fetch_add(1);
   m->name = name;
   onnx::Model om = onnx::parse_file(path);
   m->plan = lower_model(om);
@@ -390,7 +418,7 @@ std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::str
   return m;
 }
 
-void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows) {
+void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows) {
   if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
   if (rows <= 0) return;
   const int slot = home_slot();
@@ -404,16 +432,71 @@ void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t row
   ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows_pass) * out_row);
   ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_dev(ctx.dev_out, ctx.dev_out_cap, size_t(rows_pass) * out_row);
+  const bool use_graph = Config::get().use_hipgraph;
   for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
     const int64_t nr = std::min(rows_pass, rows - r0);
     // The caller's buffer is only borrowed for the call (SURVEY.md 8b "Ownership"): stage it.
-    std::memcpy(ctx.pin_in, h_in + size_t(r0) * (in_row / 4), size_t(nr) * in_row);
-    HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
-    exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr);
-    HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+    fill(ctx.pin_in, r0, nr);
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+      (void)prepare_scratch(m, ctx, nr);  // may reallocate (and drop graphs) -- before the lookup
+      for (auto &g : ctx.graphs)
+        if (g.uid == m.uid && g.rows == nr) {
+          g.last_use = ++ctx.graph_clock;
+          exec = g.exec;
+        }
+      if (exec) {
+        HIP_TRY(hipGraphLaunch(exec, ctx.stream));
+      } else {
+        // First chunk of this (model, rows) on this context: run it directly -- one-time work such as
+        // hipFuncSetAttribute / code-object loading must not happen inside a capture -- and then record
+        // the graph (capturing does not execute anything) for the chunks that follow.
+        HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+        exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr);
+        HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        std::memcpy(h_out + size_t(r0) * (out_row / 4), ctx.pin_out, size_t(nr) * out_row);
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream);
+        try {
+          if (e == hipSuccess) exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr);
+        } catch (...) {
+          (void)hipStreamEndCapture(ctx.stream, &graph);
+          if (graph) (void)hipGraphDestroy(graph);
+          throw;
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream);
+        hipError_t e2 = hipStreamEndCapture(ctx.stream, &graph);
+        if (e != hipSuccess) hip_fail(e, "stream capture");
+        if (e2 != hipSuccess) hip_fail(e2, "hipStreamEndCapture");
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) hip_fail(e, "hipGraphInstantiate");
+        if (ctx.graphs.size() >= 16) {  // evict the least recently used entry
+          size_t victim = 0;
+          for (size_t i = 1; i < ctx.graphs.size(); i++)
+            if (ctx.graphs[i].last_use < ctx.graphs[victim].last_use) victim = i;
+          (void)hipGraphExecDestroy(ctx.graphs[victim].exec);
+          ctx.graphs.erase(ctx.graphs.begin() + long(victim));
+        }
+        ctx.graphs.push_back({m.uid, nr, exec, ++ctx.graph_clock});
+        continue;  // this chunk's result is already in h_out
+      }
+    } else {
+      HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+      exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr);
+      HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx.stream));
     std::memcpy(h_out + size_t(r0) * (out_row / 4), ctx.pin_out, size_t(nr) * out_row);
   }
+}
+
+void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows) {
+  const size_t in_per_row = size_t(m.plan.in_per_row());
+  run_host_fill(m, [&](float *dst, int64_t r0, int64_t nr) { std::memcpy(dst, h_in + size_t(r0) * in_per_row, size_t(nr) * in_per_row * 4); },
+                h_out, rows);
 }
 
 void run_device(const LoadedModel &m, int device_ordinal, const float *d_in, float *d_out, int64_t rows) {

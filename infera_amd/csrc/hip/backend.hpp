@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -46,6 +47,7 @@ struct DeviceModel {
 
 class LoadedModel {
  public:
+  uint64_t uid = 0;  // unique per build_model call (keys the per-thread hipGraph cache)
   std::string name;
   Plan plan;
   // execution schedule (device independent)
@@ -68,6 +70,10 @@ std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::str
 // Host-memory inference (infera_predict / infera_predict_from_blob): `h_in` is rows x in_per_row
 // f32 in pageable host memory; result written to `h_out` (rows x out_per_row).  Blocks until done.
 void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows);
+// Same, but the input rows are PRODUCED straight into the pinned staging buffer by `fill(dst, row0,
+// nrows)` (columnar gather, blob concatenation): no intermediate host copy.
+using FillFn = std::function<void(float *dst, int64_t row0, int64_t nrows)>;
+void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows);
 
 // Device-resident inference: d_in / d_out live on HIP device `device_ordinal`.  Enqueues on the
 // calling thread's stream for that device and returns without synchronising.

@@ -33,6 +33,7 @@
 //   * X is read with one 16-byte load per lane per 8 k-indices directly in B-fragment shape; the
 //     next tile's rows are requested right after this tile's last layer-2 L2 load, so nothing in
 //     this tile ever queues behind HBM latency on the in-order vmcnt counter.
+#include <atomic>
 #include <cstdlib>
 
 #include "device_common.hpp"
@@ -352,9 +353,16 @@ void pack_cfg(const float *W1, const float *b1, const float *W2, const float *b2
 
 template <class C>
 void launch_cfg(hipStream_t s, const float *X, const float *packed, float *Y, int64_t rows, int num_cus) {
-  // > 64 KiB of dynamic LDS needs the attribute; it is per device, so set it on every launch (cheap).
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            C::N_LDS * 4);
+  // > 64 KiB of dynamic LDS needs the attribute, once per device (not per launch: it is a runtime
+  // API call behind a lock, and launches may be inside a stream capture).
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::N_LDS * 4);
+    attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+  }
   const int64_t ntiles = (rows + 31) / 32;
   int64_t blocks = (ntiles + C::WAVES - 1) / C::WAVES;
   if (blocks > num_cus) blocks = num_cus;  // persistent: one workgroup per CU (the LDS image allows only one)

@@ -15,6 +15,7 @@
 #include "../hip/backend.hpp"
 #include "common.hpp"
 #include "engine.hpp"
+#include "gather.hpp"
 
 using namespace infera_hip;
 
@@ -337,8 +338,9 @@ int32_t infera_hip_free(int32_t device, void *ptr) {
 int32_t infera_hip_memcpy_h2d(int32_t device, void *dst, const void *src, uint64_t bytes) {
   return guarded([&] {
            if (!dst || !src) throw InferaError::null_pointer();
-           hipError_t e = hipSetDevice(device);
-           if (e == hipSuccess) e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+           hipStream_t st = thread_stream(device);  // explicit stream: never the legacy stream (see backend.cpp upload)
+           hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+           if (e == hipSuccess) e = hipStreamSynchronize(st);
            if (e != hipSuccess) throw InferaError::onnx(std::string("HIP: hipMemcpy H2D: ") + hipGetErrorString(e));
          })
              ? 0
@@ -348,8 +350,9 @@ int32_t infera_hip_memcpy_h2d(int32_t device, void *dst, const void *src, uint64
 int32_t infera_hip_memcpy_d2h(int32_t device, void *dst, const void *src, uint64_t bytes) {
   return guarded([&] {
            if (!dst || !src) throw InferaError::null_pointer();
-           hipError_t e = hipSetDevice(device);
-           if (e == hipSuccess) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+           hipStream_t st = thread_stream(device);
+           hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+           if (e == hipSuccess) e = hipStreamSynchronize(st);
            if (e != hipSuccess) throw InferaError::onnx(std::string("HIP: hipMemcpy D2H: ") + hipGetErrorString(e));
          })
              ? 0
@@ -391,33 +394,25 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
   guarded([&] {
     if (!model_name || !columns) throw InferaError::null_pointer();
     auto m = engine::find(checked_str(model_name));
-    // gather first (a NULL cell must fail before any model-level error, as ExtractFeatures runs
-    // before the FFI call in the reference: infera_extension.cpp:267-270)
-    std::vector<float> feat(size_t(rows) * size_t(ncols));
+    // A NULL cell or an unsupported type must fail before any model-level error, as ExtractFeatures
+    // runs before the FFI call in the reference (infera_extension.cpp:267-270).
     for (uintptr_t c = 0; c < ncols; c++) {
       const InferaColumn &col = columns[c];
       if (!col.data) throw InferaError::null_pointer();
-      const bool cst = col.is_constant != 0;
+      if (col.type < INFERA_COL_FLOAT || col.type > INFERA_COL_BIGINT)
+        throw InferaError(ErrKind::Onnx, "Unsupported feature type: " + std::to_string(col.type));
       if (col.validity) {
-        for (uintptr_t r = 0; r < (cst ? (rows ? 1 : 0) : rows); r++)
+        const uintptr_t n = col.is_constant ? (rows ? 1 : 0) : rows;
+        for (uintptr_t r = 0; r < n; r++)
           if (!((col.validity[r >> 6] >> (r & 63)) & 1)) throw InferaError(ErrKind::Onnx, "Feature values cannot be NULL");
-      }
-      float *dst = feat.data() + c;
-      auto gather = [&](auto *src) {
-        for (uintptr_t r = 0; r < rows; r++) dst[size_t(r) * ncols] = static_cast<float>(src[cst ? 0 : r]);
-      };
-      switch (col.type) {
-        case INFERA_COL_FLOAT: gather(static_cast<const float *>(col.data)); break;
-        case INFERA_COL_DOUBLE: gather(static_cast<const double *>(col.data)); break;
-        case INFERA_COL_INTEGER: gather(static_cast<const int32_t *>(col.data)); break;
-        case INFERA_COL_BIGINT: gather(static_cast<const int64_t *>(col.data)); break;
-        default: throw InferaError(ErrKind::Onnx, "Unsupported feature type: " + std::to_string(col.type));
       }
     }
     OutShape o = engine::validate_predict(*m, rows, ncols);
     float *out = alloc_out(o.len);
     try {
-      run_host(*m, feat.data(), out, int64_t(rows));
+      // gather straight into the pinned staging buffer (no intermediate row-major copy)
+      run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) { gather_columns(columns, ncols, size_t(r0), size_t(nr), dst); }, out,
+                    int64_t(rows));
     } catch (...) {
       std::free(out);
       throw;
@@ -431,6 +426,24 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
   return res;
 }
 
+int32_t infera_gather_columns(const InferaColumn *columns, uintptr_t ncols, uintptr_t row0, uintptr_t nrows, float *dst) {
+  return guarded([&] {
+           if (!columns || !dst) throw InferaError::null_pointer();
+           for (uintptr_t c = 0; c < ncols; c++) {
+             const InferaColumn &col = columns[c];
+             if (!col.data) throw InferaError::null_pointer();
+             if (col.type < INFERA_COL_FLOAT || col.type > INFERA_COL_BIGINT)
+               throw InferaError(ErrKind::Onnx, "Unsupported feature type: " + std::to_string(col.type));
+             if (col.validity)
+               for (uintptr_t r = col.is_constant ? 0 : row0; r < (col.is_constant ? (nrows ? 1 : 0) : row0 + nrows); r++)
+                 if (!((col.validity[r >> 6] >> (r & 63)) & 1)) throw InferaError(ErrKind::Onnx, "Feature values cannot be NULL");
+           }
+           gather_columns(columns, ncols, row0, nrows, dst);
+         })
+             ? 0
+             : -1;
+}
+
 struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_name, const uint8_t *const *blobs,
                                                             const uintptr_t *lens, uintptr_t n) {
   InferaInferenceResult res = error_result();
@@ -442,17 +455,19 @@ struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_na
     for (size_t i = 1; i < in.size(); i++) per_sample *= uint64_t(in[i]);
     if (in.empty() || in[0] != -1)
       throw InferaError::onnx("batched BLOB inference needs a model with a symbolic leading (batch) dimension");
-    std::vector<float> stage(size_t(n) * size_t(per_sample));
     for (uintptr_t i = 0; i < n; i++) {
       if (!blobs[i]) throw InferaError::null_pointer();
       if (lens[i] % 4 != 0) throw InferaError::invalid_blob_size();
       if (lens[i] / 4 != per_sample) throw InferaError::blob_shape_mismatch(size_t(per_sample), size_t(lens[i] / 4));
-      std::memcpy(stage.data() + size_t(i) * per_sample, blobs[i], lens[i]);
     }
     OutShape o = engine::out_shape_for_rows(*m, n);
     float *out = alloc_out(o.len);
     try {
-      run_host(*m, stage.data(), out, int64_t(n));
+      run_host_fill(*m,
+                    [&](float *dst, int64_t r0, int64_t nr) {
+                      for (int64_t i = 0; i < nr; i++) std::memcpy(dst + size_t(i) * per_sample, blobs[size_t(r0 + i)], size_t(per_sample) * 4);
+                    },
+                    out, int64_t(n));
     } catch (...) {
       std::free(out);
       throw;

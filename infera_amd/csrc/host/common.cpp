@@ -76,7 +76,7 @@ const Config &Config::get() {
       if (!tok.empty() && tok.find_first_not_of("0123456789") == std::string::npos) c.devices.push_back(std::atoi(tok.c_str()));
       pos = e + 1;
     }
-    c.use_hipgraph = env_flag("INFERA_HIPGRAPH", true);
+    c.use_hipgraph = env_flag("INFERA_HIPGRAPH", false);
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);
     c.max_rows_per_pass = env_u64("INFERA_MAX_ROWS_PER_PASS", 1ull << 18);
     return c;

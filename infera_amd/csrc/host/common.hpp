@@ -84,7 +84,9 @@ struct Config {
   int log_level;                      // INFERA_LOG_LEVEL        ERROR=0 WARN=1 INFO=2 DEBUG=3 (default WARN)
   // MI355X backend knobs (new; same style)
   std::vector<int> devices;           // INFERA_DEVICES="0,1,.."  (default: all visible)
-  bool use_hipgraph;                  // INFERA_HIPGRAPH=0|1      per-(model,rows) hipGraph for host-path chunks
+  bool use_hipgraph;                  // INFERA_HIPGRAPH=0|1      replay a per-(model,rows) hipGraph {H2D,kernels,D2H} per
+                                      //   host-path chunk.  Default 0: measured SLOWER than three direct stream
+                                      //   enqueues on MI355X/ROCm 7.2 (60 vs 82 M rows/s at 16 threads)
   bool fused_mlp;                     // INFERA_FUSED_MLP=0|1     whole-chain fused kernel when the plan allows
   uint64_t max_rows_per_pass;         // INFERA_MAX_ROWS_PER_PASS scratch bound for unfused plans
   static const Config &get();

@@ -55,6 +55,9 @@ def lib() -> C.CDLL:
         L.infera_sql_call.restype = C.c_int32
         L.infera_sql_free_result.argtypes = [C.POINTER(_Result)]
         L.infera_sql_list_functions.restype = C.c_void_p
+        L.infera_sql_bench_scan.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64,
+                                            C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
+        L.infera_sql_bench_scan.restype = C.c_double
         _lib = L
     return _lib
 
@@ -189,3 +192,14 @@ def sql(function: str, *args: Any, rows: int | None = None):
         return out
     finally:
         lib().infera_sql_free_result(C.byref(res))
+
+
+def bench_scan(function: str, model: str, rows: int, ncols: int, threads: int, pool_chunks: int = 8, seed: int = 42):
+    """Native multi-threaded table scan through the SQL surface; returns (seconds, checksum)."""
+    cs = C.c_double()
+    err = C.create_string_buffer(512)
+    sec = lib().infera_sql_bench_scan(function.encode(), model.encode(), rows, ncols, threads, pool_chunks, seed, C.byref(cs),
+                                      err, len(err))
+    if sec < 0:
+        raise SqlError(err.value.decode())
+    return sec, cs.value

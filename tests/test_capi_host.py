@@ -224,3 +224,33 @@ def test_predict_without_gpu_fails_loudly(api):
     with pytest.raises(api.InferaError, match="^ONNX error: HIP backend unavailable: "):
         api.predict("nogpu", np.array([[1, 2, 3]], np.float32))
     api.unload_model("nogpu")
+
+
+def test_gather_columns_matches_extract_features(api):
+    """The vectorised ExtractFeatures (AVX2 8x8 transposes for FLOAT runs, scalar casts elsewhere)
+    against the oracle's restatement of infera_extension.cpp:199-227, incl. ragged row counts,
+    column counts that are not multiples of 8, mixed types, constant vectors and row windows."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(0)
+    for rows, ncols in [(2048, 128), (2047, 128), (5, 3), (1, 1), (100, 17), (9, 8), (64, 130)]:
+        cols = [rng.standard_normal(rows).astype(np.float32) for _ in range(ncols)]
+        np.testing.assert_array_equal(api.gather_columns(cols), oracle.extract_features(cols))
+        if rows > 10:
+            np.testing.assert_array_equal(api.gather_columns(cols, row0=3, nrows=rows - 7), oracle.extract_features(cols)[3:rows - 4])
+    rows = 333
+    mixed = []
+    for j in range(37):
+        kind = j % 4
+        if kind == 0: mixed.append(rng.standard_normal(rows).astype(np.float32))
+        elif kind == 1: mixed.append(rng.standard_normal(rows) * 1e3)
+        elif kind == 2: mixed.append(rng.integers(-2 ** 31, 2 ** 31 - 1, rows).astype(np.int32))
+        else: mixed.append(rng.integers(-2 ** 62, 2 ** 62, rows).astype(np.int64))
+    np.testing.assert_array_equal(api.gather_columns(mixed), oracle.extract_features(mixed))
+    const = [np.array([2.5], np.float32), mixed[0], np.array([7], np.int64)]
+    want = np.stack([np.full(rows, 2.5, np.float32), mixed[0], np.full(rows, 7.0, np.float32)], axis=1)
+    np.testing.assert_array_equal(api.gather_columns(const, rows=rows), want)
+    valid = np.full((rows + 63) // 64, np.uint64(0xFFFFFFFFFFFFFFFF))
+    valid[2] &= ~np.uint64(1 << 5)
+    with pytest.raises(api.InferaError, match="^Feature values cannot be NULL$"):
+        api.gather_columns(mixed[:3], validity=[None, valid, None])

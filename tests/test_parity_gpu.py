@@ -285,3 +285,47 @@ def test_full_size_c2_properties(api, models):
     total = y1.astype(np.float64).sum()
     parts = sum(y1[a:a + 1_000_000].astype(np.float64).sum() for a in range(0, rows, 1_000_000))
     assert abs(total - parts) <= 1e-6 * abs(total) + 1e-6
+
+
+def test_hipgraph_mode_matches_direct_mode(models):
+    """INFERA_HIPGRAPH=1 (a captured {H2D, kernels, D2H} graph per (model, rows), north_star) in a fresh
+    process: same values as the default direct-enqueue mode, and safe against concurrent model loads
+    in other threads (loads must not touch the legacy stream while a capture is open)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, threading, json, numpy as np
+sys.path.insert(0, %r)
+from infera_amd import capi, synth
+capi.load_model("mlp", %r)
+x = synth.table(42, 0, 2048, 128)
+errors, outs = [], {}
+def scan(t):
+    try:
+        for i in range(20):
+            outs[(t, i)] = capi.predict("mlp", x)
+    except Exception as e:
+        errors.append(repr(e))
+def loader(t):
+    try:
+        for i in range(10):
+            capi.load_model(f"l{t}_{i}", %r); capi.unload_model(f"l{t}_{i}")
+    except Exception as e:
+        errors.append(repr(e))
+th = [threading.Thread(target=scan, args=(t,)) for t in range(4)] + [threading.Thread(target=loader, args=(t,)) for t in range(2)]
+[t.start() for t in th]; [t.join() for t in th]
+ref = next(iter(outs.values()), np.zeros(1))
+print(json.dumps({"errors": errors, "same": len(outs) == 80 and all(np.array_equal(v, ref) for v in outs.values()), "sum": float(ref.astype(np.float64).sum())}))
+''' % (root, models["mlp"], models["linear"])
+    res = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, INFERA_HIPGRAPH=mode)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+        assert res[mode]["errors"] == [] and res[mode]["same"], res[mode]
+    assert res["0"]["sum"] == res["1"]["sum"]

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the SQL path: T worker threads x 2048-row chunks through
+infera_sql_call("infera_predict") (gather -> C ABI -> H2D -> kernel -> D2H -> result vector)."""
+import argparse
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from infera_amd import capi, onnx_writer, sqlmock  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=4_000_000)
+ap.add_argument("--threads", default="1,2,4,8,16,32,64")
+ap.add_argument("--workload", default="mlp")
+a = ap.parse_args()
+tmp = tempfile.mkdtemp()
+blob = onnx_writer.mlp() if a.workload == "mlp" else onnx_writer.logreg_softmax()
+fn = "infera_predict" if a.workload == "mlp" else "infera_predict_array"
+capi.load_model("m", onnx_writer.write(os.path.join(tmp, "m.onnx"), blob))
+sqlmock.bench_scan(fn, "m", 2048 * 64, 128, 4)  # warm
+print(f"devices={capi.device_count()} workload={a.workload} rows={a.rows}")
+for t in [int(x) for x in a.threads.split(",")]:
+    sec, cs = sqlmock.bench_scan(fn, "m", a.rows, 128, t)
+    print(f"threads={t:>3}  {a.rows / sec / 1e6:>9.2f} M rows/s  ({a.rows * 512 / sec / 1e9:.2f} GB/s of features)  checksum={cs:.4f}")
