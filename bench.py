@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="table rows per GPU (C2: 10M)")
+    ap.add_argument("--rows", type=int, default=None, help="table rows per GPU (default: C2 10M for mlp, C4 50M for logreg)")
     ap.add_argument("--workload", default="mlp", choices=["mlp", "logreg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
@@ -78,7 +78,7 @@ def main():
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: " + capi.get_devices()["reason"])
     dev = local_rank
-    rows, cols = args.rows, 128
+    rows, cols = (args.rows or (10_000_000 if args.workload == "mlp" else 50_000_000)), 128
     tmp = tempfile.mkdtemp(prefix="infera_bench_")
     if args.workload == "mlp":
         path = onnx_writer.write(os.path.join(tmp, "mlp.onnx"), onnx_writer.mlp((128, 256, 64, 1)))
@@ -86,7 +86,7 @@ def main():
         bound, flops_row, bytes_row = "mfma", 98432.0, 516.0
     else:
         path = onnx_writer.write(os.path.join(tmp, "logreg.onnx"), onnx_writer.logreg_softmax(128, 10))
-        out_cols, wl_name = 10, "C4: Gemm(128->10)+Softmax, 128-col FLOAT table"
+        out_cols, wl_name = 10, "C4: logistic regression Gemm(128->10)+Softmax(axis=1), 50M-row x 128-col FLOAT table, list output of 10"
         bound, flops_row, bytes_row = "hbm", 2560.0, 552.0
     capi.load_model("bench", path)
     plan = capi.get_plan("bench")

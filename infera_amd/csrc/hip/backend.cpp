@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <sstream>
 
 #include "../host/common.hpp"
@@ -20,6 +21,19 @@ namespace {
     hipError_t _e = (expr);                         \
     if (_e != hipSuccess) hip_fail(_e, #expr);      \
   } while (0)
+
+// hipGraph mode only: allocation / free / device-wide synchronisation from ANY thread invalidates an
+// open stream capture on ROCm 7.2 even in ThreadLocal capture mode ("operation failed due to a previous
+// error during capture").  Captures therefore hold this lock shared, and the operations that would
+// break them hold it exclusively.  In the default direct-enqueue mode nobody captures and the guards
+// are not taken.
+std::shared_mutex g_capture_mu;
+struct UnsafeOpGuard {
+  std::unique_lock<std::shared_mutex> lk;
+  UnsafeOpGuard() {
+    if (Config::get().use_hipgraph) lk = std::unique_lock<std::shared_mutex>(g_capture_mu);
+  }
+};
 
 constexpr size_t kHostPassBytes = 64ull << 20;     // pinned staging per direction per thread
 constexpr size_t kScratchBudgetBytes = 8ull << 30; // activation scratch per thread for unfused plans
@@ -50,6 +64,7 @@ struct ThreadCtx {
 
   void ensure_pinned(float *&p, size_t &cap, size_t bytes) {
     if (bytes <= cap) return;
+    UnsafeOpGuard guard;
     drop_graphs();
     if (p) HIP_TRY(hipHostFree(p));
     p = nullptr;
@@ -59,6 +74,7 @@ struct ThreadCtx {
   }
   void ensure_dev(float *&p, size_t &cap, size_t bytes) {
     if (bytes <= cap) return;
+    UnsafeOpGuard guard;
     drop_graphs();
     if (p) {
       HIP_TRY(hipStreamSynchronize(stream));
@@ -242,6 +258,7 @@ void schedule(LoadedModel &m) {
 }
 
 void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
+  UnsafeOpGuard guard;
   hipStream_t us = ctx_for_slot(slot_of_ordinal(dm.device)).stream;  // also does hipSetDevice
   const auto &st = m.plan.steps;
   dm.steps.resize(st.size());
@@ -383,6 +400,7 @@ const DeviceSet &devices() {
 
 DeviceModel::~DeviceModel() {
   if (device < 0) return;
+  UnsafeOpGuard guard;
   if (hipSetDevice(device) != hipSuccess) return;
   (void)hipDeviceSynchronize();
   for (auto &d : steps) {
@@ -457,6 +475,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
         HIP_TRY(hipStreamSynchronize(ctx.stream));
         std::memcpy(h_out + size_t(r0) * (out_row / 4), ctx.pin_out, size_t(nr) * out_row);
         hipGraph_t graph = nullptr;
+        std::shared_lock<std::shared_mutex> capture_lock(g_capture_mu);
         HIP_TRY(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
         hipError_t e = hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream);
         try {

@@ -138,24 +138,126 @@ __global__ __launch_bounds__(WAVES * 64) void dense_kernel(const float *__restri
   }
 }
 
+// ---- narrow-output variant: M <= 32, K % 8 == 0 --------------------------------------------------------
+// The HBM-bound case (C4: 128 -> 10 + softmax, 552 B/row vs 2,560 flop/row).  No LDS staging of X and no
+// block barrier in the row loop: each lane reads its table row in 16-byte pieces directly in B-fragment
+// shape (lane half h takes k = 8g+4h..+3, as in mlp_fused.hip), four pieces in flight per wave, many
+// waves per CU to cover HBM latency.  The zero-padded 32-column weight fragments (K*128 B) are packed
+// into LDS once per block, fragment-major, so one ds_read_b128 feeds four MFMA k-steps.
+template <int SM>
+__global__ __launch_bounds__(WAVES * 64) void dense_narrow_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                                 const float *__restrict__ bias, float *__restrict__ Y,
+                                                                 int64_t rows, int K, int M, ActParam act) {
+  extern __shared__ __attribute__((aligned(16))) float wf[];  // [K/8][64 lanes][4]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int G = K >> 3;
+  for (int i = threadIdx.x; i < G * 256; i += WAVES * 64) {
+    const int g = i >> 8, l = (i >> 2) & 63, j = i & 3;
+    const int k = 8 * g + 4 * (l >> 5) + j, m = l & 31;
+    wf[i] = m < M ? W[int64_t(k) * M + m] : 0.f;
+  }
+  __syncthreads();
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(wf) + lane;
+  float bq[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int f = 8 * (i >> 2) + 4 * h + (i & 3);
+    bq[i] = (bias != nullptr && f < M) ? bias[f] : 0.f;
+  }
+  const int64_t ntiles = (rows + 31) >> 5;
+  const int64_t tstride = int64_t(gridDim.x) * WAVES;
+  for (int64_t tile = int64_t(blockIdx.x) * WAVES + wave; tile < ntiles; tile += tstride) {
+    int64_t row = (tile << 5) + r;
+    const bool valid = row < rows;
+    if (!valid) row = rows - 1;
+    const f32x4 *xp = reinterpret_cast<const f32x4 *>(X + row * K + 4 * h);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+      const f32x4 x0 = xp[2 * g], x1 = xp[2 * g + 2], x2 = xp[2 * g + 4], x3 = xp[2 * g + 6];
+      const f32x4 a0 = wq[g * 64], a1 = wq[(g + 1) * 64], a2 = wq[(g + 2) * 64], a3 = wq[(g + 3) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], x0[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], x1[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], x2[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[j], x3[j], acc, 0, 0, 0);
+    }
+    for (; g < G; g++) {
+      const f32x4 x0 = xp[2 * g];
+      const f32x4 a0 = wq[g * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], x0[j], acc, 0, 0, 0);
+    }
+    // epilogue: lane (r,h) holds features 8*(i>>2) + 4h + (i&3) of table row `row`
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = apply_act(acc[i] + bq[i], act);
+    if constexpr (SM != 0) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (8 * (i >> 2) + 4 * h + (i & 3) < M) mx = fmaxf(mx, acc[i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (8 * (i >> 2) + 4 * h + (i & 3) < M) {
+          const float e = expf(acc[i] - mx);
+          sum += e;
+          acc[i] = SM == 1 ? e : acc[i] - mx;
+        }
+      sum += __shfl_xor(sum, 32);
+      const float ls = logf(sum);
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[i] = SM == 1 ? acc[i] / sum : acc[i] - ls;
+    }
+    if (valid) {
+      float *yrow = Y + row * M;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int f = 8 * (i >> 2) + 4 * h + (i & 3);
+        if (f < M) yrow[f] = acc[i];
+      }
+    }
+  }
+}
+
 template <int MT>
 void launch(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
             ActParam act, int sm) {
   const int64_t blocks = (rows + 32 * WAVES - 1) / (32 * WAVES);
   const int vec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   dim3 grid((unsigned)blocks), block(WAVES * 64);
-  if (sm == 0) hipLaunchKernelGGL((dense_kernel<MT, 0>), grid, block, 0, s, X, W, bias, Y, rows, K, M, act, vec_ok);
-  else if (sm == 1) hipLaunchKernelGGL((dense_kernel<MT, 1>), grid, block, 0, s, X, W, bias, Y, rows, K, M, act, vec_ok);
-  else hipLaunchKernelGGL((dense_kernel<MT, 2>), grid, block, 0, s, X, W, bias, Y, rows, K, M, act, vec_ok);
+  if constexpr (MT <= 2) {  // softmax epilogues exist for M <= 64 only (the scheduler never asks for more)
+    if (sm == 1) { hipLaunchKernelGGL((dense_kernel<MT, 1>), grid, block, 0, s, X, W, bias, Y, rows, K, M, act, vec_ok); return; }
+    if (sm == 2) { hipLaunchKernelGGL((dense_kernel<MT, 2>), grid, block, 0, s, X, W, bias, Y, rows, K, M, act, vec_ok); return; }
+  }
+  hipLaunchKernelGGL((dense_kernel<MT, 0>), grid, block, 0, s, X, W, bias, Y, rows, K, M, act, vec_ok);
 }
 
 }  // namespace
 
-bool dense_can_fuse_softmax(int M) { return M <= 256; }
+bool dense_can_fuse_softmax(int M) { return M <= 64; }
 
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
            ActParam act, int softmax_mode) {
   if (rows <= 0) return;
+  if (M <= 32 && K % 8 == 0 && K <= 512 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    const int64_t ntiles = (rows + 31) / 32;
+    int64_t blocks = (ntiles + WAVES - 1) / WAVES;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 blocks per CU
+    const size_t lds = size_t(K) * 32 * sizeof(float);
+    dim3 grid((unsigned)blocks), block(WAVES * 64);
+    if (softmax_mode == 0) hipLaunchKernelGGL((dense_narrow_kernel<0>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+    else if (softmax_mode == 1) hipLaunchKernelGGL((dense_narrow_kernel<1>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+    else hipLaunchKernelGGL((dense_narrow_kernel<2>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+    return;
+  }
   if (M <= 32) launch<1>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   else if (M <= 64) launch<2>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   else if (M <= 128) launch<4>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
