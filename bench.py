@@ -37,9 +37,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=None, help="table rows per GPU (default: C2 10M for mlp, C4 50M for logreg)")
-    ap.add_argument("--workload", default="mlp", choices=["mlp", "logreg"])
+    ap.add_argument("--workload", default="mlp", choices=["mlp", "logreg", "resnet18"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
+    ap.add_argument("--share-device", type=int, default=None,
+                    help="testing only: every rank uses this one HIP device (lets the N>1 control path run on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -67,23 +69,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = local_rank if args.share_device is None else args.share_device
+    # One process per GPU: this rank's library instance must only create a context / upload weights on
+    # ITS device (read once at library load, so set before importing the binding).
+    os.environ.setdefault("INFERA_DEVICES", str(dev))
     if world > 1:
         # control plane only (barrier + max-reduce of one float); the data path has no collective
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(dev)
     torch.cuda.init()
 
     from infera_amd import capi, onnx_writer, shard
 
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: " + capi.get_devices()["reason"])
-    dev = local_rank
-    rows, cols = (args.rows or (10_000_000 if args.workload == "mlp" else 50_000_000)), 128
+    rows = args.rows or {"mlp": 10_000_000, "logreg": 50_000_000, "resnet18": 512}[args.workload]
+    cols = 3 * 224 * 224 if args.workload == "resnet18" else 128
     tmp = tempfile.mkdtemp(prefix="infera_bench_")
     if args.workload == "mlp":
         path = onnx_writer.write(os.path.join(tmp, "mlp.onnx"), onnx_writer.mlp((128, 256, 64, 1)))
         out_cols, wl_name = 1, "C2: 3-layer MLP 128->256->64->1 (Gemm+Relu, Gemm+Relu, Gemm), 10M-row x 128-col FLOAT table"
         bound, flops_row, bytes_row = "mfma", 98432.0, 516.0
+    elif args.workload == "resnet18":
+        path = onnx_writer.write(os.path.join(tmp, "resnet18.onnx"), onnx_writer.resnet18())
+        out_cols, wl_name = 1000, "C5: ResNet-18 topology (random weights), BLOB[3x224x224] f32 images resident in HBM"
+        bound, flops_row, bytes_row = "mfma", 3628146688.0, 606112.0
     else:
         path = onnx_writer.write(os.path.join(tmp, "logreg.onnx"), onnx_writer.logreg_softmax(128, 10))
         out_cols, wl_name = 10, "C4: logistic regression Gemm(128->10)+Softmax(axis=1), 50M-row x 128-col FLOAT table, list output of 10"

@@ -36,7 +36,8 @@ char *infera_hip_get_plan(const char *model_name);
  * [rows x out_cols] f32 on the same device, out_capacity in elements.  Same validation and error
  * strings as infera_predict (engine.rs:111-164).  The kernels are ENQUEUED on the calling thread's
  * stream for that device; call infera_hip_sync before reading d_out.  out_rows/out_cols receive
- * shape_rows_cols of the output (may be NULL). */
+ * shape_rows_cols of the output (may be NULL).  For models whose input rank is not 2 (images) the
+ * buffer holds `rows` samples of cols = prod(input_shape[1:]) elements (the BLOB rule, engine.rs:233-238). */
 int32_t infera_hip_predict_device(const char *model_name, int32_t device, const float *d_in, uint64_t rows,
                                   uint64_t cols, float *d_out, uint64_t out_capacity, uint64_t *out_rows,
                                   uint64_t *out_cols);

@@ -275,7 +275,7 @@ int32_t infera_hip_predict_device(const char *model_name, int32_t device, const 
   return guarded([&] {
            if (!model_name || !d_in || !d_out) throw InferaError::null_pointer();
            auto m = engine::find(checked_str(model_name));
-           OutShape o = engine::validate_predict(*m, rows, cols);
+           OutShape o = engine::validate_device(*m, rows, cols);
            if (o.len > out_capacity)
              throw InferaError::onnx("output buffer too small: need " + std::to_string(o.len) + " elements, have " + std::to_string(out_capacity));
            run_device(*m, device, d_in, d_out, int64_t(rows));
@@ -293,7 +293,7 @@ int32_t infera_hip_time_predict_device(const char *model_name, int32_t device, c
   return guarded([&] {
            if (!model_name || !d_in || !d_out || !elapsed_ms) throw InferaError::null_pointer();
            auto m = engine::find(checked_str(model_name));
-           OutShape o = engine::validate_predict(*m, rows, cols);
+           OutShape o = engine::validate_device(*m, rows, cols);
            if (o.len > out_capacity) throw InferaError::onnx("output buffer too small");
            hipStream_t s = thread_stream(device);
            hipEvent_t e0, e1;

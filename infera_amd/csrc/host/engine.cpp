@@ -115,6 +115,18 @@ OutShape validate_predict(const LoadedModel &m, uint64_t rows, uint64_t cols) {
   return out_shape_for_rows(m, rows);
 }
 
+OutShape validate_device(const LoadedModel &m, uint64_t rows, uint64_t cols) {
+  const auto &in = m.plan.input_shape;
+  if (in.size() == 2) return validate_predict(m, rows, cols);
+  uint64_t per_sample = 1;
+  for (size_t i = 1; i < in.size(); i++) per_sample *= uint64_t(in[i]);
+  if (cols != per_sample)
+    throw InferaError::invalid_input_shape("batch x " + debug_i64(in, 1), std::to_string(rows) + " x " + std::to_string(cols));
+  if (!in.empty() && in[0] > 0 && uint64_t(in[0]) != rows)
+    throw InferaError::onnx("input shape mismatch at axis 0: model expects " + std::to_string(in[0]) + ", got " + std::to_string(rows));
+  return out_shape_for_rows(m, rows);
+}
+
 uint64_t validate_blob(const LoadedModel &m, uint64_t blob_len) {
   if (blob_len % 4 != 0) throw InferaError::invalid_blob_size();  // engine.rs:209-211
   const uint64_t n = blob_len / 4;

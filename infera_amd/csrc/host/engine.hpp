@@ -36,6 +36,9 @@ std::string model_metadata_json(const std::string &name);
 // Validation shared by every predict flavour (engine.rs:126-137 + the backend's input-fact check).
 // Returns the output geometry for `rows` input rows.
 OutShape validate_predict(const LoadedModel &m, uint64_t rows, uint64_t cols);
+// Device-resident flavour: rank-2 models follow validate_predict; models with another input rank take
+// `rows` samples of `cols` = prod(input_shape[1:]) elements each (the blob rule, engine.rs:233-238).
+OutShape validate_device(const LoadedModel &m, uint64_t rows, uint64_t cols);
 // Blob flavour (engine.rs:209-238): returns the batch (row) count.
 uint64_t validate_blob(const LoadedModel &m, uint64_t blob_len);
 OutShape out_shape_for_rows(const LoadedModel &m, uint64_t rows);
