@@ -226,6 +226,31 @@ void schedule(LoadedModel &m) {
       i += 1;
     }
   }
+  // ---- layout decision for convolutional plans ----
+  auto is4d = [&](int b) { return b >= 0 && m.plan.buf_shape[size_t(b)].size() == 4; };
+  auto spatial = [&](int b) { return is4d(b) ? m.plan.buf_shape[size_t(b)][2] * m.plan.buf_shape[size_t(b)][3] : int64_t(1); };
+  bool any_conv = false, ok = true;
+  for (const auto &s : st) {
+    any_conv = any_conv || s.kind == StepKind::Conv2d;
+    const bool layout_free = s.kind == StepKind::Conv2d || s.kind == StepKind::Pool2d || s.kind == StepKind::GlobalAvgPool ||
+                             s.kind == StepKind::BinaryAct || s.kind == StepKind::Unary || s.kind == StepKind::AffineChannel;
+    for (int b : {s.in0, s.in1}) {
+      if (b < 0) continue;
+      if (b == 0 && is4d(0) && s.kind != StepKind::Conv2d) ok = false;  // the caller's NCHW input is read by convs only
+      if (!layout_free && spatial(b) > 1) ok = false;                    // e.g. Flatten(C,H,W) -> Gemm needs NCHW order
+    }
+  }
+  if (spatial(m.plan.out_buf) > 1) ok = false;  // results leave in the caller's (NCHW) order
+  m.nhwc_mode = any_conv && ok;
+  if (m.nhwc_mode)
+    for (size_t i = 0; i < n; i++) {
+      const Step &s = st[i];
+      if (m.exec[i] != ExecKind::Normal || s.kind != StepKind::Conv2d || s.in0 == 0) continue;
+      kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
+                       int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
+      if (kern::conv2d_tiled_supported(g)) m.exec[i] = ExecKind::ConvTiled;
+    }
+
   // scratch slots by liveness: a slot is reused once its buffer has been read for the last time
   auto eff = effective_steps(m);
   const size_t nb = m.plan.buf_per_row.size();
@@ -275,7 +300,23 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       dm.mlp3_packed = upload(packed, us);
       continue;
     }
-    d.W = upload(s.W, us);
+    if (m.exec[i] == ExecKind::ConvTiled) {
+      kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
+                       int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
+      std::vector<float> packed(kern::conv2d_tiled_packed_floats(g));
+      kern::conv2d_tiled_pack(g, s.W.data(), packed.data());
+      d.W = upload(packed, us);
+    } else if (s.kind == StepKind::Conv2d) {
+      kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
+                       int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
+      if (!kern::conv2d_generic_supported(g))
+        throw InferaError::onnx("Conv with (C/group)*kh*kw = " + std::to_string(s.K) + " > 8192 is not supported by the generic kernel");
+      std::vector<float> packed(s.W.size());
+      kern::conv2d_generic_pack(g, s.W.data(), packed.data());
+      d.W = upload(packed, us);
+    } else {
+      d.W = upload(s.W, us);
+    }
     d.bias = upload(s.bias, us);
     d.cst = upload(s.cst, us);
     d.scale = upload(s.scale, us);
@@ -330,13 +371,19 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           kern::dense(s, buf(x.in0), d.W, d.bias, buf(st[i + 1].out), nr, int(x.K), int(x.M), act_of(x),
                       st[i + 1].log_softmax ? 2 : 1);
           continue;
+        case ExecKind::ConvTiled: {
+          kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
+                           int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
+          kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x));
+          continue;
+        }
         default: break;
       }
       switch (x.kind) {
         case StepKind::Dense: kern::dense(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, int(x.K), int(x.M), act_of(x), 0); break;
         case StepKind::Unary: kern::unary(s, buf(x.in0), buf(x.out), nr * p.buf_per_row[size_t(x.out)], act_of(x)); break;
         case StepKind::AffineChannel:
-          kern::affine_channel(s, buf(x.in0), d.scale, d.shift, buf(x.out), nr, x.C, x.S, act_of(x));
+          kern::affine_channel(s, buf(x.in0), d.scale, d.shift, buf(x.out), nr, x.C, x.S, act_of(x), m.nhwc_mode && x.in0 != 0);
           break;
         case StepKind::BinaryConst:
           kern::binary_const(s, buf(x.in0), d.cst, buf(x.out), nr, p.buf_per_row[size_t(x.out)], x.bop, x.const_left, act_of(x));
@@ -348,14 +395,17 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case StepKind::Conv2d: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
-          kern::conv2d(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x));
+          kern::conv2d(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), m.nhwc_mode && x.in0 != 0, m.nhwc_mode);
           break;
         }
         case StepKind::Pool2d:
           kern::pool2d(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.H), int(x.Wd), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
-                       int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), x.is_max, x.count_pad);
+                       int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), x.is_max, x.count_pad,
+                       m.nhwc_mode && x.in0 != 0);
           break;
-        case StepKind::GlobalAvgPool: kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S)); break;
+        case StepKind::GlobalAvgPool:
+          kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.nhwc_mode && x.in0 != 0);
+          break;
       }
     }
     HIP_TRY(hipGetLastError());
@@ -533,11 +583,11 @@ void sync_device(int device_ordinal) {
 hipStream_t thread_stream(int device_ordinal) { return ctx_for_slot(slot_of_ordinal(device_ordinal)).stream; }
 
 std::string LoadedModel::describe_json() const {
-  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax"};
+  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_nhwc"};
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";
-  o << "],\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
+  o << "],\"activation_layout\":\"" << (nhwc_mode ? "NHWC" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";
   for (size_t i = 0; i < exec.size(); i++)

@@ -35,7 +35,7 @@ struct DeviceStep {
 };
 
 // How the executor runs a step.
-enum class ExecKind : int { Normal = 0, Skipped = 1, Mlp3Head = 2, DenseSoftmax = 3 };
+enum class ExecKind : int { Normal = 0, Skipped = 1, Mlp3Head = 2, DenseSoftmax = 3, ConvTiled = 4 };
 
 struct DeviceModel {
   int device = -1;  // HIP ordinal
@@ -53,6 +53,9 @@ class LoadedModel {
   // execution schedule (device independent)
   std::vector<ExecKind> exec;
   kern::Mlp3Shape mlp3_shape{};
+  // Convolutional plans keep every 4-D activation except the caller's input CHANNELS-LAST (NHWC) so
+  // the implicit-GEMM gathers and stores are 16-byte vectors; decided per plan in schedule().
+  bool nhwc_mode = false;
   std::vector<int> slot_of_buf;        // scratch slot per activation buffer (-1: external in/out)
   std::vector<int64_t> slot_per_row;   // floats per row of each scratch slot
   int64_t scratch_per_row = 0;         // sum over slots

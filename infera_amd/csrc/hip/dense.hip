@@ -34,7 +34,10 @@ __global__ __launch_bounds__(WAVES * 64) void dense_kernel(const float *__restri
   const int64_t row0 = (int64_t(blockIdx.x) * WAVES + wave) * 32;
   float(*tile)[LDS_STRIDE] = xs[wave];
 
-  for (int m0 = 0; m0 < M; m0 += 32 * MT) {
+  // blockIdx.y selects the group of MT output tiles (a skinny batch with a wide layer, e.g. 256 rows x
+  // 1000 classes, would otherwise run on rows/128 workgroups only)
+  {
+    const int m0 = blockIdx.y * 32 * MT;
     f32x16 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++)
@@ -232,7 +235,7 @@ void launch(hipStream_t s, const float *X, const float *W, const float *bias, fl
             ActParam act, int sm) {
   const int64_t blocks = (rows + 32 * WAVES - 1) / (32 * WAVES);
   const int vec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  dim3 grid((unsigned)blocks), block(WAVES * 64);
+  dim3 grid((unsigned)blocks, unsigned((M + 32 * MT - 1) / (32 * MT))), block(WAVES * 64);
   if constexpr (MT <= 2) {  // softmax epilogues exist for M <= 64 only (the scheduler never asks for more)
     if (sm == 1) { hipLaunchKernelGGL((dense_kernel<MT, 1>), grid, block, 0, s, X, W, bias, Y, rows, K, M, act, vec_ok); return; }
     if (sm == 2) { hipLaunchKernelGGL((dense_kernel<MT, 2>), grid, block, 0, s, X, W, bias, Y, rows, K, M, act, vec_ok); return; }
@@ -258,9 +261,15 @@ void dense(hipStream_t s, const float *X, const float *W, const float *bias, flo
     else hipLaunchKernelGGL((dense_narrow_kernel<2>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
     return;
   }
-  if (M <= 32) launch<1>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
-  else if (M <= 64) launch<2>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
-  else if (M <= 128) launch<4>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
+  // MT = output tiles per workgroup: as many as the layer has (X is staged once per workgroup), but never
+  // so many that a small batch leaves most of the 256 CUs idle.
+  const int64_t row_blocks = (rows + 32 * WAVES - 1) / (32 * WAVES);
+  int mt = M <= 32 ? 1 : M <= 64 ? 2 : M <= 128 ? 4 : 8;
+  if (softmax_mode == 0)
+    while (mt > 1 && row_blocks * ((M + 32 * mt - 1) / (32 * mt)) < 512) mt >>= 1;
+  if (mt == 1) launch<1>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
+  else if (mt == 2) launch<2>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
+  else if (mt == 4) launch<4>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   else launch<8>(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
 }
 

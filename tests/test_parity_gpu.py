@@ -329,3 +329,40 @@ print(json.dumps({"errors": errors, "same": len(outs) == 80 and all(np.array_equ
         res[mode] = json.loads(out.stdout.strip().splitlines()[-1])
         assert res[mode]["errors"] == [] and res[mode]["same"], res[mode]
     assert res["0"]["sum"] == res["1"]["sum"]
+
+
+def test_resnet18_full_width_vs_oracle(api, tmp_path):
+    """Full-width ResNet-18 topology (64..512 channels: every tiled-NHWC conv variant, stride-2 and 1x1
+    downsample convs, residual adds, BN folding, max/global-average pooling) at 64x64 input."""
+    from infera_amd import onnx_writer as W, synth
+    from oracle import oracle
+
+    path = W.write(str(tmp_path / "rn64.onnx"), W.resnet18(classes=10, in_hw=64, width=64))
+    api.load_model("rn64", path)
+    plan = api.get_plan("rn64")
+    assert plan["activation_layout"] == "NHWC" and plan["exec"].count("conv_tiled_nhwc") == 19
+    imgs = synth.table(21, 0, 3, 3 * 64 * 64)
+    got = api.predict_from_blob("rn64", imgs.tobytes())
+    want = oracle.Model(path).predict_blob(imgs.tobytes())
+    assert got.shape == (3, 10)
+    assert_close(got, want)
+    api.unload_model("rn64")
+
+
+def test_conv_plan_falls_back_to_nchw_when_flatten_needs_it(api, tmp_path):
+    """Conv -> Flatten(C*H*W) -> Gemm consumes the feature map in NCHW order: the plan must stay NCHW."""
+    from infera_amd import onnx_writer as W
+    from oracle import oracle
+
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((8, 3, 3, 3)).astype(np.float32) * 0.2
+    fc = rng.standard_normal((8 * 6 * 6, 5)).astype(np.float32) * 0.1
+    nodes = [W.node("Conv", ["X", "w"], ["c"], [W.attr_ints("kernel_shape", [3, 3])]), W.node("Relu", ["c"], ["r"]),
+             W.node("Flatten", ["r"], ["f"], [W.attr_i("axis", 1)]), W.node("MatMul", ["f", "fc"], ["Y"])]
+    blob = W.model("convfc", nodes, [W.tensor("w", w), W.tensor("fc", fc)], [W.value_info("X", ["N", 3, 8, 8])], [W.value_info("Y", ["N", 5])])
+    path = W.write(str(tmp_path / "convfc.onnx"), blob)
+    api.load_model("convfc", path)
+    assert api.get_plan("convfc")["activation_layout"] == "NCHW"
+    x = rng.standard_normal((4, 3, 8, 8)).astype(np.float32)
+    assert_close(api.predict_from_blob("convfc", x.tobytes()), oracle.Model(path).predict_blob(x.tobytes()))
+    api.unload_model("convfc")
