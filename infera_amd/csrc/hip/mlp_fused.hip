@@ -298,6 +298,166 @@ __global__ __launch_bounds__(C::WAVES * 64) void mlp3_kernel(const float *__rest
   }
 }
 
+// ---- two-waves-per-SIMD variant ------------------------------------------------------------------------
+// Same math and packed blob as mlp3_kernel, but 8 waves per workgroup (two per SIMD, <= 256 registers
+// each) so that one wave's VALU-only phases, s_waitcnt stalls and epilogue are covered by the sibling
+// wave's MFMAs.  To fit 256 registers layer 1 is evaluated in SPLIT feature halves; each half is fed to
+// layer 2 (a partial sum over that half's k range) before the next half is computed, so only
+// MT1/SPLIT accumulator tiles are live at a time.  X stays in registers across the halves.  The narrow
+// head runs on the VALU at the end of the tile (no cross-tile software pipelining needed here).
+template <class C, int SPLIT, int P2S, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp3_split_kernel(const float *__restrict__ X, const float *__restrict__ packed,
+                                                        float *__restrict__ Y, int64_t rows) {
+  static_assert(C::L3V && C::MT1 % SPLIT == 0 && C::G1 % SPLIT == 0, "split kernel: VALU head, even split");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(packed);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+    for (int i = threadIdx.x; i < C::L_SMALL / 4; i += NW * 64) dst[i] = src[i];
+    const f32x4 *ssrc = reinterpret_cast<const f32x4 *>(packed + C::OFF_SMALL);
+    f32x4 *sdst = reinterpret_cast<f32x4 *>(lds + C::L_SMALL);
+    for (int i = threadIdx.x; i < C::N_SMALL / 4; i += NW * 64) sdst[i] = ssrc[i];
+  }
+  __syncthreads();
+  const f32x4 *w1 = reinterpret_cast<const f32x4 *>(lds + C::L_W1) + lane;
+  const f32x4 *w2l = reinterpret_cast<const f32x4 *>(lds + C::L_W2) + lane;
+  const float *small = lds + C::L_SMALL;
+  const f32x4 *b1 = reinterpret_cast<const f32x4 *>(small + C::S_B1) + h;
+  const f32x4 *b2 = reinterpret_cast<const f32x4 *>(small + C::S_B2) + h;
+  const f32x4 *w3 = reinterpret_cast<const f32x4 *>(small + C::S_W3) + h * C::D3;
+  const float *b3 = small + C::S_B3;
+  const f32x4 *w2g_base = reinterpret_cast<const f32x4 *>(packed + C::OFF_W2) + lane;
+
+  const int64_t ntiles = (rows + 31) >> 5;
+  const int64_t tstride = int64_t(gridDim.x) * NW;
+  int64_t tile = int64_t(blockIdx.x) * NW + wave;
+  if (tile >= ntiles) return;
+
+  auto load_x = [&](f32x4(&x)[C::G0], int64_t t) {
+    int64_t row = (t << 5) + r;
+    if (row >= rows) row = rows - 1;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(X + row * C::D0 + 4 * h);
+#pragma unroll
+    for (int g = 0; g < C::G0; g++) x[g] = p[2 * g];
+  };
+
+  constexpr int MTH = C::MT1 / SPLIT, G1H = C::G1 / SPLIT;
+  constexpr int U1H = C::G0 * MTH, P1 = C::P1;
+  constexpr int U2 = C::G1 * C::MT2, U2H = G1H * C::MT2, P2 = P2S;
+  constexpr int U2L = C::NL2 * C::MT2;
+  constexpr int NQ = C::MT2 * 4;
+  // unit after which next tile's X may be requested: x must be dead (last split) and, if possible, the
+  // last L2 fragment load of the tile already issued
+  constexpr int LAST_G = U2L < U2 ? U2 - P2 - 1 : -1;
+  constexpr int XPF = LAST_G > U2 - U2H ? LAST_G : U2 - U2H;
+  static_assert(U1H >= P1 && U2H >= P2, "chain too small for the pipeline depths");
+
+  f32x4 x[C::G0];
+  load_x(x, tile);
+  for (; tile < ntiles; tile += tstride) {
+    const bool has_next = tile + tstride < ntiles;
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    const f32x4 *w2g = w2g_base + zero;
+    auto frag2 = [&](int u) -> f32x4 { return u < U2L ? w2l[u * 64] : w2g[u * 64]; };
+
+    f32x16 acc2[C::MT2];
+#pragma unroll
+    for (int mt = 0; mt < C::MT2; mt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc2[mt][i] = 0.f;
+    f32x4 ring2[P2];
+#pragma unroll
+    for (int u = 0; u < P2; u++) ring2[u] = frag2(u);
+
+#pragma unroll
+    for (int s = 0; s < SPLIT; s++) {
+      // ---- layer 1, feature tiles [s*MTH, (s+1)*MTH) ----
+      f32x16 acc1[MTH];
+#pragma unroll
+      for (int mt = 0; mt < MTH; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc1[mt][i] = 0.f;
+      {
+        f32x4 ring1[P1];
+#pragma unroll
+        for (int u = 0; u < P1; u++) ring1[u] = w1[((u / MTH) * C::MT1 + s * MTH + (u % MTH)) * 64];
+#pragma unroll
+        for (int u = 0; u < U1H; u++) {
+          const int g = u / MTH, mt = u % MTH;
+          const f32x4 a = ring1[u % P1];
+          if (u + P1 < U1H) ring1[u % P1] = w1[(((u + P1) / MTH) * C::MT1 + s * MTH + ((u + P1) % MTH)) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x[g][j], acc1[mt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- layer 2, k groups [s*G1H, (s+1)*G1H): partial sums into acc2 ----
+      f32x4 bring1[2];
+      bring1[0] = b1[(s * G1H) * 2];
+#pragma unroll
+      for (int gl = 0; gl < G1H; gl++) {
+        const int g = s * G1H + gl, ktl = gl / 4, rg = gl % 4;
+        const f32x4 bq = bring1[gl % 2];
+        if (gl + 1 < G1H) bring1[(gl + 1) % 2] = b1[(g + 1) * 2];
+        float hv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) hv[j] = apply_act_c<C::A1>(acc1[ktl][4 * rg + j] + bq[j], 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < C::MT2; mt++) {
+          const int u = g * C::MT2 + mt;
+          const f32x4 a = ring2[u % P2];
+          if (u + P2 < U2) ring2[u % P2] = frag2(u + P2);
+          if (u == XPF && has_next) load_x(x, tile + tstride);  // x is dead in the last split
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], hv[j], acc2[mt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- narrow head on the VALU ----
+    float yacc[C::D3];
+#pragma unroll
+    for (int m = 0; m < C::D3; m++) yacc[m] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int kt = q / 4, rg = q % 4;
+      const f32x4 bq = b2[q * 2];
+#pragma unroll
+      for (int m = 0; m < C::D3; m++) {
+        const f32x4 wq = w3[q * 2 * C::D3 + m];
+#pragma unroll
+        for (int j = 0; j < 4; j++) yacc[m] = fmaf(wq[j], apply_act_c<C::A2>(acc2[kt][4 * rg + j] + bq[j], 0.f, 0.f), yacc[m]);
+      }
+    }
+    const int64_t row = (tile << 5) + r;
+#pragma unroll
+    for (int m = 0; m < C::D3; m++) {
+      const float tot = yacc[m] + __shfl_xor(yacc[m], 32);
+      if (h == 0 && row < rows) Y[row * C::D3 + m] = apply_act_c<C::A3>(tot + b3[m], 0.f, 0.f);
+    }
+  }
+}
+
+template <class C, int SPLIT, int P2S, int NW = 8>
+void launch_split(hipStream_t s, const float *X, const float *packed, float *Y, int64_t rows, int num_cus) {
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp3_split_kernel<C, SPLIT, P2S, NW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::N_LDS * 4);
+    attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+  }
+  const int64_t ntiles = (rows + 31) / 32;
+  int64_t blocks = (ntiles + NW - 1) / NW;
+  if (blocks > num_cus) blocks = num_cus;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((mlp3_split_kernel<C, SPLIT, P2S, NW>), dim3((unsigned)blocks), dim3(NW * 64), C::N_LDS * 4, s, X, packed, Y, rows);
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 
 // k index consumed by MFMA k-step s (0-based within the layer) on lane half h.
@@ -430,17 +590,32 @@ void mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packe
       case 3: launch_cfg<CfgC2_v3>(s, X, packed, Y, rows, num_cus); return;
       case 4: launch_cfg<CfgC2_v4>(s, X, packed, Y, rows, num_cus); return;
       case 5: launch_cfg<CfgC2_v5>(s, X, packed, Y, rows, num_cus); return;
+      case 6: launch_split<CfgC2, 2, 8>(s, X, packed, Y, rows, num_cus); return;
+      case 7: launch_split<CfgC2, 2, 4>(s, X, packed, Y, rows, num_cus); return;
+      case 8: launch_split<CfgC2, 4, 8>(s, X, packed, Y, rows, num_cus); return;
+      case 9: launch_split<CfgC2, 8, 8>(s, X, packed, Y, rows, num_cus); return;
+      case 10: launch_split<CfgC2, 8, 4, 12>(s, X, packed, Y, rows, num_cus); return;
+      case 11: launch_split<CfgC2, 4, 4, 12>(s, X, packed, Y, rows, num_cus); return;
+      case 12: launch_split<CfgC2, 4, 4>(s, X, packed, Y, rows, num_cus); return;
+      case 13: launch_cfg<CfgC2>(s, X, packed, Y, rows, num_cus); return;  // the one-wave-per-SIMD kernel
       default: break;
     }
   }
 #endif
-#define X_(C) if (matches<C>(sh)) { launch_cfg<C>(s, X, packed, Y, rows, num_cus); return; }
+  // shipped choice (round-1 A/B, 10M rows): two waves per SIMD with layer 1 in 4 feature slices 6.77-6.83 ms
+  // vs one wave per SIMD 7.11 ms; 3 waves per SIMD 6.9 ms.  Heads wider than 4 keep the 1-wave kernel.
+#define X_(C)                                                                  \
+  if (matches<C>(sh)) {                                                        \
+    if constexpr (C::L3V) launch_split<C, 4, 8, 8>(s, X, packed, Y, rows, num_cus); \
+    else launch_cfg<C>(s, X, packed, Y, rows, num_cus);                        \
+    return;                                                                    \
+  }
   INFERA_MLP3_CONFIGS(X_)
 #undef X_
 }
 
 const char *mlp3_kernel_name(const Mlp3Shape &sh) {
-#define X_(C) if (matches<C>(sh)) return "mlp3_kernel<" #C ">";
+#define X_(C) if (matches<C>(sh)) return C::L3V ? "mlp3_split_kernel<" #C ", 4, 8, 8>" : "mlp3_kernel<" #C ">";
   INFERA_MLP3_CONFIGS(X_)
 #undef X_
   return "";
