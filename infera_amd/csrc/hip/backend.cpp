@@ -208,7 +208,10 @@ void schedule(LoadedModel &m) {
         uses[size_t(st[i].out)] == 1 && uses[size_t(st[i + 1].out)] == 1) {
       kern::Mlp3Shape sh{int(st[i].K), int(st[i].M), int(st[i + 1].M), int(st[i + 2].M), int(st[i].act), int(st[i + 1].act),
                          int(st[i + 2].act)};
-      if (kern::mlp3_supported(sh)) {
+      std::string why;
+      // only parameter-free activations can be baked into the fused chain (LeakyRelu/Clip carry arguments)
+      const bool acts_ok = sh.act1 <= 3 && sh.act2 <= 3 && sh.act3 <= 3;
+      if (acts_ok && kern::mlp3_supported(sh, &why)) {
         m.exec[i] = ExecKind::Mlp3Head;
         m.exec[i + 1] = m.exec[i + 2] = ExecKind::Skipped;
         m.mlp3_shape = sh;
@@ -216,6 +219,7 @@ void schedule(LoadedModel &m) {
         i += 2;
         continue;
       }
+      if (!why.empty()) log_msg(2, "model '" + m.name + "': Dense x3 chain stays layer-by-layer: " + why);
     }
     // Dense + row Softmax over exactly its M outputs: softmax in the GEMM epilogue
     if (i + 1 < n && st[i].kind == StepKind::Dense && st[i + 1].kind == StepKind::Softmax && st[i + 1].in0 == st[i].out &&
@@ -365,8 +369,12 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
       switch (m.exec[i]) {
         case ExecKind::Skipped: continue;
         case ExecKind::Mlp3Head:
-          kern::mlp3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_packed, buf(st[i + 2].out), nr, dm.num_cus);
+        {
+          std::string why;
+          if (!kern::mlp3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_packed, buf(st[i + 2].out), nr, dm.num_cus, &why))
+            throw InferaError::onnx("fused MLP kernel launch failed: " + why);
           continue;
+        }
         case ExecKind::DenseSoftmax:
           kern::dense(s, buf(x.in0), d.W, d.bias, buf(st[i + 1].out), nr, int(x.K), int(x.M), act_of(x),
                       st[i + 1].log_softmax ? 2 : 1);

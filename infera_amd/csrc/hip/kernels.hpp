@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <string>
 
 namespace infera_hip::kern {
 
@@ -43,13 +44,17 @@ struct Mlp3Shape {
   int d0, d1, d2, d3;
   int act1, act2, act3;  // only None/Relu chains are instantiated ahead of time
 };
-bool mlp3_supported(const Mlp3Shape &sh);
+// True if a fused kernel exists for the chain: an ahead-of-time instantiation, or one compiled right now
+// by hipRTC from the same device source (needs a visible GPU).  On false, `why` explains and the caller
+// keeps the layer-by-layer plan.
+bool mlp3_supported(const Mlp3Shape &sh, std::string *why = nullptr);
 // Size in floats of the packed weight blob and host-side packing (fragment-major order, see mlp_fused.hip).
 size_t mlp3_packed_floats(const Mlp3Shape &sh);
 void mlp3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                const float *b3, float *packed);
-void mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus);
-const char *mlp3_kernel_name(const Mlp3Shape &sh);
+bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
+          std::string *why = nullptr);
+std::string mlp3_kernel_name(const Mlp3Shape &sh);
 
 // ---- convolution / pooling (conv.hip) ----------------------------------------------------------
 struct ConvGeom {

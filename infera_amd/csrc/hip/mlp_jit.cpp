@@ -1,0 +1,242 @@
+#include "mlp_jit.hpp"
+
+#include <dlfcn.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "mlp_layout.hpp"
+
+// generated at build time from hip/mlp_device.inc (csrc/Makefile): `static const char kMlpDeviceSrc[] = R"..."`
+#include "mlp_device_src.inc"
+
+namespace infera_hip::kern {
+
+namespace {
+
+// ---- minimal hipRTC binding, resolved with dlopen so libinfera.so has no link-time dependency on it ----
+using hiprtcProgram = struct _hiprtcProgram *;
+struct Rtc {
+  void *lib = nullptr;
+  int (*CreateProgram)(hiprtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+  int (*AddNameExpression)(hiprtcProgram, const char *) = nullptr;
+  int (*CompileProgram)(hiprtcProgram, int, const char **) = nullptr;
+  int (*GetLoweredName)(hiprtcProgram, const char *, const char **) = nullptr;
+  int (*GetCodeSize)(hiprtcProgram, size_t *) = nullptr;
+  int (*GetCode)(hiprtcProgram, char *) = nullptr;
+  int (*GetProgramLogSize)(hiprtcProgram, size_t *) = nullptr;
+  int (*GetProgramLog)(hiprtcProgram, char *) = nullptr;
+  int (*DestroyProgram)(hiprtcProgram *) = nullptr;
+  std::string why;
+  bool ok = false;
+};
+
+const Rtc &rtc() {
+  static const Rtc r = [] {
+    Rtc x;
+    for (const char *name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+      x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (x.lib) break;
+    }
+    if (!x.lib) {
+      x.why = std::string("hipRTC not available: ") + dlerror();
+      return x;
+    }
+#define SYM(field, sym)                                                            \
+  x.field = reinterpret_cast<decltype(x.field)>(dlsym(x.lib, sym));               \
+  if (!x.field) {                                                                  \
+    x.why = std::string("hipRTC symbol missing: ") + sym;                         \
+    return x;                                                                      \
+  }
+    SYM(CreateProgram, "hiprtcCreateProgram")
+    SYM(AddNameExpression, "hiprtcAddNameExpression")
+    SYM(CompileProgram, "hiprtcCompileProgram")
+    SYM(GetLoweredName, "hiprtcGetLoweredName")
+    SYM(GetCodeSize, "hiprtcGetCodeSize")
+    SYM(GetCode, "hiprtcGetCode")
+    SYM(GetProgramLogSize, "hiprtcGetProgramLogSize")
+    SYM(GetProgramLog, "hiprtcGetProgramLog")
+    SYM(DestroyProgram, "hiprtcDestroyProgram")
+#undef SYM
+    x.ok = true;
+    return x;
+  }();
+  return r;
+}
+
+using Key = std::tuple<int, int, int, int, int, int, int>;
+Key key_of(const Mlp3Shape &s) { return {s.d0, s.d1, s.d2, s.d3, s.act1, s.act2, s.act3}; }
+
+struct Compiled {
+  bool ok = false;
+  std::string why, expr, lowered;
+  std::vector<char> code;
+  int threads = 256, lds_bytes = 0;
+  std::map<int, hipFunction_t> fn_by_device;
+};
+
+std::mutex g_mu;
+std::map<Key, Compiled> g_cache;
+
+// Picks the kernel template and its tuning parameters for a shape; returns the name expression.
+bool plan_kernel(const Mlp3Shape &s, const Mlp3Layout &L, std::string &expr, int &threads, std::string &why) {
+  if (s.d0 % 8 || s.d1 % 32 || s.d2 % 32 || s.d0 < 8 || s.d1 < 32 || s.d2 < 32 || s.d3 < 1 || s.d3 > 32) {
+    why = "chain dims must satisfy d0%8==0, d1%32==0, d2%32==0, 1<=d3<=32";
+    return false;
+  }
+  for (int a : {s.act1, s.act2, s.act3})
+    if (a < 0 || a > 3) {
+      why = "only None/Relu/Sigmoid/Tanh can be fused";
+      return false;
+    }
+  if (!L.fits_lds) {
+    why = "layer-1 fragments exceed the 160 KiB LDS";
+    return false;
+  }
+  const std::string cfg_head = "infera_hip::kern::mlpdev::Cfg<" + std::to_string(s.d0) + "," + std::to_string(s.d1) + "," +
+                               std::to_string(s.d2) + "," + std::to_string(s.d3) + "," + std::to_string(s.act1) + "," +
+                               std::to_string(s.act2) + "," + std::to_string(s.act3) + ",4,";
+  const int U2 = L.G1 * L.MT2;
+  // two waves per SIMD (<= 256 registers): x = G0*4, two layer-1 tiles, acc2 = MT2*16, rings
+  if (L.l3v && L.MT1 >= 2) {
+    const int mth = (L.MT1 % 2 == 0) ? 2 : 1, split = L.MT1 / mth;
+    const int u2h = (L.G1 / split) * L.MT2, p2s = u2h >= 8 ? 8 : 4;
+    const int regs = L.G0 * 4 + mth * 16 + L.MT2 * 16 + 12 + p2s * 4 + 40;
+    const int p1 = L.G0 * mth < 3 ? L.G0 * mth : 3;
+    if (regs <= 250 && u2h >= p2s && L.G1 % split == 0) {
+      expr = "infera_hip::kern::mlpdev::mlp3_split_kernel<" + cfg_head + std::to_string(p1) + ",16>," + std::to_string(split) + "," +
+             std::to_string(p2s) + ",8>";
+      threads = 512;
+      return true;
+    }
+  }
+  // one wave per SIMD (<= 512 registers)
+  int p2 = 16;
+  while (p2 > U2) p2 >>= 1;
+  const int regs = L.G0 * 4 + L.MT1 * 16 + L.MT2 * 16 * (L.l3v ? 2 : 1) + (L.l3v ? 0 : 16) + 12 + p2 * 4 + 48;
+  const int nq = L.MT2 * 4;
+  const int u1 = L.G0 * L.MT1, p1 = u1 < 3 ? u1 : 3;
+  if (regs <= 480 && p2 >= 1 && (!L.l3v || u1 > nq) && (L.l3v || L.G2 >= 2)) {
+    expr = "infera_hip::kern::mlpdev::mlp3_kernel<" + cfg_head + std::to_string(p1) + "," + std::to_string(p2) + ">>";
+    threads = 256;
+    return true;
+  }
+  why = "chain too wide for the register budget of the fused kernels (est. " + std::to_string(regs) + " registers)";
+  return false;
+}
+
+Compiled &compile_locked(const Mlp3Shape &s) {
+  Compiled &c = g_cache[key_of(s)];
+  if (c.ok || !c.why.empty()) return c;
+  const Mlp3Layout L = mlp3_layout(s.d0, s.d1, s.d2, s.d3);
+  if (!plan_kernel(s, L, c.expr, c.threads, c.why)) return c;
+  c.lds_bytes = L.N_LDS * 4;
+  const Rtc &r = rtc();
+  if (!r.ok) {
+    c.why = r.why;
+    return c;
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    c.why = "no HIP device to compile for";
+    return c;
+  }
+  // hipRTC pre-includes its own runtime header (threadIdx, __global__, device math); no #include needed
+  const std::string src = kMlpDeviceSrc;
+  hiprtcProgram prog = nullptr;
+  if (r.CreateProgram(&prog, src.c_str(), "infera_mlp_jit.hip", 0, nullptr, nullptr) != 0) {
+    c.why = "hiprtcCreateProgram failed";
+    return c;
+  }
+  r.AddNameExpression(prog, c.expr.c_str());
+  const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const char *opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+  const int rc = r.CompileProgram(prog, 3, opts);
+  if (rc != 0) {
+    size_t n = 0;
+    r.GetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) r.GetProgramLog(prog, log.data());
+    c.why = "hipRTC compile failed: " + log.substr(0, 600);
+    r.DestroyProgram(&prog);
+    return c;
+  }
+  const char *low = nullptr;
+  size_t n = 0;
+  if (r.GetLoweredName(prog, c.expr.c_str(), &low) != 0 || !low || r.GetCodeSize(prog, &n) != 0 || n == 0) {
+    c.why = "hipRTC produced no code object";
+    r.DestroyProgram(&prog);
+    return c;
+  }
+  c.lowered = low;
+  c.code.resize(n);
+  r.GetCode(prog, c.code.data());
+  r.DestroyProgram(&prog);
+  c.ok = true;
+  return c;
+}
+
+}  // namespace
+
+bool mlp3_jit_prepare(const Mlp3Shape &sh, std::string *why) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Compiled &c = compile_locked(sh);
+  if (!c.ok && why) *why = c.why;
+  return c.ok;
+}
+
+bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows,
+                     int num_cus, std::string *why) {
+  hipFunction_t fn = nullptr;
+  int threads = 256, lds = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Compiled &c = compile_locked(sh);
+    if (!c.ok) {
+      if (why) *why = c.why;
+      return false;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto it = c.fn_by_device.find(dev);
+    if (it == c.fn_by_device.end()) {
+      hipModule_t mod = nullptr;
+      hipError_t e = hipModuleLoadData(&mod, c.code.data());
+      if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, c.lowered.c_str());
+      if (e == hipSuccess && c.lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds_bytes);
+      if (e != hipSuccess) {
+        if (why) *why = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
+        return false;
+      }
+      c.fn_by_device[dev] = fn;
+    } else {
+      fn = it->second;
+    }
+    threads = c.threads;
+    lds = c.lds_bytes;
+  }
+  const int waves = threads / 64;
+  const int64_t ntiles = (rows + 31) / 32;
+  int64_t blocks = (ntiles + waves - 1) / waves;
+  if (blocks > num_cus) blocks = num_cus;
+  if (blocks < 1) blocks = 1;
+  void *args[] = {(void *)&X, (void *)&packed, (void *)&Y, (void *)&rows};
+  hipError_t e = hipModuleLaunchKernel(fn, unsigned(blocks), 1, 1, unsigned(threads), 1, 1, unsigned(lds), s, args, nullptr);
+  if (e != hipSuccess) {
+    if (why) *why = std::string("hipModuleLaunchKernel: ") + hipGetErrorString(e);
+    return false;
+  }
+  return true;
+}
+
+std::string mlp3_jit_kernel_name(const Mlp3Shape &sh) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_cache.find(key_of(sh));
+  return it != g_cache.end() && it->second.ok ? it->second.expr + " [hipRTC]" : std::string();
+}
+
+}  // namespace infera_hip::kern

@@ -1,0 +1,21 @@
+// mlp_jit.hpp -- load-time specialisation of the fused-MLP device code (mlp_device.inc) with hipRTC for
+// chain shapes that have no ahead-of-time instantiation.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+
+#include "kernels.hpp"
+
+namespace infera_hip::kern {
+
+// True if a kernel for `sh` is (or was just) compiled; on failure `why` says what went wrong (shape
+// constraints, hipRTC missing, compile error) and the caller falls back to layer-by-layer kernels.
+bool mlp3_jit_prepare(const Mlp3Shape &sh, std::string *why);
+bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows,
+                     int num_cus, std::string *why);
+std::string mlp3_jit_kernel_name(const Mlp3Shape &sh);
+
+}  // namespace infera_hip::kern

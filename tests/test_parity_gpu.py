@@ -366,3 +366,72 @@ def test_conv_plan_falls_back_to_nchw_when_flatten_needs_it(api, tmp_path):
     x = rng.standard_normal((4, 3, 8, 8)).astype(np.float32)
     assert_close(api.predict_from_blob("convfc", x.tobytes()), oracle.Model(path).predict_blob(x.tobytes()))
     api.unload_model("convfc")
+
+
+def test_empty_and_multi_pass_host_inputs(api, models):
+    """Edge sizes of the host ABI: zero rows (empty DataChunk) and a call larger than the 64 MiB pinned
+    staging window (several H2D/D2H passes inside one infera_predict)."""
+    from infera_amd import synth
+    from oracle import oracle
+
+    api.load_model("mlp", models["mlp"])
+    out = api.predict("mlp", np.zeros((0, 128), np.float32))
+    assert out.size == 0
+    rows = 300_001  # 153.6 MB of features -> 3 staging passes, ragged tail
+    x = synth.table(5, 0, rows, 128)
+    got = api.predict("mlp", x)
+    om = oracle.Model(models["mlp"])
+    for s in (0, 131_000, rows - 4097):
+        assert_close(got[s:s + 4097], om.predict(x[s:s + 4097]))
+    api.load_model("idn", models["identity_dyn"])
+    assert api.predict("idn", np.zeros((0, 4), np.float32)).size == 0
+    api.unload_model("idn")
+    # unaligned BLOB pointer (DuckDB string_t payloads carry no alignment guarantee)
+    raw = bytearray(1 + 128 * 4 * 3)
+    raw[1:] = x[:3].tobytes()
+    import ctypes as C
+    buf = (C.c_uint8 * len(raw)).from_buffer(raw)
+    L = api.load_library()
+    res = L.infera_predict_from_blob(b"mlp", C.addressof(buf) + 1, 128 * 4 * 3)
+    assert res.status == 0 and res.rows == 3
+    got3 = np.ctypeslib.as_array(res.data, shape=(3,)).copy()
+    L.infera_free_result(res)
+    assert np.array_equal(got3, got[:3].ravel())
+
+
+@pytest.mark.parametrize("dims,acts,kernel", [
+    ((64, 128, 32, 1), ["Relu", "Relu", ""], "mlp3_split_kernel"),      # regression head, 2 waves/SIMD
+    ((32, 64, 64, 2), ["Sigmoid", "Tanh", ""], "mlp3_split_kernel"),    # other activations baked in
+    ((128, 96, 32, 3), ["Relu", "Relu", "Sigmoid"], "mlp3_split_kernel"),  # odd tile count (MT1 = 3)
+    ((16, 32, 32, 7), ["Relu", "", ""], "mlp3_kernel"),                 # wide head -> MFMA head, 1 wave/SIMD
+    ((256, 128, 128, 16), ["Relu", "Relu", ""], "mlp3_kernel"),         # wide input (x = 128 regs)
+])
+def test_load_time_specialised_fused_chains(api, tmp_path, dims, acts, kernel):
+    """Chains with no ahead-of-time instantiation are specialised by hipRTC at infera_load_model time
+    from the same device source; results must match the oracle and the layer-by-layer plan."""
+    import os
+    import subprocess
+    import sys
+
+    from infera_amd import onnx_writer as W, synth
+    from oracle import oracle
+
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp(dims, acts=acts))
+    api.load_model("jit", path)
+    plan = api.get_plan("jit")
+    assert plan["exec"] == ["mlp3_fused", "skipped", "skipped"], plan
+    assert kernel in plan["fused_kernel"] and "hipRTC" in plan["fused_kernel"], plan["fused_kernel"]
+    rows = 5000 + 13
+    x = synth.table(17, 3, rows, dims[0])
+    got = api.predict("jit", x)
+    assert_close(got, oracle.Model(path).predict(x))
+    api.unload_model("jit")
+    # same model with fusion disabled (fresh process: INFERA_FUSED_MLP is read once): layer-by-layer kernels
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from infera_amd import capi, synth\n"
+            "capi.load_model('m', %r); assert capi.get_plan('m')['exec'][0] == 'normal'\n"
+            "np.save(%r, capi.predict('m', synth.table(17, 3, %d, %d)))\n") % (
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, str(tmp_path / "unfused.npy"), rows, dims[0])
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, INFERA_FUSED_MLP="0"), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert_close(got, np.load(tmp_path / "unfused.npy"))
