@@ -47,19 +47,30 @@ def parse_args():
 
 def cpu_baseline(model_path: str, cols: int, target_s: float) -> dict:
     """The oracle ("port") timed on this box's host cores with the reference's execution shape:
-    T threads, 2048-row chunks, per-cell boxed gather, single-threaded graph per chunk."""
+    T threads, 2048-row chunks, per-cell boxed gather, single-threaded graph per chunk.  T is the best
+    of a short sweep (containers often expose more logical CPUs than their cgroup lets them use at
+    once; oversubscribed threads get throttled and the scan slows down)."""
     from oracle import oracle
 
     m = oracle.Model(model_path)
-    threads = os.cpu_count() or 1
-    probe_rows = 2048 * threads * 2
-    sec, _ = m.bench_scan(probe_rows, cols, seed=42, threads=threads, chunk_rows=2048, boxed=True)
-    rate = probe_rows / max(sec, 1e-9)
-    rows = int(max(probe_rows, min(rate * target_s, 50_000_000)) // 2048 * 2048)
-    sec, _ = m.bench_scan(rows, cols, seed=42, threads=threads, chunk_rows=2048, boxed=True)
-    return {"value": rows / sec, "unit": "rows/s", "cores": threads, "kind": "port",
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    cands = sorted({max(1, ncpu // d) for d in (16, 8, 4, 2, 1)})
+    best_t, best_rate = 1, 0.0
+    for t in cands:
+        rows = 2048 * t * 2
+        sec, _ = m.bench_scan(rows, cols, seed=42, threads=t, chunk_rows=2048, boxed=True)
+        if rows / sec > best_rate:
+            best_t, best_rate = t, rows / sec
+    rows = int(max(2048 * best_t * 2, min(best_rate * target_s, 50_000_000)) // 2048 * 2048)
+    sec, _ = m.bench_scan(rows, cols, seed=42, threads=best_t, chunk_rows=2048, boxed=True)
+    return {"value": rows / sec, "unit": "rows/s", "cores": best_t, "kind": "port",
             "sample": f"{rows} rows x {cols} f32 in 2048-row chunks, oracle/infera_oracle.c orc_bench_scan, "
-                      f"boxed per-cell gather + single-threaded graph per chunk, {sec:.2f} s wall"}
+                      f"boxed per-cell gather + single-threaded graph per chunk, {sec:.2f} s wall; "
+                      f"threads = best of sweep {cands} on {os.cpu_count()} logical CPUs"}
 
 
 def main():

@@ -89,6 +89,9 @@ struct Config {
                                       //   enqueues on MI355X/ROCm 7.2 (60 vs 82 M rows/s at 16 threads)
   bool fused_mlp;                     // INFERA_FUSED_MLP=0|1     whole-chain fused kernel when the plan allows
   uint64_t max_rows_per_pass;         // INFERA_MAX_ROWS_PER_PASS scratch bound for unfused plans
+  bool batch_split;                   // INFERA_BATCH_SPLIT=0|1   a model with a FIXED leading dim B accepts any multiple
+                                      //   of B rows (every supported operator is row-independent).  Default 0 =
+                                      //   the reference's behaviour: rows != B is an error (test/models/README.md:5)
   static const Config &get();
 };
 

@@ -79,7 +79,9 @@ OutShape out_shape_for_rows(const LoadedModel &m, uint64_t rows) {
   std::vector<uint64_t> shp;
   for (size_t i = 0; i < m.plan.output_shape.size(); i++) {
     int64_t d = m.plan.output_shape[i];
-    shp.push_back(d < 0 ? rows : uint64_t(d));
+    // the leading (row) axis follows the input rows: symbolic, or a fixed batch under INFERA_BATCH_SPLIT
+    const bool row_axis = i == 0 && (d < 0 || (m.plan.fixed_batch > 0 && Config::get().batch_split));
+    shp.push_back(row_axis || d < 0 ? rows : uint64_t(d));
   }
   OutShape o;
   auto rc = shape_rows_cols(shp);
@@ -108,7 +110,7 @@ OutShape validate_predict(const LoadedModel &m, uint64_t rows, uint64_t cols) {
   // inside run(); the text after "ONNX error: " is this backend's own).
   if (in.size() != 2)
     throw InferaError::onnx("input rank mismatch: model expects rank " + std::to_string(in.size()) + ", got rank 2");
-  if (in[0] > 0 && uint64_t(in[0]) != rows)
+  if (in[0] > 0 && uint64_t(in[0]) != rows && !(Config::get().batch_split && rows % uint64_t(in[0]) == 0))
     throw InferaError::onnx("input shape mismatch at axis 0: model expects " + std::to_string(in[0]) + ", got " + std::to_string(rows));
   if (in[1] > 0 && uint64_t(in[1]) != cols)
     throw InferaError::onnx("input shape mismatch at axis 1: model expects " + std::to_string(in[1]) + ", got " + std::to_string(cols));

@@ -435,3 +435,31 @@ def test_load_time_specialised_fused_chains(api, tmp_path, dims, acts, kernel):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, INFERA_FUSED_MLP="0"), capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-1500:]
     assert_close(got, np.load(tmp_path / "unfused.npy"))
+
+
+def test_config_c1_linear_1k_rows_with_batch_split(models):
+    """BASELINE config C1: the reference's linear.onnx (fixed batch of 1) on a 1,000-row x 3 FLOAT table.
+    The reference rejects any chunk with more than one row (fixed batch, test/models/README.md:5); with
+    INFERA_BATCH_SPLIT=1 (read once, hence a fresh process) the fixed leading dim is treated as the row
+    axis: expected 2*x1 - x2 + 0.5*x3 + 0.25 per row, and the dynamic-batch twin gives the same values."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from infera_amd import capi, synth
+from oracle import oracle
+capi.load_model("linear", %r); capi.load_model("twin", %r)
+x = synth.table(3, 0, 1000, 3)
+y = capi.predict("linear", x)
+want = (2 * x[:, 0].astype(np.float64) - x[:, 1] + 0.5 * x[:, 2] + 0.25).reshape(-1, 1)
+assert y.shape == (1000, 1) and np.allclose(y, want, rtol=1e-5, atol=1e-6)
+assert np.array_equal(y, capi.predict("twin", x))
+assert np.allclose(y, oracle.Model(%r).predict(x), rtol=1e-6, atol=1e-7)
+print("ok")
+''' % (root, models["linear"], models["linear_dyn"], models["linear_dyn"])
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, INFERA_BATCH_SPLIT="1"), capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
