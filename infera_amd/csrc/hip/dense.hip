@@ -230,6 +230,115 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow_kernel(const float *_
   }
 }
 
+// ---- narrowest variant: M <= 16 on v_mfma_f32_16x16x4_f32 ---------------------------------------------------
+// Half the matrix-core time of the 32-wide tile for heads like C4's 10 classes (a 32x32 tile would be 69 %
+// padding and keeps the MFMA pipe 40 % busy in an HBM-bound kernel).  Lane (n = lane&15, q = lane>>4):
+//   B operand: X[row n][16g + 4q + j]   -- one 16-byte load per lane per 16 k, 64 contiguous bytes per row
+//   A operand: W[16g + 4q + j][m = lane&15]  (zero-padded, fragment-major in LDS)
+//   D: lane holds features 4q..4q+3 of row n.
+// A wave owns 32 rows = two 16-row tiles with independent accumulators (the 16x16x4 dependent-issue
+// latency of 40 cycles is hidden by alternating them).
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+template <int SM>
+__global__ __launch_bounds__(WAVES * 64) void dense_narrow16_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                                   const float *__restrict__ bias, float *__restrict__ Y,
+                                                                   int64_t rows, int K, int M, ActParam act) {
+  extern __shared__ __attribute__((aligned(16))) float wf[];  // [K/16][64 lanes][4]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 15, q = lane >> 4;
+  const int G = K >> 4;
+  for (int i = threadIdx.x; i < G * 256; i += WAVES * 64) {
+    const int g = i >> 8, l = (i >> 2) & 63, j = i & 3;
+    const int k = 16 * g + 4 * (l >> 4) + j, m = l & 15;
+    wf[i] = m < M ? W[int64_t(k) * M + m] : 0.f;
+  }
+  __syncthreads();
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(wf) + lane;
+  float bq[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) bq[i] = (bias != nullptr && 4 * q + i < M) ? bias[4 * q + i] : 0.f;
+  const int64_t ntiles = (rows + 31) >> 5;
+  const int64_t tstride = int64_t(gridDim.x) * WAVES;
+  for (int64_t tile = int64_t(blockIdx.x) * WAVES + wave; tile < ntiles; tile += tstride) {
+    int64_t row[2];
+    bool valid[2];
+    const f32x4 *xp[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      row[t] = (tile << 5) + 16 * t + n;
+      valid[t] = row[t] < rows;
+      if (!valid[t]) row[t] = rows - 1;
+      xp[t] = reinterpret_cast<const f32x4 *>(X + row[t] * K + 4 * q);
+    }
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int g = 0;
+    // two groups per iteration = 4 row-pieces in flight per wave (four groups measured slower: 5.73 vs
+    // 5.40 ms on C4 -- the extra registers cost more occupancy than the extra loads buy)
+    for (; g + 2 <= G; g += 2) {
+      const f32x4 x00 = xp[0][4 * g], x10 = xp[1][4 * g], x01 = xp[0][4 * g + 4], x11 = xp[1][4 * g + 4];
+      const f32x4 a0 = wq[g * 64], a1 = wq[(g + 1) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x00[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x10[j], acc[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], x01[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], x11[j], acc[1], 0, 0, 0);
+      }
+    }
+    for (; g < G; g++) {
+      const f32x4 x0 = xp[0][4 * g], x1 = xp[1][4 * g];
+      const f32x4 a0 = wq[g * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x1[j], acc[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      f32x4 v = acc[t];
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[i] = apply_act(v[i] + bq[i], act);
+      if constexpr (SM != 0) {  // the row's features live in lanes n, n+16, n+32, n+48
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) mx = fmaxf(mx, v[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) {
+            const float e = expf(v[i] - mx);
+            sum += e;
+            v[i] = SM == 1 ? e : v[i] - mx;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float ls = logf(sum);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = SM == 1 ? v[i] / sum : v[i] - ls;
+      }
+      if (valid[t]) {
+        float *yrow = Y + row[t] * M + 4 * q;
+        if ((M & 1) == 0 && 4 * q + 3 < M) {  // row stride M*4 is 8-byte aligned: two 8-byte stores
+          *reinterpret_cast<f32x2 *>(yrow) = f32x2{v[0], v[1]};
+          *reinterpret_cast<f32x2 *>(yrow + 2) = f32x2{v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (4 * q + i < M) yrow[i] = v[i];
+        }
+      }
+    }
+  }
+}
+
 template <int MT>
 void launch(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
             ActParam act, int sm) {
@@ -250,6 +359,17 @@ bool dense_can_fuse_softmax(int M) { return M <= 64; }
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
            ActParam act, int softmax_mode) {
   if (rows <= 0) return;
+  if (M <= 16 && K % 16 == 0 && K <= 1024 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    const int64_t ntiles = (rows + 31) / 32;
+    int64_t blocks = (ntiles + WAVES - 1) / WAVES;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const size_t lds = size_t(K) * 16 * sizeof(float);
+    dim3 grid((unsigned)blocks), block(WAVES * 64);
+    if (softmax_mode == 0) hipLaunchKernelGGL((dense_narrow16_kernel<0>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+    else if (softmax_mode == 1) hipLaunchKernelGGL((dense_narrow16_kernel<1>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+    else hipLaunchKernelGGL((dense_narrow16_kernel<2>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+    return;
+  }
   if (M <= 32 && K % 8 == 0 && K <= 512 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
     const int64_t ntiles = (rows + 31) / 32;
     int64_t blocks = (ntiles + WAVES - 1) / WAVES;
