@@ -178,6 +178,12 @@ std::vector<EffStep> effective_steps(const LoadedModel &m) {
       case ExecKind::Skipped: break;
       case ExecKind::Mlp3Head: out.push_back({int(i), {st[i].in0}, st[i + 2].out}); break;
       case ExecKind::DenseSoftmax: out.push_back({int(i), {st[i].in0}, st[i + 1].out}); break;
+      case ExecKind::ConvTiled:
+        if (i < m.conv_fused_add.size() && m.conv_fused_add[i] >= 0)
+          out.push_back({int(i), {st[i].in0, m.conv_residual_buf[i]}, st[size_t(m.conv_fused_add[i])].out});
+        else
+          out.push_back({int(i), {st[i].in0}, st[i].out});
+        break;
       default: {
         EffStep e{int(i), {st[i].in0}, st[i].out};
         if (st[i].in1 >= 0) e.reads.push_back(st[i].in1);
@@ -254,6 +260,29 @@ void schedule(LoadedModel &m) {
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
       if (kern::conv2d_tiled_supported(g)) m.exec[i] = ExecKind::ConvTiled;
     }
+  // Residual Add (+ activation) of a ResNet block -> epilogue of whichever of its two producers runs LAST
+  // (conv2, or the 1x1 downsample conv when the block has one), the other operand being the skip tensor.
+  m.conv_fused_add.assign(n, -1);
+  m.conv_residual_buf.assign(n, -1);
+  if (m.nhwc_mode) {
+    std::vector<int> prod(m.plan.buf_per_row.size(), -1);
+    for (size_t i = 0; i < n; i++)
+      if (m.exec[i] != ExecKind::Skipped) prod[size_t(st[i].out)] = int(i);
+    for (size_t j = 0; j < n; j++) {
+      const Step &a = st[j];
+      if (m.exec[j] != ExecKind::Normal || a.kind != StepKind::BinaryAct || a.bop != '+' || !is4d(a.out)) continue;
+      const int pa = prod[size_t(a.in0)], pb = prod[size_t(a.in1)];
+      const int late = std::max(pa, pb);
+      if (late < 0 || a.in0 == a.in1) continue;
+      const int fused_in = late == pa ? a.in0 : a.in1, skip = late == pa ? a.in1 : a.in0;
+      const Step &c = st[size_t(late)];
+      if (m.exec[size_t(late)] != ExecKind::ConvTiled || c.act != Act::None || uses[size_t(fused_in)] != 1) continue;
+      if (m.conv_fused_add[size_t(late)] >= 0) continue;
+      m.conv_fused_add[size_t(late)] = int(j);
+      m.conv_residual_buf[size_t(late)] = skip;
+      m.exec[j] = ExecKind::Skipped;
+    }
+  }
 
   // scratch slots by liveness: a slot is reused once its buffer has been read for the last time
   auto eff = effective_steps(m);
@@ -382,7 +411,9 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case ExecKind::ConvTiled: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
-          kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x));
+          const int fj = m.conv_fused_add[i];
+          if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, g, act_of(st[size_t(fj)]));
+          else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x));
           continue;
         }
         default: break;

@@ -56,6 +56,10 @@ class LoadedModel {
   // Convolutional plans keep every 4-D activation except the caller's input CHANNELS-LAST (NHWC) so
   // the implicit-GEMM gathers and stores are 16-byte vectors; decided per plan in schedule().
   bool nhwc_mode = false;
+  // A ConvTiled step that absorbed the residual Add (+ activation) following it: per conv step, the
+  // index of the fused BinaryAct step (-1: none) and which of its operands is the skip tensor.
+  std::vector<int> conv_fused_add;
+  std::vector<int> conv_residual_buf;
   std::vector<int> slot_of_buf;        // scratch slot per activation buffer (-1: external in/out)
   std::vector<int64_t> slot_per_row;   // floats per row of each scratch slot
   int64_t scratch_per_row = 0;         // sum over slots

@@ -121,8 +121,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
 //   = Wt[m = 32mt + (lane&31)][tap][c = 32cc + 8g + 4*(lane>>5) + j]
 template <int MT>
 __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
-                                                             const float *__restrict__ bias, float *__restrict__ Y,
-                                                             int64_t total_pix, ConvGeom g, ActParam act) {
+                                                             const float *__restrict__ bias, const float *__restrict__ residual,
+                                                             float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
   __shared__ __attribute__((aligned(16))) float wbuf[2][MT * 1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -196,17 +196,60 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   }
   if (!pvalid) return;
   // epilogue: lane (r,h) holds pixel `pix`, channels 32*(mt0+t) + 8*q + 4h + j -> one 16-byte NHWC store per quad
+  // (optional residual: the block's skip tensor, same NHWC layout -- the Add of a ResNet block is fused here)
   float *yp = Y + pix * g.M + 32 * mt0 + 4 * h;
+  const float *rp = residual ? residual + pix * g.M + 32 * mt0 + 4 * h : nullptr;
   const float *bp = bias ? bias + 32 * mt0 + 4 * h : nullptr;
 #pragma unroll
   for (int t = 0; t < MT; t++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      f32x4 v;
+      f32x4 v, res = {0.f, 0.f, 0.f, 0.f};
+      if (rp) res = *reinterpret_cast<const f32x4 *>(rp + 32 * t + 8 * q);
 #pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = apply_act(acc[t][4 * q + j] + (bp ? bp[32 * t + 8 * q + j] : 0.f), act);
+      for (int j = 0; j < 4; j++) {
+        float x = acc[t][4 * q + j] + (bp ? bp[32 * t + 8 * q + j] : 0.f);
+        if (rp) x += res[j];
+        v[j] = apply_act(x, act);
+      }
       *reinterpret_cast<f32x4 *>(yp + 32 * t + 8 * q) = v;
     }
+}
+
+// NHWC pooling, 4 channels (16 bytes) per thread: consecutive lanes walk the channel axis, so every tap
+// is a fully coalesced read and the output a coalesced 16-byte store.
+__global__ __launch_bounds__(kBlock) void pool2d_nhwc4_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total4,
+                                                             int C4, int H, int W, int OH, int OW, int kh, int kw, int sh,
+                                                             int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X);
+  f32x4 *y4 = reinterpret_cast<f32x4 *>(Y);
+  for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < total4; o += stride) {
+    const int c4 = int(o % C4);
+    const int ow = int((o / C4) % OW);
+    const int oh = int((o / (int64_t(C4) * OW)) % OH);
+    const int64_t n = o / (int64_t(C4) * OW * OH);
+    f32x4 acc = is_max ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    for (int i = 0; i < kh; i++) {
+      const int iy = oh * sh - pt + i * dh;
+      if (iy < 0 || iy >= H) continue;
+      for (int j = 0; j < kw; j++) {
+        const int ix = ow * sw - pl + j * dw;
+        if (ix < 0 || ix >= W) continue;
+        const f32x4 v = x4[((n * H + iy) * W + ix) * C4 + c4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] = is_max ? fmaxf(acc[e], v[e]) : acc[e] + v[e];
+        cnt++;
+      }
+    }
+    if (!is_max) {
+      const float d = float(count_pad ? kh * kw : (cnt ? cnt : 1));
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[e] = acc[e] / d;
+    }
+    y4[o] = acc;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void pool2d_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total,
@@ -325,15 +368,15 @@ void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed) {
             }
 }
 
-void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
-                  const ConvGeom &g, ActParam act) {
+void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y,
+                  int64_t rows, const ConvGeom &g, ActParam act) {
   const int64_t total_pix = rows * g.OH * g.OW;
   if (total_pix <= 0) return;
   const unsigned bx = unsigned((total_pix + 127) / 128);
   if (g.M % 128 == 0) {
-    hipLaunchKernelGGL(conv2d_tiled_kernel<4>, dim3(bx, unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, Y, total_pix, g, act);
+    hipLaunchKernelGGL(conv2d_tiled_kernel<4>, dim3(bx, unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
   } else {
-    hipLaunchKernelGGL(conv2d_tiled_kernel<2>, dim3(bx, unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, Y, total_pix, g, act);
+    hipLaunchKernelGGL(conv2d_tiled_kernel<2>, dim3(bx, unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
   }
 }
 
@@ -341,6 +384,11 @@ void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H,
             int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool nhwc) {
   const int64_t total = rows * C * OH * OW;
   if (total <= 0) return;
+  if (nhwc && C % 4 == 0) {
+    hipLaunchKernelGGL(pool2d_nhwc4_kernel, dim3(grid_for(total / 4)), dim3(kBlock), 0, s, X, Y, total / 4, C / 4, H, W, OH, OW, kh, kw,
+                       sh, sw, pt, pl, dh, dw, is_max, count_pad);
+    return;
+  }
   hipLaunchKernelGGL(pool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, X, Y, total, C, H, W, OH, OW, kh, kw, sh, sw, pt,
                      pl, dh, dw, is_max, count_pad, nhwc);
 }
