@@ -251,8 +251,11 @@ void schedule(LoadedModel &m) {
     }
   }
   if (spatial(m.plan.out_buf) > 1) ok = false;  // results leave in the caller's (NCHW) order
-  m.nhwc_mode = any_conv && ok;
-  if (m.nhwc_mode)
+  // channel-quad planes need whole quads in every internal 4-D tensor (the caller's input stays NCHW)
+  for (size_t b = 1; b < m.plan.buf_shape.size(); b++)
+    if (m.plan.buf_shape[b].size() == 4 && m.plan.buf_shape[b][1] % 4 != 0) ok = false;
+  m.cq_mode = any_conv && ok;
+  if (m.cq_mode)
     for (size_t i = 0; i < n; i++) {
       const Step &s = st[i];
       if (m.exec[i] != ExecKind::Normal || s.kind != StepKind::Conv2d || s.in0 == 0) continue;
@@ -264,7 +267,7 @@ void schedule(LoadedModel &m) {
   // (conv2, or the 1x1 downsample conv when the block has one), the other operand being the skip tensor.
   m.conv_fused_add.assign(n, -1);
   m.conv_residual_buf.assign(n, -1);
-  if (m.nhwc_mode) {
+  if (m.cq_mode) {
     std::vector<int> prod(m.plan.buf_per_row.size(), -1);
     for (size_t i = 0; i < n; i++)
       if (m.exec[i] != ExecKind::Skipped) prod[size_t(st[i].out)] = int(i);
@@ -422,7 +425,7 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case StepKind::Dense: kern::dense(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, int(x.K), int(x.M), act_of(x), 0); break;
         case StepKind::Unary: kern::unary(s, buf(x.in0), buf(x.out), nr * p.buf_per_row[size_t(x.out)], act_of(x)); break;
         case StepKind::AffineChannel:
-          kern::affine_channel(s, buf(x.in0), d.scale, d.shift, buf(x.out), nr, x.C, x.S, act_of(x), m.nhwc_mode && x.in0 != 0);
+          kern::affine_channel(s, buf(x.in0), d.scale, d.shift, buf(x.out), nr, x.C, x.S, act_of(x), m.cq_mode && x.in0 != 0);
           break;
         case StepKind::BinaryConst:
           kern::binary_const(s, buf(x.in0), d.cst, buf(x.out), nr, p.buf_per_row[size_t(x.out)], x.bop, x.const_left, act_of(x));
@@ -434,16 +437,16 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case StepKind::Conv2d: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
-          kern::conv2d(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), m.nhwc_mode && x.in0 != 0, m.nhwc_mode);
+          kern::conv2d(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), m.cq_mode && x.in0 != 0, m.cq_mode);
           break;
         }
         case StepKind::Pool2d:
           kern::pool2d(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.H), int(x.Wd), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                        int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), x.is_max, x.count_pad,
-                       m.nhwc_mode && x.in0 != 0);
+                       m.cq_mode && x.in0 != 0);
           break;
         case StepKind::GlobalAvgPool:
-          kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.nhwc_mode && x.in0 != 0);
+          kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.cq_mode && x.in0 != 0);
           break;
       }
     }
@@ -622,11 +625,11 @@ void sync_device(int device_ordinal) {
 hipStream_t thread_stream(int device_ordinal) { return ctx_for_slot(slot_of_ordinal(device_ordinal)).stream; }
 
 std::string LoadedModel::describe_json() const {
-  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_nhwc"};
+  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq"};
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";
-  o << "],\"activation_layout\":\"" << (nhwc_mode ? "NHWC" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
+  o << "],\"activation_layout\":\"" << (cq_mode ? "NC/4HW4" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";
   for (size_t i = 0; i < exec.size(); i++)

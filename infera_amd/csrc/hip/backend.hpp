@@ -55,7 +55,7 @@ class LoadedModel {
   kern::Mlp3Shape mlp3_shape{};
   // Convolutional plans keep every 4-D activation except the caller's input CHANNELS-LAST (NHWC) so
   // the implicit-GEMM gathers and stores are 16-byte vectors; decided per plan in schedule().
-  bool nhwc_mode = false;
+  bool cq_mode = false;
   // A ConvTiled step that absorbed the residual Add (+ activation) following it: per conv step, the
   // index of the fused BinaryAct step (-1: none) and which of its operands is the skip tensor.
   std::vector<int> conv_fused_add;

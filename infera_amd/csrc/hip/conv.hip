@@ -7,18 +7,24 @@
 //   B operand = im2col gather of the input, computed on the fly per lane -- never materialised in HBM.
 //
 // Two kernels:
-//   * conv2d_tiled_kernel  -- the workhorse (every ResNet layer except the stem).  Activations are kept
-//     CHANNELS-LAST (NHWC) inside a conv plan, and K is ordered (ky, kx, c), so the 4 k-values a lane
-//     feeds to 4 consecutive MFMA k-steps are 4 consecutive channels of ONE input pixel: one 16-byte load
-//     per lane per 8 k (bounds-checked once per filter tap), and one 16-byte store per lane per 4 output
-//     channels.  A workgroup = 4 waves = 128 output pixels x (MT*32) output channels; weight fragments
-//     (pre-packed fragment-major at load time) are staged through LDS in 32-channel chunks,
-//     double-buffered, one barrier per chunk, and shared by the 4 waves; the next chunk's B operands are
-//     in flight while the current chunk's 16*MT MFMAs run.  Bias (BatchNormalization already folded in by
-//     the loader) + activation are fused in the epilogue.
+// Inside a conv plan activations live in CHANNEL-QUAD PLANES ("CQ"): [N][C/4][H][W][4] -- the 4 k-values a
+// lane feeds to 4 consecutive MFMA k-steps are one 16-byte load, the 4 output channels a lane holds per
+// accumulator quad are one 16-byte store, and -- unlike NHWC -- the 32 pixels of a wave (lane&31) are 32
+// CONSECUTIVE 16-byte pieces of a plane row, so every gather and every store is a coalesced 512-byte run
+// (NHWC measured 64 L1 accesses per gather instruction, CQ 16).
+//   * conv2d_tiled_kernel  -- the workhorse (every ResNet layer except the stem), K ordered (ky, kx, c).
+//     A workgroup = 4 waves = 128 output pixels x (MT*32) output channels; weight fragments (pre-packed
+//     fragment-major at load time) are staged through LDS, double-buffered, one barrier per stage, shared
+//     by the 4 waves; the next stage's B operands are in flight while the current stage's MFMAs run.
+//     Bias (BatchNormalization already folded in by the loader), the residual Add of a ResNet block and
+//     the activation are fused in the epilogue.
 //   * conv2d_generic_kernel -- any geometry / groups / layouts (the C=3 stem reads the caller's NCHW
-//     blob and writes NHWC); scalar gathers, weights straight from L2.
+//     blob and writes CQ); scalar gathers, weights straight from L2.
 #include "device_common.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 namespace infera_hip::kern {
 
@@ -26,8 +32,8 @@ namespace {
 
 constexpr int kBlock = 256;
 
-__device__ __forceinline__ int64_t act_index(bool nhwc, int64_t n, int c, int y, int x, int C, int H, int W) {
-  return nhwc ? ((n * H + y) * W + x) * C + c : ((n * C + c) * H + y) * int64_t(W) + x;
+__device__ __forceinline__ int64_t act_index(bool cq, int64_t n, int c, int y, int x, int C, int H, int W) {
+  return cq ? (((n * (C >> 2) + (c >> 2)) * H + y) * W + x) * 4 + (c & 3) : ((n * C + c) * H + y) * int64_t(W) + x;
 }
 
 // Generic kernel.  Wk = weights transposed at load time to [group][k][Mg] (k = (c, ky, kx) as in ONNX), so
@@ -41,8 +47,8 @@ struct KEntry {
 template <int MT>
 __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__restrict__ X, const float *__restrict__ Wk,
                                                                const float *__restrict__ bias, float *__restrict__ Y,
-                                                               int64_t total_pix, ConvGeom g, ActParam act, bool in_nhwc,
-                                                               bool out_nhwc) {
+                                                               int64_t total_pix, ConvGeom g, ActParam act, bool in_cq,
+                                                               bool out_cq) {
   extern __shared__ __attribute__((aligned(16))) KEntry ktab[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
   for (int k = threadIdx.x; k < KK; k += kBlock) {
     const int c = k / khw, rem = k - c * khw, ky = rem / g.kw, kx = rem - ky * g.kw;
     const int cy = ky * g.dh, cx = kx * g.dw, cc = grp * Cg + c;
-    ktab[k].off = in_nhwc ? (cy * g.W + cx) * g.C + cc : (cc * g.H + cy) * g.W + cx;
+    ktab[k].off = in_cq ? (((cc >> 2) * g.H + cy) * g.W + cx) * 4 + (cc & 3) : (cc * g.H + cy) * g.W + cx;
     ktab[k].ky = short(cy);
     ktab[k].kx = short(cx);
   }
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
   const int oh = prem / g.OW, ow = prem % g.OW;
   const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
   // corner of the receptive field (may lie outside the image; only in-bounds taps are dereferenced)
-  const float *xc = X + n * int64_t(g.C) * g.H * g.W + (in_nhwc ? (int64_t(ih0) * g.W + iw0) * g.C : int64_t(ih0) * g.W + iw0);
+  const float *xc = X + n * int64_t(g.C) * g.H * g.W + (int64_t(ih0) * g.W + iw0) * (in_cq ? 4 : 1);
   const float *wg = Wk + int64_t(grp) * KK * Mg + mt0 + r;
 
   f32x16 acc[MT];
@@ -94,24 +100,35 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
   }
   if (!pvalid) return;
   // lane (r,h) holds pixel `pix`, channels mt0 + 32t + 8*q + 4h + j
+  // bias first (all loads in flight together), activation resolved once, then the stores
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int ml = mt0 + 32 * t + 8 * (i >> 2) + 4 * h + (i & 3);
+      acc[t][i] += (bias && ml < Mg) ? bias[grp * Mg + ml] : 0.f;
+    }
+  dispatch_act(act.kind, [&](auto kind_tag) {
+    constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[t][i] = apply_act_c<KIND>(acc[t][i], act.a, act.b);
+  });
 #pragma unroll
   for (int t = 0; t < MT; t++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int ml = mt0 + 32 * t + 8 * q + 4 * h;
-      if (out_nhwc && ml + 3 < Mg && (g.M & 3) == 0) {  // one 16-byte NHWC store per channel quad
+      if (out_cq && ml + 3 < Mg && (Mg & 3) == 0) {  // one 16-byte store per channel quad, coalesced over the wave's pixels
         f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = apply_act(acc[t][4 * q + j] + (bias ? bias[grp * Mg + ml + j] : 0.f), act);
-        *reinterpret_cast<f32x4 *>(Y + pix * g.M + grp * Mg + ml) = v;
+        for (int j = 0; j < 4; j++) v[j] = acc[t][4 * q + j];
+        *reinterpret_cast<f32x4 *>(Y + act_index(true, n, grp * Mg + ml, oh, ow, g.M, g.OH, g.OW)) = v;
       } else {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (ml + j < Mg) {
-            const int m = grp * Mg + ml + j;
-            const float v = acc[t][4 * q + j] + (bias ? bias[m] : 0.f);
-            Y[act_index(out_nhwc, n, m, oh, ow, g.M, g.OH, g.OW)] = apply_act(v, act);
-          }
+          if (ml + j < Mg) Y[act_index(out_cq, n, grp * Mg + ml + j, oh, ow, g.M, g.OH, g.OW)] = acc[t][4 * q + j];
       }
     }
 }
@@ -119,23 +136,60 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
 // ---- tiled NHWC kernel --------------------------------------------------------------------------------------
 // packed weights: [chunk = tap*(C/32) + cc][mt (all M/32 tiles)][g (4)][lane (64)][j (4)]
 //   = Wt[m = 32mt + (lane&31)][tap][c = 32cc + 8g + 4*(lane>>5) + j]
-template <int MT>
+//
+// One LDS stage = S consecutive 32-channel chunks of one filter tap (S = 2 when C % 64 == 0): S*MT KB of
+// fragments shared by the 4 waves, double-buffered, ONE barrier per stage (= per 16*S*MT MFMAs per wave).
+// Inside a stage the wave runs the same "unit" pipeline as mlp_device.inc: a unit = one 16-byte A fragment
+// (ds_read_b128, P units ahead in a register ring) + 4 MFMAs, pinned with sched_barrier so the loads stay
+// interleaved with the matrix stream.  The next stage's B operands (S*4 16-byte gathers per lane) and weight
+// slab are requested in the first units and land under the remaining MFMAs.  Out-of-image taps do not
+// branch: a per-lane bit mask (one bit per tap, built once) redirects the gather to a page of zeros.
+__device__ __attribute__((aligned(256))) float g_zero_page[128];
+#ifdef INFERA_CONV_PROBES
+// [MT==4][phase]: summed shader cycles per wave: prologue, main loop, epilogue issue, store drain; [4] = waves
+__device__ unsigned long long g_conv_stamps[2][8];
+#endif
+
+template <int MT, int S, int PROBE = 0>
 __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                              const float *__restrict__ bias, const float *__restrict__ residual,
                                                              float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
-  __shared__ __attribute__((aligned(16))) float wbuf[2][MT * 1024];
+  constexpr int NB = 4 * S;   // B fragments (16 B per lane) per stage
+  constexpr int U = NB * MT;  // units per stage
+  constexpr int P = 3;        // A-fragment ring depth
+  __shared__ __attribute__((aligned(16))) float wbuf[2][S * MT * 1024];
+#ifdef INFERA_CONV_PROBES
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, tc = 0;
+  if constexpr (PROBE == 5) t0 = __builtin_readcyclecounter();
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous
+  // range of pixel tiles (neighbouring tiles share halo rows -> they share that XCD's L2).
+  const unsigned nfull = gridDim.x & ~7u;
+  const unsigned lb = blockIdx.x < nfull ? (blockIdx.x & 7u) * (nfull >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int OHW = g.OH * g.OW;
   const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
-  const int CC = g.C / 32, ntaps = g.kh * g.kw, nchunks = ntaps * CC;
-  const int64_t pix = (int64_t(blockIdx.x) * 4 + wave) * 32 + r;
+  const int CS = g.C / (32 * S), ntaps = g.kh * g.kw, nstages = ntaps * CS;
+  const int64_t pix = (int64_t(lb) * 4 + wave) * 32 + r;
   const bool pvalid = pix < total_pix;
   const int64_t n = pvalid ? pix / OHW : 0;
   const int prem = pvalid ? int(pix % OHW) : 0;
   const int oh = prem / g.OW, ow = prem % g.OW;
   const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
-  const float *xn = X + n * int64_t(g.H) * g.W * g.C + 4 * h;
+  // receptive-field corner of this lane's pixel (may lie outside the image; masked taps never dereference it)
+  const int HW4 = g.H * g.W * 4;  // floats per channel-quad plane
+  const float *xc = X + n * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
+  const float *zp = g_zero_page + 4 * h;
+  uint64_t okmask = 0;
+  if (pvalid) {
+    int tap = 0;
+    for (int ky = 0; ky < g.kh; ky++)
+      for (int kx = 0; kx < g.kw; kx++, tap++) {
+        const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
+        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) okmask |= uint64_t(1) << tap;
+      }
+  }
 
   f32x16 acc[MT];
 #pragma unroll
@@ -143,92 +197,188 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
 
-  // B operands of one chunk: 4 groups x 16 bytes per lane (zeros outside the image / past the table)
-  auto gather = [&](f32x4(&b)[4], int chunk) {
-    const int tap = chunk / CC, cc = chunk - tap * CC;
-    const int ky = tap / g.kw, kx = tap - ky * g.kw;
-    const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
-    const bool ok = pvalid && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-    const f32x4 *p = reinterpret_cast<const f32x4 *>(xn + (int64_t(iy) * g.W + ix) * g.C + cc * 32);
+  // wave-uniform position of the stage being PREFETCHED: tap, channel block, element offset from the corner
+  int n_tap = 0, n_cs = 0, n_kx = 0, n_off = 0;
+  auto gather = [&](f32x4(&b)[NB]) {
+    const bool ok = (okmask >> n_tap) & 1;
+    const float *p = ok ? xc + n_off : zp;
+    const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;  // group q+1 = two channel-quad planes further
 #pragma unroll
-    for (int q = 0; q < 4; q++) b[q] = ok ? p[2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
+    // advance to the following stage
+    n_cs++;
+    n_off += 2 * NB * HW4;
+    if (n_cs == CS) {
+      n_cs = 0;
+      n_tap++;
+      n_kx++;
+      n_off += g.dw * 4 - 2 * NB * CS * HW4;
+      if (n_kx == g.kw) {
+        n_kx = 0;
+        n_off += (g.dh * g.W - g.kw * g.dw) * 4;
+      }
+    }
   };
-  // this block's MT tiles of one chunk are contiguous in the packed blob: MT*1024 floats, MT float4 per thread
-  auto stage_load = [&](f32x4(&wreg)[MT], int chunk) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(Wp + (int64_t(chunk) * MTtot + mt0) * 1024) + threadIdx.x;
+  // this block's MT tiles of one 32-channel chunk are contiguous in the packed blob (MT*1024 floats)
+  auto stage_load = [&](f32x4(&wreg)[S * MT], int stage) {
 #pragma unroll
-    for (int t = 0; t < MT; t++) wreg[t] = src[t * 256];
+    for (int sl = 0; sl < S; sl++) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(Wp + (int64_t(stage * S + sl) * MTtot + mt0) * 1024) + threadIdx.x;
+#pragma unroll
+      for (int t = 0; t < MT; t++) wreg[sl * MT + t] = src[t * 256];
+    }
   };
-  auto stage_store = [&](const f32x4(&wreg)[MT], int buf) {
+  auto stage_store = [&](const f32x4(&wreg)[S * MT], int buf) {
     f32x4 *dst = reinterpret_cast<f32x4 *>(wbuf[buf]) + threadIdx.x;
 #pragma unroll
-    for (int t = 0; t < MT; t++) dst[t * 256] = wreg[t];
+    for (int i = 0; i < S * MT; i++) dst[i * 256] = wreg[i];
   };
 
-  f32x4 bcur[4], bnext[4], wreg[MT];
-  gather(bcur, 0);
+  f32x4 wreg[S * MT];
+  // `more` is a compile-time constant per call site: with a run-time flag the prefetch sits in a branch and
+  // hipcc's waitcnt pass, merging the two paths, makes every other stage wait on the loads it has just issued.
+  auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;
+    const f32x4 *wl = reinterpret_cast<const f32x4 *>(wbuf[stage & 1]) + lane;
+    // unit u -> B fragment q = u / MT (slab q/4, group q%4), feature tile t = u % MT
+    auto fidx = [](int u) { return (((u / MT) / 4 * MT + u % MT) * 4 + (u / MT) % 4) * 64; };
+    f32x4 ring[P];
+#pragma unroll
+    for (int u = 0; u < P && u < U; u++) ring[u] = wl[fidx(u)];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int q = u / MT, t = u % MT;
+      f32x4 a = ring[u % P];
+      if constexpr (PROBE == 4) {
+        asm volatile("" : "+v"(a));
+      } else {
+        if (u + P < U) ring[u % P] = wl[fidx(u + P)];
+      }
+      if constexpr (more) {
+        if constexpr (PROBE != 2 && PROBE != 3 && PROBE != 4) {
+          if (u == 0) gather(bn);
+        }
+        if constexpr (PROBE != 3 && PROBE != 4 && PROBE != 6) {
+          if (u == 1) stage_load(wreg, stage + 1);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bc[q][j], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (more && (PROBE == 0 || PROBE == 5 || PROBE == 6 || PROBE == 2)) {
+      stage_store(wreg, (stage + 1) & 1);
+      __syncthreads();
+    }
+    if constexpr (PROBE == 2 || PROBE == 3 || PROBE == 4) {
+#pragma unroll
+      for (int q = 0; q < NB; q++) bn[q] = bc[q];
+    }
+  };
+
+  f32x4 b0[NB], b1[NB];
+#ifdef INFERA_CONV_PROBES
+  if constexpr (PROBE == 5) ta = __builtin_readcyclecounter();
+#endif
+  gather(b0);
   stage_load(wreg, 0);
+#ifdef INFERA_CONV_PROBES
+  if constexpr (PROBE == 5) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tb = __builtin_readcyclecounter();
+  }
+#endif
   stage_store(wreg, 0);
   __syncthreads();
-  for (int chunk = 0; chunk < nchunks; chunk++) {
-    const bool more = chunk + 1 < nchunks;
-    if (more) {
-      gather(bnext, chunk + 1);
-      stage_load(wreg, chunk + 1);
-    }
-    const f32x4 *wl = reinterpret_cast<const f32x4 *>(wbuf[chunk & 1]) + lane;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      f32x4 a[MT];
-#pragma unroll
-      for (int t = 0; t < MT; t++) a[t] = wl[(t * 4 + q) * 64];
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], bcur[q][j], acc[t], 0, 0, 0);
-    }
-    if (more) {
-      stage_store(wreg, (chunk + 1) & 1);
-#pragma unroll
-      for (int q = 0; q < 4; q++) bcur[q] = bnext[q];
-    }
-    __syncthreads();
+#ifdef INFERA_CONV_PROBES
+  if constexpr (PROBE == 5) t1 = __builtin_readcyclecounter();
+#endif
+  constexpr std::true_type kMore{};
+  constexpr std::false_type kLast{};
+  int stage = 0;
+  for (; stage + 2 < nstages; stage += 2) {
+    step(b0, b1, stage, kMore);
+    step(b1, b0, stage + 1, kMore);
   }
+  if (stage + 2 == nstages) {
+    step(b0, b1, stage, kMore);
+    step(b1, b0, stage + 1, kLast);
+  } else {
+    step(b0, b1, stage, kLast);
+  }
+#ifdef INFERA_CONV_PROBES
+  if constexpr (PROBE == 5) t2 = __builtin_readcyclecounter();
+#endif
   if (!pvalid) return;
   // epilogue: lane (r,h) holds pixel `pix`, channels 32*(mt0+t) + 8*q + 4h + j -> one 16-byte NHWC store per quad
   // (optional residual: the block's skip tensor, same NHWC layout -- the Add of a ResNet block is fused here)
-  float *yp = Y + pix * g.M + 32 * mt0 + 4 * h;
-  const float *rp = residual ? residual + pix * g.M + 32 * mt0 + 4 * h : nullptr;
-  const float *bp = bias ? bias + 32 * mt0 + 4 * h : nullptr;
-#pragma unroll
-  for (int t = 0; t < MT; t++)
+  const int64_t OHW4 = int64_t(OHW) * 4;
+  const int64_t yoff = n * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+  float *yp = Y + yoff;
+  const float *rp = residual ? residual + yoff : nullptr;
+  const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
+  // bias quads + residual quads of tile t+1 are requested before tile t is finished and stored, and the
+  // activation is resolved once (dispatch_act), so the epilogue is two memory latencies, not one per element
+  auto fetch = [&](f32x4(&bv)[4], f32x4(&rv)[4], int t) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      f32x4 v, res = {0.f, 0.f, 0.f, 0.f};
-      if (rp) res = *reinterpret_cast<const f32x4 *>(rp + 32 * t + 8 * q);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float x = acc[t][4 * q + j] + (bp ? bp[32 * t + 8 * q + j] : 0.f);
-        if (rp) x += res[j];
-        v[j] = apply_act(x, act);
-      }
-      *reinterpret_cast<f32x4 *>(yp + 32 * t + 8 * q) = v;
+      bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+      rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  dispatch_act(act.kind, [&](auto kind_tag) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    f32x4 bv[2][4], rv[2][4];
+    fetch(bv[0], rv[0], 0);
+#ifdef INFERA_CONV_PROBES
+    if constexpr (PROBE == 5) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tc = __builtin_readcyclecounter();
+    }
+#endif
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+      if (t + 1 < MT) fetch(bv[(t + 1) & 1], rv[(t + 1) & 1], t + 1);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[t][4 * q + j] + bv[t & 1][q][j]) + rv[t & 1][q][j], act.a, act.b);
+        *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
+      }
+    }
+  });
+#ifdef INFERA_CONV_PROBES
+  if constexpr (PROBE == 5) {
+    t3 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t4 = __builtin_readcyclecounter();
+    if (lane == 0) {
+      unsigned long long *st = g_conv_stamps[MT == 4];
+      atomicAdd(st + 0, ta - t0);
+      atomicAdd(st + 1, tb - ta);
+      atomicAdd(st + 2, t1 - tb);
+      atomicAdd(st + 3, t2 - t1);
+      atomicAdd(st + 4, tc - t2);
+      atomicAdd(st + 5, t3 - tc);
+      atomicAdd(st + 6, t4 - t3);
+      atomicAdd(st + 7, 1ull);
+    }
+  }
+#endif
 }
 
-// NHWC pooling, 4 channels (16 bytes) per thread: consecutive lanes walk the channel axis, so every tap
-// is a fully coalesced read and the output a coalesced 16-byte store.
-__global__ __launch_bounds__(kBlock) void pool2d_nhwc4_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total4,
-                                                             int C4, int H, int W, int OH, int OW, int kh, int kw, int sh,
-                                                             int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad) {
+// CQ pooling: one thread per (n, channel quad, oh, ow) -- 16 bytes per tap, consecutive lanes walk a plane row.
+__global__ __launch_bounds__(kBlock) void pool2d_cq_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total4,
+                                                          int H, int W, int OH, int OW, int kh, int kw, int sh, int sw, int pt,
+                                                          int pl, int dh, int dw, bool is_max, bool count_pad) {
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X);
   f32x4 *y4 = reinterpret_cast<f32x4 *>(Y);
   for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < total4; o += stride) {
-    const int c4 = int(o % C4);
-    const int ow = int((o / C4) % OW);
-    const int oh = int((o / (int64_t(C4) * OW)) % OH);
-    const int64_t n = o / (int64_t(C4) * OW * OH);
+    const int ow = int(o % OW);
+    const int oh = int((o / OW) % OH);
+    const int64_t plane = o / (int64_t(OW) * OH);  // n * C/4 + c/4
     f32x4 acc = is_max ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
     int cnt = 0;
     for (int i = 0; i < kh; i++) {
@@ -237,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void pool2d_nhwc4_kernel(const float *__res
       for (int j = 0; j < kw; j++) {
         const int ix = ow * sw - pl + j * dw;
         if (ix < 0 || ix >= W) continue;
-        const f32x4 v = x4[((n * H + iy) * W + ix) * C4 + c4];
+        const f32x4 v = x4[(plane * H + iy) * W + ix];
 #pragma unroll
         for (int e = 0; e < 4; e++) acc[e] = is_max ? fmaxf(acc[e], v[e]) : acc[e] + v[e];
         cnt++;
@@ -254,29 +404,20 @@ __global__ __launch_bounds__(kBlock) void pool2d_nhwc4_kernel(const float *__res
 
 __global__ __launch_bounds__(kBlock) void pool2d_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total,
                                                        int C, int H, int W, int OH, int OW, int kh, int kw, int sh, int sw,
-                                                       int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool nhwc) {
+                                                       int pt, int pl, int dh, int dw, bool is_max, bool count_pad) {
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < total; o += stride) {
-    int c, oh, ow;
-    int64_t n;
-    if (nhwc) {
-      c = int(o % C);
-      ow = int((o / C) % OW);
-      oh = int((o / (int64_t(C) * OW)) % OH);
-      n = o / (int64_t(C) * OW * OH);
-    } else {
-      ow = int(o % OW);
-      oh = int((o / OW) % OH);
-      c = int((o / (int64_t(OW) * OH)) % C);
-      n = o / (int64_t(OW) * OH * C);
-    }
+    const int ow = int(o % OW);
+    const int oh = int((o / OW) % OH);
+    const int c = int((o / (int64_t(OW) * OH)) % C);
+    const int64_t n = o / (int64_t(OW) * OH * C);
     float acc = is_max ? -INFINITY : 0.f;
     int cnt = 0;
     for (int i = 0; i < kh; i++)
       for (int j = 0; j < kw; j++) {
         const int iy = oh * sh - pt + i * dh, ix = ow * sw - pl + j * dw;
         if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-        const float v = X[act_index(nhwc, n, c, iy, ix, C, H, W)];
+        const float v = X[act_index(false, n, c, iy, ix, C, H, W)];
         acc = is_max ? fmaxf(acc, v) : acc + v;
         cnt++;
       }
@@ -285,18 +426,16 @@ __global__ __launch_bounds__(kBlock) void pool2d_kernel(const float *__restrict_
   }
 }
 
-// NCHW: one wave per (n, c) over S contiguous elements.  NHWC: one lane per (n, c), stride C.
+// NCHW: one wave per (n, c) over S contiguous elements.  CQ: one lane per (n, channel quad), 16 bytes per step.
 __global__ __launch_bounds__(kBlock) void global_avgpool_kernel(const float *__restrict__ X, float *__restrict__ Y,
-                                                               int64_t nc_total, int C, int S, bool nhwc) {
-  if (nhwc) {
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < nc_total; o += stride) {
-      const int64_t n = o / C;
-      const int c = int(o % C);
-      const float *src = X + n * int64_t(S) * C + c;
-      float acc = 0.f;
-      for (int i = 0; i < S; i++) acc += src[int64_t(i) * C];
-      Y[o] = acc / float(S);
+                                                               int64_t nc_total, int C, int S, bool cq) {
+  if (cq) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock, nq = nc_total >> 2;
+    for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < nq; o += stride) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(X) + o * S;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < S; i++) acc += src[i];
+      reinterpret_cast<f32x4 *>(Y)[o] = acc / float(S);
     }
     return;
   }
@@ -332,7 +471,7 @@ void conv2d_generic_pack(const ConvGeom &g, const float *Wt, float *packed) {
 }
 
 void conv2d(hipStream_t s, const float *X, const float *Wk, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
-            ActParam act, bool in_nhwc, bool out_nhwc) {
+            ActParam act, bool in_cq, bool out_cq) {
   const int64_t total_pix = rows * g.OH * g.OW;
   if (total_pix <= 0) return;
   const int Mg = g.M / g.groups;
@@ -340,17 +479,20 @@ void conv2d(hipStream_t s, const float *X, const float *Wk, const float *bias, f
   const unsigned bx = unsigned((total_pix + 127) / 128);
   if (Mg <= 32) {
     dim3 grid(bx, unsigned(g.groups * ((Mg + 31) / 32)));
-    hipLaunchKernelGGL(conv2d_generic_kernel<1>, grid, dim3(kBlock), lds, s, X, Wk, bias, Y, total_pix, g, act, in_nhwc, out_nhwc);
+    hipLaunchKernelGGL(conv2d_generic_kernel<1>, grid, dim3(kBlock), lds, s, X, Wk, bias, Y, total_pix, g, act, in_cq, out_cq);
   } else if (Mg <= 64) {
     dim3 grid(bx, unsigned(g.groups * ((Mg + 63) / 64)));
-    hipLaunchKernelGGL(conv2d_generic_kernel<2>, grid, dim3(kBlock), lds, s, X, Wk, bias, Y, total_pix, g, act, in_nhwc, out_nhwc);
+    hipLaunchKernelGGL(conv2d_generic_kernel<2>, grid, dim3(kBlock), lds, s, X, Wk, bias, Y, total_pix, g, act, in_cq, out_cq);
   } else {
     dim3 grid(bx, unsigned(g.groups * ((Mg + 127) / 128)));
-    hipLaunchKernelGGL(conv2d_generic_kernel<4>, grid, dim3(kBlock), lds, s, X, Wk, bias, Y, total_pix, g, act, in_nhwc, out_nhwc);
+    hipLaunchKernelGGL(conv2d_generic_kernel<4>, grid, dim3(kBlock), lds, s, X, Wk, bias, Y, total_pix, g, act, in_cq, out_cq);
   }
 }
 
-bool conv2d_tiled_supported(const ConvGeom &g) { return g.groups == 1 && g.C % 32 == 0 && g.M % 64 == 0; }
+bool conv2d_tiled_supported(const ConvGeom &g) {
+  return g.groups == 1 && g.C % 32 == 0 && g.M % 64 == 0 && g.kh * g.kw <= 64 /* per-lane tap mask */ &&
+         int64_t(g.H) * g.W * g.C < (int64_t(1) << 30);
+}
 
 size_t conv2d_tiled_packed_floats(const ConvGeom &g) { return size_t(g.kh) * g.kw * g.C * g.M; }
 
@@ -368,35 +510,77 @@ void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed) {
             }
 }
 
+#ifdef INFERA_CONV_PROBES
+namespace {
+void dump_stamps() {
+  unsigned long long st[2][8];
+  if (hipDeviceSynchronize() != hipSuccess) return;
+  if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_conv_stamps), sizeof st) != hipSuccess) return;
+  for (int k = 0; k < 2; k++)
+    if (st[k][7]) {
+      const double w = double(st[k][7]);
+      fprintf(stderr, "[conv stamps MT=%d] waves=%.0f avg cycles: index %.0f first-loads %.0f lds+barrier %.0f loop %.0f epi-loads %.0f epi-issue %.0f drain %.0f\n",
+              k ? 4 : 2, w, st[k][0] / w, st[k][1] / w, st[k][2] / w, st[k][3] / w, st[k][4] / w, st[k][5] / w, st[k][6] / w);
+    }
+  unsigned long long zero[2][8] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), zero, sizeof zero);
+}
+}  // namespace
+#endif
+
 void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y,
                   int64_t rows, const ConvGeom &g, ActParam act) {
   const int64_t total_pix = rows * g.OH * g.OW;
   if (total_pix <= 0) return;
   const unsigned bx = unsigned((total_pix + 127) / 128);
-  if (g.M % 128 == 0) {
-    hipLaunchKernelGGL(conv2d_tiled_kernel<4>, dim3(bx, unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
-  } else {
-    hipLaunchKernelGGL(conv2d_tiled_kernel<2>, dim3(bx, unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+  auto launch = [&](auto kernel, int mt) {
+    hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / (32 * mt))), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+  };
+  const bool wide = g.M % 128 == 0, deep = g.C % 64 == 0;
+#ifdef INFERA_CONV_PROBES
+  static const int probe = getenv("INFERA_CONV_PROBE") ? atoi(getenv("INFERA_CONV_PROBE")) : 0;
+  static int launches = 0;
+  if (probe == 5 && ++launches % 38 == 0) dump_stamps();
+  if (probe && deep) {
+    switch (probe * 2 + (wide ? 1 : 0)) {
+      case 2: return launch(conv2d_tiled_kernel<2, 2, 1>, 2);
+      case 3: return launch(conv2d_tiled_kernel<4, 2, 1>, 4);
+      case 4: return launch(conv2d_tiled_kernel<2, 2, 2>, 2);
+      case 5: return launch(conv2d_tiled_kernel<4, 2, 2>, 4);
+      case 6: return launch(conv2d_tiled_kernel<2, 2, 3>, 2);
+      case 7: return launch(conv2d_tiled_kernel<4, 2, 3>, 4);
+      case 8: return launch(conv2d_tiled_kernel<2, 2, 4>, 2);
+      case 9: return launch(conv2d_tiled_kernel<4, 2, 4>, 4);
+      case 12: return launch(conv2d_tiled_kernel<2, 2, 6>, 2);
+      case 13: return launch(conv2d_tiled_kernel<4, 2, 6>, 4);
+      case 10: return launch(conv2d_tiled_kernel<2, 2, 5>, 2);
+      case 11: return launch(conv2d_tiled_kernel<4, 2, 5>, 4);
+    }
   }
+#endif
+  if (wide && deep) launch(conv2d_tiled_kernel<4, 2>, 4);
+  else if (wide) launch(conv2d_tiled_kernel<4, 1>, 4);
+  else if (deep) launch(conv2d_tiled_kernel<2, 2>, 2);
+  else launch(conv2d_tiled_kernel<2, 1>, 2);
 }
 
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
-            int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool nhwc) {
+            int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq) {
   const int64_t total = rows * C * OH * OW;
   if (total <= 0) return;
-  if (nhwc && C % 4 == 0) {
-    hipLaunchKernelGGL(pool2d_nhwc4_kernel, dim3(grid_for(total / 4)), dim3(kBlock), 0, s, X, Y, total / 4, C / 4, H, W, OH, OW, kh, kw,
-                       sh, sw, pt, pl, dh, dw, is_max, count_pad);
+  if (cq) {  // the plan guarantees C % 4 == 0 in CQ mode
+    hipLaunchKernelGGL(pool2d_cq_kernel, dim3(grid_for(total / 4)), dim3(kBlock), 0, s, X, Y, total / 4, H, W, OH, OW, kh, kw, sh, sw,
+                       pt, pl, dh, dw, is_max, count_pad);
     return;
   }
   hipLaunchKernelGGL(pool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, X, Y, total, C, H, W, OH, OW, kh, kw, sh, sw, pt,
-                     pl, dh, dw, is_max, count_pad, nhwc);
+                     pl, dh, dw, is_max, count_pad);
 }
 
-void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool nhwc) {
+void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool cq) {
   const int64_t nc = rows * C;
   if (nc <= 0) return;
-  hipLaunchKernelGGL(global_avgpool_kernel, dim3(grid_for(nhwc ? nc : nc * 64)), dim3(kBlock), 0, s, X, Y, nc, C, S, nhwc);
+  hipLaunchKernelGGL(global_avgpool_kernel, dim3(grid_for(cq ? nc / 4 : nc * 64)), dim3(kBlock), 0, s, X, Y, nc, C, S, cq);
 }
 
 }  // namespace infera_hip::kern

@@ -82,15 +82,23 @@ __global__ __launch_bounds__(WAVES * 64) void dense_kernel(const float *__restri
 
     // ---- epilogue: lane (r,h) holds, for table row row0+r, features m0 + 32t + 8*(i>>2) + 4h + (i&3)
     const int64_t grow = row0 + r;
+    {
+      float bv[MT][16];  // all bias values requested before the first is used (one memory latency)
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+      for (int t = 0; t < MT; t++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int f = m0 + 32 * t + 8 * (i >> 2) + 4 * h + (i & 3);
-        float v = acc[t][i];
-        if (bias != nullptr && f < M) v += bias[f];
-        acc[t][i] = apply_act(v, act);
-      }
+        for (int i = 0; i < 16; i++) {
+          const int f = m0 + 32 * t + 8 * (i >> 2) + 4 * h + (i & 3);
+          bv[t][i] = (bias != nullptr && f < M) ? bias[f] : 0.f;
+        }
+      dispatch_act(act.kind, [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) acc[t][i] = apply_act_c<KIND>(acc[t][i] + bv[t][i], act.a, act.b);
+      });
+    }
     if constexpr (SM != 0) {  // row softmax over all M outputs (host guarantees M <= 32*MT)
       float mx = -INFINITY;
 #pragma unroll
@@ -198,8 +206,11 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow_kernel(const float *_
       for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], x0[j], acc, 0, 0, 0);
     }
     // epilogue: lane (r,h) holds features 8*(i>>2) + 4h + (i&3) of table row `row`
+    dispatch_act(act.kind, [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = apply_act(acc[i] + bq[i], act);
+      for (int i = 0; i < 16; i++) acc[i] = apply_act_c<KIND>(acc[i] + bq[i], act.a, act.b);
+    });
     if constexpr (SM != 0) {
       float mx = -INFINITY;
 #pragma unroll
@@ -301,8 +312,11 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16_kernel(const float 
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       f32x4 v = acc[t];
+      dispatch_act(act.kind, [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
-      for (int i = 0; i < 4; i++) v[i] = apply_act(v[i] + bq[i], act);
+        for (int i = 0; i < 4; i++) v[i] = apply_act_c<KIND>(v[i] + bq[i], act.a, act.b);
+      });
       if constexpr (SM != 0) {  // the row's features live in lanes n, n+16, n+32, n+48
         float mx = -INFINITY;
 #pragma unroll

@@ -58,10 +58,10 @@ __global__ __launch_bounds__(kBlock) void binary_act_kernel(const float *__restr
 
 __global__ __launch_bounds__(kBlock) void affine_channel_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                                const float *__restrict__ shift, float *__restrict__ y,
-                                                               int64_t n, int64_t C, int64_t S, ActParam act, bool nhwc) {
+                                                               int64_t n, int64_t C, int64_t S, ActParam act, bool cq) {
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
-    const int64_t c = nhwc ? i % C : (i / S) % C;
+    const int64_t c = cq ? ((i >> 2) / S) % (C >> 2) * 4 + (i & 3) : (i / S) % C;
     y[i] = apply_act(x[i] * scale[c] + shift[c], act);
   }
 }
@@ -147,10 +147,10 @@ void binary_act(hipStream_t s, const float *a, const float *b, float *y, int64_t
 }
 
 void affine_channel(hipStream_t s, const float *x, const float *scale, const float *shift, float *y, int64_t rows,
-                    int64_t C, int64_t S, ActParam act, bool nhwc) {
+                    int64_t C, int64_t S, ActParam act, bool cq) {
   const int64_t n = rows * C * S;
   if (n <= 0) return;
-  hipLaunchKernelGGL(affine_channel_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, scale, shift, y, n, C, S, act, nhwc);
+  hipLaunchKernelGGL(affine_channel_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, scale, shift, y, n, C, S, act, cq);
 }
 
 void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner,

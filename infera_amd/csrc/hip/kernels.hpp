@@ -21,9 +21,9 @@ void unary(hipStream_t s, const float *x, float *y, int64_t n, ActParam act);
 void binary_const(hipStream_t s, const float *x, const float *c, float *y, int64_t rows, int64_t per_row, char op,
                   bool const_left, ActParam act);
 void binary_act(hipStream_t s, const float *a, const float *b, float *y, int64_t n, char op, ActParam act);
-// y[r, c, i] = act(x * scale[c] + shift[c])
+// y[r, c, i] = act(x * scale[c] + shift[c]);  cq: activations in channel-quad planes [N][C/4][S][4] (conv.hip)
 void affine_channel(hipStream_t s, const float *x, const float *scale, const float *shift, float *y, int64_t rows,
-                    int64_t C, int64_t S, ActParam act, bool nhwc);
+                    int64_t C, int64_t S, ActParam act, bool cq);
 // softmax over `len` with element stride `inner`, repeated rows*outer*inner times
 void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner,
              bool log_softmax);
@@ -61,20 +61,20 @@ struct ConvGeom {
   int C, H, W, M, OH, OW, kh, kw, sh, sw, pt, pl, dh, dw, groups;
 };
 // Generic implicit-GEMM convolution: any geometry / groups; Wk = conv2d_generic_pack() of the ONNX
-// weights ([group][k][M/g], k = (c, ky, kx)); activations NCHW or NHWC per flag.
+// weights ([group][k][M/g], k = (c, ky, kx)); activations NCHW or channel-quad planes (CQ) per flag.
 bool conv2d_generic_supported(const ConvGeom &g);  // (C/g)*kh*kw <= 8192 (the per-k offset table lives in LDS)
 void conv2d_generic_pack(const ConvGeom &g, const float *Wt, float *packed);
 void conv2d(hipStream_t s, const float *X, const float *Wk, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
-            ActParam act, bool in_nhwc, bool out_nhwc);
-// Tiled NHWC convolution (groups == 1, C % 32 == 0, M % 64 == 0) on fragment-major packed weights.
+            ActParam act, bool in_cq, bool out_cq);
+// Tiled CQ-layout convolution (groups == 1, C % 32 == 0, M % 64 == 0) on fragment-major packed weights.
 bool conv2d_tiled_supported(const ConvGeom &g);
 size_t conv2d_tiled_packed_floats(const ConvGeom &g);
 void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed);
-// residual (nullable): NHWC tensor of the output's shape added before the activation (fused ResNet Add)
+// residual (nullable): CQ tensor of the output's shape added before the activation (fused ResNet Add)
 void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y,
                   int64_t rows, const ConvGeom &g, ActParam act);
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
-            int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool nhwc);
-void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool nhwc);
+            int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq);
+void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool cq);
 
 }  // namespace infera_hip::kern

@@ -332,7 +332,7 @@ print(json.dumps({"errors": errors, "same": len(outs) == 80 and all(np.array_equ
 
 
 def test_resnet18_full_width_vs_oracle(api, tmp_path):
-    """Full-width ResNet-18 topology (64..512 channels: every tiled-NHWC conv variant, stride-2 and 1x1
+    """Full-width ResNet-18 topology (64..512 channels: every tiled channel-quad conv variant, stride-2 and 1x1
     downsample convs, residual adds, BN folding, max/global-average pooling) at 64x64 input."""
     from infera_amd import onnx_writer as W, synth
     from oracle import oracle
@@ -340,7 +340,7 @@ def test_resnet18_full_width_vs_oracle(api, tmp_path):
     path = W.write(str(tmp_path / "rn64.onnx"), W.resnet18(classes=10, in_hw=64, width=64))
     api.load_model("rn64", path)
     plan = api.get_plan("rn64")
-    assert plan["activation_layout"] == "NHWC" and plan["exec"].count("conv_tiled_nhwc") == 19
+    assert plan["activation_layout"] == "NC/4HW4" and plan["exec"].count("conv_tiled_cq") == 19
     imgs = synth.table(21, 0, 3, 3 * 64 * 64)
     got = api.predict_from_blob("rn64", imgs.tobytes())
     want = oracle.Model(path).predict_blob(imgs.tobytes())
