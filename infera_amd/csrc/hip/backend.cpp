@@ -258,9 +258,13 @@ void schedule(LoadedModel &m) {
   if (m.cq_mode)
     for (size_t i = 0; i < n; i++) {
       const Step &s = st[i];
-      if (m.exec[i] != ExecKind::Normal || s.kind != StepKind::Conv2d || s.in0 == 0) continue;
+      if (m.exec[i] != ExecKind::Normal || s.kind != StepKind::Conv2d) continue;
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
+      if (s.in0 == 0) {  // the caller's NCHW blob: few channels -> LDS patch kernel
+        if (kern::conv2d_patch_supported(g)) m.exec[i] = ExecKind::ConvPatch;
+        continue;
+      }
       if (kern::conv2d_tiled_supported(g)) m.exec[i] = ExecKind::ConvTiled;
     }
   // Residual Add (+ activation) of a ResNet block -> epilogue of whichever of its two producers runs LAST
@@ -342,6 +346,12 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       std::vector<float> packed(kern::conv2d_tiled_packed_floats(g));
       kern::conv2d_tiled_pack(g, s.W.data(), packed.data());
       d.W = upload(packed, us);
+    } else if (m.exec[i] == ExecKind::ConvPatch) {
+      kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
+                       int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
+      std::vector<float> packed(kern::conv2d_patch_packed_floats(g));
+      kern::conv2d_patch_pack(g, s.W.data(), packed.data());
+      d.W = upload(packed, us);
     } else if (s.kind == StepKind::Conv2d) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
@@ -417,6 +427,12 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           const int fj = m.conv_fused_add[i];
           if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, g, act_of(st[size_t(fj)]));
           else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x));
+          continue;
+        }
+        case ExecKind::ConvPatch: {
+          kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
+                           int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
+          kern::conv2d_patch(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), dm.num_cus);
           continue;
         }
         default: break;
@@ -625,7 +641,7 @@ void sync_device(int device_ordinal) {
 hipStream_t thread_stream(int device_ordinal) { return ctx_for_slot(slot_of_ordinal(device_ordinal)).stream; }
 
 std::string LoadedModel::describe_json() const {
-  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq"};
+  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch"};
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";

@@ -22,6 +22,7 @@
 //     blob and writes CQ); scalar gathers, weights straight from L2.
 #include "device_common.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -368,6 +369,194 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
 #endif
 }
 
+// ---- patch kernel: few input channels, NCHW input (the network's first convolution) -------------------------
+// With C = 3 a "channel quad" gather has nothing to load 16 bytes of, and the generic kernel's scalar gathers
+// + bounds tests leave the matrix cores at ~30 %.  Here a persistent workgroup owns a (4*TR) x TC tile of
+// output pixels, stages the tile's whole receptive field (all C channels, zero-padded) in LDS once --
+// coalesced row reads of the caller's NCHW blob, double-buffered across tiles -- and every B operand is a
+// conflict-free ds_read_b32: patch columns are de-interleaved by (col mod stride) so the wave's TC pixels
+// read consecutive words.  The fragment-major weights (K padded to 8) and the per-k patch offsets stay in
+// LDS for the whole launch.  Output: channel-quad planes, bias + activation fused.
+struct PatchGeom {
+  int TR, TC;       // per-wave tile: TR rows x TC columns of output pixels (TR * TC == 32); 4 waves stack vertically
+  int PR, PC;       // patch rows / columns (input pixels) per workgroup tile
+  int HALF, ROWS;   // de-interleaved column count per stride phase; words per patch row (padded)
+  int PLANE;        // words per channel = PR * ROWS
+  int K8;           // 8-wide k groups (C*kh*kw rounded up)
+  int tiles_x, tiles_y;
+  int NE;           // patch words each thread moves per tile
+};
+constexpr int kPatchMaxE = 16;
+
+static PatchGeom patch_geom(const ConvGeom &g) {
+  PatchGeom p{};
+  p.TC = g.OW % 32 == 0 ? 32 : (g.OW % 16 == 0 ? 16 : (g.OW >= 24 ? 32 : (g.OW >= 12 ? 16 : 8)));
+  p.TR = 32 / p.TC;
+  p.PR = (4 * p.TR - 1) * g.sh + (g.kh - 1) * g.dh + 1;
+  p.PC = (p.TC - 1) * g.sw + (g.kw - 1) * g.dw + 1;
+  p.HALF = (p.PC + g.sw - 1) / g.sw;
+  p.ROWS = g.sw * p.HALF;
+  // the wave's second pixel row should start TC banks after the first: sh * ROWS == TC (mod 32)
+  if (p.TR > 1)
+    for (int pad = 0; pad < 32; pad++)
+      if (((p.ROWS + pad) * g.sh) % 32 == p.TC % 32) {
+        p.ROWS += pad;
+        break;
+      }
+  p.PLANE = p.PR * p.ROWS;
+  p.K8 = (g.C * g.kh * g.kw + 7) / 8;
+  p.tiles_x = (g.OW + p.TC - 1) / p.TC;
+  p.tiles_y = (g.OH + 4 * p.TR - 1) / (4 * p.TR);
+  p.NE = (g.C * p.PR * p.PC + kBlock - 1) / kBlock;
+  return p;
+}
+
+static size_t patch_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
+  return (size_t(p.K8) * (g.M / 32) * 256 + size_t(p.K8) * 8 + 2 * size_t(g.C) * p.PLANE) * sizeof(float);
+}
+
+template <int MT>
+__global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+                                                             const float *__restrict__ bias, float *__restrict__ Y,
+                                                             int64_t ntiles, ConvGeom g, PatchGeom pg, ActParam act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *wl = smem;                                                  // [K8][MT][64 lanes][4]
+  int *ktab = reinterpret_cast<int *>(smem + pg.K8 * MT * 256);       // [K8][h][4] patch offsets of k = 8g + 4h + j
+  float *patch = smem + pg.K8 * MT * 256 + pg.K8 * 8;                 // [2][C * PLANE]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int psz = g.C * pg.PLANE;
+
+  // weights + offsets: once per (persistent) workgroup
+  {
+    const int nw4 = (pg.K8 * MT * 256 + pg.K8 * 8) / 4;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(Wp);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+    for (int i = threadIdx.x; i < nw4; i += kBlock) dst[i] = src[i];
+  }
+  // this thread's share of the patch: word e of the (c, row, col) enumeration -> global offset relative to
+  // the patch corner, (row, col) for the bounds test, and the de-interleaved LDS slot
+  int e_rel[kPatchMaxE], e_rc[kPatchMaxE], e_lds[kPatchMaxE];
+#pragma unroll
+  for (int i = 0; i < kPatchMaxE; i++) {
+    const int e = threadIdx.x + i * kBlock;
+    const int c = e / (pg.PR * pg.PC), rem = e - c * (pg.PR * pg.PC), row = rem / pg.PC, col = rem - row * pg.PC;
+    const bool live = i < pg.NE && c < g.C;
+    e_rel[i] = (c * g.H + row) * g.W + col;
+    e_rc[i] = live ? (row << 16) | col : -1;
+    e_lds[i] = c * pg.PLANE + row * pg.ROWS + (col % g.sw) * pg.HALF + col / g.sw;
+  }
+  const int tiles_per_img = pg.tiles_x * pg.tiles_y;
+  auto tile_origin = [&](int64_t t, int64_t &img, int &oy0, int &ox0) {
+    img = t / tiles_per_img;
+    const int rem = int(t - img * tiles_per_img), ty = rem / pg.tiles_x, tx = rem - ty * pg.tiles_x;
+    oy0 = ty * 4 * pg.TR;
+    ox0 = tx * pg.TC;
+  };
+  auto load_patch = [&](float(&v)[kPatchMaxE], int64_t t) {
+    int64_t img;
+    int oy0, ox0;
+    tile_origin(t, img, oy0, ox0);
+    const int iy0 = oy0 * g.sh - g.pt, ix0 = ox0 * g.sw - g.pl;
+    const float *corner = X + img * g.C * g.H * g.W + int64_t(iy0) * g.W + ix0;
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++) {
+      const int iy = iy0 + (e_rc[i] >> 16), ix = ix0 + (e_rc[i] & 0xffff);
+      const bool ok = e_rc[i] >= 0 && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+      v[i] = ok ? corner[e_rel[i]] : 0.f;
+    }
+  };
+  auto store_patch = [&](const float(&v)[kPatchMaxE], int buf) {
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++)
+      if (e_rc[i] >= 0) patch[buf * psz + e_lds[i]] = v[i];
+  };
+
+  // lane's pixel inside the workgroup tile, and its word offset inside a patch channel
+  const int py = wave * pg.TR + r / pg.TC, px = r % pg.TC;
+  const int lbase = py * g.sh * pg.ROWS + px;
+  const f32x4 *wfrag = reinterpret_cast<const f32x4 *>(wl) + lane;
+  const int4 *ktab4 = reinterpret_cast<const int4 *>(ktab) + h;
+  const int OHW = g.OH * g.OW;
+
+  float pv[kPatchMaxE];
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) {
+    load_patch(pv, tile);
+    store_patch(pv, 0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const int64_t next = tile + gridDim.x;
+    if (next < ntiles) load_patch(pv, next);  // lands under this tile's MFMAs
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+    const float *pb = patch + buf * psz + lbase;
+    // software pipeline: offsets two groups ahead, B words and A fragments one group ahead
+    int4 ko_n = ktab4[0];
+    f32x4 a_n[MT];
+    float b_n[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) b_n[j] = pb[(&ko_n.x)[j]];
+#pragma unroll
+    for (int t = 0; t < MT; t++) a_n[t] = wfrag[t * 64];
+    ko_n = ktab4[pg.K8 > 1 ? 2 : 0];
+    for (int grp = 0; grp < pg.K8; grp++) {
+      f32x4 a[MT];
+      float b[4];
+#pragma unroll
+      for (int t = 0; t < MT; t++) a[t] = a_n[t];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = b_n[j];
+      if (grp + 1 < pg.K8) {
+        const int4 ko = ko_n;
+        if (grp + 2 < pg.K8) ko_n = ktab4[(grp + 2) * 2];
+#pragma unroll
+        for (int j = 0; j < 4; j++) b_n[j] = pb[(&ko.x)[j]];
+#pragma unroll
+        for (int t = 0; t < MT; t++) a_n[t] = wfrag[((grp + 1) * MT + t) * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[j], acc[t], 0, 0, 0);
+    }
+
+    // epilogue: lane (r,h) holds pixel (oy, ox), channels 32t + 8q + 4h + j -> channel quad 8t + 2q + h
+    int64_t img;
+    int oy0, ox0;
+    tile_origin(tile, img, oy0, ox0);
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy < g.OH && ox < g.OW) {
+      float *yp = Y + img * OHW * g.M + (int64_t(h) * OHW + oy * g.OW + ox) * 4;
+      const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias) + h : nullptr;
+      dispatch_act(act.kind, [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+          f32x4 bv[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>(acc[t][4 * q + j] + bv[q][j], act.a, act.b);
+            *reinterpret_cast<f32x4 *>(yp + int64_t(8 * t + 2 * q) * OHW * 4) = v;
+          }
+        }
+      });
+    }
+    if (next < ntiles) store_patch(pv, buf ^ 1);
+    __syncthreads();
+  }
+}
+
 // CQ pooling: one thread per (n, channel quad, oh, ow) -- 16 bytes per tap, consecutive lanes walk a plane row.
 __global__ __launch_bounds__(kBlock) void pool2d_cq_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total4,
                                                           int H, int W, int OH, int OW, int kh, int kw, int sh, int sw, int pt,
@@ -486,6 +675,62 @@ void conv2d(hipStream_t s, const float *X, const float *Wk, const float *bias, f
   } else {
     dim3 grid(bx, unsigned(g.groups * ((Mg + 127) / 128)));
     hipLaunchKernelGGL(conv2d_generic_kernel<4>, grid, dim3(kBlock), lds, s, X, Wk, bias, Y, total_pix, g, act, in_cq, out_cq);
+  }
+}
+
+bool conv2d_patch_supported(const ConvGeom &g) {
+  if (g.groups != 1 || g.M % 32 != 0 || g.M > 128 || g.C > 8) return false;
+  if (int64_t(g.C) * g.H * g.W >= (int64_t(1) << 30)) return false;
+  const PatchGeom p = patch_geom(g);
+  return p.NE <= kPatchMaxE && p.PR < 32768 && p.PC < 65536 && patch_lds_bytes(g, p) <= 160 * 1024;
+}
+
+size_t conv2d_patch_packed_floats(const ConvGeom &g) {
+  const PatchGeom p = patch_geom(g);
+  return size_t(p.K8) * (g.M / 32) * 256 + size_t(p.K8) * 8;
+}
+
+// [K8][MT][lane][j] = Wt[m = 32mt + (lane&31)][k = 8g + 4*(lane>>5) + j] (zero past C*kh*kw), then the
+// per-k patch offsets [K8][h][j] (as int bit patterns), k = (c, ky, kx) in ONNX order
+void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed) {
+  const PatchGeom p = patch_geom(g);
+  const int MT = g.M / 32, KK = g.C * g.kh * g.kw;
+  for (int grp = 0; grp < p.K8; grp++)
+    for (int mt = 0; mt < MT; mt++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 4; j++) {
+          const int m = 32 * mt + (lane & 31), k = 8 * grp + 4 * (lane >> 5) + j;
+          packed[((size_t(grp) * MT + mt) * 64 + lane) * 4 + j] = k < KK ? Wt[size_t(m) * KK + k] : 0.f;
+        }
+  int *kt = reinterpret_cast<int *>(packed + size_t(p.K8) * MT * 256);
+  for (int k = 0; k < p.K8 * 8; k++) {
+    int off = 0;
+    if (k < KK) {
+      const int c = k / (g.kh * g.kw), rem = k % (g.kh * g.kw), cy = (rem / g.kw) * g.dh, cx = (rem % g.kw) * g.dw;
+      off = c * p.PLANE + cy * p.ROWS + (cx % g.sw) * p.HALF + cx / g.sw;
+    }
+    kt[k] = off;
+  }
+}
+
+void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
+                  const ConvGeom &g, ActParam act, int num_cus) {
+  if (rows <= 0) return;
+  const PatchGeom p = patch_geom(g);
+  const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
+  const size_t lds = patch_lds_bytes(g, p);
+  const int per_cu = int(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds)));
+  const unsigned grid = unsigned(std::min<int64_t>(ntiles, int64_t(num_cus > 0 ? num_cus : 256) * per_cu));
+  auto launch = [&](auto kernel) {
+    if (lds > 64 * 1024)  // dynamic LDS beyond 64 KB is opt-in (per device, so not cached here)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, s, X, packed, bias, Y, ntiles, g, p, act);
+  };
+  switch (g.M / 32) {
+    case 1: launch(conv2d_patch_kernel<1>); break;
+    case 2: launch(conv2d_patch_kernel<2>); break;
+    case 3: launch(conv2d_patch_kernel<3>); break;
+    default: launch(conv2d_patch_kernel<4>); break;
   }
 }
 

@@ -66,6 +66,13 @@ bool conv2d_generic_supported(const ConvGeom &g);  // (C/g)*kh*kw <= 8192 (the p
 void conv2d_generic_pack(const ConvGeom &g, const float *Wt, float *packed);
 void conv2d(hipStream_t s, const float *X, const float *Wk, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
             ActParam act, bool in_cq, bool out_cq);
+// Patch convolution for the network's first layer: few input channels (C <= 8), NCHW input, CQ output,
+// M in {32, 64, 96, 128}, groups == 1; the receptive field of a pixel tile is staged in LDS.
+bool conv2d_patch_supported(const ConvGeom &g);
+size_t conv2d_patch_packed_floats(const ConvGeom &g);
+void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed);
+void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
+                  const ConvGeom &g, ActParam act, int num_cus);
 // Tiled CQ-layout convolution (groups == 1, C % 32 == 0, M % 64 == 0) on fragment-major packed weights.
 bool conv2d_tiled_supported(const ConvGeom &g);
 size_t conv2d_tiled_packed_floats(const ConvGeom &g);
