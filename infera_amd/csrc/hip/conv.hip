@@ -145,6 +145,9 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
 // interleaved with the matrix stream.  The next stage's B operands (S*4 16-byte gathers per lane) and weight
 // slab are requested in the first units and land under the remaining MFMAs.  Out-of-image taps do not
 // branch: a per-lane bit mask (one bit per tap, built once) redirects the gather to a page of zeros.
+// (Measured and dropped: a persistent variant walking a tile list with the pipeline running through the
+// tile boundary -- same time at 25k tiles, worse tails at <= 1.5k tiles; 64-feature tiles for the deep
+// layers; static s_setprio staggering of co-resident workgroups.  Probes: tools/conv_probe.sh.)
 __device__ __attribute__((aligned(256))) float g_zero_page[128];
 #ifdef INFERA_CONV_PROBES
 // [MT==4][phase]: summed shader cycles per wave: prologue, main loop, epilogue issue, store drain; [4] = waves
@@ -774,7 +777,7 @@ void dump_stamps() {
 #endif
 
 void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y,
-                  int64_t rows, const ConvGeom &g, ActParam act) {
+                  int64_t rows, const ConvGeom &g, ActParam act, int num_cus) {
   const int64_t total_pix = rows * g.OH * g.OW;
   if (total_pix <= 0) return;
   const unsigned bx = unsigned((total_pix + 127) / 128);
