@@ -94,7 +94,7 @@ def main():
 
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: " + capi.get_devices()["reason"])
-    rows = args.rows or {"mlp": 10_000_000, "logreg": 50_000_000, "resnet18": 512}[args.workload]
+    rows = args.rows or {"mlp": 10_000_000, "logreg": 50_000_000, "resnet18": 1024}[args.workload]
     cols = 3 * 224 * 224 if args.workload == "resnet18" else 128
     tmp = tempfile.mkdtemp(prefix="infera_bench_")
     if args.workload == "mlp":
