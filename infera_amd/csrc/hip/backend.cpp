@@ -242,8 +242,10 @@ void schedule(LoadedModel &m) {
   bool any_conv = false, ok = true;
   for (const auto &s : st) {
     any_conv = any_conv || s.kind == StepKind::Conv2d;
+    // (CopyCols = channel concat: a contiguous per-row block in NCHW and in channel-quad planes alike)
     const bool layout_free = s.kind == StepKind::Conv2d || s.kind == StepKind::Pool2d || s.kind == StepKind::GlobalAvgPool ||
-                             s.kind == StepKind::BinaryAct || s.kind == StepKind::Unary || s.kind == StepKind::AffineChannel;
+                             s.kind == StepKind::BinaryAct || s.kind == StepKind::Unary || s.kind == StepKind::AffineChannel ||
+                             s.kind == StepKind::CopyCols;
     for (int b : {s.in0, s.in1}) {
       if (b < 0) continue;
       if (b == 0 && is4d(0) && s.kind != StepKind::Conv2d) ok = false;  // the caller's NCHW input is read by convs only
@@ -266,6 +268,7 @@ void schedule(LoadedModel &m) {
         continue;
       }
       if (kern::conv2d_tiled_supported(g)) m.exec[i] = ExecKind::ConvTiled;
+      else if (kern::conv2d_depthwise_supported(g)) m.exec[i] = ExecKind::ConvDepthwise;
     }
   // Residual Add (+ activation) of a ResNet block -> epilogue of whichever of its two producers runs LAST
   // (conv2, or the 1x1 downsample conv when the block has one), the other operand being the skip tensor.
@@ -278,6 +281,7 @@ void schedule(LoadedModel &m) {
     for (size_t j = 0; j < n; j++) {
       const Step &a = st[j];
       if (m.exec[j] != ExecKind::Normal || a.kind != StepKind::BinaryAct || a.bop != '+' || !is4d(a.out)) continue;
+      if (int(a.act) > kMaxMfmaFusedAct) continue;  // the conv epilogue resolves only the MFMA-fusable kinds
       const int pa = prod[size_t(a.in0)], pb = prod[size_t(a.in1)];
       const int late = std::max(pa, pb);
       if (late < 0 || a.in0 == a.in1) continue;
@@ -303,6 +307,7 @@ void schedule(LoadedModel &m) {
   for (size_t e = 0; e < eff.size(); e++) {
     const int b = eff[e].writes;
     if (b == m.plan.out_buf || b == 0) continue;
+    if (m.slot_of_buf[size_t(b)] >= 0) continue;  // a Concat output: its first CopyCols piece already placed it
     int chosen = -1;
     for (size_t s = 0; s < slot_free_after.size(); s++)
       if (slot_free_after[s] < int(e)) {  // strictly before this step: in-place reuse is not allowed
@@ -345,6 +350,12 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
       std::vector<float> packed(kern::conv2d_tiled_packed_floats(g));
       kern::conv2d_tiled_pack(g, s.W.data(), packed.data());
+      d.W = upload(packed, us);
+    } else if (m.exec[i] == ExecKind::ConvDepthwise) {
+      kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
+                       int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
+      std::vector<float> packed(s.W.size());
+      kern::conv2d_depthwise_pack(g, s.W.data(), packed.data());
       d.W = upload(packed, us);
     } else if (m.exec[i] == ExecKind::ConvPatch) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
@@ -429,6 +440,12 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x), dm.num_cus);
           continue;
         }
+        case ExecKind::ConvDepthwise: {
+          kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
+                           int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
+          kern::conv2d_depthwise(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x));
+          continue;
+        }
         case ExecKind::ConvPatch: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
@@ -464,6 +481,10 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case StepKind::GlobalAvgPool:
           kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.cq_mode && x.in0 != 0);
           break;
+        case StepKind::CopyCols:
+          kern::copy_cols(s, buf(x.in0), buf(x.out), nr, p.buf_per_row[size_t(x.in0)], p.buf_per_row[size_t(x.out)], x.col_off);
+          break;
+        case StepKind::ArgMax: kern::argmax_rows(s, buf(x.in0), buf(x.out), nr, x.K); break;
       }
     }
     HIP_TRY(hipGetLastError());
@@ -641,7 +662,7 @@ void sync_device(int device_ordinal) {
 hipStream_t thread_stream(int device_ordinal) { return ctx_for_slot(slot_of_ordinal(device_ordinal)).stream; }
 
 std::string LoadedModel::describe_json() const {
-  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch"};
+  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch", "conv_depthwise"};
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";

@@ -560,6 +560,40 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
   }
 }
 
+// Depthwise convolution (groups == C == M) in channel-quad planes: HBM-bound, no matrix cores.  One thread per
+// (n, channel quad, oh, ow): every tap is one 16-byte load (consecutive lanes walk a plane row) times one
+// 16-byte weight quad [c/4][tap][4] that the whole wave shares.
+__global__ __launch_bounds__(kBlock) void conv2d_depthwise_cq_kernel(const float *__restrict__ X, const float *__restrict__ Wd,
+                                                                    const float *__restrict__ bias, float *__restrict__ Y,
+                                                                    int64_t total4, ConvGeom g, ActParam act) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X), *w4 = reinterpret_cast<const f32x4 *>(Wd);
+  f32x4 *y4 = reinterpret_cast<f32x4 *>(Y);
+  const int C4 = g.C >> 2, ntaps = g.kh * g.kw;
+  for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < total4; o += stride) {
+    const int ow = int(o % g.OW);
+    const int oh = int((o / g.OW) % g.OH);
+    const int64_t plane = o / (int64_t(g.OW) * g.OH);  // n * C/4 + c/4
+    const int c4 = int(plane % C4);
+    f32x4 acc = bias ? reinterpret_cast<const f32x4 *>(bias)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 *wq = w4 + int64_t(c4) * ntaps;
+    for (int ky = 0; ky < g.kh; ky++) {
+      const int iy = oh * g.sh - g.pt + ky * g.dh;
+      if (iy < 0 || iy >= g.H) continue;
+      for (int kx = 0; kx < g.kw; kx++) {
+        const int ix = ow * g.sw - g.pl + kx * g.dw;
+        if (ix < 0 || ix >= g.W) continue;
+        const f32x4 v = x4[(plane * g.H + iy) * g.W + ix], w = wq[ky * g.kw + kx];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] = fmaf(v[e], w[e], acc[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc[e] = apply_act(acc[e], act);
+    y4[o] = acc;
+  }
+}
+
 // CQ pooling: one thread per (n, channel quad, oh, ow) -- 16 bytes per tap, consecutive lanes walk a plane row.
 __global__ __launch_bounds__(kBlock) void pool2d_cq_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total4,
                                                           int H, int W, int OH, int OW, int kh, int kw, int sh, int sw, int pt,
@@ -735,6 +769,22 @@ void conv2d_patch(hipStream_t s, const float *X, const float *packed, const floa
     case 3: launch(conv2d_patch_kernel<3>); break;
     default: launch(conv2d_patch_kernel<4>); break;
   }
+}
+
+bool conv2d_depthwise_supported(const ConvGeom &g) { return g.groups == g.C && g.M == g.C && g.C % 4 == 0; }
+
+// [C/4][tap][4] <- Wt[m][0][ky][kx]
+void conv2d_depthwise_pack(const ConvGeom &g, const float *Wt, float *packed) {
+  const int ntaps = g.kh * g.kw;
+  for (int c = 0; c < g.C; c++)
+    for (int t = 0; t < ntaps; t++) packed[(size_t(c >> 2) * ntaps + t) * 4 + (c & 3)] = Wt[size_t(c) * ntaps + t];
+}
+
+void conv2d_depthwise(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
+                      const ConvGeom &g, ActParam act) {
+  const int64_t total4 = rows * (g.C / 4) * g.OH * g.OW;
+  if (total4 <= 0) return;
+  hipLaunchKernelGGL(conv2d_depthwise_cq_kernel, dim3(grid_for(total4)), dim3(kBlock), 0, s, X, packed, bias, Y, total4, g, act);
 }
 
 bool conv2d_tiled_supported(const ConvGeom &g) {

@@ -111,6 +111,42 @@ __global__ __launch_bounds__(kBlock) void softmax_wave_kernel(const float *__res
   }
 }
 
+// One piece of a Concat along the feature / channel axis: dst[r, off : off+len] = src[r, :].  16-byte moves
+// when every offset is a multiple of 4 floats.
+__global__ __launch_bounds__(kBlock) void copy_cols_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t rows,
+                                                          int64_t len, int64_t dst_stride, int64_t dst_off, bool vec4) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  if (vec4) {
+    const int64_t l4 = len >> 2, n4 = rows * l4;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += stride) {
+      const int64_t r = i / l4, c = i - r * l4;
+      *reinterpret_cast<f32x4 *>(dst + r * dst_stride + dst_off + 4 * c) = reinterpret_cast<const f32x4 *>(src)[i];
+    }
+    return;
+  }
+  const int64_t n = rows * len;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / len, c = i - r * len;
+    dst[r * dst_stride + dst_off + c] = src[i];
+  }
+}
+
+// Index of the first maximum of each row, as an f32 value (NaN never wins: ONNX ArgMax on comparisons).
+__global__ __launch_bounds__(kBlock) void argmax_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t rows, int64_t len) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < rows; r += stride) {
+    const float *src = x + r * len;
+    float best = src[0];
+    int64_t bi = 0;
+    for (int64_t j = 1; j < len; j++)
+      if (src[j] > best) {
+        best = src[j];
+        bi = j;
+      }
+    y[r] = float(bi);
+  }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -163,6 +199,18 @@ void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t oute
     // vectors index as (row*outer + ou, in): flatten (row,outer) into the `ou` coordinate
     hipLaunchKernelGGL(softmax_small_kernel, dim3(grid_for(nvec)), dim3(kBlock), 0, s, x, y, nvec, len, inner, log_softmax);
   }
+}
+
+void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t dst_stride, int64_t dst_off) {
+  if (rows <= 0 || len <= 0) return;
+  const bool vec4 = ((len | dst_stride | dst_off) & 3) == 0;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(vec4 ? rows * len / 4 : rows * len)), dim3(kBlock), 0, s, src, dst, rows, len,
+                     dst_stride, dst_off, vec4);
+}
+
+void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t len) {
+  if (rows <= 0 || len <= 0) return;
+  hipLaunchKernelGGL(argmax_kernel, dim3(grid_for(rows)), dim3(kBlock), 0, s, x, y, rows, len);
 }
 
 void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_t rows, uint64_t ncols) {

@@ -11,7 +11,7 @@ namespace infera_hip::kern {
 
 // Activation codes shared with plan.hpp (Act enum values).
 struct ActParam {
-  int kind = 0;  // 0 none, 1 relu, 2 sigmoid, 3 tanh, 4 leaky-relu(a), 5 clip(a,b)
+  int kind = 0;  // plan.hpp Act: 0 none, 1 relu, 2 sigmoid, 3 tanh, 4 leaky-relu(a), 5 clip(a,b), 6.. elementwise-only kinds
   float a = 0.f, b = 0.f;
 };
 
@@ -27,6 +27,9 @@ void affine_channel(hipStream_t s, const float *x, const float *scale, const flo
 // softmax over `len` with element stride `inner`, repeated rows*outer*inner times
 void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner,
              bool log_softmax);
+// dst[r, dst_off : dst_off+len] = src[r, 0:len]  (one input of a Concat); y[r] = float(argmax_j x[r, j])
+void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t dst_stride, int64_t dst_off);
+void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t len);
 // synthetic table fill (SURVEY.md 8d generator), row-major [rows, ncols]
 void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_t rows, uint64_t ncols);
 
@@ -73,6 +76,11 @@ size_t conv2d_patch_packed_floats(const ConvGeom &g);
 void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed);
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                   const ConvGeom &g, ActParam act, int num_cus);
+// Depthwise convolution (groups == C == M, C % 4 == 0) in channel-quad planes; packed = [C/4][tap][4].
+bool conv2d_depthwise_supported(const ConvGeom &g);
+void conv2d_depthwise_pack(const ConvGeom &g, const float *Wt, float *packed);
+void conv2d_depthwise(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
+                      const ConvGeom &g, ActParam act);
 // Tiled CQ-layout convolution (groups == 1, C % 32 == 0, M % 64 == 0) on fragment-major packed weights.
 bool conv2d_tiled_supported(const ConvGeom &g);
 size_t conv2d_tiled_packed_floats(const ConvGeom &g);

@@ -5,9 +5,13 @@
 //   Gemm(transB, alpha, beta)          -> Dense (constants folded into W / bias)
 //   Dense|Conv|Binary|Affine + act     -> trailing activation fused into the producing step
 //   Conv + BatchNormalization          -> BN folded into conv weights/bias
-//   Identity/Dropout/Flatten/Reshape/Squeeze/Unsqueeze -> buffer alias (no kernel)
+//   Identity/Dropout/Flatten/Reshape/Squeeze/Unsqueeze/Cast(f32) -> buffer alias (no kernel)
+//   Shape/Gather/Concat/Unsqueeze/Squeeze/Slice/Cast on constants -> folded (the usual exporter pattern
+//     Shape -> Gather -> Unsqueeze -> Concat -> Reshape; the symbolic row count is carried as 0 = "copy")
+//   ReduceMean over the spatial axes -> GlobalAvgPool;  Concat(axis=1) -> one CopyCols step per input
 // Dense chains are kept as consecutive Dense steps; the device executor decides whether a chain
 // runs as one whole-chain fused kernel or layer by layer.
+#include <algorithm>
 #include <cmath>
 #include <functional>
 #include <map>
@@ -184,9 +188,24 @@ struct Lowerer {
     return out;
   }
 
+  static float fold_bop(char op, float u, float v) {
+    switch (op) {
+      case '+': return u + v;
+      case '-': return u - v;
+      case '*': return u * v;
+      case '/': return u / v;
+      case 'm': return std::fmin(u, v);
+      case 'M': return std::fmax(u, v);
+      case '^': return std::pow(u, v);
+      default: return u >= 0.f ? u : v * u;  // 'p'
+    }
+  }
+
   void binary(const NodeDef &n, char op) {
+    if (n.inputs.size() != 2) unsupported(n, "exactly two inputs are supported");
     const Val &a = get(n, 0);
     const Val &b = get(n, 1);
+    if (a.is_const && b.is_const && a.c->dtype == onnx::kInt64 && b.c->dtype == onnx::kInt64) return fold_int_binary(n, op, a, b);
     if (a.is_const && b.is_const) {  // fold
       const auto &x = cf32(n, a), &y = cf32(n, b);
       if (a.shape != b.shape && x.size() != 1 && y.size() != 1) unsupported(n, "constant folding needs equal shapes or a scalar");
@@ -197,7 +216,7 @@ struct Lowerer {
       t->f32.resize(cnt);
       for (size_t i = 0; i < cnt; i++) {
         float u = x[x.size() == 1 ? 0 : i], v = y[y.size() == 1 ? 0 : i];
-        t->f32[i] = op == '+' ? u + v : op == '-' ? u - v : op == '*' ? u * v : u / v;
+        t->f32[i] = fold_bop(op, u, v);
       }
       Val v;
       v.is_const = true;
@@ -220,6 +239,16 @@ struct Lowerer {
     const Val &act = const_left ? b : a;
     const Val &cst = const_left ? a : b;
     std::vector<int64_t> act_shape = act.shape;
+    if (op == 'p' && const_left) unsupported(n, "PRelu needs a constant slope");
+    if ((op == 'm' || op == 'M') && const_left) {  // commutative: keep the activation on the left
+      Step s;
+      s.kind = StepKind::BinaryConst;
+      s.in0 = act.buf;
+      s.bop = op;
+      s.cst = broadcast_const(n, cst, act_shape);
+      emit(std::move(s), n, act_shape);
+      return;
+    }
     // MatMul + Add(const over M) -> Dense bias
     if (op == '+') {
       Step *p = fusable_producer(n, const_left ? 1 : 0);
@@ -242,13 +271,234 @@ struct Lowerer {
     emit(std::move(s), n, act_shape);
   }
 
+  // ---- constant folding of the integer (shape) sub-graphs exporters emit around Reshape ----
+  void set_const_i64(const NodeDef &n, std::vector<int64_t> v, std::vector<int64_t> dims) {
+    auto t = std::make_shared<TensorData>();
+    t->dtype = onnx::kInt64;
+    t->dims = std::move(dims);
+    t->i64 = std::move(v);
+    Val o;
+    o.is_const = true;
+    o.c = t;
+    o.shape = t->dims;
+    vals[n.outputs[0]] = o;
+  }
+  void fold_int_binary(const NodeDef &n, char op, const Val &a, const Val &b) {
+    const auto &x = a.c->i64, &y = b.c->i64;
+    if (x.size() != y.size() && x.size() != 1 && y.size() != 1) unsupported(n, "integer folding needs equal sizes or a scalar");
+    std::vector<int64_t> o(std::max(x.size(), y.size()));
+    for (size_t i = 0; i < o.size(); i++) {
+      const int64_t u = x[x.size() == 1 ? 0 : i], v = y[y.size() == 1 ? 0 : i];
+      if (op == '/' && v == 0) unsupported(n, "integer division by zero");
+      o[i] = op == '+' ? u + v : op == '-' ? u - v : op == '*' ? u * v : op == '/' ? u / v : op == 'm' ? std::min(u, v) : std::max(u, v);
+    }
+    set_const_i64(n, o, x.size() >= y.size() ? a.shape : b.shape);
+  }
+  void shape_op(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    std::vector<int64_t> d = a.shape;
+    // the symbolic row count is carried as 0, which Reshape reads as "copy this dim from the input"
+    if (!a.is_const && !d.empty() && d[0] < 0) d[0] = 0;
+    int64_t r = int64_t(d.size()), st = n.attr_i("start", 0), en = n.attr_i("end", r);
+    if (st < 0) st += r;
+    if (en < 0) en += r;
+    st = std::clamp<int64_t>(st, 0, r);
+    en = std::clamp<int64_t>(en, st, r);
+    std::vector<int64_t> o(d.begin() + st, d.begin() + en);
+    const int64_t cnt = int64_t(o.size());
+    set_const_i64(n, std::move(o), {cnt});
+  }
+  std::vector<int64_t> const_ints(const NodeDef &n, size_t i, const char *what) {
+    const Val &v = get(n, i);
+    if (!v.is_const || v.c->dtype != onnx::kInt64) unsupported(n, std::string(what) + " must be a constant integer tensor");
+    return v.c->i64;
+  }
+  void gather(const NodeDef &n) {
+    const Val &d = get(n, 0);
+    const Val &ix = get(n, 1);
+    if (!d.is_const || !ix.is_const || ix.c->dtype != onnx::kInt64) unsupported(n, "only constant data with constant indices is folded");
+    if (d.shape.size() > 1 || n.attr_i("axis", 0) != 0) unsupported(n, "only 1-D data / axis 0");
+    const int64_t len = d.c->dtype == onnx::kInt64 ? int64_t(d.c->i64.size()) : int64_t(d.c->f32.size());
+    auto at = [&](int64_t i) {
+      if (i < 0) i += len;
+      if (i < 0 || i >= len) unsupported(n, "index out of range");
+      return size_t(i);
+    };
+    if (d.c->dtype == onnx::kInt64) {
+      std::vector<int64_t> o;
+      for (auto i : ix.c->i64) o.push_back(d.c->i64[at(i)]);
+      set_const_i64(n, std::move(o), ix.shape);
+    } else {
+      auto t = std::make_shared<TensorData>();
+      t->dtype = onnx::kFloat;
+      t->dims = ix.shape;
+      for (auto i : ix.c->i64) t->f32.push_back(d.c->f32[at(i)]);
+      Val o;
+      o.is_const = true;
+      o.c = t;
+      o.shape = t->dims;
+      vals[n.outputs[0]] = o;
+    }
+  }
+  void slice(const NodeDef &n) {
+    const Val &d = get(n, 0);
+    if (!d.is_const || d.c->dtype != onnx::kInt64 || d.shape.size() != 1) unsupported(n, "only 1-D constant integer data is folded");
+    std::vector<int64_t> st, en, ax, sp;
+    if (has_input(n, 1)) {
+      st = const_ints(n, 1, "starts");
+      en = const_ints(n, 2, "ends");
+      if (has_input(n, 3)) ax = const_ints(n, 3, "axes");
+      if (has_input(n, 4)) sp = const_ints(n, 4, "steps");
+    } else {
+      if (auto *p = n.attr_ints("starts")) st = *p;
+      if (auto *p = n.attr_ints("ends")) en = *p;
+    }
+    if (st.size() != 1 || en.size() != 1 || (!ax.empty() && ax[0] != 0 && ax[0] != -1)) unsupported(n, "one axis only");
+    const int64_t len = int64_t(d.c->i64.size()), step = sp.empty() ? 1 : sp[0];
+    if (step != 1) unsupported(n, "step must be 1");
+    int64_t b = st[0] < 0 ? st[0] + len : st[0], e = en[0] < 0 ? en[0] + len : en[0];
+    b = std::clamp<int64_t>(b, 0, len);
+    e = std::clamp<int64_t>(e, b, len);
+    std::vector<int64_t> o(d.c->i64.begin() + b, d.c->i64.begin() + e);
+    const int64_t cnt = int64_t(o.size());
+    set_const_i64(n, std::move(o), {cnt});
+  }
+  void cast(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    const int64_t to = n.attr_i("to", onnx::kFloat);
+    const bool to_int = to == onnx::kInt64 || to == onnx::kInt32, to_f = to == onnx::kFloat || to == onnx::kDouble;
+    if (!to_int && !to_f) unsupported(n, "only casts to f32/f64/int32/int64");
+    if (a.is_const) {
+      if ((a.c->dtype == onnx::kInt64) == to_int) { vals[n.outputs[0]] = a; return; }
+      if (to_int) {
+        std::vector<int64_t> o;
+        for (float f : a.c->f32) o.push_back(int64_t(f));
+        set_const_i64(n, std::move(o), a.shape);
+      } else {
+        auto t = std::make_shared<TensorData>();
+        t->dtype = onnx::kFloat;
+        t->dims = a.shape;
+        for (int64_t i : a.c->i64) t->f32.push_back(float(i));
+        Val o;
+        o.is_const = true;
+        o.c = t;
+        o.shape = t->dims;
+        vals[n.outputs[0]] = o;
+      }
+      return;
+    }
+    // activations are always f32 here: a float cast is an alias, an integer cast truncates toward zero and
+    // the values stay in f32 storage (the C ABI returns f32, rust.h:28-49)
+    if (to_f) { alias(n, a.shape); return; }
+    Step s;
+    s.kind = StepKind::Unary;
+    s.in0 = a.buf;
+    s.act = Act::Trunc;
+    std::vector<int64_t> shape = a.shape;
+    emit(std::move(s), n, shape);
+  }
+  void concat(const NodeDef &n) {
+    if (n.inputs.empty()) unsupported(n, "no inputs");
+    bool all_const = true;
+    for (size_t i = 0; i < n.inputs.size(); i++) all_const = all_const && get(n, i).is_const;
+    if (all_const) {
+      std::vector<int64_t> o;
+      for (size_t i = 0; i < n.inputs.size(); i++) {
+        const Val &v = get(n, i);
+        if (v.c->dtype != onnx::kInt64 || v.shape.size() > 1) unsupported(n, "only 1-D integer constants are folded");
+        o.insert(o.end(), v.c->i64.begin(), v.c->i64.end());
+      }
+      const int64_t cnt = int64_t(o.size());
+      set_const_i64(n, std::move(o), {cnt});
+      return;
+    }
+    const Val &first = get(n, 0);
+    if (first.is_const) unsupported(n, "mixing constants and activations");
+    const int64_t rank = int64_t(first.shape.size());
+    int64_t axis = n.attr_i("axis", 1);
+    if (axis < 0) axis += rank;
+    if (axis != 1) unsupported(n, "only axis 1 (features / channels) is supported");
+    std::vector<int64_t> out_shape = first.shape;
+    out_shape[1] = 0;
+    for (size_t i = 0; i < n.inputs.size(); i++) {
+      const Val &v = get(n, i);
+      if (v.is_const) unsupported(n, "mixing constants and activations");
+      if (v.shape.size() != first.shape.size()) unsupported(n, "rank mismatch");
+      for (size_t d = 0; d < v.shape.size(); d++)
+        if (d != 1 && v.shape[d] != first.shape[d]) unsupported(n, "shape mismatch " + shape_str(v.shape) + " vs " + shape_str(first.shape));
+      out_shape[1] += v.shape[1];
+    }
+    const int out = new_buf(out_shape);
+    int64_t off = 0;
+    for (size_t i = 0; i < n.inputs.size(); i++) {
+      const Val &v = get(n, i);
+      Step s;
+      s.kind = StepKind::CopyCols;
+      s.in0 = v.buf;
+      s.out = out;
+      s.col_off = off;
+      s.origin = n.op + (n.name.empty() ? "" : ":" + n.name) + "[" + std::to_string(i) + "]";
+      off += prod(v.shape, 1);
+      plan.steps.push_back(std::move(s));
+    }
+    producer[out] = int(plan.steps.size()) - 1;
+    set_act(n, out, out_shape);
+  }
+  void reduce_mean(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    if (a.is_const || a.shape.size() < 3) unsupported(n, "only spatial means of [N,C,...] activations");
+    std::vector<int64_t> axes;
+    if (has_input(n, 1)) axes = const_ints(n, 1, "axes");
+    else if (auto *p = n.attr_ints("axes")) axes = *p;
+    const int64_t rank = int64_t(a.shape.size());
+    std::vector<bool> red(size_t(rank), false);
+    for (auto ax : axes) red[size_t(ax < 0 ? ax + rank : ax)] = true;
+    for (int64_t i = 0; i < rank; i++)
+      if (red[size_t(i)] != (i >= 2)) unsupported(n, "axes must be exactly the spatial axes");
+    Step s;
+    s.kind = StepKind::GlobalAvgPool;
+    s.in0 = a.buf;
+    s.C = a.shape[1];
+    s.S = prod(a.shape, 2);
+    std::vector<int64_t> shape = {a.shape[0], a.shape[1]};
+    if (n.attr_i("keepdims", 1) != 0)
+      for (int64_t i = 2; i < rank; i++) shape.push_back(1);
+    emit(std::move(s), n, shape);
+  }
+  void argmax(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    if (a.is_const || a.shape.size() != 2) unsupported(n, "only [rows, classes] activations");
+    int64_t axis = n.attr_i("axis", 0);
+    if (axis < 0) axis += 2;
+    if (axis != 1) unsupported(n, "only axis 1 keeps rows independent");
+    if (n.attr_i("select_last_index", 0) != 0) unsupported(n, "select_last_index=1");
+    Step s;
+    s.kind = StepKind::ArgMax;
+    s.in0 = a.buf;
+    s.K = a.shape[1];
+    std::vector<int64_t> shape = {a.shape[0]};
+    if (n.attr_i("keepdims", 1) != 0) shape.push_back(1);
+    emit(std::move(s), n, shape);
+  }
+
   void unary(const NodeDef &n) {
     Act act;
     float pa = 0.f, pb = 0.f;
-    if (n.op == "Relu") act = Act::Relu;
-    else if (n.op == "Sigmoid") act = Act::Sigmoid;
-    else if (n.op == "Tanh") act = Act::Tanh;
+    static const std::map<std::string, Act> simple = {
+        {"Relu", Act::Relu}, {"Sigmoid", Act::Sigmoid}, {"Tanh", Act::Tanh}, {"Exp", Act::Exp}, {"Log", Act::Log},
+        {"Sqrt", Act::Sqrt}, {"Neg", Act::Neg}, {"Abs", Act::Abs}, {"Softplus", Act::Softplus}, {"HardSwish", Act::HardSwish},
+        {"Erf", Act::Erf}, {"Reciprocal", Act::Reciprocal}, {"Floor", Act::Floor}, {"Ceil", Act::Ceil},
+        {"Softsign", Act::Softsign}, {"Round", Act::Round}};
+    auto si = simple.find(n.op);
+    if (si != simple.end()) act = si->second;
     else if (n.op == "LeakyRelu") { act = Act::LeakyRelu; pa = n.attr_f("alpha", 0.01f); }
+    else if (n.op == "Elu") { act = Act::Elu; pa = n.attr_f("alpha", 1.0f); }
+    else if (n.op == "Selu") { act = Act::Selu; pa = n.attr_f("alpha", 1.67326319217681884765625f); pb = n.attr_f("gamma", 1.05070102214813232421875f); }
+    else if (n.op == "HardSigmoid") { act = Act::HardSigmoid; pa = n.attr_f("alpha", 0.2f); pb = n.attr_f("beta", 0.5f); }
+    else if (n.op == "Gelu") {
+      if (n.attr_s("approximate", "none") != "none") unsupported(n, "only the exact (erf) form");
+      act = Act::Gelu;
+    }
     else {  // Clip
       act = Act::Clip;
       pa = -INFINITY;
@@ -262,7 +512,10 @@ struct Lowerer {
     if (a.is_const) unsupported(n, "activation of a constant");
     std::vector<int64_t> shape = a.shape;
     if (Step *p = fusable_producer(n, 0)) {
-      if (p->act == Act::None && p->kind != StepKind::Softmax && p->kind != StepKind::Pool2d && p->kind != StepKind::GlobalAvgPool) {
+      const bool mfma_step = p->kind == StepKind::Dense || p->kind == StepKind::Conv2d;
+      const bool takes_act = p->kind == StepKind::Dense || p->kind == StepKind::Conv2d || p->kind == StepKind::AffineChannel ||
+                             p->kind == StepKind::BinaryConst || p->kind == StepKind::BinaryAct;
+      if (p->act == Act::None && takes_act && (!mfma_step || int(act) <= kMaxMfmaFusedAct)) {
         p->act = act;
         p->act_a = pa;
         p->act_b = pb;
@@ -292,6 +545,16 @@ struct Lowerer {
     const Val &a = get(n, 0);
     if (a.is_const) {
       if (n.op == "Identity") { vals[n.outputs[0]] = a; return; }
+      if ((n.op == "Unsqueeze" || n.op == "Squeeze") && a.shape.size() <= 1) {  // scalar <-> [1] in shape sub-graphs
+        Val v = a;
+        auto t = std::make_shared<TensorData>(*a.c);
+        t->dims = n.op == "Unsqueeze" ? std::vector<int64_t>{1} : std::vector<int64_t>{};
+        if (n.op == "Unsqueeze" && a.shape.size() == 1) unsupported(n, "only scalar constants are unsqueezed");
+        v.c = t;
+        v.shape = t->dims;
+        vals[n.outputs[0]] = v;
+        return;
+      }
       unsupported(n, "reshaping constants is not supported");
     }
     std::vector<int64_t> out;
@@ -527,7 +790,22 @@ struct Lowerer {
       else if (op == "Sub") binary(n, '-');
       else if (op == "Mul") binary(n, '*');
       else if (op == "Div") binary(n, '/');
-      else if (op == "Relu" || op == "Sigmoid" || op == "Tanh" || op == "LeakyRelu" || op == "Clip") unary(n);
+      else if (op == "Min") binary(n, 'm');
+      else if (op == "Max") binary(n, 'M');
+      else if (op == "Pow") binary(n, '^');
+      else if (op == "PRelu") binary(n, 'p');
+      else if (op == "Relu" || op == "Sigmoid" || op == "Tanh" || op == "LeakyRelu" || op == "Clip" || op == "Exp" || op == "Log" ||
+               op == "Sqrt" || op == "Neg" || op == "Abs" || op == "Elu" || op == "Selu" || op == "Softplus" || op == "HardSigmoid" ||
+               op == "HardSwish" || op == "Erf" || op == "Gelu" || op == "Reciprocal" || op == "Floor" || op == "Ceil" ||
+               op == "Softsign" || op == "Round")
+        unary(n);
+      else if (op == "Shape") shape_op(n);
+      else if (op == "Gather") gather(n);
+      else if (op == "Slice") slice(n);
+      else if (op == "Cast") cast(n);
+      else if (op == "Concat") concat(n);
+      else if (op == "ReduceMean") reduce_mean(n);
+      else if (op == "ArgMax") argmax(n);
       else if (op == "Identity" || op == "Dropout" || op == "Flatten" || op == "Reshape" || op == "Squeeze" || op == "Unsqueeze") reshape_like(n);
       else if (op == "Softmax") softmax(n, false);
       else if (op == "LogSoftmax") softmax(n, true);
@@ -553,7 +831,15 @@ struct Lowerer {
     auto it = vals.find(out.name);
     if (it == vals.end()) throw InferaError::onnx("output '" + out.name + "' is never produced");
     if (it->second.is_const) throw InferaError::onnx("output '" + out.name + "' is a constant; nothing to run");
-    if (out.elem_type != 0 && out.elem_type != onnx::kFloat) throw InferaError::onnx("output '" + out.name + "' is not f32");
+    if (out.elem_type != 0 && out.elem_type != onnx::kFloat) {
+      // integer outputs (ArgMax labels, Cast to int) are returned as f32 VALUES: the C ABI carries f32 only
+      // (rust.h:28-49; the reference itself rejects non-f32 outputs at engine.rs:150-152)
+      auto pit = producer.find(it->second.buf);
+      const Step *ps = pit == producer.end() ? nullptr : &plan.steps[size_t(pit->second)];
+      const bool int_valued = ps && (ps->kind == StepKind::ArgMax || ps->act == Act::Trunc);
+      if (!(int_valued && (out.elem_type == onnx::kInt64 || out.elem_type == onnx::kInt32)))
+        throw InferaError::onnx("output '" + out.name + "' is not f32");
+    }
     plan.out_buf = it->second.buf;
     plan.output_shape = it->second.shape;
     if (plan.fixed_batch < 0) plan.output_shape[0] = -1;
@@ -583,8 +869,9 @@ double Plan::flops_per_row() const {
 }
 
 std::string Plan::describe_json() const {
-  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool"};
-  static const char *acts[] = {"", "Relu", "Sigmoid", "Tanh", "LeakyRelu", "Clip"};
+  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool", "CopyCols", "ArgMax"};
+  static const char *acts[] = {"", "Relu", "Sigmoid", "Tanh", "LeakyRelu", "Clip", "Exp", "Log", "Sqrt", "Neg", "Abs", "Elu", "Selu", "Softplus",
+                               "HardSigmoid", "HardSwish", "Erf", "Gelu", "Reciprocal", "Floor", "Ceil", "Softsign", "Trunc", "Round"};
   std::ostringstream o;
   o << "{\"input_shape\":" << json_int_array(input_shape) << ",\"output_shape\":" << json_int_array(output_shape)
     << ",\"flops_per_row\":" << (long long)flops_per_row() << ",\"steps\":[";

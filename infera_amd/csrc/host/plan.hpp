@@ -14,7 +14,14 @@
 
 namespace infera_hip {
 
-enum class Act : int { None = 0, Relu = 1, Sigmoid = 2, Tanh = 3, LeakyRelu = 4, Clip = 5 };
+// Kinds 1..5 may be fused into the epilogue of a Dense / Conv2d step (the MFMA kernels resolve them at
+// compile time); the rest run in the elementwise kernels (fused into Binary*/AffineChannel or as a Unary step).
+enum class Act : int {
+  None = 0, Relu = 1, Sigmoid = 2, Tanh = 3, LeakyRelu = 4, Clip = 5,
+  Exp = 6, Log = 7, Sqrt = 8, Neg = 9, Abs = 10, Elu = 11, Selu = 12, Softplus = 13, HardSigmoid = 14, HardSwish = 15,
+  Erf = 16, Gelu = 17, Reciprocal = 18, Floor = 19, Ceil = 20, Softsign = 21, Trunc = 22, Round = 23,
+};
+constexpr int kMaxMfmaFusedAct = 5;
 
 enum class StepKind : int {
   Dense = 0,        // Y[rows,M] = act(X[rows,K] . W[K,M] + bias[M])       (MatMul / Gemm [+Add] [+act])
@@ -26,6 +33,8 @@ enum class StepKind : int {
   Conv2d = 6,       // NCHW convolution as implicit GEMM (BatchNormalization folded when adjacent)
   Pool2d = 7,       // MaxPool / AveragePool
   GlobalAvgPool = 8,
+  CopyCols = 9,     // out[r, col_off : col_off+len] = in0[r, :]   (one piece of a Concat along the feature/channel axis)
+  ArgMax = 10,      // out[r, 0] = float(index of the first maximum of in0[r, 0:len])   (labels as f32 values)
 };
 
 struct Step {
@@ -40,10 +49,12 @@ struct Step {
   // AffineChannel: scale/shift per channel, S = elements per channel
   std::vector<float> scale, shift;
   int64_t S = 1;
-  // BinaryConst / BinaryAct
+  // BinaryConst / BinaryAct: + - * /  m(in) M(ax) ^(pow)  p(relu: x >= 0 ? x : c*x, BinaryConst only)
   char bop = '+';
   bool const_left = false;
   std::vector<float> cst;  // per_row elements
+  // CopyCols: destination column offset (elements inside a row); the length is in0's per_row
+  int64_t col_off = 0;
   // Softmax
   int64_t sm_outer = 1, sm_len = 1, sm_inner = 1;
   bool log_softmax = false;

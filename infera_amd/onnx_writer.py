@@ -250,6 +250,143 @@ def resnet18(classes: int = 1000, seed: int = 1234, in_hw: int = 224, width: int
     return model("resnet18", nodes, inits, [value_info("X", ["N", 3, in_hw, in_hw])], [value_info("Y", ["N", classes])], opset=13)
 
 
+def unary_zoo(features: int = 16) -> bytes:
+    """Every elementwise operator of the breadth set in one graph: a Gemm feeds parallel branches (one per
+    operator, inputs pre-conditioned where the domain needs it), the branches are concatenated (axis 1)."""
+    ws = _WeightStream(77)
+    w = ws.take((features, features), features)
+    b = ws.take((features,), features)
+    inits = [tensor("W", w), tensor("B", b), tensor("one", np.array([1.5], np.float32)), tensor("two", np.array([2.0], np.float32)),
+             tensor("slope", (0.05 + 0.2 * np.abs(ws.take((features,), 1))).astype(np.float32)),
+             tensor("lo", (-0.25 * np.ones((1, features))).astype(np.float32))]
+    nodes = [node("Gemm", ["X", "W", "B"], ["H"]),
+             node("Abs", ["H"], ["Hp0"]), node("Add", ["Hp0", "one"], ["Hpos"])]  # strictly positive branch input
+    outs = []
+
+    def br(op, src="H", attrs=()):
+        o = f"o_{len(outs)}"
+        nodes.append(node(op, [src], [o], list(attrs)))
+        outs.append(o)
+
+    for op in ("Exp", "Neg", "Abs", "Softplus", "HardSwish", "Erf", "Floor", "Ceil", "Softsign", "Round", "Sigmoid", "Tanh", "Relu"):
+        br(op)
+    br("Elu", attrs=[attr_f("alpha", 0.7)])
+    br("Selu")
+    br("HardSigmoid", attrs=[attr_f("alpha", 0.3), attr_f("beta", 0.4)])
+    br("LeakyRelu", attrs=[attr_f("alpha", 0.2)])
+    for op in ("Log", "Sqrt", "Reciprocal"):
+        br(op, "Hpos")
+    for op, rhs in (("Pow", "two"), ("Min", "lo"), ("Max", "lo"), ("PRelu", "slope")):
+        o = f"o_{len(outs)}"
+        nodes.append(node(op, ["H", rhs], [o]))
+        outs.append(o)
+    o = f"o_{len(outs)}"
+    nodes.append(node("Max", ["lo", "H"], [o]))  # constant on the left
+    outs.append(o)
+    nodes.append(node("Concat", outs, ["Y"], [attr_i("axis", 1)]))
+    return model("unary_zoo", nodes, inits, [value_info("X", ["N", features])], [value_info("Y", ["N", features * len(outs)])], opset=13)
+
+
+def exporter_reshape(c: int = 8, hw: int = 6, classes: int = 5) -> bytes:
+    """The PyTorch-exporter idiom `x.view(x.size(0), -1)`: Shape -> Gather(0) -> Unsqueeze -> Concat([n, -1]) -> Reshape,
+    after a small conv + ReduceMean-free head, then Gemm + ArgMax with an INT64 output (label as f32 value)."""
+    ws = _WeightStream(91)
+    wc = ws.take((c, 3, 3, 3), 27)
+    bc = ws.take((c,), 27)
+    feat = c * hw * hw
+    wf = ws.take((feat, classes), feat)
+    bf = ws.take((classes,), feat)
+    inits = [tensor("wc", wc), tensor("bc", bc), tensor("wf", wf), tensor("bf", bf), tensor("i0", np.array(0, np.int64).reshape(())),
+             tensor("ax0", np.array([0], np.int64)), tensor("m1", np.array([-1], np.int64))]
+    nodes = [node("Conv", ["X", "wc", "bc"], ["c1"], [attr_ints("kernel_shape", [3, 3]), attr_ints("pads", [1, 1, 1, 1])]),
+             node("Relu", ["c1"], ["r1"]),
+             node("Shape", ["r1"], ["shp"]),
+             node("Gather", ["shp", "i0"], ["n"], [attr_i("axis", 0)]),
+             node("Unsqueeze", ["n", "ax0"], ["n1"]),
+             node("Concat", ["n1", "m1"], ["tgt"], [attr_i("axis", 0)]),
+             node("Reshape", ["r1", "tgt"], ["flat"]),
+             node("Gemm", ["flat", "wf", "bf"], ["logits"]),
+             node("ArgMax", ["logits"], ["Y"], [attr_i("axis", 1), attr_i("keepdims", 1)])]
+    return model("exporter_reshape", nodes, inits, [value_info("X", ["N", 3, hw, hw])], [value_info("Y", ["N", 1], INT64)], opset=13)
+
+
+def concat_heads(features: int = 24) -> bytes:
+    """Two dense towers over the same input, concatenated on the feature axis, then a head + Softmax."""
+    ws = _WeightStream(55)
+    inits, nodes = [], []
+    for t, m in enumerate((12, 20)):
+        w, b = ws.take((features, m), features), ws.take((m,), features)
+        inits += [tensor(f"W{t}", w), tensor(f"B{t}", b)]
+        nodes += [node("Gemm", ["X", f"W{t}", f"B{t}"], [f"h{t}"]), node("Tanh" if t else "Relu", [f"h{t}"], [f"a{t}"])]
+    nodes.append(node("Concat", ["a0", "X", "a1"], ["cat"], [attr_i("axis", 1)]))
+    k = 12 + features + 20
+    w, b = ws.take((k, 7), k), ws.take((7,), k)
+    inits += [tensor("Wh", w), tensor("Bh", b)]
+    nodes += [node("Gemm", ["cat", "Wh", "Bh"], ["z"]), node("Softmax", ["z"], ["Y"], [attr_i("axis", 1)])]
+    return model("concat_heads", nodes, inits, [value_info("X", ["N", features])], [value_info("Y", ["N", 7])], opset=13)
+
+
+def mobilenet_v2(classes: int = 100, in_hw: int = 64, width_mult: float = 0.5, seed: int = 4321) -> bytes:
+    """MobileNetV2 topology (the model family of the reference's blob test, test_advanced_features.test:46-63):
+    3x3/2 stem, inverted residual blocks (1x1 expand + ReLU6, 3x3 DEPTHWISE + ReLU6, 1x1 linear project, residual Add
+    when shapes match), 1x1 head, ReduceMean over the spatial axes, Gemm.  ReLU6 = Clip(0, 6) with tensor bounds;
+    BatchNormalization after every conv (folded by the loader)."""
+    ws = _WeightStream(seed)
+    nodes, inits = [], [tensor("zero", np.array(0.0, np.float32).reshape(())), tensor("six", np.array(6.0, np.float32).reshape(()))]
+    uid = [0]
+
+    def fresh(p):
+        uid[0] += 1
+        return f"{p}{uid[0]}"
+
+    def ch(v):
+        return max(8, int(v * width_mult + 4) // 8 * 8)
+
+    def conv_bn(x, cin, cout, k, stride, groups, relu6):
+        w = ws.take((cout, cin // groups, k, k), (cin // groups) * k * k)
+        wn, y = fresh("w"), fresh("c")
+        inits.append(tensor(wn, w))
+        nodes.append(node("Conv", [x, wn], [y], [attr_ints("kernel_shape", [k, k]), attr_ints("strides", [stride, stride]),
+                                                 attr_ints("pads", [k // 2] * 4), attr_i("group", groups)]))
+        names = [fresh("bn_s"), fresh("bn_b"), fresh("bn_m"), fresh("bn_v")]
+        arrs = ((1.0 + 0.1 * ws.take((cout,), 1)), 0.1 * ws.take((cout,), 1), 0.1 * ws.take((cout,), 1), 1.0 + 0.5 * np.abs(ws.take((cout,), 1)))
+        for nme, arr in zip(names, arrs):
+            inits.append(tensor(nme, arr.astype(np.float32)))
+        z = fresh("b")
+        nodes.append(node("BatchNormalization", [y] + names, [z], [attr_f("epsilon", 1e-5)]))
+        if relu6:
+            r = fresh("r")
+            nodes.append(node("Clip", [z, "zero", "six"], [r]))
+            return r
+        return z
+
+    cin = ch(32)
+    x = conv_bn("X", 3, cin, 3, 2, 1, True)
+    for t, c, n, s in ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 2, 2), (6, 96, 1, 1)):
+        cout = ch(c)
+        for i in range(n):
+            stride = s if i == 0 else 1
+            hid = cin * t
+            y = x
+            if t != 1:
+                y = conv_bn(y, cin, hid, 1, 1, 1, True)
+            y = conv_bn(y, hid, hid, 3, stride, hid, True)  # depthwise
+            y = conv_bn(y, hid, cout, 1, 1, 1, False)
+            if stride == 1 and cin == cout:
+                a = fresh("s")
+                nodes.append(node("Add", [x, y], [a]))
+                y = a
+            x, cin = y, cout
+    head = ch(640)
+    x = conv_bn(x, cin, head, 1, 1, 1, True)
+    g = fresh("g")
+    nodes.append(node("ReduceMean", [x], [g], [attr_ints("axes", [2, 3]), attr_i("keepdims", 0)]))
+    w, b = ws.take((head, classes), head), ws.take((classes,), head)
+    inits += [tensor("fc_w", w), tensor("fc_b", b)]
+    nodes.append(node("Gemm", [g, "fc_w", "fc_b"], ["Y"]))
+    return model("mobilenet_v2", nodes, inits, [value_info("X", ["N", 3, in_hw, in_hw])], [value_info("Y", ["N", classes])], opset=13)
+
+
 def write(path: str, blob: bytes) -> str:
     with open(path, "wb") as fh:
         fh.write(blob)

@@ -632,14 +632,31 @@ static size_t bcast_index(const Tensor *t, int r, const int64_t *odims, size_t f
 static int op_binary(Exec *x, const Node *nd, char kind) {
   const Tensor *a = get_in(x, nd, 0), *b = get_in(x, nd, 1);
   if (!a || !b) FAIL("%s: missing input", nd->op);
-  if (a->dtype != DT_FLOAT || b->dtype != DT_FLOAT) FAIL("%s: only f32 supported", nd->op);
+  if (a->dtype != b->dtype) FAIL("%s: operand types differ", nd->op);
   int64_t od[MAXRANK];
   int r = bcast_shape(a, b, od);
   if (r < 0) FAIL("%s: shapes not broadcastable", nd->op);
-  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, r, od);
+  const int dt = a->dtype;
+  Tensor *o = env_new(&x->env, nd->out[0], dt, r, od);
   a = get_in(x, nd, 0);
   b = get_in(x, nd, 1);
   int same = (a->n == o->n && b->n == o->n);
+  if (dt == DT_INT64) { /* integer shape arithmetic (exporter sub-graphs around Reshape) */
+    for (size_t i = 0; i < o->n; i++) {
+      int64_t va = a->i64[same ? i : bcast_index(a, r, od, i)], vb = b->i64[same ? i : bcast_index(b, r, od, i)], v;
+      switch (kind) {
+        case '+': v = va + vb; break;
+        case '-': v = va - vb; break;
+        case '*': v = va * vb; break;
+        case '/': if (vb == 0) FAIL("%s: integer division by zero", nd->op); v = va / vb; break;
+        case 'm': v = va < vb ? va : vb; break;
+        case 'M': v = va > vb ? va : vb; break;
+        default: FAIL("%s: not defined on integers", nd->op);
+      }
+      o->i64[i] = v;
+    }
+    return 0;
+  }
   for (size_t i = 0; i < o->n; i++) {
     float va = a->f[same ? i : bcast_index(a, r, od, i)];
     float vb = b->f[same ? i : bcast_index(b, r, od, i)];
@@ -648,7 +665,11 @@ static int op_binary(Exec *x, const Node *nd, char kind) {
       case '+': v = va + vb; break;
       case '-': v = va - vb; break;
       case '*': v = va * vb; break;
-      default: v = va / vb; break;
+      case '/': v = va / vb; break;
+      case 'm': v = fminf(va, vb); break;
+      case 'M': v = fmaxf(va, vb); break;
+      case '^': v = powf(va, vb); break;
+      default: v = va >= 0.0f ? va : vb * va; break; /* PRelu: b = slope */
     }
     o->f[i] = v;
   }
@@ -685,9 +706,231 @@ static int op_unary(Exec *x, const Node *nd) {
       float v = a->f[i];
       o->f[i] = v < lo ? lo : (v > hi ? hi : v);
     }
+  } else if (!strcmp(op, "Elu")) {
+    float alpha = attr_f(nd, "alpha", 1.0f);
+    for (size_t i = 0; i < o->n; i++) o->f[i] = a->f[i] >= 0.0f ? a->f[i] : alpha * (expf(a->f[i]) - 1.0f);
+  } else if (!strcmp(op, "Selu")) {
+    float alpha = attr_f(nd, "alpha", 1.67326319217681884765625f), gamma = attr_f(nd, "gamma", 1.05070102214813232421875f);
+    for (size_t i = 0; i < o->n; i++) o->f[i] = a->f[i] > 0.0f ? gamma * a->f[i] : gamma * (alpha * expf(a->f[i]) - alpha);
+  } else if (!strcmp(op, "HardSigmoid")) {
+    float alpha = attr_f(nd, "alpha", 0.2f), beta = attr_f(nd, "beta", 0.5f);
+    for (size_t i = 0; i < o->n; i++) o->f[i] = fmaxf(0.0f, fminf(1.0f, alpha * a->f[i] + beta));
+  } else if (!strcmp(op, "Gelu")) {
+    const Attr *ap = find_attr(nd, "approximate");
+    if (ap && ap->s && strcmp(ap->s, "none")) FAIL("Gelu: only the exact form");
+    for (size_t i = 0; i < o->n; i++) o->f[i] = 0.5f * a->f[i] * (1.0f + erff(a->f[i] * 0.707106781186547524f));
   } else {
+#define ORC_UN(NAME, EXPR)                                            \
+  if (!strcmp(op, NAME)) {                                            \
+    for (size_t i = 0; i < o->n; i++) { const float v = a->f[i]; o->f[i] = (EXPR); } \
+    return 0;                                                         \
+  }
+    ORC_UN("Exp", expf(v))
+    ORC_UN("Log", logf(v))
+    ORC_UN("Sqrt", sqrtf(v))
+    ORC_UN("Neg", -v)
+    ORC_UN("Abs", fabsf(v))
+    ORC_UN("Softplus", logf(expf(v) + 1.0f))
+    ORC_UN("HardSwish", v * fmaxf(0.0f, fminf(1.0f, v * (1.0f / 6.0f) + 0.5f)))
+    ORC_UN("Erf", erff(v))
+    ORC_UN("Reciprocal", 1.0f / v)
+    ORC_UN("Floor", floorf(v))
+    ORC_UN("Ceil", ceilf(v))
+    ORC_UN("Softsign", v / (1.0f + fabsf(v)))
+    ORC_UN("Round", rintf(v))
+#undef ORC_UN
     FAIL("unsupported unary op %s", op);
   }
+  return 0;
+}
+
+/* ---- integer / shape sub-graph operators and the few data-movement ops exported models use ---- */
+static int op_shape(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a) FAIL("Shape: missing input");
+  int64_t r = a->rank, st = attr_i(nd, "start", 0), en = attr_i(nd, "end", r);
+  if (st < 0) st += r;
+  if (en < 0) en += r;
+  if (st < 0) st = 0;
+  if (st > r) st = r;
+  if (en < st) en = st;
+  if (en > r) en = r;
+  int64_t cnt = en - st, dims[MAXRANK];
+  for (int64_t i = 0; i < cnt; i++) dims[i] = a->dims[st + i];
+  Tensor *o = env_new(&x->env, nd->out[0], DT_INT64, 1, &cnt);
+  memcpy(o->i64, dims, (size_t)cnt * 8);
+  return 0;
+}
+
+static int op_gather(Exec *x, const Node *nd) {
+  const Tensor *d = get_in(x, nd, 0), *ix = get_in(x, nd, 1);
+  if (!d || !ix || ix->dtype != DT_INT64) FAIL("Gather: needs data and int64 indices");
+  if (d->rank > 1 || attr_i(nd, "axis", 0) != 0) FAIL("Gather: only 1-D data / axis 0");
+  Tensor *o = env_new(&x->env, nd->out[0], d->dtype, ix->rank, ix->dims);
+  d = get_in(x, nd, 0);
+  ix = get_in(x, nd, 1);
+  for (size_t i = 0; i < o->n; i++) {
+    int64_t k = ix->i64[i];
+    if (k < 0) k += (int64_t)d->n;
+    if (k < 0 || (size_t)k >= d->n) FAIL("Gather: index out of range");
+    if (d->dtype == DT_FLOAT) o->f[i] = d->f[k];
+    else o->i64[i] = d->i64[k];
+  }
+  return 0;
+}
+
+static int op_slice(Exec *x, const Node *nd) {
+  const Tensor *d = get_in(x, nd, 0);
+  if (!d || d->rank != 1) FAIL("Slice: only 1-D data");
+  int64_t st, en, step = 1, len = (int64_t)d->n;
+  const Tensor *ts = get_in(x, nd, 1), *te = get_in(x, nd, 2), *ta = get_in(x, nd, 3), *tp = get_in(x, nd, 4);
+  if (ts && te) {
+    st = ts->i64[0];
+    en = te->i64[0];
+    if (ta && ta->i64[0] != 0 && ta->i64[0] != -1) FAIL("Slice: bad axis");
+    if (tp) step = tp->i64[0];
+  } else {
+    const Attr *as = find_attr(nd, "starts"), *ae = find_attr(nd, "ends");
+    if (!as || !ae || as->nints != 1 || ae->nints != 1) FAIL("Slice: starts/ends");
+    st = as->ints[0];
+    en = ae->ints[0];
+  }
+  if (step != 1) FAIL("Slice: step must be 1");
+  if (st < 0) st += len;
+  if (en < 0) en += len;
+  if (st < 0) st = 0;
+  if (st > len) st = len;
+  if (en < st) en = st;
+  if (en > len) en = len;
+  int64_t cnt = en - st;
+  const int dt = d->dtype;
+  Tensor *o = env_new(&x->env, nd->out[0], dt, 1, &cnt);
+  d = get_in(x, nd, 0);
+  if (dt == DT_FLOAT) memcpy(o->f, d->f + st, (size_t)cnt * 4);
+  else memcpy(o->i64, d->i64 + st, (size_t)cnt * 8);
+  return 0;
+}
+
+static int op_cast(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a) FAIL("Cast: missing input");
+  int64_t to = attr_i(nd, "to", DT_FLOAT);
+  int to_int = to == DT_INT64 || to == DT_INT32, to_f = to == DT_FLOAT || to == DT_DOUBLE;
+  if (!to_int && !to_f) FAIL("Cast: only f32/f64/int32/int64 targets");
+  Tensor *o = env_new(&x->env, nd->out[0], to_int ? DT_INT64 : DT_FLOAT, a->rank, a->dims);
+  a = get_in(x, nd, 0);
+  for (size_t i = 0; i < o->n; i++) {
+    if (to_int) o->i64[i] = a->dtype == DT_INT64 ? a->i64[i] : (int64_t)a->f[i]; /* C conversion truncates toward zero */
+    else o->f[i] = a->dtype == DT_INT64 ? (float)a->i64[i] : a->f[i];
+  }
+  return 0;
+}
+
+static int op_concat(Exec *x, const Node *nd) {
+  if (nd->nin < 1) FAIL("Concat: no inputs");
+  const Tensor *a0 = get_in(x, nd, 0);
+  if (!a0) FAIL("Concat: missing input");
+  int rank = a0->rank, dt = a0->dtype;
+  int64_t axis = attr_i(nd, "axis", 0);
+  if (axis < 0) axis += rank;
+  if (rank == 0 || axis < 0 || axis >= rank) FAIL("Concat: bad axis");
+  int64_t od[MAXRANK];
+  memcpy(od, a0->dims, sizeof od);
+  od[axis] = 0;
+  for (size_t k = 0; k < nd->nin; k++) {
+    const Tensor *t = get_in(x, nd, k);
+    if (!t || t->rank != rank || t->dtype != dt) FAIL("Concat: operand mismatch");
+    for (int i = 0; i < rank; i++)
+      if (i != axis && t->dims[i] != a0->dims[i]) FAIL("Concat: shape mismatch");
+    od[axis] += t->dims[axis];
+  }
+  Tensor *o = env_new(&x->env, nd->out[0], dt, rank, od);
+  size_t outer = 1, inner = 1;
+  for (int i = 0; i < axis; i++) outer *= (size_t)od[i];
+  for (int i = (int)axis + 1; i < rank; i++) inner *= (size_t)od[i];
+  size_t off = 0, esz = dt == DT_FLOAT ? 4 : 8;
+  char *dst = dt == DT_FLOAT ? (char *)o->f : (char *)o->i64;
+  for (size_t k = 0; k < nd->nin; k++) {
+    const Tensor *t = get_in(x, nd, k);
+    const char *src = dt == DT_FLOAT ? (const char *)t->f : (const char *)t->i64;
+    size_t blk = (size_t)t->dims[axis] * inner;
+    for (size_t u = 0; u < outer; u++)
+      memcpy(dst + (u * (size_t)od[axis] * inner + off) * esz, src + u * blk * esz, blk * esz);
+    off += blk;
+  }
+  return 0;
+}
+
+static int op_reduce_mean(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT) FAIL("ReduceMean: bad input");
+  int red[MAXRANK] = {0};
+  const Tensor *ax = get_in(x, nd, 1);
+  const Attr *aax = find_attr(nd, "axes");
+  const int64_t *av = NULL;
+  size_t na = 0;
+  if (ax && ax->dtype == DT_INT64) { av = ax->i64; na = ax->n; }
+  else if (aax) { av = aax->ints; na = aax->nints; }
+  if (na == 0) for (int i = 0; i < a->rank; i++) red[i] = 1;
+  for (size_t k = 0; k < na; k++) {
+    int64_t v = av[k] < 0 ? av[k] + a->rank : av[k];
+    if (v < 0 || v >= a->rank) FAIL("ReduceMean: axis out of range");
+    red[v] = 1;
+  }
+  int keep = attr_i(nd, "keepdims", 1) != 0;
+  int64_t od[MAXRANK], full[MAXRANK];
+  int r = 0;
+  size_t cnt = 1;
+  for (int i = 0; i < a->rank; i++) {
+    full[i] = red[i] ? 1 : a->dims[i];
+    if (red[i]) cnt *= (size_t)a->dims[i];
+    if (!red[i] || keep) od[r++] = full[i];
+  }
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, r, od);
+  a = get_in(x, nd, 0);
+  for (size_t i = 0; i < o->n; i++) o->f[i] = 0.0f;
+  /* sequential sum in input order per output element, then one division (as GlobalAveragePool above) */
+  for (size_t flat = 0; flat < a->n; flat++) {
+    size_t rem = flat, oi = 0, stride = 1;
+    for (int i = a->rank - 1; i >= 0; i--) {
+      size_t c = rem % (size_t)a->dims[i];
+      rem /= (size_t)a->dims[i];
+      if (!red[i]) { oi += c * stride; stride *= (size_t)a->dims[i]; }
+    }
+    o->f[oi] += a->f[flat];
+  }
+  for (size_t i = 0; i < o->n; i++) o->f[i] = o->f[i] / (float)cnt;
+  return 0;
+}
+
+static int op_argmax(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT) FAIL("ArgMax: bad input");
+  int64_t axis = attr_i(nd, "axis", 0);
+  if (axis < 0) axis += a->rank;
+  if (axis < 0 || axis >= a->rank) FAIL("ArgMax: axis out of range");
+  if (attr_i(nd, "select_last_index", 0)) FAIL("ArgMax: select_last_index=1");
+  int keep = attr_i(nd, "keepdims", 1) != 0;
+  int64_t od[MAXRANK] = {0};
+  int r = 0;
+  size_t outer = 1, inner = 1, len = (size_t)a->dims[axis];
+  for (int i = 0; i < a->rank; i++) {
+    if (i < axis) outer *= (size_t)a->dims[i];
+    if (i > axis) inner *= (size_t)a->dims[i];
+    if (i != axis) od[r++] = a->dims[i];
+    else if (keep) od[r++] = 1;
+  }
+  Tensor *o = env_new(&x->env, nd->out[0], DT_INT64, r, od);
+  a = get_in(x, nd, 0);
+  for (size_t u = 0; u < outer; u++)
+    for (size_t v = 0; v < inner; v++) {
+      const float *src = a->f + u * len * inner + v;
+      float best = src[0];
+      int64_t bi = 0;
+      for (size_t j = 1; j < len; j++)
+        if (src[j * inner] > best) { best = src[j * inner]; bi = (int64_t)j; }
+      o->i64[u * inner + v] = bi;
+    }
   return 0;
 }
 
@@ -1051,9 +1294,24 @@ static int run_node(Exec *x, const Node *nd) {
   if (!strcmp(op, "Sub")) return op_binary(x, nd, '-');
   if (!strcmp(op, "Mul")) return op_binary(x, nd, '*');
   if (!strcmp(op, "Div")) return op_binary(x, nd, '/');
-  if (!strcmp(op, "Relu") || !strcmp(op, "Sigmoid") || !strcmp(op, "Tanh") || !strcmp(op, "LeakyRelu") ||
-      !strcmp(op, "Identity") || !strcmp(op, "Dropout") || !strcmp(op, "Clip"))
-    return op_unary(x, nd);
+  if (!strcmp(op, "Min")) return op_binary(x, nd, 'm');
+  if (!strcmp(op, "Max")) return op_binary(x, nd, 'M');
+  if (!strcmp(op, "Pow")) return op_binary(x, nd, '^');
+  if (!strcmp(op, "PRelu")) return op_binary(x, nd, 'p');
+  {
+    static const char *const unary_ops[] = {"Relu", "Sigmoid", "Tanh", "LeakyRelu", "Identity", "Dropout", "Clip", "Exp", "Log", "Sqrt",
+                                            "Neg", "Abs", "Elu", "Selu", "Softplus", "HardSigmoid", "HardSwish", "Erf", "Gelu",
+                                            "Reciprocal", "Floor", "Ceil", "Softsign", "Round", NULL};
+    for (int i = 0; unary_ops[i]; i++)
+      if (!strcmp(op, unary_ops[i])) return op_unary(x, nd);
+  }
+  if (!strcmp(op, "Shape")) return op_shape(x, nd);
+  if (!strcmp(op, "Gather")) return op_gather(x, nd);
+  if (!strcmp(op, "Slice")) return op_slice(x, nd);
+  if (!strcmp(op, "Cast")) return op_cast(x, nd);
+  if (!strcmp(op, "Concat")) return op_concat(x, nd);
+  if (!strcmp(op, "ReduceMean")) return op_reduce_mean(x, nd);
+  if (!strcmp(op, "ArgMax")) return op_argmax(x, nd);
   if (!strcmp(op, "Softmax")) return op_softmax(x, nd, 0);
   if (!strcmp(op, "LogSoftmax")) return op_softmax(x, nd, 1);
   if (!strcmp(op, "Flatten") || !strcmp(op, "Reshape") || !strcmp(op, "Squeeze") || !strcmp(op, "Unsqueeze"))
@@ -1091,14 +1349,16 @@ static int run_graph(const OrcModel *m, const float *data, int rank, const int64
   long oi = env_find(&x->env, m->outputs[0].name);
   const Tensor *ot = oi >= 0 ? &x->env.v[oi] : find_init(m, m->outputs[0].name);
   if (!ot) { set_err(err, errlen, "output '%s' was never produced", m->outputs[0].name); env_free(&x->env); return -1; }
-  if (ot->dtype != DT_FLOAT) { set_err(err, errlen, "output tensor is not f32"); env_free(&x->env); return -1; }
+  /* The reference rejects non-f32 outputs (engine.rs:150-152).  The build's documented extension:
+   * integer outputs (ArgMax labels, Cast to int) come back as f32 VALUES, since the C ABI carries f32 only. */
   memset(result, 0, sizeof *result);
   result->dtype = DT_FLOAT;
   result->rank = ot->rank;
   memcpy(result->dims, ot->dims, sizeof(ot->dims));
   result->n = ot->n;
   result->f = (float *)xmalloc(ot->n * 4);
-  memcpy(result->f, ot->f, ot->n * 4);
+  if (ot->dtype == DT_FLOAT) memcpy(result->f, ot->f, ot->n * 4);
+  else for (size_t i = 0; i < ot->n; i++) result->f[i] = (float)ot->i64[i];
   env_free(&x->env);
   return 0;
 }

@@ -1,0 +1,247 @@
+"""ONNX front-end breadth: elementwise operators beyond the reference's fixtures, Concat,
+ReduceMean, ArgMax with an int64 output, depthwise convolution and the exporter's Shape->Gather->Concat->Reshape
+idiom.  The reference pins none of these (its fixtures are MatMul+Add and Identity): "parity unpinned" -- the
+ONNX operator specification is the authority.
+
+CPU part: the ORACLE against an independent float64 numpy evaluation, and the product's lowering (models load
+and lower without a GPU).  GPU part (`-m gpu`): the HIP path against the oracle through the C ABI.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from infera_amd import onnx_writer as W
+from infera_amd import synth
+
+RTOL, ATOL = 1e-4, 1e-6
+
+
+def assert_close(got, want, rtol=RTOL, atol=ATOL):
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    bad = err > rtol * np.abs(want.astype(np.float64)) + atol
+    assert not bad.any(), f"{bad.sum()} / {bad.size} out of tolerance; worst err {err.max():.3e}"
+
+
+@pytest.fixture(scope="module")
+def O(built):
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def paths(tmp_path_factory, built):
+    d = tmp_path_factory.mktemp("breadth")
+    return {
+        "zoo": W.write(str(d / "zoo.onnx"), W.unary_zoo(16)),
+        "exporter": W.write(str(d / "exporter.onnx"), W.exporter_reshape()),
+        "concat": W.write(str(d / "concat.onnx"), W.concat_heads(24)),
+        "mnv2": W.write(str(d / "mnv2.onnx"), W.mobilenet_v2(classes=20, in_hw=32, width_mult=0.5)),
+    }
+
+
+# ---- independent numpy restatements (float64) -------------------------------------------------------------
+def _weights(seed):
+    return W._WeightStream(seed)
+
+
+def np_unary_zoo(x, features=16):
+    ws = _weights(77)
+    w, b = ws.take((features, features), features).astype(np.float64), ws.take((features,), features).astype(np.float64)
+    slope = (0.05 + 0.2 * np.abs(ws.take((features,), 1))).astype(np.float32).astype(np.float64)
+    h = x.astype(np.float64) @ w + b
+    h = h.astype(np.float32).astype(np.float64)  # the graph's intermediate is f32
+    hpos = np.abs(h) + 1.5
+    erf = np.vectorize(math.erf)
+    lo = -0.25
+    outs = [np.exp(h), -h, np.abs(h), np.log(np.exp(h) + 1), h * np.clip(h / 6 + 0.5, 0, 1), erf(h), np.floor(h), np.ceil(h),
+            h / (1 + np.abs(h)), np.rint(h), 1 / (1 + np.exp(-h)), np.tanh(h), np.maximum(h, 0),
+            np.where(h >= 0, h, 0.7 * (np.exp(h) - 1)),
+            np.where(h > 0, 1.05070102214813232421875 * h, 1.05070102214813232421875 * (1.67326319217681884765625 * np.exp(h) - 1.67326319217681884765625)),
+            np.clip(np.float64(np.float32(0.3)) * h + np.float64(np.float32(0.4)), 0, 1), np.where(h >= 0, h, np.float64(np.float32(0.2)) * h),
+            np.log(hpos), np.sqrt(hpos), 1 / hpos, h ** 2, np.minimum(h, lo), np.maximum(h, lo), np.where(h >= 0, h, slope * h),
+            np.maximum(lo, h)]
+    return np.concatenate(outs, axis=1)
+
+
+def np_conv2d(x, w, b, stride=1, pad=0, groups=1):
+    n, c, hh, ww = x.shape
+    m, cg, kh, kw = w.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    win = np.lib.stride_tricks.sliding_window_view(xp, (kh, kw), axis=(2, 3))[:, :, ::stride, ::stride]  # n c oh ow kh kw
+    mg = m // groups
+    out = np.empty((n, m, win.shape[2], win.shape[3]))
+    for g in range(groups):
+        out[:, g * mg:(g + 1) * mg] = np.einsum("ncxykl,mckl->nmxy", win[:, g * cg:(g + 1) * cg], w[g * mg:(g + 1) * mg])
+    return out + (0 if b is None else b.reshape(1, -1, 1, 1))
+
+
+def np_exporter(x):
+    ws = _weights(91)
+    wc, bc = ws.take((8, 3, 3, 3), 27).astype(np.float64), ws.take((8,), 27).astype(np.float64)
+    wf, bf = ws.take((8 * 36, 5), 8 * 36).astype(np.float64), ws.take((5,), 8 * 36).astype(np.float64)
+    r = np.maximum(np_conv2d(x.astype(np.float64), wc, bc, 1, 1), 0)
+    logits = r.reshape(x.shape[0], -1) @ wf + bf
+    return logits
+
+
+def np_concat_heads(x, features=24):
+    ws = _weights(55)
+    x = x.astype(np.float64)
+    towers = []
+    for t, m in enumerate((12, 20)):
+        w, b = ws.take((features, m), features).astype(np.float64), ws.take((m,), features).astype(np.float64)
+        h = x @ w + b
+        towers.append(np.tanh(h) if t else np.maximum(h, 0))
+    cat = np.concatenate([towers[0], x, towers[1]], axis=1)
+    k = 12 + features + 20
+    w, b = ws.take((k, 7), k).astype(np.float64), ws.take((7,), k).astype(np.float64)
+    z = cat @ w + b
+    e = np.exp(z - z.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+# ---- CPU: the oracle against numpy --------------------------------------------------------------------------
+def test_oracle_elementwise_zoo_vs_numpy(O, paths):
+    x = synth.table(5, 0, 33, 16)
+    got = O.Model(paths["zoo"]).predict(x)
+    want = np_unary_zoo(x)
+    assert got.shape == want.shape == (33, 16 * 25)
+    # floor/ceil/round branches are discontinuous: compare those exactly where the f64 value is not within 1e-5 of a step
+    assert_close(got, want.astype(np.float32), rtol=2e-5, atol=2e-6)
+
+
+def test_oracle_exporter_idiom_and_argmax_vs_numpy(O, paths):
+    m = O.Model(paths["exporter"])
+    assert m.input_shape == [-1, 3, 6, 6] and m.output_shape == [-1, 1]
+    x = synth.table(8, 0, 7, 3 * 6 * 6).reshape(7, 3, 6, 6)
+    logits = np_exporter(x)
+    top2 = np.sort(logits, axis=1)[:, -2:]
+    assert (top2[:, 1] - top2[:, 0]).min() > 1e-4  # labels are well separated on this input
+    got = m.predict_blob(x.tobytes())
+    assert got.dtype == np.float32 and got.shape == (7, 1)
+    assert got[:, 0].tolist() == logits.argmax(axis=1).astype(np.float32).tolist()
+
+
+def test_oracle_concat_vs_numpy(O, paths):
+    x = synth.table(9, 0, 17, 24)
+    assert_close(O.Model(paths["concat"]).predict(x), np_concat_heads(x).astype(np.float32), rtol=2e-5)
+
+
+@pytest.mark.parametrize("groups,stride,pad", [(1, 1, 1), (4, 2, 1), (8, 1, 0)])
+def test_oracle_grouped_conv_vs_numpy(O, tmp_path, groups, stride, pad):
+    rng = np.random.default_rng(groups * 10 + stride)
+    w = (rng.standard_normal((8, 8 // groups, 3, 3)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32)
+    x = rng.standard_normal((2, 8, 9, 9)).astype(np.float32)
+    want = np_conv2d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), stride, pad, groups)
+    nodes = [W.node("Conv", ["X", "w", "b"], ["Y"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("strides", [stride] * 2),
+                                                     W.attr_ints("pads", [pad] * 4), W.attr_i("group", groups)])]
+    blob = W.model("gconv", nodes, [W.tensor("w", w), W.tensor("b", b)], [W.value_info("X", ["N", 8, 9, 9])],
+                   [W.value_info("Y", ["N", 8, want.shape[2], want.shape[3]])])
+    got = O.Model(W.write(str(tmp_path / "gconv.onnx"), blob)).predict_blob(x.tobytes())
+    assert_close(got.reshape(want.shape), want.astype(np.float32), rtol=2e-5, atol=2e-6)
+
+
+def test_oracle_mobilenet_runs_and_is_batch_consistent(O, paths):
+    m = O.Model(paths["mnv2"])
+    assert m.input_shape == [-1, 3, 32, 32] and m.output_shape == [-1, 20]
+    x = synth.table(4, 0, 3, 3 * 32 * 32)
+    y = m.predict_blob(x.tobytes())
+    assert y.shape == (3, 20) and np.isfinite(y).all() and np.abs(y).max() > 1e-3
+    y1 = m.predict_blob(x[1:2].tobytes())
+    assert np.array_equal(y1[0], y[1])  # rows are independent: batching must not change a row's value
+
+
+# ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
+def test_lowering_of_breadth_models(built, paths):
+    from infera_amd import capi
+
+    for name, p in paths.items():
+        capi.load_model("b_" + name, p)
+    plan = capi.get_plan("b_exporter")
+    kinds = [s["kind"] for s in plan["plan"]["steps"]]
+    assert kinds == ["Conv2d", "Dense", "ArgMax"], kinds  # Shape/Gather/Unsqueeze/Concat/Reshape folded away
+    assert capi.get_model_info("b_exporter")["output_shape"] == [-1, 1]
+    zoo = [s["kind"] for s in capi.get_plan("b_zoo")["plan"]["steps"]]
+    assert zoo.count("CopyCols") == 25 and zoo[0] == "Dense"
+    cat = capi.get_plan("b_concat")["plan"]["steps"]
+    assert [s["kind"] for s in cat].count("CopyCols") == 3 and cat[-1]["kind"] in ("Softmax", "Dense")
+    mn = capi.get_plan("b_mnv2")["plan"]["steps"]
+    assert all(s["kind"] in ("Conv2d", "BinaryAct", "GlobalAvgPool", "Dense") for s in mn), {s["kind"] for s in mn}
+    assert sum("BatchNormalization" in s["origin"] for s in mn) == sum(s["kind"] == "Conv2d" for s in mn)  # all folded
+    for name in paths:
+        capi.unload_model("b_" + name)
+
+
+def test_unsupported_forms_fail_loudly(built, tmp_path):
+    from infera_amd import capi
+
+    w = np.ones((4, 4), np.float32)
+    bad = [
+        ("concat_axis0", [W.node("Concat", ["X", "X"], ["Y"], [W.attr_i("axis", 0)])], [], r"Concat\): only axis 1"),
+        ("argmax_axis0", [W.node("ArgMax", ["X"], ["Y"], [W.attr_i("axis", 0)])], [], r"ArgMax\): only axis 1"),
+        ("gelu_tanh", [W.node("Gelu", ["X"], ["Y"], [W.attr_s("approximate", "tanh")])], [], r"Gelu\): only the exact"),
+        ("unknown", [W.node("Einsum", ["X", "w"], ["Y"])], [W.tensor("w", w)], r"Einsum\): unsupported operator"),
+    ]
+    for name, nodes, inits, pat in bad:
+        p = W.write(str(tmp_path / f"{name}.onnx"), W.model(name, nodes, inits, [W.value_info("X", ["N", 4])], [W.value_info("Y", ["N", 4])]))
+        with pytest.raises(capi.InferaError, match=pat):
+            capi.load_model(name, p)
+
+
+# ---- GPU: the HIP path against the oracle ---------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def api(built):
+    from infera_amd import capi
+
+    assert capi.device_count() >= 1, capi.get_devices()
+    return capi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 77, 4099])
+def test_gpu_elementwise_zoo(api, O, paths, rows):
+    api.load_model("zoo", paths["zoo"])
+    x = synth.table(11, 0, rows, 16)
+    got, want = api.predict("zoo", x), O.Model(paths["zoo"]).predict(x)
+    # Floor/Ceil/Round of values within an ulp of an integer may legitimately differ: mask those columns' steps
+    step_cols = np.zeros(got.shape[1], bool)
+    for k in (6, 7, 9):
+        step_cols[16 * k:16 * (k + 1)] = True
+    assert_close(got[:, ~step_cols], want[:, ~step_cols])
+    assert (np.abs(got[:, step_cols] - want[:, step_cols]) > 0).mean() < 1e-3
+    api.unload_model("zoo")
+
+
+@pytest.mark.gpu
+def test_gpu_exporter_idiom_and_int64_labels(api, O, paths):
+    api.load_model("exp", paths["exporter"])
+    x = synth.table(8, 0, 301, 3 * 6 * 6)
+    got, want = api.predict_from_blob("exp", x.tobytes()), O.Model(paths["exporter"]).predict_blob(x.tobytes())
+    assert got.shape == want.shape == (301, 1)
+    assert (got != want).mean() <= 0.01  # a label may flip only where two logits tie within fp32 summation order
+    api.unload_model("exp")
+
+
+@pytest.mark.gpu
+def test_gpu_concat_heads(api, O, paths):
+    api.load_model("cat", paths["concat"])
+    x = synth.table(9, 0, 2500, 24)
+    assert_close(api.predict("cat", x), O.Model(paths["concat"]).predict(x))
+    api.unload_model("cat")
+
+
+@pytest.mark.gpu
+def test_gpu_mobilenet_v2_vs_oracle(api, O, paths):
+    api.load_model("mnv2", paths["mnv2"])
+    plan = api.get_plan("mnv2")
+    assert plan["activation_layout"] == "NC/4HW4" and plan["exec"].count("conv_depthwise") == 9, plan["exec"]
+    x = synth.table(4, 0, 5, 3 * 32 * 32)
+    got, want = api.predict_from_blob("mnv2", x.tobytes()), O.Model(paths["mnv2"]).predict_blob(x.tobytes())
+    assert got.shape == (5, 20)
+    assert_close(got, want)
+    api.unload_model("mnv2")
