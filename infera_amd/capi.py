@@ -16,7 +16,7 @@ from typing import Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinfera.so")
+LIB_PATH = os.environ.get("INFERA_LIB_PATH") or os.path.join(_HERE, "libinfera.so")  # override: A/B builds (tools/)
 
 REFERENCE_SYMBOLS = [
     "infera_load_model", "infera_unload_model", "infera_predict", "infera_predict_from_blob",

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
                                                              float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
   constexpr int NB = 4 * S;   // B fragments (16 B per lane) per stage
   constexpr int U = NB * MT;  // units per stage
-  constexpr int P = 3;        // A-fragment ring depth
+  constexpr int P = 3;        // A-fragment ring depth (2 and 4 measured identical)
   __shared__ __attribute__((aligned(16))) float wbuf[2][S * MT * 1024];
 #ifdef INFERA_CONV_PROBES
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, tc = 0;
