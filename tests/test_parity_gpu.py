@@ -287,6 +287,60 @@ def test_full_size_c2_properties(api, models):
     assert abs(total - parts) <= 1e-6 * abs(total) + 1e-6
 
 
+def test_full_size_c4_properties(api, models):
+    """BASELINE config C4 at full size (50M rows x 128 -> softmax over 10 classes, device-resident):
+      * every output row is a probability vector (sums to 1 within 4 ulp * 10, entries in [0, 1]);
+      * determinism across two scans; chunk invariance against the host ABI; oracle parity on sampled chunks;
+      * invariance to a row permutation of the input (rows are independent): a reversed copy of a slice
+        gives the reversed outputs bit for bit."""
+    from infera_amd import synth
+    from oracle import oracle
+
+    rows, cols, classes = 50_000_000 + 777, 128, 10
+    api.load_model("lr", models["logreg"])
+    dev = api.device_ordinal(0)
+    d_in = api.DeviceBuffer(dev, rows * cols * 4)
+    d_out = api.DeviceBuffer(dev, rows * classes * 4)
+    api.synth_fill(d_in, 42, 0, rows, cols)
+    assert api.predict_device("lr", d_in, rows, cols, d_out) == (rows, classes)
+    y1 = d_out.download((rows, classes))
+    api.predict_device("lr", d_in, rows, cols, d_out)
+    assert np.array_equal(y1, d_out.download((rows, classes)))
+    sums = y1.astype(np.float64).sum(axis=1)
+    assert np.abs(sums - 1.0).max() < 5e-6 and y1.min() >= 0.0 and y1.max() <= 1.0
+    om = oracle.Model(models["logreg"])
+    for s in [0, rows - 2048, rows - 777 - 2048] + list(np.random.default_rng(2).integers(0, rows - 2048, 13)):
+        x = synth.table(42, int(s), 2048, cols)
+        host = api.predict("lr", x)
+        assert np.array_equal(host, y1[s:s + 2048])
+        assert_close(host, om.predict(x))
+        assert np.array_equal(api.predict("lr", x[::-1].copy()), host[::-1])
+    api.unload_model("lr")
+
+
+def test_c5_batch_position_invariance(api, tmp_path):
+    """C5 (ResNet-18 at the BASELINE resolution 224x224, full width): an image's logits do not depend on the
+    batch it travels in or on its position -- 40 images in one call == the same images one by one and in
+    reversed order (this crosses pixel-tile boundaries of every conv kernel: 40*49 pixels is not a multiple of
+    128) -- and 2 of them match the oracle."""
+    from infera_amd import onnx_writer as W, synth
+    from oracle import oracle
+
+    path = W.write(str(tmp_path / "rn224.onnx"), W.resnet18())
+    api.load_model("rn224", path)
+    n, per = 40, 3 * 224 * 224
+    imgs = synth.table(5, 0, n, per)
+    y = api.predict_from_blob("rn224", imgs.tobytes())
+    assert y.shape == (n, 1000) and np.isfinite(y).all()
+    yr = api.predict_from_blob("rn224", imgs[::-1].copy().tobytes())
+    assert np.array_equal(yr[::-1], y)
+    for i in (0, 17, 39):
+        assert np.array_equal(api.predict_from_blob("rn224", imgs[i:i + 1].tobytes())[0], y[i])
+    want = oracle.Model(path).predict_blob(imgs[:2].tobytes())
+    assert_close(y[:2], want)
+    api.unload_model("rn224")
+
+
 def test_hipgraph_mode_matches_direct_mode(models):
     """INFERA_HIPGRAPH=1 (a captured {H2D, kernels, D2H} graph per (model, rows), north_star) in a fresh
     process: same values as the default direct-enqueue mode, and safe against concurrent model loads
