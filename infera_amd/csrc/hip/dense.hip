@@ -16,6 +16,9 @@
 // the C4 logistic regression (128 -> 10: 2,560 flop/row vs 552 B/row).
 #include "device_common.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace infera_hip::kern {
 
 namespace {
@@ -368,11 +371,145 @@ void launch(hipStream_t s, const float *X, const float *W, const float *bias, fl
 
 }  // namespace
 
+// ---- M <= 16, K in {64, 128, 256}: the same 16x16x4 arithmetic fed by COALESCED table reads -----------------
+// dense_narrow16_kernel reads X in fragment shape: 64 separate 16-byte accesses per load instruction (the four
+// lanes that share a row are 16 lanes apart), each cache line touched by 8 instructions and kept alive in L1
+// in between.  Here a wave's 32-row tile is what it is in memory -- one contiguous 128*K-byte run -- and is
+// fetched as such (lane l of instruction i takes 16-byte piece 64i + l: the float4-copy access pattern),
+// parked in a wave-private LDS region and read back in fragment shape.  Piece (row, c) sits at slot
+// row*(K/4) + (c ^ (row & 15)): conflict-free for the linear writes and for the fragment reads (16 lanes =
+// 16 rows at one column -> 16 distinct bank quads).  No barrier: the region belongs to one wave, whose LDS
+// operations execute in order; the next tile's K/8 loads are in flight (in registers) during the MFMAs.
+template <int K, int SM>
+__global__ __launch_bounds__(WAVES * 64) void dense_narrow16s_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                                    const float *__restrict__ bias, float *__restrict__ Y,
+                                                                    int64_t rows, int M, ActParam act) {
+  constexpr int G = K / 16, PR = K / 4, NL = K / 8;  // k groups, 16-byte pieces per row, load instructions per tile
+  static_assert(PR % 16 == 0, "the XOR swizzle needs a multiple of 16 pieces per row");
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [G][64][4] weights, then WAVES x [32 rows][K] tiles
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 15, q = lane >> 4;
+  for (int i = threadIdx.x; i < G * 256; i += WAVES * 64) {
+    const int g = i >> 8, l = (i >> 2) & 63, j = i & 3;
+    const int k = 16 * g + 4 * (l >> 4) + j, m = l & 15;
+    smem[i] = m < M ? W[int64_t(k) * M + m] : 0.f;
+  }
+  __syncthreads();
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(smem) + lane;
+  f32x4 *xs = reinterpret_cast<f32x4 *>(smem + G * 256) + wave * (32 * PR);
+  float bq[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) bq[i] = (bias != nullptr && 4 * q + i < M) ? bias[4 * q + i] : 0.f;
+  // where this lane's piece of load instruction i goes, and where its fragments come from
+  int wslot[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int p = i * 64 + lane, row = p / PR, c = p % PR;
+    wslot[i] = row * PR + (c ^ (row & 15));
+  }
+  const int64_t ntiles = (rows + 31) >> 5, total4 = rows * PR;
+  const int64_t tstride = int64_t(gridDim.x) * WAVES;
+  const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X);
+  auto fetch = [&](f32x4(&v)[NL], int64_t tile) {
+    const int64_t base = tile * (32 * PR) + lane;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int64_t p = base + i * 64;
+      v[i] = p < total4 ? x4[p] : f32x4{0.f, 0.f, 0.f, 0.f};  // ragged last tile
+    }
+  };
+  f32x4 stage[NL];
+  int64_t tile = int64_t(blockIdx.x) * WAVES + wave;
+  if (tile < ntiles) fetch(stage, tile);
+  for (; tile < ntiles; tile += tstride) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) xs[wslot[i]] = stage[i];
+    if (tile + tstride < ntiles) fetch(stage, tile + tstride);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const f32x4 x0 = xs[n * PR + ((4 * g + q) ^ n)], x1 = xs[(16 + n) * PR + ((4 * g + q) ^ n)];
+      const f32x4 a0 = wq[g * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x1[j], acc[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int64_t row = (tile << 5) + 16 * t + n;
+      f32x4 v = acc[t];
+      dispatch_act(act.kind, [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = apply_act_c<KIND>(v[i] + bq[i], act.a, act.b);
+      });
+      if constexpr (SM != 0) {  // the row's features live in lanes n, n+16, n+32, n+48
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) mx = fmaxf(mx, v[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) {
+            const float e = expf(v[i] - mx);
+            sum += e;
+            v[i] = SM == 1 ? e : v[i] - mx;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float ls = logf(sum);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = SM == 1 ? v[i] / sum : v[i] - ls;
+      }
+      if (row < rows) {
+        float *yrow = Y + row * M + 4 * q;
+        if ((M & 1) == 0 && 4 * q + 3 < M) {  // row stride M*4 is 8-byte aligned: two 8-byte stores
+          *reinterpret_cast<f32x2 *>(yrow) = f32x2{v[0], v[1]};
+          *reinterpret_cast<f32x2 *>(yrow + 2) = f32x2{v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (4 * q + i < M) yrow[i] = v[i];
+        }
+      }
+    }
+  }
+}
+
+template <int K>
+static void launch_narrow16s(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int M,
+                             ActParam act, int softmax_mode) {
+  const int64_t ntiles = (rows + 31) / 32;
+  const size_t lds = (size_t(K) * 16 + size_t(WAVES) * 32 * K) * sizeof(float);
+  const int per_cu = int(std::max<size_t>(1, (160 * 1024) / lds));
+  int64_t blocks = std::min<int64_t>((ntiles + WAVES - 1) / WAVES, 256 * per_cu);
+  dim3 grid((unsigned)blocks), block(WAVES * 64);
+  auto go = [&](auto kernel) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, X, W, bias, Y, rows, M, act);
+  };
+  if (softmax_mode == 0) go(dense_narrow16s_kernel<K, 0>);
+  else if (softmax_mode == 1) go(dense_narrow16s_kernel<K, 1>);
+  else go(dense_narrow16s_kernel<K, 2>);
+}
+
 bool dense_can_fuse_softmax(int M) { return M <= 64; }
 
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
            ActParam act, int softmax_mode) {
   if (rows <= 0) return;
+  static const bool staged16 = !(getenv("INFERA_DENSE16_STAGED") && atoi(getenv("INFERA_DENSE16_STAGED")) == 0);
+  if (staged16 && M <= 16 && (K == 64 || K == 128 || K == 256) && rows >= 4096 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    if (K == 64) launch_narrow16s<64>(s, X, W, bias, Y, rows, M, act, softmax_mode);
+    else if (K == 128) launch_narrow16s<128>(s, X, W, bias, Y, rows, M, act, softmax_mode);
+    else launch_narrow16s<256>(s, X, W, bias, Y, rows, M, act, softmax_mode);
+    return;
+  }
   if (M <= 16 && K % 16 == 0 && K <= 1024 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
     const int64_t ntiles = (rows + 31) / 32;
     int64_t blocks = (ntiles + WAVES - 1) / WAVES;
