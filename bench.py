@@ -95,14 +95,15 @@ def main():
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: " + capi.get_devices()["reason"])
     rows = args.rows or {"mlp": 10_000_000, "logreg": 50_000_000, "resnet18": 1024}[args.workload]
-    cols = 3 * 224 * 224 if args.workload == "resnet18" else 128
+    hw = int(os.environ.get("INFERA_BENCH_RESNET_HW", "224"))  # experiments only; C5 is 224
+    cols = 3 * hw * hw if args.workload == "resnet18" else 128
     tmp = tempfile.mkdtemp(prefix="infera_bench_")
     if args.workload == "mlp":
         path = onnx_writer.write(os.path.join(tmp, "mlp.onnx"), onnx_writer.mlp((128, 256, 64, 1)))
         out_cols, wl_name = 1, "C2: 3-layer MLP 128->256->64->1 (Gemm+Relu, Gemm+Relu, Gemm), 10M-row x 128-col FLOAT table"
         bound, flops_row, bytes_row = "mfma", 98432.0, 516.0
     elif args.workload == "resnet18":
-        path = onnx_writer.write(os.path.join(tmp, "resnet18.onnx"), onnx_writer.resnet18())
+        path = onnx_writer.write(os.path.join(tmp, "resnet18.onnx"), onnx_writer.resnet18(in_hw=hw))
         out_cols, wl_name = 1000, "C5: ResNet-18 topology (random weights), BLOB[3x224x224] f32 images resident in HBM"
         bound, flops_row, bytes_row = "mfma", 3628146688.0, 606112.0
     else:

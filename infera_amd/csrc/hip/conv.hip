@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
 __device__ __attribute__((aligned(256))) float g_zero_page[128];
 #ifdef INFERA_CONV_PROBES
 // [MT==4][phase]: summed shader cycles per wave: prologue, main loop, epilogue issue, store drain; [4] = waves
-__device__ unsigned long long g_conv_stamps[2][8];
+__device__ unsigned long long g_conv_stamps[2][12];
 #endif
 
 template <int MT, int S, int PROBE = 0>
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   constexpr int P = 3;        // A-fragment ring depth (2 and 4 measured identical)
   __shared__ __attribute__((aligned(16))) float wbuf[2][S * MT * 1024];
 #ifdef INFERA_CONV_PROBES
-  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, tc = 0;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, tc = 0, w_vm = 0, w_bar = 0, w_ring = 0;
   if constexpr (PROBE == 5) t0 = __builtin_readcyclecounter();
 #endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -270,7 +270,22 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
       for (int j = 0; j < 4; j++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bc[q][j], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (more && (PROBE == 0 || PROBE == 5 || PROBE == 6 || PROBE == 2)) {
+#ifdef INFERA_CONV_PROBES
+    if constexpr (more && PROBE == 5) {  // where a stage boundary spends its time
+      const unsigned long long s0 = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long s1 = __builtin_readcyclecounter();
+      stage_store(wreg, (stage + 1) & 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long s2 = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long s3 = __builtin_readcyclecounter();
+      w_vm += s1 - s0;
+      w_ring += s2 - s1;
+      w_bar += s3 - s2;
+    }
+#endif
+    if constexpr (more && (PROBE == 0 || PROBE == 6 || PROBE == 2)) {
       stage_store(wreg, (stage + 1) & 1);
       __syncthreads();
     }
@@ -367,6 +382,9 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
       atomicAdd(st + 5, t3 - tc);
       atomicAdd(st + 6, t4 - t3);
       atomicAdd(st + 7, 1ull);
+      atomicAdd(st + 8, w_vm);
+      atomicAdd(st + 9, w_ring);
+      atomicAdd(st + 10, w_bar);
     }
   }
 #endif
@@ -811,16 +829,17 @@ void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed) {
 #ifdef INFERA_CONV_PROBES
 namespace {
 void dump_stamps() {
-  unsigned long long st[2][8];
+  unsigned long long st[2][12];
   if (hipDeviceSynchronize() != hipSuccess) return;
   if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_conv_stamps), sizeof st) != hipSuccess) return;
   for (int k = 0; k < 2; k++)
     if (st[k][7]) {
       const double w = double(st[k][7]);
-      fprintf(stderr, "[conv stamps MT=%d] waves=%.0f avg cycles: index %.0f first-loads %.0f lds+barrier %.0f loop %.0f epi-loads %.0f epi-issue %.0f drain %.0f\n",
-              k ? 4 : 2, w, st[k][0] / w, st[k][1] / w, st[k][2] / w, st[k][3] / w, st[k][4] / w, st[k][5] / w, st[k][6] / w);
+      fprintf(stderr, "[conv stamps MT=%d] waves=%.0f avg cycles: index %.0f first-loads %.0f lds+barrier %.0f loop %.0f epi-loads %.0f epi-issue %.0f drain %.0f | in loop: vmcnt-wait %.0f lds-store %.0f barrier %.0f\n",
+              k ? 4 : 2, w, st[k][0] / w, st[k][1] / w, st[k][2] / w, st[k][3] / w, st[k][4] / w, st[k][5] / w, st[k][6] / w,
+              st[k][8] / w, st[k][9] / w, st[k][10] / w);
     }
-  unsigned long long zero[2][8] = {};
+  unsigned long long zero[2][12] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), zero, sizeof zero);
 }
 }  // namespace
