@@ -149,13 +149,13 @@ def main():
     # HBM traffic per launch: PMC counters cannot be read from inside this process; they are collected by
     # tools/profile_bench.sh (separate rocprofv3 --pmc passes of this same command) and committed as
     # profiles/traffic_<workload>.json.  Reported only when that file matches this workload and row count.
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("rows") == rows:
-            traffic = {"bytes": tj["traffic_bytes_per_launch"], "algorithmic_bytes": bytes_row * rows,
-                       "source": f"profiles/{os.path.basename(tpath)} (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, {tj.get('round', '')})"}
+            traffic = tj["traffic_bytes_per_launch"]  # HBM bytes per launch, a plain number as the contract asks
+            traffic_source = f"profiles/{os.path.basename(tpath)} (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, {tj.get('round', '')})"
 
     # a cheap end-of-run sanity check so a silently wrong kernel cannot post a number
     y = d_out.download((4, out_cols))
@@ -180,8 +180,8 @@ def main():
                        "entry": "infera_hip_predict_device (inputs resident in HBM)",
                        "kernel": plan.get("fused_kernel", ",".join(plan["exec"]))},
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                         "traffic": traffic, "kernel_ms": kernel_s * 1e3,
-                         "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}},
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": bytes_row * rows,
+                         "kernel_ms": kernel_s * 1e3, "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(path, cols, args.cpu_seconds)
