@@ -436,7 +436,10 @@ static size_t patch_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
   return (size_t(p.K8) * (g.M / 32) * 256 + size_t(p.K8) * 8 + 2 * size_t(g.C) * p.PLANE) * sizeof(float);
 }
 
-template <int MT>
+// K8C > 0: the number of k groups is a compile-time constant and the group loop is fully unrolled (register
+// double-buffers indexed by constants: no rotation copies, no loop branches between MFMA batches -- the
+// run-time loop leaves ~30 non-MFMA instructions per 8 MFMAs).  K8C == 0: any K8 (run-time loop).
+template <int MT, int K8C>
 __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                              const float *__restrict__ bias, float *__restrict__ Y,
                                                              int64_t ntiles, ConvGeom g, PatchGeom pg, ActParam act) {
@@ -519,6 +522,33 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
       for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
     const float *pb = patch + buf * psz + lbase;
     // software pipeline: offsets two groups ahead, B words and A fragments one group ahead
+    if constexpr (K8C > 0) {
+      int4 ko[3];
+      float b[2][4];
+      f32x4 a[2][MT];
+      ko[0] = ktab4[0];
+      if (K8C > 1) ko[1] = ktab4[2];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[0][j] = pb[(&ko[0].x)[j]];
+#pragma unroll
+      for (int t = 0; t < MT; t++) a[0][t] = wfrag[t * 64];
+#pragma unroll
+      for (int grp = 0; grp < K8C; grp++) {
+        if (grp + 2 < K8C) ko[(grp + 2) % 3] = ktab4[(grp + 2) * 2];
+        if (grp + 1 < K8C) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) b[(grp + 1) & 1][j] = pb[(&ko[(grp + 1) % 3].x)[j]];
+#pragma unroll
+          for (int t = 0; t < MT; t++) a[(grp + 1) & 1][t] = wfrag[((grp + 1) * MT + t) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int t = 0; t < MT; t++)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][t][j], b[grp & 1][j], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     int4 ko_n = ktab4[0];
     f32x4 a_n[MT];
     float b_n[4];
@@ -546,6 +576,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[j], acc[t], 0, 0, 0);
+    }
+
     }
 
     // epilogue: lane (r,h) holds pixel (oy, ox), channels 32t + 8q + 4h + j -> channel quad 8t + 2q + h
@@ -781,11 +813,20 @@ void conv2d_patch(hipStream_t s, const float *X, const float *packed, const floa
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, s, X, packed, bias, Y, ntiles, g, p, act);
   };
+  auto by_k8 = [&](auto mt_tag) {
+    constexpr int MT = decltype(mt_tag)::value;
+    switch (p.K8) {  // the usual 3-channel stems: 7x7 (147 -> 19 groups), 5x5 (75 -> 10), 3x3 (27 -> 4)
+      case 19: launch(conv2d_patch_kernel<MT, 19>); break;
+      case 10: launch(conv2d_patch_kernel<MT, 10>); break;
+      case 4: launch(conv2d_patch_kernel<MT, 4>); break;
+      default: launch(conv2d_patch_kernel<MT, 0>); break;
+    }
+  };
   switch (g.M / 32) {
-    case 1: launch(conv2d_patch_kernel<1>); break;
-    case 2: launch(conv2d_patch_kernel<2>); break;
-    case 3: launch(conv2d_patch_kernel<3>); break;
-    default: launch(conv2d_patch_kernel<4>); break;
+    case 1: by_k8(std::integral_constant<int, 1>{}); break;
+    case 2: by_k8(std::integral_constant<int, 2>{}); break;
+    case 3: by_k8(std::integral_constant<int, 3>{}); break;
+    default: by_k8(std::integral_constant<int, 4>{}); break;
   }
 }
 
