@@ -436,8 +436,8 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
           const int fj = m.conv_fused_add[i];
-          if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, g, act_of(st[size_t(fj)]), dm.num_cus);
-          else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x), dm.num_cus);
+          if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, g, act_of(st[size_t(fj)]));
+          else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x));
           continue;
         }
         case ExecKind::ConvDepthwise: {

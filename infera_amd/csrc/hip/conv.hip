@@ -888,7 +888,7 @@ void dump_stamps() {
 #endif
 
 void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y,
-                  int64_t rows, const ConvGeom &g, ActParam act, int num_cus) {
+                  int64_t rows, const ConvGeom &g, ActParam act) {
   const int64_t total_pix = rows * g.OH * g.OW;
   if (total_pix <= 0) return;
   const unsigned bx = unsigned((total_pix + 127) / 128);

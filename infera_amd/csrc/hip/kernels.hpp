@@ -87,7 +87,7 @@ size_t conv2d_tiled_packed_floats(const ConvGeom &g);
 void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed);
 // residual (nullable): CQ tensor of the output's shape added before the activation (fused ResNet Add)
 void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y,
-                  int64_t rows, const ConvGeom &g, ActParam act, int num_cus);
+                  int64_t rows, const ConvGeom &g, ActParam act);
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
             int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq);
 void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool cq);
