@@ -253,6 +253,64 @@ def test_concurrent_scans_share_one_model(api, models):
     assert_close(got, want)
 
 
+def test_unload_and_replace_during_inference(api, models, tmp_path):
+    """The registry hands out shared ownership (host/engine.cpp): a model unloaded or REPLACED under the same
+    name while other threads are inside infera_predict must neither crash nor corrupt results -- every answer is
+    the old model's or the new model's, bit for bit, and an unloaded name fails with the reference's text.
+    (The reference blocks unload until readers drain, model.rs:41-42; here the HBM is released by the last user.)"""
+    import threading
+    import time
+
+    from infera_amd import onnx_writer as W, synth
+    from oracle import oracle
+
+    pa = W.write(str(tmp_path / "va.onnx"), W.mlp((128, 256, 64, 1), seed=1))
+    pb = W.write(str(tmp_path / "vb.onnx"), W.mlp((128, 256, 64, 1), seed=2))
+    x = synth.table(3, 0, 2048, 128)
+    ya, yb = oracle.Model(pa).predict(x), oracle.Model(pb).predict(x)
+    assert np.abs(ya - yb).max() > 1e-2
+    api.load_model("swap", pa)
+    ga = api.predict("swap", x)
+    api.load_model("swap", pb)
+    gb = api.predict("swap", x)
+    assert_close(ga, ya)
+    assert_close(gb, yb)
+    stop, errors, counts = threading.Event(), [], {"a": 0, "b": 0, "missing": 0}
+
+    def reader():
+        try:
+            while not stop.is_set():
+                try:
+                    y = api.predict("swap", x)
+                except api.InferaError as e:
+                    assert str(e) == "Model not found: swap", str(e)
+                    counts["missing"] += 1
+                    continue
+                if np.array_equal(y, ga):
+                    counts["a"] += 1
+                elif np.array_equal(y, gb):
+                    counts["b"] += 1
+                else:
+                    raise AssertionError("result is neither model's output")
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=reader) for _ in range(6)]
+    [t.start() for t in th]
+    t_end = time.time() + 3.0
+    i = 0
+    while time.time() < t_end:
+        i += 1
+        if i % 3 == 0:
+            api.load_library().infera_unload_model(b"swap")
+        api.load_model("swap", pa if i % 2 else pb)
+    stop.set()
+    [t.join() for t in th]
+    assert not errors, errors[:3]
+    assert counts["a"] > 0 and counts["b"] > 0, counts
+    api.load_library().infera_unload_model(b"swap")
+
+
 def test_full_size_c2_properties(api, models):
     """BASELINE config C2 at full size (10M rows x 128, one device-resident scan): the oracle cannot
     cover 10M rows in seconds, so check size-independent properties --
