@@ -2,6 +2,8 @@
 
 #include <immintrin.h>
 
+#include <vector>
+
 namespace infera_hip {
 
 namespace {
@@ -39,38 +41,100 @@ __attribute__((target("avx2"))) inline void transpose8x8(const float *const in[8
   _mm256_storeu_ps(dst + 7 * ld, _mm256_permute2f128_ps(u3, u7, 0x31));
 }
 
-__attribute__((target("avx2"))) void gather_float_avx2(const infera::InferaColumn *cols, size_t c0, size_t c1, size_t ncols,
-                                                       size_t row0, size_t nrows, float *dst) {
-  // columns [c0, c1) are all flat FLOAT and (c1-c0) % 8 == 0; rows in blocks of 8
-  const size_t full = nrows & ~size_t(7);
+// 8 consecutive rows of one column as f32, whatever its type (casts as the reference: static_cast<float>,
+// infera_extension.cpp:211-222).  DOUBLE and INTEGER convert in registers; BIGINT has no AVX2 conversion.
+__attribute__((target("avx2"))) inline const float *rows8_as_float(const infera::InferaColumn &c, size_t row, float *tmp) {
+  if (c.is_constant) {
+    _mm256_storeu_ps(tmp, _mm256_set1_ps(cell(c, 0)));
+    return tmp;
+  }
+  switch (c.type) {
+    case infera::INFERA_COL_FLOAT: return static_cast<const float *>(c.data) + row;
+    case infera::INFERA_COL_DOUBLE: {
+      const double *p = static_cast<const double *>(c.data) + row;
+      _mm_storeu_ps(tmp, _mm256_cvtpd_ps(_mm256_loadu_pd(p)));
+      _mm_storeu_ps(tmp + 4, _mm256_cvtpd_ps(_mm256_loadu_pd(p + 4)));
+      return tmp;
+    }
+    case infera::INFERA_COL_INTEGER:
+      _mm256_storeu_ps(tmp, _mm256_cvtepi32_ps(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(static_cast<const int32_t *>(c.data) + row))));
+      return tmp;
+    default: {
+      const int64_t *p = static_cast<const int64_t *>(c.data) + row;
+      for (int i = 0; i < 8; i++) tmp[i] = static_cast<float>(p[i]);
+      return tmp;
+    }
+  }
+}
+
+// One 8-column block whose columns are all flat and of ONE type: no per-cell dispatch.
+template <int TYPE>
+__attribute__((target("avx2"))) inline void block_uniform(const infera::InferaColumn *cols, size_t row, float *dst, size_t ld) {
+  alignas(32) float tmp[8][8];
+  const float *in[8];
+  for (int j = 0; j < 8; j++) {
+    if constexpr (TYPE == infera::INFERA_COL_FLOAT) {
+      in[j] = static_cast<const float *>(cols[j].data) + row;
+    } else if constexpr (TYPE == infera::INFERA_COL_DOUBLE) {
+      const double *p = static_cast<const double *>(cols[j].data) + row;
+      _mm_store_ps(tmp[j], _mm256_cvtpd_ps(_mm256_loadu_pd(p)));
+      _mm_store_ps(tmp[j] + 4, _mm256_cvtpd_ps(_mm256_loadu_pd(p + 4)));
+      in[j] = tmp[j];
+    } else if constexpr (TYPE == infera::INFERA_COL_INTEGER) {
+      const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(static_cast<const int32_t *>(cols[j].data) + row));
+      _mm256_store_ps(tmp[j], _mm256_cvtepi32_ps(v));
+      in[j] = tmp[j];
+    } else {
+      const int64_t *p = static_cast<const int64_t *>(cols[j].data) + row;
+      for (int i = 0; i < 8; i++) tmp[j][i] = static_cast<float>(p[i]);
+      in[j] = tmp[j];
+    }
+  }
+  transpose8x8(in, dst, ld);
+}
+
+// Columns [0, blocked), blocked % 8 == 0: 8x8 blocks, each written as eight 32-byte row pieces (the scalar path
+// writes one float per 4*ncols-byte stride).  kind[b]: the block's uniform type, or -1 = mixed / constant vectors.
+__attribute__((target("avx2"))) void gather_blocks_avx2(const infera::InferaColumn *cols, size_t blocked, size_t ncols, size_t row0,
+                                                        size_t nrows, float *dst) {
+  const size_t nb = blocked / 8, full = nrows & ~size_t(7);
+  std::vector<int8_t> kind(nb);
+  for (size_t b = 0; b < nb; b++) {
+    int k = cols[8 * b].type;
+    for (int j = 0; j < 8; j++)
+      if (cols[8 * b + size_t(j)].is_constant || cols[8 * b + size_t(j)].type != k) k = -1;
+    kind[b] = int8_t(k);
+  }
+  alignas(32) float tmp[8][8];
   for (size_t r = 0; r < full; r += 8)
-    for (size_t c = c0; c < c1; c += 8) {
-      const float *in[8];
-      for (int j = 0; j < 8; j++) in[j] = static_cast<const float *>(cols[c + size_t(j)].data) + row0 + r;
-      transpose8x8(in, dst + r * ncols + c, ncols);
+    for (size_t b = 0; b < nb; b++) {
+      const infera::InferaColumn *cb = cols + 8 * b;
+      float *d = dst + r * ncols + 8 * b;
+      switch (kind[b]) {
+        case infera::INFERA_COL_FLOAT: block_uniform<infera::INFERA_COL_FLOAT>(cb, row0 + r, d, ncols); break;
+        case infera::INFERA_COL_DOUBLE: block_uniform<infera::INFERA_COL_DOUBLE>(cb, row0 + r, d, ncols); break;
+        case infera::INFERA_COL_INTEGER: block_uniform<infera::INFERA_COL_INTEGER>(cb, row0 + r, d, ncols); break;
+        case infera::INFERA_COL_BIGINT: block_uniform<infera::INFERA_COL_BIGINT>(cb, row0 + r, d, ncols); break;
+        default: {
+          const float *in[8];
+          for (int j = 0; j < 8; j++) in[j] = rows8_as_float(cb[j], row0 + r, tmp[j]);
+          transpose8x8(in, d, ncols);
+        }
+      }
     }
   for (size_t r = full; r < nrows; r++)
-    for (size_t c = c0; c < c1; c++) dst[r * ncols + c] = static_cast<const float *>(cols[c].data)[row0 + r];
+    for (size_t c = 0; c < blocked; c++) dst[r * ncols + c] = cell(cols[c], row0 + r);
 }
 
 }  // namespace
 
 void gather_columns(const infera::InferaColumn *cols, size_t ncols, size_t row0, size_t nrows, float *dst) {
   static const bool have_avx2 = __builtin_cpu_supports("avx2");
-  size_t c = 0;
-  while (c < ncols) {
-    // maximal run of flat FLOAT columns, in multiples of 8 -> AVX2 block transpose
-    size_t e = c;
-    while (e < ncols && cols[e].type == infera::INFERA_COL_FLOAT && !cols[e].is_constant) e++;
-    const size_t run8 = have_avx2 ? ((e - c) & ~size_t(7)) : 0;
-    if (run8) gather_float_avx2(cols, c, c + run8, ncols, row0, nrows, dst);
-    c += run8;
-    if (c < ncols && (c < e || true)) {
-      // one leftover / non-FLOAT / constant column, cache-blocked over rows
-      const infera::InferaColumn &col = cols[c];
-      for (size_t r = 0; r < nrows; r++) dst[r * ncols + c] = cell(col, row0 + r);
-      c++;
-    }
+  const size_t blocked = have_avx2 ? (ncols & ~size_t(7)) : 0;
+  if (blocked) gather_blocks_avx2(cols, blocked, ncols, row0, nrows, dst);
+  for (size_t c = blocked; c < ncols; c++) {  // < 8 leftover columns (or no AVX2)
+    const infera::InferaColumn &col = cols[c];
+    for (size_t r = 0; r < nrows; r++) dst[r * ncols + c] = cell(col, row0 + r);
   }
 }
 

@@ -227,7 +227,7 @@ def test_predict_without_gpu_fails_loudly(api):
 
 
 def test_gather_columns_matches_extract_features(api):
-    """The vectorised ExtractFeatures (AVX2 8x8 transposes for FLOAT runs, scalar casts elsewhere)
+    """The vectorised ExtractFeatures (AVX2 8x8 block transposes, conversions in registers)
     against the oracle's restatement of infera_extension.cpp:199-227, incl. ragged row counts,
     column counts that are not multiples of 8, mixed types, constant vectors and row windows."""
     from oracle import oracle
@@ -247,6 +247,15 @@ def test_gather_columns_matches_extract_features(api):
         elif kind == 2: mixed.append(rng.integers(-2 ** 31, 2 ** 31 - 1, rows).astype(np.int32))
         else: mixed.append(rng.integers(-2 ** 62, 2 ** 62, rows).astype(np.int64))
     np.testing.assert_array_equal(api.gather_columns(mixed), oracle.extract_features(mixed))
+    # uniform-type 8-column blocks (the registered overloads are all-FLOAT and all-DOUBLE, infera_extension.cpp:554-557)
+    for make in (lambda: rng.standard_normal(rows) * 1e3, lambda: rng.integers(-2 ** 31, 2 ** 31 - 1, rows).astype(np.int32),
+                 lambda: rng.integers(-2 ** 62, 2 ** 62, rows).astype(np.int64)):
+        uni = [make() for _ in range(19)]
+        np.testing.assert_array_equal(api.gather_columns(uni), oracle.extract_features(uni))
+        np.testing.assert_array_equal(api.gather_columns(uni, row0=5, nrows=300), oracle.extract_features(uni)[5:305])
+        uni[3] = uni[3][:1]  # a CONSTANT_VECTOR inside a block
+        want = oracle.extract_features([np.full(rows, c[0]) if len(c) == 1 else c for c in uni])
+        np.testing.assert_array_equal(api.gather_columns(uni, rows=rows), want)
     const = [np.array([2.5], np.float32), mixed[0], np.array([7], np.int64)]
     want = np.stack([np.full(rows, 2.5, np.float32), mixed[0], np.full(rows, 7.0, np.float32)], axis=1)
     np.testing.assert_array_equal(api.gather_columns(const, rows=rows), want)
