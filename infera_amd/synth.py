@@ -2,7 +2,7 @@
 
     u = splitmix64(seed ^ (row*F + col));  x = ((u >> 40) * 2^-24) * 2 - 1     (f32, in [-1, 1))
 
-The same function exists as a HIP fill kernel (csrc/hip/synth.hip) and in the C oracle
+The same function exists as a HIP fill kernel (csrc/hip/eltwise.hip: synth_fill_kernel) and in the C oracle
 (oracle/infera_oracle.c: orc_synth_value); all three agree bit-for-bit because every
 intermediate is exactly representable in f32.
 """
