@@ -280,7 +280,7 @@ void schedule(LoadedModel &m) {
       if (m.exec[i] != ExecKind::Skipped) prod[size_t(st[i].out)] = int(i);
     for (size_t j = 0; j < n; j++) {
       const Step &a = st[j];
-      if (m.exec[j] != ExecKind::Normal || a.kind != StepKind::BinaryAct || a.bop != '+' || !is4d(a.out)) continue;
+      if (m.exec[j] != ExecKind::Normal || a.kind != StepKind::BinaryAct || a.bop != '+' || !is4d(a.out) || a.S > 1) continue;
       if (int(a.act) > kMaxMfmaFusedAct) continue;  // the conv epilogue resolves only the MFMA-fusable kinds
       const int pa = prod[size_t(a.in0)], pb = prod[size_t(a.in1)];
       const int late = std::max(pa, pb);
@@ -464,7 +464,8 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           kern::binary_const(s, buf(x.in0), d.cst, buf(x.out), nr, p.buf_per_row[size_t(x.out)], x.bop, x.const_left, act_of(x));
           break;
         case StepKind::BinaryAct:
-          kern::binary_act(s, buf(x.in0), buf(x.in1), buf(x.out), nr * p.buf_per_row[size_t(x.out)], x.bop, act_of(x));
+          if (x.S > 1) kern::binary_gate(s, buf(x.in0), buf(x.in1), buf(x.out), nr, x.C, x.S, x.bop, act_of(x), m.cq_mode && x.in0 != 0);
+          else kern::binary_act(s, buf(x.in0), buf(x.in1), buf(x.out), nr * p.buf_per_row[size_t(x.out)], x.bop, act_of(x));
           break;
         case StepKind::Softmax: kern::softmax(s, buf(x.in0), buf(x.out), nr, x.sm_outer, x.sm_len, x.sm_inner, x.log_softmax); break;
         case StepKind::Conv2d: {

@@ -56,6 +56,18 @@ __global__ __launch_bounds__(kBlock) void binary_act_kernel(const float *__restr
     y[i] = apply_act(apply_bop(a[i], b[i], op, false), act);
 }
 
+// y[r, c, s] = act(a[r, c, s] (op) gate[r, c])   (squeeze-and-excitation style per-channel gate)
+__global__ __launch_bounds__(kBlock) void binary_gate_kernel(const float *__restrict__ a, const float *__restrict__ gate,
+                                                            float *__restrict__ y, int64_t n, int64_t C, int64_t S, char op, ActParam act,
+                                                            bool cq) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock, per_row = C * S;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t row = i / per_row, j = i - row * per_row;
+    const int64_t c = cq ? ((j >> 2) / S) * 4 + (j & 3) : j / S;
+    y[i] = apply_act(apply_bop(a[i], gate[row * C + c], op, false), act);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void affine_channel_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                                const float *__restrict__ shift, float *__restrict__ y,
                                                                int64_t n, int64_t C, int64_t S, ActParam act, bool cq) {
@@ -180,6 +192,13 @@ void binary_const(hipStream_t s, const float *x, const float *c, float *y, int64
 void binary_act(hipStream_t s, const float *a, const float *b, float *y, int64_t n, char op, ActParam act) {
   if (n <= 0) return;
   hipLaunchKernelGGL(binary_act_kernel, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, s, a, b, y, n, op, act);
+}
+
+void binary_gate(hipStream_t s, const float *a, const float *gate, float *y, int64_t rows, int64_t C, int64_t S, char op, ActParam act,
+                 bool cq) {
+  const int64_t n = rows * C * S;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(binary_gate_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, a, gate, y, n, C, S, op, act, cq);
 }
 
 void affine_channel(hipStream_t s, const float *x, const float *scale, const float *shift, float *y, int64_t rows,

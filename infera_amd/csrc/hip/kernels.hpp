@@ -21,6 +21,9 @@ void unary(hipStream_t s, const float *x, float *y, int64_t n, ActParam act);
 void binary_const(hipStream_t s, const float *x, const float *c, float *y, int64_t rows, int64_t per_row, char op,
                   bool const_left, ActParam act);
 void binary_act(hipStream_t s, const float *a, const float *b, float *y, int64_t n, char op, ActParam act);
+// y[r, c, i] = act(a[r, c, i] (op) gate[r, c]): per-channel gate broadcast over the S positions of a channel
+void binary_gate(hipStream_t s, const float *a, const float *gate, float *y, int64_t rows, int64_t C, int64_t S, char op, ActParam act,
+                 bool cq);
 // y[r, c, i] = act(x * scale[c] + shift[c]);  cq: activations in channel-quad planes [N][C/4][S][4] (conv.hip)
 void affine_channel(hipStream_t s, const float *x, const float *scale, const float *shift, float *y, int64_t rows,
                     int64_t C, int64_t S, ActParam act, bool cq);

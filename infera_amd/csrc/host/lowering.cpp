@@ -226,7 +226,29 @@ struct Lowerer {
       return;
     }
     if (!a.is_const && !b.is_const) {
-      if (a.shape != b.shape) unsupported(n, "activation operands must have equal shapes, got " + shape_str(a.shape) + " and " + shape_str(b.shape));
+      // per-channel gate: [N,C,H,W] (op) [N,C,1,1]  (squeeze-and-excitation blocks); either order for + * min max
+      auto is_gate = [](const Val &big, const Val &small) {
+        if (big.shape.size() < 3 || small.shape.size() != big.shape.size() || small.shape[0] != big.shape[0] || small.shape[1] != big.shape[1]) return false;
+        for (size_t i = 2; i < small.shape.size(); i++)
+          if (small.shape[i] != 1) return false;
+        return prod(big.shape, 2) > 1;
+      };
+      const bool commutes = op == '+' || op == '*' || op == 'm' || op == 'M';
+      if (a.shape != b.shape && (is_gate(a, b) || (commutes && is_gate(b, a)))) {
+        const bool swap = !is_gate(a, b);
+        const Val &big = swap ? b : a, &small = swap ? a : b;
+        Step s;
+        s.kind = StepKind::BinaryAct;
+        s.in0 = big.buf;
+        s.in1 = small.buf;
+        s.bop = op;
+        s.C = big.shape[1];
+        s.S = prod(big.shape, 2);  // > 1 marks the broadcast form
+        std::vector<int64_t> shape = big.shape;
+        emit(std::move(s), n, shape);
+        return;
+      }
+      if (a.shape != b.shape) unsupported(n, "activation operands must have equal shapes (or [N,C,H,W] with [N,C,1,1]), got " + shape_str(a.shape) + " and " + shape_str(b.shape));
       Step s;
       s.kind = StepKind::BinaryAct;
       s.in0 = a.buf;

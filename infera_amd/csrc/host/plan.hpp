@@ -28,7 +28,7 @@ enum class StepKind : int {
   Unary = 1,        // elementwise activation
   AffineChannel = 2,// y = x*scale[c] + shift[c]  per channel              (unfused BatchNormalization)
   BinaryConst = 3,  // y = x (op) cst[per_row]  (constant pre-broadcast to one row)
-  BinaryAct = 4,    // y = a (op) b             (residual adds)
+  BinaryAct = 4,    // y = a (op) b             (residual adds; S > 1: b is a per-channel gate [rows, C] broadcast over S positions)
   Softmax = 5,      // softmax / log-softmax over `sm_len` with (outer, len, inner) strides inside a row
   Conv2d = 6,       // NCHW convolution as implicit GEMM (BatchNormalization folded when adjacent)
   Pool2d = 7,       // MaxPool / AveragePool

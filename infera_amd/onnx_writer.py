@@ -387,6 +387,37 @@ def mobilenet_v2(classes: int = 100, in_hw: int = 64, width_mult: float = 0.5, s
     return model("mobilenet_v2", nodes, inits, [value_info("X", ["N", 3, in_hw, in_hw])], [value_info("Y", ["N", classes])], opset=13)
 
 
+def se_net(c: int = 16, hw: int = 10, classes: int = 6) -> bytes:
+    """Conv -> squeeze-and-excitation block (GlobalAveragePool -> 1x1 Conv -> Relu -> 1x1 Conv -> HardSigmoid ->
+    Mul gate [N,C,1,1] over [N,C,H,W]) -> residual Add with a gated copy -> GAP -> Gemm.  MobileNetV3 / EfficientNet idiom."""
+    ws = _WeightStream(31)
+    inits, nodes = [], []
+
+    def conv(x, cin, cout, k, out, act=None):
+        w, b = ws.take((cout, cin, k, k), cin * k * k), ws.take((cout,), cin * k * k)
+        inits.extend([tensor(out + "_w", w), tensor(out + "_b", b)])
+        nodes.append(node("Conv", [x, out + "_w", out + "_b"], [out if act is None else out + "_pre"],
+                          [attr_ints("kernel_shape", [k, k]), attr_ints("pads", [k // 2] * 4)]))
+        if act:
+            nodes.append(node(act, [out + "_pre"], [out]))
+        return out
+
+    x = conv("X", 4, c, 3, "stem", "Relu")
+    sq = "sq"
+    nodes.append(node("GlobalAveragePool", [x], [sq]))
+    r = conv(sq, c, c // 4, 1, "se_r", "Relu")
+    e = conv(r, c // 4, c, 1, "se_e", "HardSigmoid")
+    nodes.append(node("Mul", [x, e], ["gated"]))
+    nodes.append(node("Mul", [e, x], ["gated2"]))  # gate on the left: commutative form
+    nodes.append(node("Add", ["gated", "gated2"], ["sum"]))
+    nodes.append(node("GlobalAveragePool", ["sum"], ["g"]))
+    nodes.append(node("Flatten", ["g"], ["f"], [attr_i("axis", 1)]))
+    w, b = ws.take((c, classes), c), ws.take((classes,), c)
+    inits += [tensor("fc_w", w), tensor("fc_b", b)]
+    nodes.append(node("Gemm", ["f", "fc_w", "fc_b"], ["Y"]))
+    return model("se_net", nodes, inits, [value_info("X", ["N", 4, hw, hw])], [value_info("Y", ["N", classes])], opset=14)
+
+
 def write(path: str, blob: bytes) -> str:
     with open(path, "wb") as fh:
         fh.write(blob)

@@ -40,6 +40,7 @@ def paths(tmp_path_factory, built):
         "exporter": W.write(str(d / "exporter.onnx"), W.exporter_reshape()),
         "concat": W.write(str(d / "concat.onnx"), W.concat_heads(24)),
         "mnv2": W.write(str(d / "mnv2.onnx"), W.mobilenet_v2(classes=20, in_hw=32, width_mult=0.5)),
+        "se": W.write(str(d / "se.onnx"), W.se_net()),
     }
 
 
@@ -156,6 +157,27 @@ def test_oracle_mobilenet_runs_and_is_batch_consistent(O, paths):
     assert np.array_equal(y1[0], y[1])  # rows are independent: batching must not change a row's value
 
 
+def test_oracle_se_gate_broadcast_vs_numpy(O, paths):
+    ws = _weights(31)
+    c, hw = 16, 10
+    x = synth.table(6, 0, 3, 4 * hw * hw).reshape(3, 4, hw, hw)
+
+    def take_conv(cin, cout, k):
+        return ws.take((cout, cin, k, k), cin * k * k).astype(np.float64), ws.take((cout,), cin * k * k).astype(np.float64)
+
+    w, b = take_conv(4, c, 3)
+    s = np.maximum(np_conv2d(x.astype(np.float64), w, b, 1, 1), 0)
+    sq = s.mean(axis=(2, 3), keepdims=True)
+    w, b = take_conv(c, c // 4, 1)
+    r = np.maximum(np_conv2d(sq, w, b), 0)
+    w, b = take_conv(c // 4, c, 1)
+    e = np.clip(np.float64(np.float32(0.2)) * np_conv2d(r, w, b) + 0.5, 0, 1)
+    tot = (s * e + e * s).mean(axis=(2, 3))
+    wf, bf = ws.take((c, 6), c).astype(np.float64), ws.take((6,), c).astype(np.float64)
+    want = tot @ wf + bf
+    assert_close(O.Model(paths["se"]).predict_blob(x.tobytes()), want.astype(np.float32), rtol=2e-5, atol=2e-6)
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
@@ -173,6 +195,8 @@ def test_lowering_of_breadth_models(built, paths):
     mn = capi.get_plan("b_mnv2")["plan"]["steps"]
     assert all(s["kind"] in ("Conv2d", "BinaryAct", "GlobalAvgPool", "Dense") for s in mn), {s["kind"] for s in mn}
     assert sum("BatchNormalization" in s["origin"] for s in mn) == sum(s["kind"] == "Conv2d" for s in mn)  # all folded
+    se = capi.get_plan("b_se")["plan"]["steps"]
+    assert [s["kind"] for s in se].count("BinaryAct") == 3  # two gates (either operand order) + the Add
     for name in paths:
         capi.unload_model("b_" + name)
 
@@ -233,6 +257,15 @@ def test_gpu_concat_heads(api, O, paths):
     x = synth.table(9, 0, 2500, 24)
     assert_close(api.predict("cat", x), O.Model(paths["concat"]).predict(x))
     api.unload_model("cat")
+
+
+@pytest.mark.gpu
+def test_gpu_se_gate_broadcast(api, O, paths):
+    api.load_model("se", paths["se"])
+    assert api.get_plan("se")["activation_layout"] == "NC/4HW4"
+    x = synth.table(6, 0, 9, 4 * 10 * 10)
+    assert_close(api.predict_from_blob("se", x.tobytes()), O.Model(paths["se"]).predict_blob(x.tobytes()))
+    api.unload_model("se")
 
 
 @pytest.mark.gpu
