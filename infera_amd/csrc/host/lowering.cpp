@@ -682,9 +682,17 @@ struct Lowerer {
       s.pt = up ? ph / 2 : ph - ph / 2; s.pb = ph - s.pt;
       s.pl = up ? pw / 2 : pw - pw / 2; s.pr = pw - s.pl;
     } else if (ap != "NOTSET") unsupported(n, "auto_pad " + ap);
-    if (n.attr_i("ceil_mode", 0) != 0) unsupported(n, "ceil_mode=1");
-    s.OH = (H + s.pt + s.pb - (s.dh * (s.kh - 1) + 1)) / s.sh + 1;
-    s.OW = (W + s.pl + s.pr - (s.dw * (s.kw - 1) + 1)) / s.sw + 1;
+    // pooling only: ceil_mode=1 rounds the extent up, and a last window that would start beyond the input plus
+    // its leading pad is dropped (ONNX MaxPool / AveragePool); the kernels already ignore out-of-image taps
+    const bool ceil_mode = n.attr_i("ceil_mode", 0) != 0;
+    auto extent = [&](int64_t in, int64_t p0, int64_t p1, int64_t k, int64_t d, int64_t st) {
+      const int64_t num = in + p0 + p1 - (d * (k - 1) + 1);
+      int64_t o = (ceil_mode ? (num + st - 1) / st : num / st) + 1;
+      if (ceil_mode && (o - 1) * st >= in + p0) o--;
+      return o;
+    };
+    s.OH = extent(H, s.pt, s.pb, s.kh, s.dh, s.sh);
+    s.OW = extent(W, s.pl, s.pr, s.kw, s.dw, s.sw);
     if (s.OH <= 0 || s.OW <= 0) unsupported(n, "empty spatial output");
   }
 
@@ -759,6 +767,7 @@ struct Lowerer {
     s.in0 = a.buf;
     s.is_max = is_max;
     s.count_pad = n.attr_i("count_include_pad", 0) != 0;
+    if (!is_max && s.count_pad && n.attr_i("ceil_mode", 0) != 0) unsupported(n, "ceil_mode=1 with count_include_pad=1");
     s.C = a.shape[1]; s.H = a.shape[2]; s.Wd = a.shape[3];
     s.kh = (*ks)[0]; s.kw = (*ks)[1];
     spatial(n, s, s.H, s.Wd);
@@ -837,12 +846,19 @@ struct Lowerer {
       else if (op == "AveragePool") pool(n, false);
       else if (op == "GlobalAveragePool") global_avgpool(n);
       else if (op == "Constant") {
-        auto *a = n.attr("value");
-        if (!a || !a->t) unsupported(n, "only the tensor `value` form is supported");
         Val v;
         v.is_const = true;
-        v.c = a->t;
-        v.shape = a->t->dims;
+        if (auto *a = n.attr("value"); a && a->t) {
+          v.c = a->t;
+        } else {  // scalar / 1-D attribute forms (opset 12+)
+          auto t = std::make_shared<TensorData>();
+          if (auto *f = n.attr("value_float")) { t->dtype = onnx::kFloat; t->f32 = {f->f}; }
+          else if (auto *i = n.attr("value_int")) { t->dtype = onnx::kInt64; t->i64 = {i->i}; }
+          else if (auto *is = n.attr_ints("value_ints")) { t->dtype = onnx::kInt64; t->i64 = *is; t->dims = {int64_t(is->size())}; }
+          else unsupported(n, "only the value / value_float / value_int / value_ints forms are supported");
+          v.c = t;
+        }
+        v.shape = v.c->dims;
         vals[n.outputs[0]] = v;
       } else {
         unsupported(n, "unsupported operator");

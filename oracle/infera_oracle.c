@@ -1148,8 +1148,16 @@ static int spatial_attrs(Exec *x, const Node *nd, int64_t kh, int64_t kw, int64_
       s->pl = upper ? pw / 2 : pw - pw / 2; s->pr = pw - s->pl;
     } else FAIL("%s: unsupported auto_pad %s", nd->op, a->s);
   }
-  if (attr_i(nd, "ceil_mode", 0) != 0) FAIL("%s: ceil_mode=1 unsupported", nd->op);
   return 0;
+}
+
+/* Pooling output extent (ONNX MaxPool/AveragePool): floor or, with ceil_mode=1, ceil -- and a last window that
+ * would START beyond the input plus its leading pad is dropped. */
+static int64_t pool_extent(int64_t in, int64_t p0, int64_t p1, int64_t k, int64_t d, int64_t s, int ceil_mode) {
+  int64_t num = in + p0 + p1 - (d * (k - 1) + 1);
+  int64_t o = (ceil_mode ? (num + s - 1) / s : num / s) + 1;
+  if (ceil_mode && (o - 1) * s >= in + p0) o--;
+  return o;
 }
 
 /* Conv (NCHW, 2-D): im2col per image then W[M x CKK] * col[CKK x P]; the dot product over
@@ -1231,9 +1239,11 @@ static int op_pool(Exec *x, const Node *nd, int is_max) {
   int64_t N = in->dims[0], C = in->dims[1], H = in->dims[2], W = in->dims[3];
   Spatial s;
   if (spatial_attrs(x, nd, ks->ints[0], ks->ints[1], H, W, &s)) return -1;
-  int64_t OH = (H + s.pt + s.pb - (s.dh * (s.kh - 1) + 1)) / s.sh + 1;
-  int64_t OW = (W + s.pl + s.pr - (s.dw * (s.kw - 1) + 1)) / s.sw + 1;
+  int ceil_mode = attr_i(nd, "ceil_mode", 0) != 0;
   int count_pad = (int)attr_i(nd, "count_include_pad", 0);
+  if (ceil_mode && count_pad && !is_max) FAIL("%s: ceil_mode=1 with count_include_pad=1 unsupported", nd->op);
+  int64_t OH = pool_extent(H, s.pt, s.pb, s.kh, s.dh, s.sh, ceil_mode);
+  int64_t OW = pool_extent(W, s.pl, s.pr, s.kw, s.dw, s.sw, ceil_mode);
   int64_t od[4] = {N, C, OH, OW};
   Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, 4, od);
   in = get_in(x, nd, 0);
@@ -1278,11 +1288,22 @@ static int op_global_avgpool(Exec *x, const Node *nd) {
 
 static int op_constant(Exec *x, const Node *nd) {
   const Attr *a = find_attr(nd, "value");
-  if (!a || !a->t) FAIL("Constant: only the tensor `value` form is supported");
-  Tensor *o = env_new(&x->env, nd->out[0], a->t->dtype, a->t->rank, a->t->dims);
-  if (a->t->dtype == DT_FLOAT) memcpy(o->f, a->t->f, o->n * 4);
-  else memcpy(o->i64, a->t->i64, o->n * 8);
-  return 0;
+  if (a && a->t) {
+    Tensor *o = env_new(&x->env, nd->out[0], a->t->dtype, a->t->rank, a->t->dims);
+    if (a->t->dtype == DT_FLOAT) memcpy(o->f, a->t->f, o->n * 4);
+    else memcpy(o->i64, a->t->i64, o->n * 8);
+    return 0;
+  }
+  int64_t one = 1;
+  if ((a = find_attr(nd, "value_float"))) { env_new(&x->env, nd->out[0], DT_FLOAT, 0, &one)->f[0] = a->f; return 0; }
+  if ((a = find_attr(nd, "value_int"))) { env_new(&x->env, nd->out[0], DT_INT64, 0, &one)->i64[0] = a->i; return 0; }
+  if ((a = find_attr(nd, "value_ints"))) {
+    int64_t cnt = (int64_t)a->nints;
+    Tensor *o = env_new(&x->env, nd->out[0], DT_INT64, 1, &cnt);
+    memcpy(o->i64, a->ints, (size_t)cnt * 8);
+    return 0;
+  }
+  FAIL("Constant: only the value / value_float / value_int / value_ints forms are supported");
 }
 
 static int run_node(Exec *x, const Node *nd) {

@@ -178,6 +178,56 @@ def test_oracle_se_gate_broadcast_vs_numpy(O, paths):
     assert_close(O.Model(paths["se"]).predict_blob(x.tobytes()), want.astype(np.float32), rtol=2e-5, atol=2e-6)
 
 
+def _pool_model(tmp_path, name, op, hw, k, stride, pad, ceil, extra=()):
+    import math
+
+    num = hw + 2 * pad - k
+    o = (math.ceil(num / stride) if ceil else num // stride) + 1
+    if ceil and (o - 1) * stride >= hw + pad:
+        o -= 1
+    nodes = [W.node(op, ["X"], ["P"], [W.attr_ints("kernel_shape", [k, k]), W.attr_ints("strides", [stride] * 2), W.attr_ints("pads", [pad] * 4),
+                                       W.attr_i("ceil_mode", int(ceil))] + list(extra)),
+             W.node("Constant", [], ["two"], [W.attr_f("value_float", 2.0)]), W.node("Mul", ["P", "two"], ["Y"])]
+    blob = W.model(name, nodes, [], [W.value_info("X", ["N", 4, hw, hw])], [W.value_info("Y", ["N", 4, o, o])])
+    return W.write(str(tmp_path / f"{name}.onnx"), blob), o
+
+
+def np_pool(x, k, stride, pad, o, is_max):
+    n, c, h, w = x.shape
+    out = np.empty((n, c, o, o))
+    for oy in range(o):
+        for ox in range(o):
+            ys, xs = oy * stride - pad, ox * stride - pad
+            win = x[:, :, max(ys, 0):min(ys + k, h), max(xs, 0):min(xs + k, w)]
+            out[:, :, oy, ox] = win.max(axis=(2, 3)) if is_max else win.mean(axis=(2, 3))
+    return out
+
+
+POOL_CASES = [("MaxPool", 7, 3, 2, 0, True), ("MaxPool", 8, 3, 2, 1, True), ("AveragePool", 7, 2, 2, 0, True), ("MaxPool", 9, 2, 2, 0, True),
+              ("AveragePool", 8, 3, 2, 1, False)]
+
+
+@pytest.mark.parametrize("op,hw,k,stride,pad,ceil", POOL_CASES)
+def test_oracle_pool_ceil_mode_vs_numpy(O, tmp_path, op, hw, k, stride, pad, ceil):
+    path, o = _pool_model(tmp_path, "pl", op, hw, k, stride, pad, ceil)
+    x = synth.table(12, 0, 2, 4 * hw * hw).reshape(2, 4, hw, hw)
+    m = O.Model(path)
+    assert m.output_shape == [-1, 4, o, o]
+    got = m.predict_blob(x.tobytes()).reshape(2, 4, o, o)
+    assert_close(got, (2 * np_pool(x.astype(np.float64), k, stride, pad, o, op == "MaxPool")).astype(np.float32), rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op,hw,k,stride,pad,ceil", POOL_CASES)
+def test_gpu_pool_ceil_mode(api, O, tmp_path, op, hw, k, stride, pad, ceil):
+    path, o = _pool_model(tmp_path, "plg", op, hw, k, stride, pad, ceil)
+    x = synth.table(12, 0, 5, 4 * hw * hw)
+    api.load_model("plg", path)
+    assert api.get_model_info("plg")["output_shape"] == [-1, 4, o, o]
+    assert_close(api.predict_from_blob("plg", x.tobytes()), O.Model(path).predict_blob(x.tobytes()))
+    api.unload_model("plg")
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
