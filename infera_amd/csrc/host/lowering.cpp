@@ -807,11 +807,31 @@ struct Lowerer {
       vals[in.name] = v;
       buf_names[v.buf].push_back(in.name);
     }
-    for (const auto &n : m.nodes)
-      for (const auto &i : n.inputs) uses[i]++;
-    for (const auto &o : m.outputs) uses[o.name]++;
+    // Only the first output is served (engine.rs:146-149): nodes that do not feed it are dead -- a second
+    // output (e.g. the probabilities next to a label) must neither cost kernels nor block loading.
+    std::vector<char> live(m.nodes.size(), 0);
+    {
+      std::map<std::string, size_t> producer_of;
+      for (size_t i = 0; i < m.nodes.size(); i++)
+        for (const auto &o : m.nodes[i].outputs) producer_of[o] = i;
+      std::vector<std::string> work{m.outputs[0].name};
+      while (!work.empty()) {
+        const std::string v = work.back();
+        work.pop_back();
+        auto it = producer_of.find(v);
+        if (it == producer_of.end() || live[it->second]) continue;
+        live[it->second] = 1;
+        for (const auto &i : m.nodes[it->second].inputs) work.push_back(i);
+      }
+    }
+    for (size_t i = 0; i < m.nodes.size(); i++)
+      if (live[i])
+        for (const auto &in_name : m.nodes[i].inputs) uses[in_name]++;
+    uses[m.outputs[0].name]++;
 
-    for (const auto &n : m.nodes) {
+    for (size_t ni = 0; ni < m.nodes.size(); ni++) {
+      if (!live[ni]) continue;
+      const auto &n = m.nodes[ni];
       if (n.outputs.empty()) throw InferaError::onnx("node " + n.op + " has no outputs");
       if (!n.domain.empty() && n.domain != "ai.onnx") unsupported(n, "operator domain '" + n.domain + "'");
       const std::string &op = n.op;

@@ -1364,8 +1364,30 @@ static int run_graph(const OrcModel *m, const float *data, int rank, const int64
   }
   Tensor *in = env_new(&x->env, vi->name, DT_FLOAT, rank, dims);
   memcpy(in->f, data, in->n * 4);
+  /* only nodes that feed the FIRST output run (engine.rs:146-149 reads outputs[0]); liveness by a backward sweep
+   * over the topologically sorted node list */
+  char *live = (char *)xcalloc(m->nnodes ? m->nnodes : 1, 1);
+  {
+    size_t nneed = 1, cap = 64;
+    const char **need = (const char **)xmalloc(cap * sizeof(char *));
+    need[0] = m->noutputs ? m->outputs[0].name : "";
+    for (size_t i = m->nnodes; i-- > 0;) {
+      const Node *nd = &m->nodes[i];
+      int hit = 0;
+      for (size_t o = 0; o < nd->nout && !hit; o++)
+        for (size_t k = 0; k < nneed && !hit; k++) hit = strcmp(nd->out[o], need[k]) == 0;
+      if (!hit) continue;
+      live[i] = 1;
+      for (size_t k = 0; k < nd->nin; k++) {
+        if (nneed == cap) { cap *= 2; need = (const char **)realloc(need, cap * sizeof(char *)); }
+        need[nneed++] = nd->in[k];
+      }
+    }
+    free(need);
+  }
   for (size_t i = 0; i < m->nnodes; i++)
-    if (run_node(x, &m->nodes[i])) { env_free(&x->env); return -1; }
+    if (live[i] && run_node(x, &m->nodes[i])) { free(live); env_free(&x->env); return -1; }
+  free(live);
   if (m->noutputs < 1) { set_err(err, errlen, "No output tensor"); env_free(&x->env); return -1; }
   long oi = env_find(&x->env, m->outputs[0].name);
   const Tensor *ot = oi >= 0 ? &x->env.v[oi] : find_init(m, m->outputs[0].name);

@@ -228,6 +228,45 @@ def test_gpu_pool_ceil_mode(api, O, tmp_path, op, hw, k, stride, pad, ceil):
     api.unload_model("plg")
 
 
+def _two_output_model(tmp_path):
+    """A classifier that exposes (label, probabilities): only output 0 (the label) is served; the second output's
+    branch holds an operator nobody supports (ai.onnx.ml ZipMap) and must be ignored, not rejected."""
+    rng = np.random.default_rng(4)
+    w, b = (rng.standard_normal((12, 5)) * 0.5).astype(np.float32), rng.standard_normal(5).astype(np.float32)
+    nodes = [W.node("Gemm", ["X", "w", "b"], ["logits"]), W.node("ArgMax", ["logits"], ["label"], [W.attr_i("axis", 1), W.attr_i("keepdims", 0)]),
+             W.node("Softmax", ["logits"], ["probs"], [W.attr_i("axis", 1)]), W.node("ZipMap", ["probs"], ["prob_map"])]
+    blob = W.model("two_out", nodes, [W.tensor("w", w), W.tensor("b", b)], [W.value_info("X", ["N", 12])],
+                   [W.value_info("label", ["N"], W.INT64), W.value_info("prob_map", ["N", 5])])
+    return W.write(str(tmp_path / "two_out.onnx"), blob), w, b
+
+
+def test_dead_branches_and_extra_outputs_are_ignored(O, built, tmp_path):
+    from infera_amd import capi
+
+    path, w, b = _two_output_model(tmp_path)
+    x = synth.table(2, 0, 50, 12)
+    want = (x.astype(np.float64) @ w + b).argmax(axis=1).astype(np.float32)
+    m = O.Model(path)
+    assert m.output_shape == [-1]
+    got = m.predict(x)
+    assert got.ravel().tolist() == want.tolist()
+    capi.load_model("two_out", path)
+    assert [s["kind"] for s in capi.get_plan("two_out")["plan"]["steps"]] == ["Dense", "ArgMax"]
+    assert capi.get_model_info("two_out")["output_shape"] == [-1]
+    capi.unload_model("two_out")
+
+
+@pytest.mark.gpu
+def test_gpu_label_output_of_a_two_output_classifier(api, O, tmp_path):
+    path, w, b = _two_output_model(tmp_path)
+    x = synth.table(2, 0, 3000, 12)
+    api.load_model("two_out", path)
+    got, want = api.predict("two_out", x), O.Model(path).predict(x)
+    assert got.shape == want.shape
+    assert (got != want).mean() < 0.005
+    api.unload_model("two_out")
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
