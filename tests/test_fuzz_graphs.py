@@ -63,13 +63,13 @@ class G:
 def dense_graph(seed):
     g = G(seed)
     rng = g.rng
-    f_in = int(rng.choice([3, 8, 16, 24, 40, 128]))
+    f_in = int(rng.choice([3, 7, 8, 16, 24, 40, 100, 128, 513]))
     vals = [("X", f_in)]  # (name, width)
     for _ in range(int(rng.integers(3, 9))):
         kind = rng.choice(["dense", "dense", "unary", "binc", "bina", "concat", "matmul_add"])
         src, w = vals[int(rng.integers(0, len(vals)))]
         if kind in ("dense", "matmul_add"):
-            m = int(rng.choice([1, 4, 8, 10, 16, 32, 48, 64]))
+            m = int(rng.choice([1, 3, 4, 8, 10, 16, 32, 48, 64, 100, 257]))
             wn = g.weight((w, m), w)
             bn = g.weight((m,), w)
             if kind == "dense":
