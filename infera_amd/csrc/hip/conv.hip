@@ -848,7 +848,7 @@ void conv2d_depthwise(hipStream_t s, const float *X, const float *packed, const 
 }
 
 bool conv2d_tiled_supported(const ConvGeom &g) {
-  return g.groups == 1 && g.C % 32 == 0 && g.M % 64 == 0 && g.kh * g.kw <= 64 /* per-lane tap mask */ &&
+  return g.groups == 1 && g.C % 32 == 0 && g.M % 32 == 0 && g.kh * g.kw <= 64 /* per-lane tap mask */ &&
          int64_t(g.H) * g.W * g.C < (int64_t(1) << 30);
 }
 
@@ -895,7 +895,10 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
   auto launch = [&](auto kernel, int mt) {
     hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / (32 * mt))), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
   };
-  const bool wide = g.M % 128 == 0, deep = g.C % 64 == 0;
+  // feature tiles per workgroup: the largest of 4, 3, 2, 1 that divides M / 32 (ResNet: 2 or 4; MobileNet-style
+  // widths such as 96, 160, 576, 960 take 3, 1, 3, 3)
+  const int m32 = g.M / 32, mt_pick = m32 % 4 == 0 ? 4 : m32 % 3 == 0 ? 3 : m32 % 2 == 0 ? 2 : 1;
+  const bool wide = mt_pick == 4, deep = g.C % 64 == 0;
 #ifdef INFERA_CONV_PROBES
   static const int probe = getenv("INFERA_CONV_PROBE") ? atoi(getenv("INFERA_CONV_PROBE")) : 0;
   static int launches = 0;
@@ -919,8 +922,9 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
 #endif
   if (wide && deep) launch(conv2d_tiled_kernel<4, 2>, 4);
   else if (wide) launch(conv2d_tiled_kernel<4, 1>, 4);
-  else if (deep) launch(conv2d_tiled_kernel<2, 2>, 2);
-  else launch(conv2d_tiled_kernel<2, 1>, 2);
+  else if (mt_pick == 3) deep ? launch(conv2d_tiled_kernel<3, 2>, 3) : launch(conv2d_tiled_kernel<3, 1>, 3);
+  else if (mt_pick == 2) deep ? launch(conv2d_tiled_kernel<2, 2>, 2) : launch(conv2d_tiled_kernel<2, 1>, 2);
+  else deep ? launch(conv2d_tiled_kernel<1, 2>, 1) : launch(conv2d_tiled_kernel<1, 1>, 1);
 }
 
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,

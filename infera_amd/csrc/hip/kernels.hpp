@@ -84,7 +84,7 @@ bool conv2d_depthwise_supported(const ConvGeom &g);
 void conv2d_depthwise_pack(const ConvGeom &g, const float *Wt, float *packed);
 void conv2d_depthwise(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                       const ConvGeom &g, ActParam act);
-// Tiled CQ-layout convolution (groups == 1, C % 32 == 0, M % 64 == 0) on fragment-major packed weights.
+// Tiled CQ-layout convolution (groups == 1, C % 32 == 0, M % 32 == 0) on fragment-major packed weights.
 bool conv2d_tiled_supported(const ConvGeom &g);
 size_t conv2d_tiled_packed_floats(const ConvGeom &g);
 void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed);

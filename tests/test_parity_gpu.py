@@ -461,6 +461,33 @@ def test_resnet18_full_width_vs_oracle(api, tmp_path):
     api.unload_model("rn64")
 
 
+def test_tiled_conv_feature_tile_variants(api, tmp_path):
+    """Every feature-tile count of the tiled conv (M/32 = 1, 2, 3, 4, 5, 6 -> MT 1, 2, 3, 4, 1, 3) with both channel
+    depths (C % 64 == 0 or not), 1x1 and 3x3, stride 1 and 2: MobileNet-style widths."""
+    from infera_amd import onnx_writer as W, synth
+    from oracle import oracle
+
+    rng = np.random.default_rng(11)
+    chain = [(32, 3, 1), (96, 1, 1), (160, 3, 2), (64, 1, 1), (192, 3, 1), (128, 1, 2), (32, 3, 1)]
+    nodes, inits, x, cin = [], [], "X", 4
+    for i, (cout, k, stride) in enumerate(chain):
+        w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        inits += [W.tensor(f"w{i}", w), W.tensor(f"b{i}", b)]
+        nodes.append(W.node("Conv", [x, f"w{i}", f"b{i}"], [f"c{i}"], [W.attr_ints("kernel_shape", [k, k]), W.attr_ints("strides", [stride] * 2),
+                                                                   W.attr_ints("pads", [k // 2] * 4)]))
+        nodes.append(W.node("Relu", [f"c{i}"], [f"r{i}"]))
+        x, cin = f"r{i}", cout
+    nodes += [W.node("GlobalAveragePool", [x], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
+    path = W.write(str(tmp_path / "widths.onnx"), W.model("widths", nodes, inits, [W.value_info("X", ["N", 4, 20, 20])], [W.value_info("Y", ["N", 32])]))
+    api.load_model("widths", path)
+    plan = api.get_plan("widths")
+    assert plan["activation_layout"] == "NC/4HW4" and plan["exec"].count("conv_tiled_cq") == 6, plan["exec"]
+    imgs = synth.table(13, 0, 7, 4 * 20 * 20)
+    assert_close(api.predict_from_blob("widths", imgs.tobytes()), oracle.Model(path).predict_blob(imgs.tobytes()))
+    api.unload_model("widths")
+
+
 def test_conv_plan_falls_back_to_nchw_when_flatten_needs_it(api, tmp_path):
     """Conv -> Flatten(C*H*W) -> Gemm consumes the feature map in NCHW order: the plan must stay NCHW."""
     from infera_amd import onnx_writer as W
