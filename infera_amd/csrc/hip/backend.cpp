@@ -36,6 +36,7 @@ struct UnsafeOpGuard {
 };
 
 constexpr size_t kHostPassBytes = 64ull << 20;     // pinned staging per direction per thread
+constexpr size_t kPipePassBytes = 16ull << 20;     // pass size of the two-slot pipeline used for larger host inputs
 constexpr size_t kScratchBudgetBytes = 8ull << 30; // activation scratch per thread for unfused plans
 
 // ---------------------------------------------------------------------------------------------
@@ -57,6 +58,7 @@ struct ThreadCtx {
   };
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
+  hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // completion of the pass that last used staging slot 0 / 1
   void drop_graphs() {
     for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
     graphs.clear();
@@ -574,13 +576,54 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   const DeviceModel &dm = device_model(m, slot);
   const size_t in_row = size_t(m.plan.in_per_row()) * 4, out_row = size_t(m.plan.out_per_row()) * 4;
   const size_t widest = std::max(in_row, out_row);
+  const bool use_graph = Config::get().use_hipgraph;
+  if (!use_graph && size_t(rows) * widest > kPipePassBytes + kPipePassBytes / 2 && size_t(rows) > 1) {
+    // Larger host inputs (a whole BLOB batch, a big infera_predict call): two staging slots.  The CPU copy of
+    // pass i+1 into pinned memory -- the slowest stage, the caller's buffer is only borrowed -- overlaps the
+    // H2D / kernels / D2H of pass i instead of following them.
+    const int64_t P = std::min<int64_t>(rows, std::max<int64_t>(1, int64_t(kPipePassBytes / widest)));
+    ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, 2 * size_t(P) * in_row);
+    ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, 2 * size_t(P) * out_row);
+    ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, 2 * size_t(P) * in_row);
+    ctx.ensure_dev(ctx.dev_out, ctx.dev_out_cap, 2 * size_t(P) * out_row);
+    for (auto &e : ctx.pipe_ev)
+      if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int64_t pend_r0[2] = {0, 0}, pend_nr[2] = {0, 0};
+    auto slot_ptr = [&](float *base, int k, size_t row_bytes) { return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + size_t(k) * size_t(P) * row_bytes); };
+    auto drain = [&](int k) {
+      if (!pend_nr[k]) return;
+      HIP_TRY(hipEventSynchronize(ctx.pipe_ev[k]));
+      std::memcpy(h_out + size_t(pend_r0[k]) * (out_row / 4), slot_ptr(ctx.pin_out, k, out_row), size_t(pend_nr[k]) * out_row);
+      pend_nr[k] = 0;
+    };
+    int k = 0;
+    try {
+      for (int64_t r0 = 0; r0 < rows; r0 += P, k ^= 1) {
+        const int64_t nr = std::min(P, rows - r0);
+        drain(k);
+        float *pin = slot_ptr(ctx.pin_in, k, in_row), *din = slot_ptr(ctx.dev_in, k, in_row), *dout = slot_ptr(ctx.dev_out, k, out_row);
+        fill(pin, r0, nr);
+        HIP_TRY(hipMemcpyAsync(din, pin, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+        exec_plan(m, dm, ctx, din, dout, nr);
+        HIP_TRY(hipMemcpyAsync(slot_ptr(ctx.pin_out, k, out_row), dout, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipEventRecord(ctx.pipe_ev[k], ctx.stream));
+        pend_r0[k] = r0;
+        pend_nr[k] = nr;
+      }
+      drain(k);
+      drain(k ^ 1);
+    } catch (...) {
+      (void)hipStreamSynchronize(ctx.stream);  // nothing may still be reading the staging slots when we unwind
+      throw;
+    }
+    return;
+  }
   int64_t rows_pass = std::max<int64_t>(1, int64_t(kHostPassBytes / widest));
   rows_pass = std::min(rows_pass, rows);
   ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows_pass) * out_row);
   ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_dev(ctx.dev_out, ctx.dev_out_cap, size_t(rows_pass) * out_row);
-  const bool use_graph = Config::get().use_hipgraph;
   for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
     const int64_t nr = std::min(rows_pass, rows - r0);
     // The caller's buffer is only borrowed for the call (SURVEY.md 8b "Ownership"): stage it.

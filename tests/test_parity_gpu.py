@@ -311,6 +311,25 @@ def test_unload_and_replace_during_inference(api, models, tmp_path):
     api.load_library().infera_unload_model(b"swap")
 
 
+def test_pipelined_host_staging_matches_single_pass(api, models):
+    """Host inputs above 24 MB go through the two-slot staging pipeline (16 MB passes, CPU copy of pass i+1
+    overlapping the GPU work of pass i): same values, bit for bit, as the same rows sent in small calls, for a
+    row count that leaves a ragged last pass; likewise a BLOB batch that spans several passes."""
+    from infera_amd import onnx_writer as W, synth
+
+    api.load_model("mlp", models["mlp"])
+    rows = 3 * 32768 + 4321  # 52.5 MB of features -> 4 passes, the last one short
+    x = synth.table(77, 0, rows, 128)
+    big = api.predict("mlp", x)
+    assert big.shape == (rows, 1)
+    for s in (0, 32768 - 5, 2 * 32768, rows - 2048):
+        assert np.array_equal(api.predict("mlp", x[s:s + 2048]), big[s:s + 2048])
+    api.load_model("lr", models["logreg"])
+    bigl = api.predict("lr", x)
+    assert np.array_equal(api.predict("lr", x[40000:42048]), bigl[40000:42048])
+    api.unload_model("lr")
+
+
 def test_full_size_c2_properties(api, models):
     """BASELINE config C2 at full size (10M rows x 128, one device-resident scan): the oracle cannot
     cover 10M rows in seconds, so check size-independent properties --
