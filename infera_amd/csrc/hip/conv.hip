@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
 }
 
 // ---- tiled NHWC kernel --------------------------------------------------------------------------------------
-// packed weights: [chunk = tap*(C/32) + cc][mt (all M/32 tiles)][g (4)][lane (64)][j (4)]
+// packed weights: [chunk = ((cc/S)*taps + tap)*S + cc%S][mt (all M/32 tiles)][g (4)][lane (64)][j (4)]
 //   = Wt[m = 32mt + (lane&31)][tap][c = 32cc + 8g + 4*(lane>>5) + j]
 //
 // One LDS stage = S consecutive 32-channel chunks of one filter tap (S = 2 when C % 64 == 0): S*MT KB of
@@ -205,26 +205,29 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
 
-  // wave-uniform position of the stage being PREFETCHED: tap, channel block, element offset from the corner
-  int n_tap = 0, n_cs = 0, n_kx = 0, n_off = 0;
+  // wave-uniform position of the stage being PREFETCHED.  Stage order is CHANNEL-BLOCK major, taps fastest: two
+  // consecutive stages read the same channel planes shifted by one tap, i.e. mostly the same cache lines while
+  // they are still in L2 (with taps outermost the shifted re-read came C/(32 S) stages -- several MB of other
+  // planes per XCD -- later and went back to HBM: 49 GB of reads per 1024-image pass against ~15 GB of tensors).
+  int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0;
   auto gather = [&](f32x4(&b)[NB]) {
     const bool ok = (okmask >> n_tap) & 1;
     const float *p = ok ? xc + n_off : zp;
     const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;  // group q+1 = two channel-quad planes further
 #pragma unroll
     for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
-    // advance to the following stage
-    n_cs++;
-    n_off += 2 * NB * HW4;
-    if (n_cs == CS) {
-      n_cs = 0;
-      n_tap++;
-      n_kx++;
-      n_off += g.dw * 4 - 2 * NB * CS * HW4;
-      if (n_kx == g.kw) {
-        n_kx = 0;
-        n_off += (g.dh * g.W - g.kw * g.dw) * 4;
-      }
+    // advance to the following stage: next tap of this channel block, else first tap of the next block
+    n_tap++;
+    n_kx++;
+    n_off += g.dw * 4;
+    if (n_kx == g.kw) {
+      n_kx = 0;
+      n_off += (g.dh * g.W - g.kw * g.dw) * 4;
+    }
+    if (n_tap == ntaps) {
+      n_tap = 0;
+      n_base += 2 * NB * HW4;
+      n_off = n_base;
     }
   };
   // this block's MT tiles of one 32-channel chunk are contiguous in the packed blob (MT*1024 floats)
@@ -858,7 +861,9 @@ bool conv2d_tiled_supported(const ConvGeom &g) {
 size_t conv2d_tiled_packed_floats(const ConvGeom &g) { return size_t(g.kh) * g.kw * g.C * g.M; }
 
 void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed) {
-  const int CC = g.C / 32, MTtot = g.M / 32, ntaps = g.kh * g.kw;
+  // 32-channel chunks in the kernel's stage order: channel block (S chunks, S = 2 when C % 64 == 0) outermost,
+  // then the filter tap, then the chunk inside the block
+  const int CC = g.C / 32, MTtot = g.M / 32, ntaps = g.kh * g.kw, S = g.C % 64 == 0 ? 2 : 1;
   for (int tap = 0; tap < ntaps; tap++)
     for (int cc = 0; cc < CC; cc++)
       for (int mt = 0; mt < MTtot; mt++)
@@ -866,7 +871,7 @@ void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed) {
           for (int lane = 0; lane < 64; lane++)
             for (int j = 0; j < 4; j++) {
               const int m = 32 * mt + (lane & 31), c = 32 * cc + 8 * q + 4 * (lane >> 5) + j;
-              const size_t chunk = size_t(tap) * CC + cc;
+              const size_t chunk = (size_t(cc / S) * ntaps + tap) * S + cc % S;
               packed[((chunk * MTtot + mt) * 4 + q) * 256 + size_t(lane) * 4 + j] = Wt[(size_t(m) * g.C + c) * ntaps + tap];
             }
 }
