@@ -511,16 +511,21 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
   const int OHW = g.OH * g.OW;
 
   float pv[kPatchMaxE];
-  int64_t tile = blockIdx.x;
-  if (tile < ntiles) {
+  // XCD x (= blockIdx.x % 8) owns the contiguous tile range [x*chunk, (x+1)*chunk): neighbouring tiles overlap in
+  // their receptive fields, and the overlap should be found in THAT XCD's L2 (with a plain grid stride the
+  // neighbours sat on eight different L2s and the blob was fetched from HBM 3.2 times)
+  const int64_t chunk = (ntiles + 7) >> 3, t_end = min(ntiles, (int64_t(blockIdx.x & 7) + 1) * chunk);
+  const int64_t tstep = (gridDim.x + 7 - (blockIdx.x & 7)) >> 3;  // workgroups on this XCD
+  int64_t tile = int64_t(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile < t_end) {
     load_patch(pv, tile);
     store_patch(pv, 0);
   }
   __syncthreads();
   int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-    const int64_t next = tile + gridDim.x;
-    if (next < ntiles) load_patch(pv, next);  // lands under this tile's MFMAs
+  for (; tile < t_end; tile += tstep, buf ^= 1) {
+    const int64_t next = tile + tstep;
+    if (next < t_end) load_patch(pv, next);  // lands under this tile's MFMAs
 
     f32x16 acc[MT];
 #pragma unroll
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
         }
       });
     }
-    if (next < ntiles) store_patch(pv, buf ^ 1);
+    if (next < t_end) store_patch(pv, buf ^ 1);
     __syncthreads();
   }
 }
