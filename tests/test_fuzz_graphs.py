@@ -129,7 +129,7 @@ def conv_graph(seed):
 
     for _ in range(int(rng.integers(2, 6))):
         cin, h, _ = shape
-        kind = rng.choice(["conv", "conv", "dw", "pool", "res", "bn_act"])
+        kind = rng.choice(["conv", "conv", "dw", "pool", "res", "bn_act", "se", "cat", "unary"])
         if kind == "conv":
             cout = int(rng.choice([4, 8, 16, 32, 64]))
             k, stride = int(rng.choice([1, 3])), int(rng.choice([1, 1, 2]))
@@ -144,13 +144,33 @@ def conv_graph(seed):
             x = g.op("Clip", [x, g.const(np.array(0.0).reshape(())), g.const(np.array(6.0).reshape(()))])
         elif kind == "pool" and h >= 4:
             mx = rng.random() < 0.5
-            x = g.op("MaxPool" if mx else "AveragePool", [x], [W.attr_ints("kernel_shape", [2, 2]), W.attr_ints("strides", [2, 2])])
-            shape = (cin, h // 2, h // 2)
+            if rng.random() < 0.5:
+                x = g.op("MaxPool" if mx else "AveragePool", [x], [W.attr_ints("kernel_shape", [2, 2]), W.attr_ints("strides", [2, 2])])
+                shape = (cin, h // 2, h // 2)
+            else:  # 3x3 / stride 2 / pad 1 with ceil_mode
+                x = g.op("MaxPool" if mx else "AveragePool", [x], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("strides", [2, 2]),
+                                                                 W.attr_ints("pads", [1, 1, 1, 1]), W.attr_i("ceil_mode", 1)])
+                o = -(-(h + 2 - 3) // 2) + 1
+                if (o - 1) * 2 >= h + 1:
+                    o -= 1
+                shape = (cin, o, o)
         elif kind == "res":
             y = conv(x, cin, cin, 3, 1)
             y = g.op("Relu", [y])
             y = conv(y, cin, cin, 3, 1, bias=False)
             x = g.op("Relu", [g.op("Add", [y, x])])
+        elif kind == "se" and cin % 4 == 0 and h > 1:
+            sq = g.op("GlobalAveragePool", [x])
+            r = g.op("Relu", [conv(sq, cin, max(4, cin // 4), 1, 1)])
+            e = g.op(str(rng.choice(["Sigmoid", "HardSigmoid"])), [conv(r, max(4, cin // 4), cin, 1, 1)])
+            x = g.op("Mul", [x, e] if rng.random() < 0.5 else [e, x])
+        elif kind == "cat":
+            cout = int(rng.choice([4, 8, 16]))
+            y = g.op("Relu", [conv(x, cin, cout, 3, 1)])
+            x = g.op("Concat", [x, y] if rng.random() < 0.5 else [y, x], [W.attr_i("axis", 1)])
+            shape = (cin + cout, h, h)
+        elif kind == "unary":
+            x = g.op(str(rng.choice(["Sigmoid", "Tanh", "Softplus", "HardSwish", "Abs"])), [x])
         else:
             x = g.op("Relu", [bn(x, cin)])
     cin = shape[0]
