@@ -151,7 +151,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
 // B buffer for the 64-feature tiles -- 2 instead of 3 waves per SIMD, same time; 8-wave workgroups sharing one
 // weight slab (half the weight stream from L2) -- 7 % slower.  A bare kernel (no loads, no stores, same MFMA
 // stream and index math) runs the 128-channel layer at 152 TFLOP/s: the matrix cores are not the limit, the
-// memory operations around them are.  Probes: tools/conv_probe.sh.)
+// memory operations around them are.  Also neutral: non-temporal output stores; s_setprio 3 during the prologue
+// and epilogue.  Probes: tools/conv_probe.sh.)
 __device__ __attribute__((aligned(256))) float g_zero_page[128];
 #ifdef INFERA_CONV_PROBES
 // [MT==4][phase]: summed shader cycles per wave: prologue, main loop, epilogue issue, store drain; [4] = waves
