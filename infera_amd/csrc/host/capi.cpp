@@ -62,10 +62,19 @@ bool guarded(F &&fn, std::string *err_text = nullptr) {
   return false;
 }
 
+// An empty result carries a non-NULL, never-dereferenced, never-freed address -- what the reference hands out for
+// an empty Box<[f32]> (a dangling aligned pointer with len 0, ffi_utils.rs:83-96) -- so infera_free_result must
+// not pass a len-0 pointer to free(), whoever made it.
+alignas(16) float g_empty_result[4];
+
 float *alloc_out(uint64_t len) {
-  float *p = static_cast<float *>(std::malloc(len ? len * sizeof(float) : 1));
+  if (len == 0) return g_empty_result;
+  float *p = static_cast<float *>(std::malloc(len * sizeof(float)));
   if (!p) throw InferaError::memory();
   return p;
+}
+void free_out(float *p) {
+  if (p != g_empty_result) std::free(p);
 }
 
 std::string error_json(const std::string &msg) { return "{\"error\":" + json_str(msg) + "}"; }
@@ -115,7 +124,7 @@ struct InferaInferenceResult infera_predict(const char *model_name, const float 
     try {
       run_host(*m, data, out, int64_t(rows));
     } catch (...) {
-      std::free(out);
+      free_out(out);
       throw;
     }
     res.data = out;
@@ -139,7 +148,7 @@ struct InferaInferenceResult infera_predict_from_blob(const char *model_name, co
       // native-endian bytes ARE the f32 row-major tensor (engine.rs:212-220); may be unaligned
       run_host(*m, reinterpret_cast<const float *>(blob_data), out, int64_t(rows));
     } catch (...) {
-      std::free(out);
+      free_out(out);
       throw;
     }
     res.data = out;
@@ -241,7 +250,7 @@ void infera_free(char *ptr) {
 }
 
 void infera_free_result(struct InferaInferenceResult res) {
-  if (res.data) std::free(res.data);
+  if (res.data && res.len) std::free(res.data);
 }
 
 // ================================ additive MI355X entry points ================================
@@ -414,7 +423,7 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
       run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) { gather_columns(columns, ncols, size_t(r0), size_t(nr), dst); }, out,
                     int64_t(rows));
     } catch (...) {
-      std::free(out);
+      free_out(out);
       throw;
     }
     res.data = out;
@@ -469,7 +478,7 @@ struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_na
                     },
                     out, int64_t(n));
     } catch (...) {
-      std::free(out);
+      free_out(out);
       throw;
     }
     res.data = out;

@@ -67,6 +67,13 @@ def test_ffi_null_pointers(api):
         assert "Null pointer passed" in js["error"]
     L.infera_free(None)  # NULL is a no-op (ffi_utils.rs:49-54)
     L.infera_free_result(api.InferaInferenceResult())  # NULL data is a no-op (ffi_utils.rs:69-77)
+    # len 0 with a dangling non-NULL pointer is legal too (ffi_utils.rs:83-96: an empty Box<[f32]>): must not reach free()
+    import ctypes
+
+    dangling = api.InferaInferenceResult()
+    dangling.data = ctypes.cast(ctypes.c_void_p(16), ctypes.POINTER(ctypes.c_float))
+    dangling.len = 0
+    L.infera_free_result(dangling)
 
 
 def test_invalid_utf8(api):
