@@ -100,6 +100,10 @@ int32_t infera_gather_columns(const InferaColumn *columns, uintptr_t ncols, uint
 struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_name, const uint8_t *const *blobs,
                                                             const uintptr_t *lens, uintptr_t n);
 
+/* sha256(data) as 64 lower-case hex characters: the key under which infera_load_model("http://...") caches a
+ * remote model (`<cache_dir>/<sha256(url)>.onnx`, reference http.rs:186-190).  Free with infera_free. */
+char *infera_hip_sha256_hex(const char *data, uintptr_t len);
+
 #ifdef __cplusplus
 } /* extern "C" */
 } /* namespace infera */

@@ -15,6 +15,7 @@
 #include "../hip/backend.hpp"
 #include "common.hpp"
 #include "engine.hpp"
+#include "remote.hpp"
 #include "gather.hpp"
 
 using namespace infera_hip;
@@ -77,6 +78,22 @@ void free_out(float *p) {
   if (p != g_empty_result) std::free(p);
 }
 
+bool remove_tree(const std::string &dir) {
+  DIR *d = ::opendir(dir.c_str());
+  if (!d) return false;
+  bool ok = true;
+  while (dirent *e = ::readdir(d)) {
+    const std::string n = e->d_name;
+    if (n == "." || n == "..") continue;
+    const std::string full = dir + "/" + n;
+    struct stat st;
+    if (::lstat(full.c_str(), &st) != 0) continue;
+    ok = (S_ISDIR(st.st_mode) ? remove_tree(full) : ::unlink(full.c_str()) == 0) && ok;
+  }
+  ::closedir(d);
+  return ::rmdir(dir.c_str()) == 0 && ok;
+}
+
 std::string error_json(const std::string &msg) { return "{\"error\":" + json_str(msg) + "}"; }
 
 bool ends_with(const std::string &s, const std::string &suf) {
@@ -97,8 +114,7 @@ int32_t infera_load_model(const char *name, const char *path) {
   return guarded([&] {
            if (!name || !path) throw InferaError::null_pointer();
            std::string n = checked_str(name), p = checked_str(path);
-           if (p.rfind("http", 0) == 0)  // lib.rs:47-48 would download; no network stack in this build
-             throw InferaError::http("remote model fetch is not available in the MI355X build (no network): " + p);
+           if (p.rfind("http", 0) == 0) p = remote::handle_remote_model(p);  // lib.rs:47-51: fetch / revalidate into the cache
            engine::load_model(n, p);
          })
              ? 0
@@ -184,7 +200,11 @@ int32_t infera_clear_cache(void) {
              std::string n = e->d_name;
              if (n == "." || n == "..") continue;
              std::string full = dir + "/" + n;
-             if (is_regular_file(full) && ::unlink(full.c_str()) != 0) {
+             struct stat st;
+             if (::lstat(full.c_str(), &st) != 0) continue;
+             // files and whole sub-directories (http.rs:132-138)
+             const bool ok = S_ISDIR(st.st_mode) ? remove_tree(full) : ::unlink(full.c_str()) == 0;
+             if (!ok) {
                ::closedir(d);
                throw InferaError::io("cannot remove " + full);
              }
@@ -254,6 +274,10 @@ void infera_free_result(struct InferaInferenceResult res) {
 }
 
 // ================================ additive MI355X entry points ================================
+
+char *infera_hip_sha256_hex(const char *data, uintptr_t len) {
+  return dup_cstr(remote::sha256_hex(std::string(data ? data : "", data ? size_t(len) : 0)));
+}
 
 int32_t infera_hip_device_count(void) { return int32_t(devices().ids.size()); }
 

@@ -64,6 +64,9 @@ const Config &Config::get() {
     std::string tmp = env_or("TMPDIR", "/tmp");
     c.cache_dir = env_or("INFERA_CACHE_DIR", tmp + "/infera_cache");
     c.cache_size_limit = env_u64("INFERA_CACHE_SIZE_LIMIT", 1024ull * 1024 * 1024);
+    c.http_timeout_secs = env_u64("INFERA_HTTP_TIMEOUT", 30);
+    c.http_retry_attempts = uint32_t(env_u64("INFERA_HTTP_RETRY_ATTEMPTS", 3));
+    c.http_retry_delay_ms = env_u64("INFERA_HTTP_RETRY_DELAY", 1000);
     std::string lvl = env_or("INFERA_LOG_LEVEL", "WARN");
     for (auto &ch : lvl) ch = (char)std::toupper((unsigned char)ch);
     c.log_level = lvl == "ERROR" ? 0 : (lvl == "INFO" ? 2 : (lvl == "DEBUG" ? 3 : 1));

@@ -82,6 +82,9 @@ struct Config {
   std::string cache_dir;              // INFERA_CACHE_DIR        (default $TMPDIR/infera_cache)
   uint64_t cache_size_limit;          // INFERA_CACHE_SIZE_LIMIT (default 1 GiB)
   int log_level;                      // INFERA_LOG_LEVEL        ERROR=0 WARN=1 INFO=2 DEBUG=3 (default WARN)
+  uint64_t http_timeout_secs;         // INFERA_HTTP_TIMEOUT        (default 30; config.rs:138-144)
+  uint32_t http_retry_attempts;       // INFERA_HTTP_RETRY_ATTEMPTS (default 3)
+  uint64_t http_retry_delay_ms;       // INFERA_HTTP_RETRY_DELAY    (default 1000, multiplied by the attempt number)
   // MI355X backend knobs (new; same style)
   std::vector<int> devices;           // INFERA_DEVICES="0,1,.."  (default: all visible)
   bool use_hipgraph;                  // INFERA_HIPGRAPH=0|1      replay a per-(model,rows) hipGraph {H2D,kernels,D2H} per
