@@ -485,7 +485,11 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.cq_mode && x.in0 != 0);
           break;
         case StepKind::CopyCols:
-          kern::copy_cols(s, buf(x.in0), buf(x.out), nr, p.buf_per_row[size_t(x.in0)], p.buf_per_row[size_t(x.out)], x.col_off);
+          kern::copy_cols(s, buf(x.in0), buf(x.out), nr, p.buf_per_row[size_t(x.in0)], p.buf_per_row[size_t(x.in0)], 0,
+                          p.buf_per_row[size_t(x.out)], x.col_off);
+          break;
+        case StepKind::SliceCols:
+          kern::copy_cols(s, buf(x.in0), buf(x.out), nr, x.K, p.buf_per_row[size_t(x.in0)], x.col_off, x.K, 0);
           break;
         case StepKind::ArgMax: kern::argmax_rows(s, buf(x.in0), buf(x.out), nr, x.K); break;
       }

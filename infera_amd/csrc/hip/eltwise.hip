@@ -123,23 +123,25 @@ __global__ __launch_bounds__(kBlock) void softmax_wave_kernel(const float *__res
   }
 }
 
-// One piece of a Concat along the feature / channel axis: dst[r, off : off+len] = src[r, :].  16-byte moves
-// when every offset is a multiple of 4 floats.
+// Column-block copy between row-major matrices: dst[r, dst_off : dst_off+len] = src[r, src_off : src_off+len].
+// One piece of a Concat along the feature / channel axis (src is a whole row) or a Slice / Split / one input of a
+// multi-input model (dst is a whole row).  16-byte moves when every offset and stride is a multiple of 4 floats.
 __global__ __launch_bounds__(kBlock) void copy_cols_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t rows,
-                                                          int64_t len, int64_t dst_stride, int64_t dst_off, bool vec4) {
+                                                          int64_t len, int64_t src_stride, int64_t src_off, int64_t dst_stride,
+                                                          int64_t dst_off, bool vec4) {
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   if (vec4) {
     const int64_t l4 = len >> 2, n4 = rows * l4;
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += stride) {
       const int64_t r = i / l4, c = i - r * l4;
-      *reinterpret_cast<f32x4 *>(dst + r * dst_stride + dst_off + 4 * c) = reinterpret_cast<const f32x4 *>(src)[i];
+      *reinterpret_cast<f32x4 *>(dst + r * dst_stride + dst_off + 4 * c) = *reinterpret_cast<const f32x4 *>(src + r * src_stride + src_off + 4 * c);
     }
     return;
   }
   const int64_t n = rows * len;
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
     const int64_t r = i / len, c = i - r * len;
-    dst[r * dst_stride + dst_off + c] = src[i];
+    dst[r * dst_stride + dst_off + c] = src[r * src_stride + src_off + c];
   }
 }
 
@@ -220,11 +222,12 @@ void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t oute
   }
 }
 
-void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t dst_stride, int64_t dst_off) {
+void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t src_stride, int64_t src_off,
+               int64_t dst_stride, int64_t dst_off) {
   if (rows <= 0 || len <= 0) return;
-  const bool vec4 = ((len | dst_stride | dst_off) & 3) == 0;
+  const bool vec4 = ((len | src_stride | src_off | dst_stride | dst_off) & 3) == 0;
   hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(vec4 ? rows * len / 4 : rows * len)), dim3(kBlock), 0, s, src, dst, rows, len,
-                     dst_stride, dst_off, vec4);
+                     src_stride, src_off, dst_stride, dst_off, vec4);
 }
 
 void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t len) {

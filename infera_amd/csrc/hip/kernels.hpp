@@ -30,8 +30,9 @@ void affine_channel(hipStream_t s, const float *x, const float *scale, const flo
 // softmax over `len` with element stride `inner`, repeated rows*outer*inner times
 void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner,
              bool log_softmax);
-// dst[r, dst_off : dst_off+len] = src[r, 0:len]  (one input of a Concat); y[r] = float(argmax_j x[r, j])
-void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t dst_stride, int64_t dst_off);
+// dst[r, dst_off : dst_off+len] = src[r, src_off : src_off+len]  (Concat piece / Slice / Split); y[r] = float(argmax_j x[r, j])
+void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t src_stride, int64_t src_off,
+               int64_t dst_stride, int64_t dst_off);
 void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t len);
 // synthetic table fill (SURVEY.md 8d generator), row-major [rows, ncols]
 void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_t rows, uint64_t ncols);

@@ -362,8 +362,72 @@ struct Lowerer {
       vals[n.outputs[0]] = o;
     }
   }
+  // feature-axis slice of a [rows, K] activation: out = in[:, b:e]
+  void emit_slice_cols(const NodeDef &n, const Val &a, int64_t b, int64_t e, const std::string &out_name) {
+    Step s;
+    s.kind = StepKind::SliceCols;
+    s.in0 = a.buf;
+    s.col_off = b;
+    s.K = e - b;
+    s.out = new_buf({a.shape[0], e - b});
+    s.origin = n.op + (n.name.empty() ? "" : ":" + n.name);
+    plan.steps.push_back(std::move(s));
+    producer[plan.steps.back().out] = int(plan.steps.size()) - 1;
+    Val v;
+    v.buf = plan.steps.back().out;
+    v.shape = {a.shape[0], e - b};
+    vals[out_name] = v;
+    buf_names[v.buf].push_back(out_name);
+  }
+  void split(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    if (a.is_const || a.shape.size() != 2) unsupported(n, "only [rows, K] activations");
+    int64_t axis = n.attr_i("axis", 0);
+    if (axis < 0) axis += 2;
+    if (axis != 1) unsupported(n, "only axis 1 keeps rows independent");
+    std::vector<int64_t> sizes;
+    if (has_input(n, 1)) sizes = const_ints(n, 1, "split");
+    else if (auto *p = n.attr_ints("split")) sizes = *p;
+    const int64_t K = a.shape[1], nout = int64_t(n.outputs.size());
+    if (sizes.empty()) {
+      const int64_t parts = n.attr_i("num_outputs", nout), each = (K + parts - 1) / parts;
+      for (int64_t i = 0; i < parts; i++) sizes.push_back(std::min(each, K - i * each));
+    }
+    if (int64_t(sizes.size()) != nout || std::accumulate(sizes.begin(), sizes.end(), int64_t(0)) != K) unsupported(n, "split sizes do not cover the axis");
+    const Val src = a;  // `a` may dangle once vals grows
+    int64_t off = 0;
+    for (int64_t i = 0; i < nout; i++) {
+      if (sizes[size_t(i)] <= 0) unsupported(n, "empty split piece");
+      if (!n.outputs[size_t(i)].empty() && uses.count(n.outputs[size_t(i)])) emit_slice_cols(n, src, off, off + sizes[size_t(i)], n.outputs[size_t(i)]);
+      off += sizes[size_t(i)];
+    }
+  }
   void slice(const NodeDef &n) {
     const Val &d = get(n, 0);
+    if (!d.is_const && d.shape.size() == 2) {  // activation: feature-axis slice with step 1
+      std::vector<int64_t> st, en, ax, sp;
+      if (has_input(n, 1)) {
+        st = const_ints(n, 1, "starts");
+        en = const_ints(n, 2, "ends");
+        if (has_input(n, 3)) ax = const_ints(n, 3, "axes");
+        if (has_input(n, 4)) sp = const_ints(n, 4, "steps");
+      } else {
+        if (auto *p = n.attr_ints("starts")) st = *p;
+        if (auto *p = n.attr_ints("ends")) en = *p;
+        if (auto *p = n.attr_ints("axes")) ax = *p;
+      }
+      if (st.size() != 1 || en.size() != 1 || ax.size() > 1 || (!sp.empty() && sp[0] != 1)) unsupported(n, "one axis, step 1");
+      const int64_t axis = ax.empty() ? 0 : (ax[0] < 0 ? ax[0] + 2 : ax[0]);
+      if (axis != 1) unsupported(n, "only axis 1 keeps rows independent");
+      const int64_t K = d.shape[1];
+      int64_t b = st[0] < 0 ? st[0] + K : st[0], e = en[0] < 0 ? en[0] + K : en[0];
+      b = std::clamp<int64_t>(b, 0, K);
+      e = std::clamp<int64_t>(e, b, K);
+      if (e == b) unsupported(n, "empty slice");
+      const Val src = d;
+      emit_slice_cols(n, src, b, e, n.outputs[0]);
+      return;
+    }
     if (!d.is_const || d.c->dtype != onnx::kInt64 || d.shape.size() != 1) unsupported(n, "only 1-D constant integer data is folded");
     std::vector<int64_t> st, en, ax, sp;
     if (has_input(n, 1)) {
@@ -800,12 +864,28 @@ struct Lowerer {
     plan.input_shape = in.dims;
     if (in.dims[0] > 0) plan.fixed_batch = in.dims[0];
     else plan.input_shape[0] = -1;
+    if (m.inputs.size() > 1) {
+      // Several runtime inputs (the reference feeds input 0 only, engine.rs:139-145, so such a model cannot run
+      // there at all): the feature columns of the call are split across the inputs in declaration order.  Every
+      // input must be an f32 [rows, k_i] matrix with the same leading dimension.
+      int64_t total = 0;
+      for (const auto &v : m.inputs) {
+        if (!v.has_shape || v.dims.size() != 2 || v.dims[1] <= 0 || (v.elem_type != 0 && v.elem_type != onnx::kFloat) ||
+            (v.dims[0] > 0 ? v.dims[0] : -1) != plan.input_shape[0])
+          throw InferaError::onnx("multi-input models need f32 [rows, k] inputs with one common leading dimension; input '" + v.name + "' is " +
+                                  (v.has_shape ? shape_str(v.dims) : std::string("unshaped")));
+        total += v.dims[1];
+      }
+      plan.input_shape[1] = total;
+    }
     {
       Val v;
       v.buf = new_buf(plan.input_shape);
       v.shape = plan.input_shape;
-      vals[in.name] = v;
-      buf_names[v.buf].push_back(in.name);
+      if (m.inputs.size() == 1) {
+        vals[in.name] = v;
+        buf_names[v.buf].push_back(in.name);
+      }
     }
     // Only the first output is served (engine.rs:146-149): nodes that do not feed it are dead -- a second
     // output (e.g. the probabilities next to a label) must neither cost kernels nor block loading.
@@ -829,6 +909,28 @@ struct Lowerer {
         for (const auto &in_name : m.nodes[i].inputs) uses[in_name]++;
     uses[m.outputs[0].name]++;
 
+    if (m.inputs.size() > 1) {
+      int64_t off = 0;
+      for (const auto &v : m.inputs) {
+        if (uses.count(v.name) && uses[v.name] > 0) {
+          Step s;
+          s.kind = StepKind::SliceCols;
+          s.in0 = 0;
+          s.col_off = off;
+          s.K = v.dims[1];
+          s.out = new_buf({plan.input_shape[0], v.dims[1]});
+          s.origin = "input:" + v.name;
+          plan.steps.push_back(std::move(s));
+          producer[plan.steps.back().out] = int(plan.steps.size()) - 1;
+          Val a;
+          a.buf = plan.steps.back().out;
+          a.shape = {plan.input_shape[0], v.dims[1]};
+          vals[v.name] = a;
+          buf_names[a.buf].push_back(v.name);
+        }
+        off += v.dims[1];
+      }
+    }
     for (size_t ni = 0; ni < m.nodes.size(); ni++) {
       if (!live[ni]) continue;
       const auto &n = m.nodes[ni];
@@ -853,6 +955,7 @@ struct Lowerer {
       else if (op == "Shape") shape_op(n);
       else if (op == "Gather") gather(n);
       else if (op == "Slice") slice(n);
+      else if (op == "Split") split(n);
       else if (op == "Cast") cast(n);
       else if (op == "Concat") concat(n);
       else if (op == "ReduceMean") reduce_mean(n);
@@ -927,7 +1030,7 @@ double Plan::flops_per_row() const {
 }
 
 std::string Plan::describe_json() const {
-  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool", "CopyCols", "ArgMax"};
+  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool", "CopyCols", "ArgMax", "SliceCols"};
   static const char *acts[] = {"", "Relu", "Sigmoid", "Tanh", "LeakyRelu", "Clip", "Exp", "Log", "Sqrt", "Neg", "Abs", "Elu", "Selu", "Softplus",
                                "HardSigmoid", "HardSwish", "Erf", "Gelu", "Reciprocal", "Floor", "Ceil", "Softsign", "Trunc", "Round"};
   std::ostringstream o;

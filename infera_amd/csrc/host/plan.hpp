@@ -35,6 +35,7 @@ enum class StepKind : int {
   GlobalAvgPool = 8,
   CopyCols = 9,     // out[r, col_off : col_off+len] = in0[r, :]   (one piece of a Concat along the feature/channel axis)
   ArgMax = 10,      // out[r, 0] = float(index of the first maximum of in0[r, 0:len])   (labels as f32 values)
+  SliceCols = 11,   // out[r, :] = in0[r, col_off : col_off+K]   (Slice / Split on the feature axis; one input of a multi-input model)
 };
 
 struct Step {
@@ -53,7 +54,7 @@ struct Step {
   char bop = '+';
   bool const_left = false;
   std::vector<float> cst;  // per_row elements
-  // CopyCols: destination column offset (elements inside a row); the length is in0's per_row
+  // CopyCols: destination column offset (elements inside a row), length = in0's per_row.  SliceCols: SOURCE offset, length K
   int64_t col_off = 0;
   // Softmax
   int64_t sm_outer = 1, sm_len = 1, sm_inner = 1;

@@ -779,35 +779,86 @@ static int op_gather(Exec *x, const Node *nd) {
   return 0;
 }
 
+/* copies dims[axis] in [b, e) of `a` into a new tensor named `name` */
+static int slice_axis(Exec *x, const char *name, const char *in_name, int axis, int64_t b, int64_t e) {
+  long ai = env_find(&x->env, in_name);
+  const Tensor *a = ai >= 0 ? &x->env.v[ai] : find_init(x->m, in_name);
+  if (!a) FAIL("slice: input '%s' not found", in_name);
+  int64_t od[MAXRANK];
+  memcpy(od, a->dims, sizeof od);
+  od[axis] = e - b;
+  const int dt = a->dtype, rank = a->rank;
+  Tensor *o = env_new(&x->env, name, dt, rank, od);
+  ai = env_find(&x->env, in_name);
+  a = ai >= 0 ? &x->env.v[ai] : find_init(x->m, in_name);
+  size_t outer = 1, inner = 1, esz = dt == DT_FLOAT ? 4 : 8;
+  for (int i = 0; i < axis; i++) outer *= (size_t)a->dims[i];
+  for (int i = axis + 1; i < rank; i++) inner *= (size_t)a->dims[i];
+  const char *src = dt == DT_FLOAT ? (const char *)a->f : (const char *)a->i64;
+  char *dst = dt == DT_FLOAT ? (char *)o->f : (char *)o->i64;
+  for (size_t u = 0; u < outer; u++)
+    memcpy(dst + u * (size_t)(e - b) * inner * esz, src + (u * (size_t)a->dims[axis] + (size_t)b) * inner * esz, (size_t)(e - b) * inner * esz);
+  return 0;
+}
+
 static int op_slice(Exec *x, const Node *nd) {
   const Tensor *d = get_in(x, nd, 0);
-  if (!d || d->rank != 1) FAIL("Slice: only 1-D data");
-  int64_t st, en, step = 1, len = (int64_t)d->n;
+  if (!d || d->rank < 1) FAIL("Slice: bad data");
+  int64_t st, en, step = 1, axis = 0;
   const Tensor *ts = get_in(x, nd, 1), *te = get_in(x, nd, 2), *ta = get_in(x, nd, 3), *tp = get_in(x, nd, 4);
   if (ts && te) {
+    if (ts->n != 1 || te->n != 1) FAIL("Slice: one axis only");
     st = ts->i64[0];
     en = te->i64[0];
-    if (ta && ta->i64[0] != 0 && ta->i64[0] != -1) FAIL("Slice: bad axis");
+    if (ta) axis = ta->i64[0];
     if (tp) step = tp->i64[0];
   } else {
-    const Attr *as = find_attr(nd, "starts"), *ae = find_attr(nd, "ends");
+    const Attr *as = find_attr(nd, "starts"), *ae = find_attr(nd, "ends"), *aa = find_attr(nd, "axes");
     if (!as || !ae || as->nints != 1 || ae->nints != 1) FAIL("Slice: starts/ends");
     st = as->ints[0];
     en = ae->ints[0];
+    if (aa && aa->nints == 1) axis = aa->ints[0];
   }
   if (step != 1) FAIL("Slice: step must be 1");
+  if (axis < 0) axis += d->rank;
+  if (axis < 0 || axis >= d->rank) FAIL("Slice: axis out of range");
+  int64_t len = d->dims[axis];
   if (st < 0) st += len;
   if (en < 0) en += len;
   if (st < 0) st = 0;
   if (st > len) st = len;
   if (en < st) en = st;
   if (en > len) en = len;
-  int64_t cnt = en - st;
-  const int dt = d->dtype;
-  Tensor *o = env_new(&x->env, nd->out[0], dt, 1, &cnt);
-  d = get_in(x, nd, 0);
-  if (dt == DT_FLOAT) memcpy(o->f, d->f + st, (size_t)cnt * 4);
-  else memcpy(o->i64, d->i64 + st, (size_t)cnt * 8);
+  return slice_axis(x, nd->out[0], nd->in[0], (int)axis, st, en);
+}
+
+static int op_split(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a) FAIL("Split: missing input");
+  int64_t axis = attr_i(nd, "axis", 0);
+  if (axis < 0) axis += a->rank;
+  if (axis < 0 || axis >= a->rank) FAIL("Split: axis out of range");
+  const int64_t K = a->dims[axis];
+  int64_t sizes[64];
+  size_t ns = 0;
+  const Tensor *tsz = get_in(x, nd, 1);
+  const Attr *asz = find_attr(nd, "split");
+  if (tsz && tsz->dtype == DT_INT64) { ns = tsz->n; if (ns > 64) FAIL("Split: too many pieces"); for (size_t i = 0; i < ns; i++) sizes[i] = tsz->i64[i]; }
+  else if (asz) { ns = asz->nints; if (ns > 64) FAIL("Split: too many pieces"); for (size_t i = 0; i < ns; i++) sizes[i] = asz->ints[i]; }
+  else {
+    ns = (size_t)attr_i(nd, "num_outputs", (int64_t)nd->nout);
+    if (ns < 1 || ns > 64) FAIL("Split: bad piece count");
+    int64_t each = (K + (int64_t)ns - 1) / (int64_t)ns;
+    for (size_t i = 0; i < ns; i++) { int64_t left = K - (int64_t)i * each; sizes[i] = left < each ? left : each; }
+  }
+  if (ns != nd->nout) FAIL("Split: %zu sizes for %zu outputs", ns, nd->nout);
+  int64_t off = 0;
+  for (size_t i = 0; i < ns; i++) {
+    if (sizes[i] < 0 || off + sizes[i] > K) FAIL("Split: sizes exceed the axis");
+    if (nd->out[i][0] && slice_axis(x, nd->out[i], nd->in[0], (int)axis, off, off + sizes[i])) return -1;
+    off += sizes[i];
+  }
+  if (off != K) FAIL("Split: sizes do not cover the axis");
   return 0;
 }
 
@@ -1329,6 +1380,7 @@ static int run_node(Exec *x, const Node *nd) {
   if (!strcmp(op, "Shape")) return op_shape(x, nd);
   if (!strcmp(op, "Gather")) return op_gather(x, nd);
   if (!strcmp(op, "Slice")) return op_slice(x, nd);
+  if (!strcmp(op, "Split")) return op_split(x, nd);
   if (!strcmp(op, "Cast")) return op_cast(x, nd);
   if (!strcmp(op, "Concat")) return op_concat(x, nd);
   if (!strcmp(op, "ReduceMean")) return op_reduce_mean(x, nd);
@@ -1353,6 +1405,26 @@ static int run_graph(const OrcModel *m, const float *data, int rank, const int64
   Exec *x = &xs;
   if (m->ninputs < 1) { set_err(err, errlen, "model has no input"); return -1; }
   const ValueInfo *vi = &m->inputs[0];
+  if (m->ninputs > 1) {
+    /* Build extension mirrored from the product (the reference feeds input 0 only, engine.rs:139-145): several f32
+     * [rows, k_i] inputs take consecutive column ranges of the fed [rows, sum k_i] matrix, in declaration order. */
+    if (rank != 2) { set_err(err, errlen, "input rank mismatch: multi-input models take a rank-2 feature matrix"); return -1; }
+    int64_t total = 0;
+    for (size_t k = 0; k < m->ninputs; k++) {
+      const ValueInfo *v = &m->inputs[k];
+      if (v->rank != 2 || v->dims[1] <= 0 || (v->has_type && v->elem_type != DT_FLOAT)) { set_err(err, errlen, "multi-input models need f32 [rows, k] inputs"); return -1; }
+      if (v->dims[0] >= 0 && v->dims[0] != dims[0]) { set_err(err, errlen, "input shape mismatch at axis 0: model expects %lld, got %lld", (long long)v->dims[0], (long long)dims[0]); return -1; }
+      total += v->dims[1];
+    }
+    if (total != dims[1]) { set_err(err, errlen, "input shape mismatch at axis 1: model expects %lld, got %lld", (long long)total, (long long)dims[1]); return -1; }
+    int64_t off = 0;
+    for (size_t k = 0; k < m->ninputs; k++) {
+      int64_t d2[2] = {dims[0], m->inputs[k].dims[1]};
+      Tensor *t = env_new(&x->env, m->inputs[k].name, DT_FLOAT, 2, d2);
+      for (int64_t r = 0; r < dims[0]; r++) memcpy(t->f + r * d2[1], data + r * dims[1] + off, (size_t)d2[1] * 4);
+      off += d2[1];
+    }
+  } else {
   /* The backend checks the fed tensor against the declared input fact (rank + fixed dims). */
   if (vi->rank >= 0) {
     if (vi->rank != rank) { set_err(err, errlen, "input rank mismatch: model expects rank %d, got rank %d", vi->rank, rank); return -1; }
@@ -1364,6 +1436,7 @@ static int run_graph(const OrcModel *m, const float *data, int rank, const int64
   }
   Tensor *in = env_new(&x->env, vi->name, DT_FLOAT, rank, dims);
   memcpy(in->f, data, in->n * 4);
+  }
   /* only nodes that feed the FIRST output run (engine.rs:146-149 reads outputs[0]); liveness by a backward sweep
    * over the topologically sorted node list */
   char *live = (char *)xcalloc(m->nnodes ? m->nnodes : 1, 1);
@@ -1448,7 +1521,7 @@ static int infer_output_shape(OrcModel *m, char *err, size_t errlen) {
   Tensor r[2];
   for (int pass = 0; pass < 2; pass++) {
     int64_t d[MAXRANK];
-    for (int i = 0; i < vi->rank; i++) d[i] = vi->dims[i] >= 0 ? vi->dims[i] : pass + 1;
+    for (int i = 0; i < vi->rank; i++) d[i] = m->in_shape[i] >= 0 ? m->in_shape[i] : pass + 1;
     size_t n = dims_count(d, vi->rank);
     float *z = (float *)xcalloc(n, 4);
     int rc = run_graph(m, z, vi->rank, d, &r[pass], err, errlen);
@@ -1505,6 +1578,11 @@ OrcModel *orc_load(const char *path, char *err, size_t errlen) {
   if (m->inputs[0].rank < 0) { snprintf(e2, sizeof e2, "input 0 has no shape"); goto fail; }
   m->in_rank = m->inputs[0].rank;
   for (int i = 0; i < m->in_rank; i++) m->in_shape[i] = m->inputs[0].dims[i] >= 0 ? m->inputs[0].dims[i] : -1;
+  if (m->ninputs > 1 && m->in_rank == 2) { /* the call's feature matrix spans all inputs (see run_graph) */
+    int64_t total = 0;
+    for (size_t k = 0; k < m->ninputs; k++) total += m->inputs[k].rank == 2 && m->inputs[k].dims[1] > 0 ? m->inputs[k].dims[1] : 0;
+    m->in_shape[1] = total;
+  }
   if (infer_output_shape(m, e2, sizeof e2)) goto fail;
   free(buf);
   return m;

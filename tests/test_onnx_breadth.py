@@ -267,6 +267,59 @@ def test_gpu_label_output_of_a_two_output_classifier(api, O, tmp_path):
     api.unload_model("two_out")
 
 
+def _wide_and_deep(tmp_path):
+    """Two runtime inputs (dense features [N,10], wide features [N,6]) -- split across the call's 16 feature columns
+    in declaration order -- plus Split and Slice on the feature axis."""
+    rng = np.random.default_rng(8)
+    w1, b1 = (rng.standard_normal((10, 12)) * 0.4).astype(np.float32), rng.standard_normal(12).astype(np.float32)
+    w2 = (rng.standard_normal((6 + 6 + 4, 3)) * 0.4).astype(np.float32)
+    nodes = [W.node("Gemm", ["dense", "w1", "b1"], ["h"]), W.node("Relu", ["h"], ["hr"]),
+             W.node("Split", ["hr"], ["ha", "hb"], [W.attr_i("axis", 1)]),                       # 12 -> 6 + 6
+             W.node("Slice", ["wide", "s0", "s4", "ax1"], ["wcut"]),                              # wide[:, 0:4]
+             W.node("Mul", ["ha", "hb"], ["hm"]),
+             W.node("Concat", ["hm", "wide", "wcut"], ["cat"], [W.attr_i("axis", 1)]),
+             W.node("MatMul", ["cat", "w2"], ["Y"])]
+    inits = [W.tensor("w1", w1), W.tensor("b1", b1), W.tensor("w2", w2), W.tensor("s0", np.array([0], np.int64)),
+             W.tensor("s4", np.array([4], np.int64)), W.tensor("ax1", np.array([1], np.int64))]
+    blob = W.model("wide_deep", nodes, inits, [W.value_info("dense", ["N", 10]), W.value_info("wide", ["N", 6])], [W.value_info("Y", ["N", 3])])
+
+    def ref(x):
+        x = x.astype(np.float64)
+        d, wd = x[:, :10], x[:, 10:]
+        h = np.maximum(d @ w1 + b1, 0)
+        return np.concatenate([h[:, :6] * h[:, 6:], wd, wd[:, :4]], axis=1) @ w2
+
+    return W.write(str(tmp_path / "wide_deep.onnx"), blob), ref
+
+
+def test_multi_input_split_slice_oracle_and_lowering(O, built, tmp_path):
+    from infera_amd import capi
+
+    path, ref = _wide_and_deep(tmp_path)
+    x = synth.table(31, 0, 40, 16)
+    m = O.Model(path)
+    assert m.input_shape == [-1, 16] and m.output_shape == [-1, 3]
+    assert_close(m.predict(x), ref(x).astype(np.float32), rtol=2e-5, atol=2e-6)
+    with pytest.raises(O.OracleError, match=r"^Invalid input shape: expected batch x \[16\], got 40 x 10$"):
+        m.predict(x[:, :10])
+    capi.load_model("wd", path)
+    assert capi.get_model_info("wd")["input_shape"] == [-1, 16]
+    kinds = [s["kind"] for s in capi.get_plan("wd")["plan"]["steps"]]
+    assert kinds.count("SliceCols") == 5 and kinds.count("CopyCols") == 3, kinds  # 2 inputs + 2 split pieces + 1 slice
+    capi.unload_model("wd")
+
+
+@pytest.mark.gpu
+def test_gpu_multi_input_split_slice(api, O, tmp_path):
+    path, _ = _wide_and_deep(tmp_path)
+    x = synth.table(31, 0, 3001, 16)
+    api.load_model("wd", path)
+    assert_close(api.predict("wd", x), O.Model(path).predict(x))
+    with pytest.raises(api.InferaError, match=r"^Invalid input shape: expected batch x \[16\], got 3001 x 10$"):
+        api.predict("wd", x[:, :10].copy())
+    api.unload_model("wd")
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
