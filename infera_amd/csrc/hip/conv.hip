@@ -139,7 +139,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_generic_kernel(const float *__r
 //   = Wt[m = 32mt + (lane&31)][tap][c = 32cc + 8g + 4*(lane>>5) + j]
 //
 // One LDS stage = S consecutive 32-channel chunks of one filter tap (S = 2 when C % 64 == 0): S*MT KB of
-// fragments shared by the 4 waves, double-buffered, ONE barrier per stage (= per 16*S*MT MFMAs per wave).
+// fragments shared by the 4 waves (loaded global -> LDS directly), double-buffered, ONE barrier per stage (= per
+// 16*S*MT MFMAs per wave).
 // Inside a stage the wave runs the same "unit" pipeline as mlp_device.inc: a unit = one 16-byte A fragment
 // (ds_read_b128, P units ahead in a register ring) + 4 MFMAs, pinned with sched_barrier so the loads stay
 // interleaved with the matrix stream.  The next stage's B operands (S*4 16-byte gathers per lane) and weight
@@ -231,22 +232,25 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
       n_off = n_base;
     }
   };
-  // this block's MT tiles of one 32-channel chunk are contiguous in the packed blob (MT*1024 floats)
-  auto stage_load = [&](f32x4(&wreg)[S * MT], int stage) {
+  // This block's MT tiles of one 32-channel chunk are contiguous in the packed blob (MT*1024 floats); they go
+  // STRAIGHT into LDS (global_load_lds_dwordx4: each wave drops 1 KB at its wave-uniform base + lane*16), no
+  // staging registers and no ds_write pass.  Completion is tracked by vmcnt like any other load.
+  auto stage_issue = [&](int stage, int buf) {
 #pragma unroll
     for (int sl = 0; sl < S; sl++) {
       const f32x4 *src = reinterpret_cast<const f32x4 *>(Wp + (int64_t(stage * S + sl) * MTtot + mt0) * 1024) + threadIdx.x;
 #pragma unroll
-      for (int t = 0; t < MT; t++) wreg[sl * MT + t] = src[t * 256];
+      for (int t = 0; t < MT; t++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + t * 256),
+                                         (__attribute__((address_space(3))) void *)(wbuf[buf] + (sl * MT + t) * 1024 + wave * 256), 16, 0, 0);
     }
   };
-  auto stage_store = [&](const f32x4(&wreg)[S * MT], int buf) {
-    f32x4 *dst = reinterpret_cast<f32x4 *>(wbuf[buf]) + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < S * MT; i++) dst[i * 256] = wreg[i];
+  // all of this wave's outstanding loads (gathers AND LDS-bound weight pieces) have landed, then the workgroup meets
+  auto stage_commit = [] {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
 
-  f32x4 wreg[S * MT];
   // `more` is a compile-time constant per call site: with a run-time flag the prefetch sits in a branch and
   // hipcc's waitcnt pass, merging the two paths, makes every other stage wait on the loads it has just issued.
   auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage, auto more_tag) {
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
           if (u == 0) gather(bn);
         }
         if constexpr (PROBE != 3 && PROBE != 4 && PROBE != 6) {
-          if (u == 1) stage_load(wreg, stage + 1);
+          if (u == 1) stage_issue(stage + 1, (stage + 1) & 1);
         }
       }
 #pragma unroll
@@ -283,9 +287,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
       const unsigned long long s0 = __builtin_readcyclecounter();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long s1 = __builtin_readcyclecounter();
-      stage_store(wreg, (stage + 1) & 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const unsigned long long s2 = __builtin_readcyclecounter();
+      const unsigned long long s2 = s1;
       __builtin_amdgcn_s_barrier();
       const unsigned long long s3 = __builtin_readcyclecounter();
       w_vm += s1 - s0;
@@ -294,8 +296,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
     }
 #endif
     if constexpr (more && (PROBE == 0 || PROBE == 6 || PROBE == 2)) {
-      stage_store(wreg, (stage + 1) & 1);
-      __syncthreads();
+      stage_commit();
     }
     if constexpr (PROBE == 2 || PROBE == 3 || PROBE == 4) {
 #pragma unroll
@@ -308,15 +309,14 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   if constexpr (PROBE == 5) ta = __builtin_readcyclecounter();
 #endif
   gather(b0);
-  stage_load(wreg, 0);
+  stage_issue(0, 0);
 #ifdef INFERA_CONV_PROBES
   if constexpr (PROBE == 5) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tb = __builtin_readcyclecounter();
   }
 #endif
-  stage_store(wreg, 0);
-  __syncthreads();
+  stage_commit();
 #ifdef INFERA_CONV_PROBES
   if constexpr (PROBE == 5) t1 = __builtin_readcyclecounter();
 #endif
