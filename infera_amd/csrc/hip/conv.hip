@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long s1 = __builtin_readcyclecounter();
       const unsigned long long s2 = s1;
-      __builtin_amdgcn_s_barrier();
+      __syncthreads();
       const unsigned long long s3 = __builtin_readcyclecounter();
       w_vm += s1 - s0;
       w_ring += s2 - s1;
