@@ -60,7 +60,7 @@ __device__ __forceinline__ float apply_act(float v, const ActParam &p) {
 // Run f(std::integral_constant<int, KIND>) for the run-time activation kind: ONE wave-uniform branch per
 // epilogue instead of a switch per element.  (A per-element switch in an MFMA epilogue costs far more than
 // its instructions: each element's bias load gets its own s_waitcnt vmcnt(0), which also drains the stores
-// issued just before it -- measured 100k cycles per wave in the conv epilogue, 2x its whole main loop.)
+// issued just before it -- measured in the conv epilogue at twice the time of its whole main loop.)
 template <typename F>
 __device__ __forceinline__ void dispatch_act(int kind, F &&f) {
   switch (kind) {
