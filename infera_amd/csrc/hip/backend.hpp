@@ -80,7 +80,9 @@ void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t row
 // Same, but the input rows are PRODUCED straight into the pinned staging buffer by `fill(dst, row0,
 // nrows)` (columnar gather, blob concatenation): no intermediate host copy.
 using FillFn = std::function<void(float *dst, int64_t row0, int64_t nrows)>;
-void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows);
+// col_major: `fill` writes the pass as [in_per_row][nrows] (column-major -- flat columns are copied as they are) and
+// the transpose to the row-major table happens on the GPU.
+void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major = false);
 
 // Device-resident inference: d_in / d_out live on HIP device `device_ordinal`.  Enqueues on the
 // calling thread's stream for that device and returns without synchronising.

@@ -34,6 +34,8 @@ void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t oute
 void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t src_stride, int64_t src_off,
                int64_t dst_stride, int64_t dst_off);
 void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t len);
+// dst[rows][ncols] = transpose of src[ncols][rows]  (column-major staging of a columnar chunk)
+void transpose_cm(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t ncols);
 // synthetic table fill (SURVEY.md 8d generator), row-major [rows, ncols]
 void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_t rows, uint64_t ncols);
 

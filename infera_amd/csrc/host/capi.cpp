@@ -443,9 +443,22 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
     OutShape o = engine::validate_predict(*m, rows, ncols);
     float *out = alloc_out(o.len);
     try {
-      // gather straight into the pinned staging buffer (no intermediate row-major copy)
-      run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) { gather_columns(columns, ncols, size_t(r0), size_t(nr), dst); }, out,
-                    int64_t(rows));
+      // All-FLOAT flat columns (the FLOAT overloads, infera_extension.cpp:554-557): each column is copied into pinned
+      // staging as the contiguous run it already is and the transpose to [rows][F] runs on the GPU -- the host does
+      // 128 memcpys per chunk instead of a 2048 x 128 transpose (SURVEY.md 7 "hard parts": the host gather is what
+      // limits an 8-GPU host).  Anything else (DOUBLE/INTEGER/BIGINT, constant vectors) converts on the host while
+      // gathering straight into the row-major staging buffer.
+      bool flat_f32 = !Config::get().use_hipgraph && ncols > 0;
+      for (uintptr_t c = 0; c < ncols && flat_f32; c++) flat_f32 = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
+      if (flat_f32) {
+        run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) {
+          for (uintptr_t c = 0; c < ncols; c++)
+            std::memcpy(dst + size_t(c) * size_t(nr), static_cast<const float *>(columns[c].data) + r0, size_t(nr) * sizeof(float));
+        }, out, int64_t(rows), /*col_major=*/true);
+      } else {
+        run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) { gather_columns(columns, ncols, size_t(r0), size_t(nr), dst); }, out,
+                      int64_t(rows));
+      }
     } catch (...) {
       free_out(out);
       throw;
