@@ -148,6 +148,9 @@ int home_slot() {
 }
 
 kern::ActParam act_of(const Step &s) { return kern::ActParam{int(s.act), s.act_a, s.act_b}; }
+// A Dense layer is a 1x1 convolution over 1x1 "images": with H = W = 1 the channel-quad layout IS the row-major
+// [rows, K] matrix, so the tiled conv kernel (packed weights through LDS, unit-pipelined MFMA stream) serves it.
+kern::ConvGeom dense_as_conv(const Step &s) { return kern::ConvGeom{int(s.K), 1, 1, int(s.M), 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1}; }
 
 // Weight upload on an explicit (non-blocking) stream: a legacy-stream hipMemcpy would try to
 // synchronise with every blocking stream of the device, which is illegal while another thread is
@@ -238,6 +241,12 @@ void schedule(LoadedModel &m) {
       i += 1;
     }
   }
+  // Remaining Dense layers with K % 32 == 0 and M % 32 == 0 -> the tiled kernel (the generic dense kernel fetches
+  // one weight per lane per MFMA from L2 and measured 13-16 TFLOP/s; narrow heads keep their streaming kernels)
+  for (size_t i = 0; i < n; i++)
+    if (m.exec[i] == ExecKind::Normal && st[i].kind == StepKind::Dense && st[i].M > 32 && int(st[i].act) <= kMaxMfmaFusedAct &&
+        kern::conv2d_tiled_supported(dense_as_conv(st[i])))
+      m.exec[i] = ExecKind::DenseTiled;
   // ---- layout decision for convolutional plans ----
   auto is4d = [&](int b) { return b >= 0 && m.plan.buf_shape[size_t(b)].size() == 4; };
   auto spatial = [&](int b) { return is4d(b) ? m.plan.buf_shape[size_t(b)][2] * m.plan.buf_shape[size_t(b)][3] : int64_t(1); };
@@ -359,6 +368,13 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       std::vector<float> packed(s.W.size());
       kern::conv2d_depthwise_pack(g, s.W.data(), packed.data());
       d.W = upload(packed, us);
+    } else if (m.exec[i] == ExecKind::DenseTiled) {
+      const kern::ConvGeom g = dense_as_conv(s);
+      std::vector<float> wt(s.W.size()), packed(kern::conv2d_tiled_packed_floats(g));
+      for (int64_t k = 0; k < s.K; k++)
+        for (int64_t j = 0; j < s.M; j++) wt[size_t(j * s.K + k)] = s.W[size_t(k * s.M + j)];  // [K][M] -> conv's [M][C]
+      kern::conv2d_tiled_pack(g, wt.data(), packed.data());
+      d.W = upload(packed, us);
     } else if (m.exec[i] == ExecKind::ConvPatch) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
@@ -442,6 +458,9 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x));
           continue;
         }
+        case ExecKind::DenseTiled:
+          kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, dense_as_conv(x), act_of(x));
+          continue;
         case ExecKind::ConvDepthwise: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
@@ -721,7 +740,7 @@ void sync_device(int device_ordinal) {
 hipStream_t thread_stream(int device_ordinal) { return ctx_for_slot(slot_of_ordinal(device_ordinal)).stream; }
 
 std::string LoadedModel::describe_json() const {
-  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch", "conv_depthwise"};
+  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch", "conv_depthwise", "dense_tiled"};
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";
