@@ -150,7 +150,11 @@ int home_slot() {
 kern::ActParam act_of(const Step &s) { return kern::ActParam{int(s.act), s.act_a, s.act_b}; }
 // A Dense layer is a 1x1 convolution over 1x1 "images": with H = W = 1 the channel-quad layout IS the row-major
 // [rows, K] matrix, so the tiled conv kernel (packed weights through LDS, unit-pipelined MFMA stream) serves it.
-kern::ConvGeom dense_as_conv(const Step &s) { return kern::ConvGeom{int(s.K), 1, 1, int(s.M), 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1}; }
+// K and M are padded to multiples of 32 with zero weights; the real row lengths travel in kvalid / mvalid.
+kern::ConvGeom dense_as_conv(const Step &s) {
+  const int kp = int((s.K + 31) / 32 * 32), mp = int((s.M + 31) / 32 * 32);
+  return kern::ConvGeom{kp, 1, 1, mp, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, int(s.K), int(s.M)};
+}
 
 // Weight upload on an explicit (non-blocking) stream: a legacy-stream hipMemcpy would try to
 // synchronise with every blocking stream of the device, which is illegal while another thread is
@@ -244,8 +248,8 @@ void schedule(LoadedModel &m) {
   // Remaining Dense layers with K % 32 == 0 and M % 32 == 0 -> the tiled kernel (the generic dense kernel fetches
   // one weight per lane per MFMA from L2 and measured 13-16 TFLOP/s; narrow heads keep their streaming kernels)
   for (size_t i = 0; i < n; i++)
-    if (m.exec[i] == ExecKind::Normal && st[i].kind == StepKind::Dense && st[i].M > 32 && int(st[i].act) <= kMaxMfmaFusedAct &&
-        kern::conv2d_tiled_supported(dense_as_conv(st[i])))
+    if (m.exec[i] == ExecKind::Normal && st[i].kind == StepKind::Dense && st[i].M > 32 && st[i].K % 4 == 0 &&
+        int(st[i].act) <= kMaxMfmaFusedAct && kern::conv2d_tiled_supported(dense_as_conv(st[i])))
       m.exec[i] = ExecKind::DenseTiled;
   // ---- layout decision for convolutional plans ----
   auto is4d = [&](int b) { return b >= 0 && m.plan.buf_shape[size_t(b)].size() == 4; };
@@ -370,11 +374,20 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       d.W = upload(packed, us);
     } else if (m.exec[i] == ExecKind::DenseTiled) {
       const kern::ConvGeom g = dense_as_conv(s);
-      std::vector<float> wt(s.W.size()), packed(kern::conv2d_tiled_packed_floats(g));
+      std::vector<float> wt(size_t(g.C) * g.M, 0.f), packed(kern::conv2d_tiled_packed_floats(g));
       for (int64_t k = 0; k < s.K; k++)
-        for (int64_t j = 0; j < s.M; j++) wt[size_t(j * s.K + k)] = s.W[size_t(k * s.M + j)];  // [K][M] -> conv's [M][C]
+        for (int64_t j = 0; j < s.M; j++) wt[size_t(j) * g.C + size_t(k)] = s.W[size_t(k * s.M + j)];  // [K][M] -> conv's [Mp][Cp]
       kern::conv2d_tiled_pack(g, wt.data(), packed.data());
       d.W = upload(packed, us);
+      if (!s.bias.empty()) {
+        std::vector<float> bp(size_t(g.M), 0.f);
+        std::copy(s.bias.begin(), s.bias.end(), bp.begin());
+        d.bias = upload(bp, us);
+      }
+      d.cst = upload(s.cst, us);
+      d.scale = upload(s.scale, us);
+      d.shift = upload(s.shift, us);
+      continue;
     } else if (m.exec[i] == ExecKind::ConvPatch) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
@@ -507,6 +520,7 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           kern::copy_cols(s, buf(x.in0), buf(x.out), nr, p.buf_per_row[size_t(x.in0)], p.buf_per_row[size_t(x.in0)], 0,
                           p.buf_per_row[size_t(x.out)], x.col_off);
           break;
+        case StepKind::PadCols: kern::pad_cols(s, buf(x.in0), buf(x.out), nr, x.K, x.M); break;
         case StepKind::SliceCols:
           kern::copy_cols(s, buf(x.in0), buf(x.out), nr, x.K, p.buf_per_row[size_t(x.in0)], x.col_off, x.K, 0);
           break;

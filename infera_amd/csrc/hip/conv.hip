@@ -160,7 +160,10 @@ __device__ __attribute__((aligned(256))) float g_zero_page[128];
 __device__ unsigned long long g_conv_stamps[2][12];
 #endif
 
-template <int MT, int S, int PROBE = 0>
+// DENSE: a fully connected layer as a 1x1 convolution over 1x1 images (the channel-quad layout of a 1x1 image is the
+// row-major matrix).  g.C / g.M are padded to multiples of 32; the input rows are g.kvalid floats long (a multiple
+// of 4: whole quads past the end read the zero page), the output rows g.mvalid (any length: stores are guarded).
+template <int MT, int S, int PROBE = 0, bool DENSE = false>
 __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                              const float *__restrict__ bias, const float *__restrict__ residual,
                                                              float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
   // receptive-field corner of this lane's pixel (may lie outside the image; masked taps never dereference it)
   const int HW4 = g.H * g.W * 4;  // floats per channel-quad plane
-  const float *xc = X + n * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
+  const float *xc = DENSE ? X + n * g.kvalid + 4 * h : X + n * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
   const float *zp = g_zero_page + 4 * h;
   uint64_t okmask = 0;
   if (pvalid) {
@@ -214,10 +217,19 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0;
   auto gather = [&](f32x4(&b)[NB]) {
     const bool ok = (okmask >> n_tap) & 1;
-    const float *p = ok ? xc + n_off : zp;
-    const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;  // group q+1 = two channel-quad planes further
+    if constexpr (DENSE) {
+      // this lane's quad of group q starts at column n_off + 8q + 4h; columns >= kvalid do not exist
 #pragma unroll
-    for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
+      for (int q = 0; q < NB; q++) {
+        const bool in = ok && n_off + 8 * q + 4 * h < g.kvalid;
+        b[q] = *reinterpret_cast<const f32x4 *>(in ? xc + n_off + 8 * q : zp);
+      }
+    } else {
+      const float *p = ok ? xc + n_off : zp;
+      const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;  // group q+1 = two channel-quad planes further
+#pragma unroll
+      for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
+    }
     // advance to the following stage: next tap of this channel block, else first tap of the next block
     n_tap++;
     n_kx++;
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   // epilogue: lane (r,h) holds pixel `pix`, channels 32*(mt0+t) + 8*q + 4h + j -> one 16-byte NHWC store per quad
   // (optional residual: the block's skip tensor, same NHWC layout -- the Add of a ResNet block is fused here)
   const int64_t OHW4 = int64_t(OHW) * 4;
-  const int64_t yoff = n * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+  const int64_t yoff = DENSE ? n * g.mvalid + (8 * mt0 + h) * 4 : n * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
   float *yp = Y + yoff;
   const float *rp = residual ? residual + yoff : nullptr;
   const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
@@ -371,7 +383,19 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[t][4 * q + j] + bv[t & 1][q][j]) + rv[t & 1][q][j], act.a, act.b);
-        *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
+        if constexpr (DENSE) {
+          const int f0 = 32 * (mt0 + t) + 8 * q + 4 * h;  // first of this quad's four features
+          float *dst = yp + (8 * t + 2 * q) * 4;
+          if (f0 + 3 < g.mvalid) {
+            *reinterpret_cast<f32x4 *>(dst) = v;  // rows are mvalid floats apart: 4-byte aligned is all a dwordx4 store needs
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (f0 + j < g.mvalid) dst[j] = v[j];
+          }
+        } else {
+          *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
+        }
       }
     }
   });
@@ -934,6 +958,13 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
     }
   }
 #endif
+  if (g.mvalid > 0) {  // dense layer
+    if (wide) deep ? launch(conv2d_tiled_kernel<4, 2, 0, true>, 4) : launch(conv2d_tiled_kernel<4, 1, 0, true>, 4);
+    else if (mt_pick == 3) deep ? launch(conv2d_tiled_kernel<3, 2, 0, true>, 3) : launch(conv2d_tiled_kernel<3, 1, 0, true>, 3);
+    else if (mt_pick == 2) deep ? launch(conv2d_tiled_kernel<2, 2, 0, true>, 2) : launch(conv2d_tiled_kernel<2, 1, 0, true>, 2);
+    else deep ? launch(conv2d_tiled_kernel<1, 2, 0, true>, 1) : launch(conv2d_tiled_kernel<1, 1, 0, true>, 1);
+    return;
+  }
   if (wide && deep) launch(conv2d_tiled_kernel<4, 2>, 4);
   else if (wide) launch(conv2d_tiled_kernel<4, 1>, 4);
   else if (mt_pick == 3) deep ? launch(conv2d_tiled_kernel<3, 2>, 3) : launch(conv2d_tiled_kernel<3, 1>, 3);

@@ -145,6 +145,16 @@ __global__ __launch_bounds__(kBlock) void copy_cols_kernel(const float *__restri
   }
 }
 
+// dst[r, 0:K] = src[r, 0:K], dst[r, K:Kp] = 0   (rows padded to a multiple of 4 floats for 16-byte operand loads)
+__global__ __launch_bounds__(kBlock) void pad_cols_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t rows, int64_t K,
+                                                         int64_t Kp) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock, n = rows * Kp;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / Kp, c = i - r * Kp;
+    dst[i] = c < K ? src[r * K + c] : 0.f;
+  }
+}
+
 // Column-major staging -> row-major table: src is [ncols][rows] (each DuckDB flat column copied as the contiguous
 // run it already is), dst is [rows][ncols].  32x32 tiles through LDS (+1 padding: conflict-free both ways), both
 // sides coalesced.  The host no longer transposes; this costs ~2 us per 2048 x 128 chunk on the GPU.
@@ -249,6 +259,11 @@ void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_
   const bool vec4 = ((len | src_stride | src_off | dst_stride | dst_off) & 3) == 0;
   hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(vec4 ? rows * len / 4 : rows * len)), dim3(kBlock), 0, s, src, dst, rows, len,
                      src_stride, src_off, dst_stride, dst_off, vec4);
+}
+
+void pad_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t K, int64_t Kp) {
+  if (rows <= 0 || Kp <= 0) return;
+  hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for(rows * Kp)), dim3(kBlock), 0, s, src, dst, rows, K, Kp);
 }
 
 void transpose_cm(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t ncols) {

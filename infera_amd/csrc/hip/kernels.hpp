@@ -34,6 +34,8 @@ void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t oute
 void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t src_stride, int64_t src_off,
                int64_t dst_stride, int64_t dst_off);
 void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t len);
+// dst[r, 0:K] = src[r, :], zeros up to Kp columns
+void pad_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t K, int64_t Kp);
 // dst[rows][ncols] = transpose of src[ncols][rows]  (column-major staging of a columnar chunk)
 void transpose_cm(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t ncols);
 // synthetic table fill (SURVEY.md 8d generator), row-major [rows, ncols]
@@ -68,6 +70,9 @@ std::string mlp3_kernel_name(const Mlp3Shape &sh);
 // ---- convolution / pooling (conv.hip) ----------------------------------------------------------
 struct ConvGeom {
   int C, H, W, M, OH, OW, kh, kw, sh, sw, pt, pl, dh, dw, groups;
+  // Dense layers on the tiled kernel (H = W = 1): C and M are the PADDED sizes (multiples of 32, zero weights / bias
+  // beyond the real ones); the real row lengths of the input and output matrices.  0 = not a dense layer.
+  int kvalid = 0, mvalid = 0;
 };
 // Generic implicit-GEMM convolution: any geometry / groups; Wk = conv2d_generic_pack() of the ONNX
 // weights ([group][k][M/g], k = (c, ky, kx)); activations NCHW or channel-quad planes (CQ) per flag.

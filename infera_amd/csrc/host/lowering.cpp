@@ -139,12 +139,30 @@ struct Lowerer {
     const auto &w = cf32(n, b);
     int64_t K = tB ? b.shape[1] : b.shape[0], M = tB ? b.shape[0] : b.shape[1];
     if (a.shape[1] != K) unsupported(n, "inner dimensions differ: " + shape_str(a.shape) + " x " + shape_str(b.shape));
+    // A wide layer over rows whose length is not a multiple of 4 floats (30 features, ...): copy the rows into a
+    // zero-padded matrix first so the MFMA kernels can read them in 16-byte quads; the padded k carry zero weights.
+    // (Narrow heads stream their input once and take any K.)
+    const int64_t Kp = (M > 32 && K % 4 != 0) ? (K + 3) / 4 * 4 : K;
+    int in_buf = a.buf;
+    const std::vector<int64_t> a_shape = a.shape;
+    if (Kp != K) {
+      Step p;
+      p.kind = StepKind::PadCols;
+      p.in0 = in_buf;
+      p.K = K;
+      p.M = Kp;
+      p.out = new_buf({a_shape[0], Kp});
+      p.origin = n.op + (n.name.empty() ? "" : ":" + n.name) + "[pad]";
+      plan.steps.push_back(std::move(p));
+      producer[plan.steps.back().out] = int(plan.steps.size()) - 1;
+      in_buf = plan.steps.back().out;
+    }
     Step s;
     s.kind = StepKind::Dense;
-    s.in0 = a.buf;
-    s.K = K;
+    s.in0 = in_buf;
+    s.K = Kp;
     s.M = M;
-    s.W.resize(size_t(K * M));
+    s.W.assign(size_t(Kp * M), 0.f);
     for (int64_t k = 0; k < K; k++)
       for (int64_t j = 0; j < M; j++) {
         float v = tB ? w[size_t(j * K + k)] : w[size_t(k * M + j)];
@@ -160,7 +178,7 @@ struct Lowerer {
         s.bias[size_t(j)] = beta == 1.f ? v : beta * v;
       }
     }
-    emit(std::move(s), n, {a.shape[0], M});
+    emit(std::move(s), n, {a_shape[0], M});
   }
 
   // Broadcast a constant against an activation's per-row shape; returns per_row floats.
@@ -1030,7 +1048,7 @@ double Plan::flops_per_row() const {
 }
 
 std::string Plan::describe_json() const {
-  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool", "CopyCols", "ArgMax", "SliceCols"};
+  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool", "CopyCols", "ArgMax", "SliceCols", "PadCols"};
   static const char *acts[] = {"", "Relu", "Sigmoid", "Tanh", "LeakyRelu", "Clip", "Exp", "Log", "Sqrt", "Neg", "Abs", "Elu", "Selu", "Softplus",
                                "HardSigmoid", "HardSwish", "Erf", "Gelu", "Reciprocal", "Floor", "Ceil", "Softsign", "Trunc", "Round"};
   std::ostringstream o;

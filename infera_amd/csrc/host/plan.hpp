@@ -36,6 +36,7 @@ enum class StepKind : int {
   CopyCols = 9,     // out[r, col_off : col_off+len] = in0[r, :]   (one piece of a Concat along the feature/channel axis)
   ArgMax = 10,      // out[r, 0] = float(index of the first maximum of in0[r, 0:len])   (labels as f32 values)
   SliceCols = 11,   // out[r, :] = in0[r, col_off : col_off+K]   (Slice / Split on the feature axis; one input of a multi-input model)
+  PadCols = 12,     // out[r, 0:K] = in0[r, :], zeros up to M columns   (row length -> multiple of 4 for the 16-byte loads of the MFMA kernels)
 };
 
 struct Step {

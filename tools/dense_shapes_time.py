@@ -11,7 +11,8 @@ from infera_amd import capi, onnx_writer as W  # noqa: E402
 d = tempfile.mkdtemp()
 dev = capi.device_ordinal(0)
 shapes = [((128, 256, 64, 1), 4_000_000), ((128, 256, 64), 4_000_000), ((128, 512, 512, 10), 2_000_000), ((256, 256, 256, 256, 1), 2_000_000),
-          ((64, 128, 1), 8_000_000), ((1024, 1024, 1024), 500_000), ((128, 96, 48, 3), 4_000_000), ((32, 64, 32, 1), 8_000_000)]
+          ((64, 128, 1), 8_000_000), ((1024, 1024, 1024), 500_000), ((128, 96, 48, 3), 4_000_000), ((32, 64, 32, 1), 8_000_000),
+          ((128, 100, 1), 4_000_000), ((100, 100, 100, 2), 4_000_000), ((30, 100, 50, 1), 4_000_000)]
 for dims, rows in shapes:
     name = "m" + "x".join(map(str, dims))
     capi.load_model(name, W.write(f"{d}/{name}.onnx", W.mlp(dims)))
