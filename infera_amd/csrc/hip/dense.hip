@@ -498,11 +498,139 @@ static void launch_narrow16s(hipStream_t s, const float *X, const float *W, cons
   else go(dense_narrow16s_kernel<K, 2>);
 }
 
+// ---- skinny layers: K <= 32 features, M <= 16 outputs (logistic / linear regression, small softmax heads) ---------
+// The most common in-database models are a handful of multiply-adds per row: no matrix core can help, and the
+// MFMA kernels' 16-byte operand loads do not even apply (rows of 3, 13, 30 floats are not 16-byte aligned).
+// The table is streamed exactly as it lies in memory -- 256 rows = one contiguous 256*K-float run, fetched with
+// perfectly coalesced loads into LDS (row stride K|1: conflict-free) -- and each lane then owns one row: a
+// k-ordered fmaf chain per output with the weights broadcast from LDS (the oracle's own summation order, so
+// results are bit-identical), bias, activation and the optional row softmax in registers.
+template <int MMAX, int SM>
+__global__ __launch_bounds__(256) void dense_skinny_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                          const float *__restrict__ bias, float *__restrict__ Y, int64_t rows, int K,
+                                                          int M, ActParam act, bool x_aligned16) {
+  extern __shared__ __attribute__((aligned(16))) float sk[];  // [K][MMAX] weights (zero-padded), [MMAX] bias, [256][KS] rows
+  const int KS = K | 1;
+  float *wl = sk, *bl = sk + K * MMAX, *xs = bl + MMAX;
+  for (int i = threadIdx.x; i < K * MMAX; i += 256) {
+    const int k = i / MMAX, m = i - k * MMAX;
+    wl[i] = m < M ? W[k * M + m] : 0.f;
+  }
+  if (threadIdx.x < MMAX) bl[threadIdx.x] = (bias != nullptr && int(threadIdx.x) < M) ? bias[threadIdx.x] : 0.f;
+  const int64_t ntiles = (rows + 255) >> 8, total = rows * K;
+  // A tile is 256*K floats = 64*K quads (16-byte aligned: 1024*K bytes per tile); thread t fetches quads t, t+256, ...
+  // (at most 8 for K <= 32, all in flight together), then scatters the four floats of each to (row, column).
+  const int nq = 64 * K;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * 256 * K;
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int q = int(threadIdx.x) + j * 256;
+      const int64_t e = base + 4 * int64_t(q);
+      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < nq) {
+        if (x_aligned16 && e + 3 < total) v[j] = *reinterpret_cast<const f32x4 *>(X + e);
+        else
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (e + u < total) v[j][u] = X[e + u];  // ragged end of the table
+      }
+    }
+    __syncthreads();  // weights visible (first trip) / previous tile's rows consumed
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int q = int(threadIdx.x) + j * 256;
+      if (q < nq) {
+        int r = (4 * q) / K, c = 4 * q - r * K;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          xs[r * KS + c] = v[j][u];
+          if (++c == K) {
+            c = 0;
+            r++;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float acc[MMAX];
+#pragma unroll
+    for (int m = 0; m < MMAX; m++) acc[m] = 0.f;
+    const float *xr = xs + threadIdx.x * KS;
+    for (int k = 0; k < K; k++) {
+      const float x = xr[k];
+#pragma unroll
+      for (int m = 0; m < MMAX; m++) acc[m] = fmaf(x, wl[k * MMAX + m], acc[m]);
+    }
+    dispatch_act(act.kind, [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+      for (int m = 0; m < MMAX; m++) acc[m] = apply_act_c<KIND>(acc[m] + bl[m], act.a, act.b);
+    });
+    if constexpr (SM != 0) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int m = 0; m < MMAX; m++)
+        if (m < M) mx = fmaxf(mx, acc[m]);
+      float sum = 0.f;
+#pragma unroll
+      for (int m = 0; m < MMAX; m++)
+        if (m < M) {
+          const float e = expf(acc[m] - mx);
+          sum += e;
+          acc[m] = SM == 1 ? e : acc[m] - mx;
+        }
+      const float ls = logf(sum);
+#pragma unroll
+      for (int m = 0; m < MMAX; m++) acc[m] = SM == 1 ? acc[m] / sum : acc[m] - ls;
+    }
+    const int64_t row = tile * 256 + threadIdx.x;
+    if (row < rows) {
+      float *y = Y + row * M;
+      if (MMAX >= 4 && M == MMAX && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {  // whole quads, 16-byte aligned rows
+#pragma unroll
+        for (int m = 0; m < MMAX; m += 4) *reinterpret_cast<f32x4 *>(y + m) = f32x4{acc[m], acc[m + 1], acc[m + 2], acc[m + 3]};
+      } else {
+#pragma unroll
+        for (int m = 0; m < MMAX; m++)
+          if (m < M) y[m] = acc[m];
+      }
+    }
+  }
+}
+
+static bool skinny_ok(int K, int M) { return K >= 1 && K <= 32 && M >= 1 && M <= 16; }
+
+static void launch_skinny(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
+                          ActParam act, int softmax_mode) {
+  const int mmax = M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : 16;
+  const size_t lds = (size_t(K) * mmax + mmax + 256 * size_t(K | 1)) * sizeof(float);
+  const int64_t ntiles = (rows + 255) / 256;
+  const unsigned grid = unsigned(std::min<int64_t>(ntiles, 256 * 8));
+  const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, X, W, bias, Y, rows, K, M, act, aligned); };
+  auto by_sm = [&](auto mm) {
+    constexpr int MM = decltype(mm)::value;
+    if (softmax_mode == 0) go(dense_skinny_kernel<MM, 0>);
+    else if (softmax_mode == 1) go(dense_skinny_kernel<MM, 1>);
+    else go(dense_skinny_kernel<MM, 2>);
+  };
+  switch (mmax) {
+    case 1: by_sm(std::integral_constant<int, 1>{}); break;
+    case 2: by_sm(std::integral_constant<int, 2>{}); break;
+    case 4: by_sm(std::integral_constant<int, 4>{}); break;
+    case 8: by_sm(std::integral_constant<int, 8>{}); break;
+    default: by_sm(std::integral_constant<int, 16>{}); break;
+  }
+}
+
 bool dense_can_fuse_softmax(int M) { return M <= 64; }
 
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
            ActParam act, int softmax_mode) {
   if (rows <= 0) return;
+  if (skinny_ok(K, M)) return launch_skinny(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   static const bool staged16 = !(getenv("INFERA_DENSE16_STAGED") && atoi(getenv("INFERA_DENSE16_STAGED")) == 0);
   if (staged16 && M <= 16 && (K == 64 || K == 128 || K == 256) && rows >= 4096 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
     if (K == 64) launch_narrow16s<64>(s, X, W, bias, Y, rows, M, act, softmax_mode);
