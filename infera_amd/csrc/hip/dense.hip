@@ -498,57 +498,62 @@ static void launch_narrow16s(hipStream_t s, const float *X, const float *W, cons
   else go(dense_narrow16s_kernel<K, 2>);
 }
 
-// ---- skinny layers: K <= 32 features, M <= 16 outputs (logistic / linear regression, small softmax heads) ---------
+// ---- skinny layers: few features (K <= 32, or <= 128 when not a multiple of 16), M <= 16 outputs --------------
 // The most common in-database models are a handful of multiply-adds per row: no matrix core can help, and the
 // MFMA kernels' 16-byte operand loads do not even apply (rows of 3, 13, 30 floats are not 16-byte aligned).
-// The table is streamed exactly as it lies in memory -- 256 rows = one contiguous 256*K-float run, fetched with
+// The table is streamed exactly as it lies in memory -- R rows = one contiguous R*K-float run, fetched with
 // perfectly coalesced loads into LDS (row stride K|1: conflict-free) -- and each lane then owns one row: a
 // k-ordered fmaf chain per output with the weights broadcast from LDS (the oracle's own summation order, so
 // results are bit-identical), bias, activation and the optional row softmax in registers.
-template <int MMAX, int SM>
-__global__ __launch_bounds__(256) void dense_skinny_kernel(const float *__restrict__ X, const float *__restrict__ W,
+// TPR threads share a row (wider rows): thread g of a row takes k = g, g + TPR, ... and the partial sums meet in a
+// butterfly over the TPR adjacent lanes (a different summation order than the k-ordered chain; TPR = 1 keeps it).
+template <int MMAX, int SM, int R, int TPR>
+__global__ __launch_bounds__(R * TPR) void dense_skinny_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                           const float *__restrict__ bias, float *__restrict__ Y, int64_t rows, int K,
                                                           int M, ActParam act, bool x_aligned16) {
-  extern __shared__ __attribute__((aligned(16))) float sk[];  // [K][MMAX] weights (zero-padded), [MMAX] bias, [256][KS] rows
+  extern __shared__ __attribute__((aligned(16))) float sk[];  // [K][MMAX] weights (zero-padded), [MMAX] bias, [R][KS] rows
   const int KS = K | 1;
   float *wl = sk, *bl = sk + K * MMAX, *xs = bl + MMAX;
-  for (int i = threadIdx.x; i < K * MMAX; i += 256) {
+  constexpr int NT = R * TPR;
+  for (int i = threadIdx.x; i < K * MMAX; i += NT) {
     const int k = i / MMAX, m = i - k * MMAX;
     wl[i] = m < M ? W[k * M + m] : 0.f;
   }
   if (threadIdx.x < MMAX) bl[threadIdx.x] = (bias != nullptr && int(threadIdx.x) < M) ? bias[threadIdx.x] : 0.f;
-  const int64_t ntiles = (rows + 255) >> 8, total = rows * K;
-  // A tile is 256*K floats = 64*K quads (16-byte aligned: 1024*K bytes per tile); thread t fetches quads t, t+256, ...
-  // (at most 8 for K <= 32, all in flight together), then scatters the four floats of each to (row, column).
-  const int nq = 64 * K;
+  const int64_t ntiles = (rows + R - 1) / R, total = rows * K;
+  // A tile is R*K floats = R*K/4 quads (16-byte aligned: R*K*4 bytes per tile, R a multiple of 4); thread t fetches
+  // quads t, t+R, ... eight at a time (all in flight together), then scatters the four floats of each to (row, column).
+  const int nq = (R / 4) * K;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t base = tile * 256 * K;
-    f32x4 v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int q = int(threadIdx.x) + j * 256;
-      const int64_t e = base + 4 * int64_t(q);
-      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (q < nq) {
-        if (x_aligned16 && e + 3 < total) v[j] = *reinterpret_cast<const f32x4 *>(X + e);
-        else
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (e + u < total) v[j][u] = X[e + u];  // ragged end of the table
-      }
-    }
+    const int64_t base = tile * R * K;
     __syncthreads();  // weights visible (first trip) / previous tile's rows consumed
+    for (int q0 = 0; q0 < nq; q0 += 8 * NT) {
+      f32x4 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int q = int(threadIdx.x) + j * 256;
-      if (q < nq) {
-        int r = (4 * q) / K, c = 4 * q - r * K;
+      for (int j = 0; j < 8; j++) {
+        const int q = q0 + int(threadIdx.x) + j * NT;
+        const int64_t e = base + 4 * int64_t(q);
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < nq) {
+          if (x_aligned16 && e + 3 < total) v[j] = *reinterpret_cast<const f32x4 *>(X + e);
+          else
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          xs[r * KS + c] = v[j][u];
-          if (++c == K) {
-            c = 0;
-            r++;
+            for (int u = 0; u < 4; u++)
+              if (e + u < total) v[j][u] = X[e + u];  // ragged end of the table / unaligned base
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int q = q0 + int(threadIdx.x) + j * NT;
+        if (q < nq) {
+          int r = (4 * q) / K, c = 4 * q - r * K;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            xs[r * KS + c] = v[j][u];
+            if (++c == K) {
+              c = 0;
+              r++;
+            }
           }
         }
       }
@@ -557,11 +562,18 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float *__restri
     float acc[MMAX];
 #pragma unroll
     for (int m = 0; m < MMAX; m++) acc[m] = 0.f;
-    const float *xr = xs + threadIdx.x * KS;
-    for (int k = 0; k < K; k++) {
+    const int lrow = int(threadIdx.x) / TPR, kg = int(threadIdx.x) % TPR;
+    const float *xr = xs + lrow * KS;
+    for (int k = kg; k < K; k += TPR) {
       const float x = xr[k];
 #pragma unroll
       for (int m = 0; m < MMAX; m++) acc[m] = fmaf(x, wl[k * MMAX + m], acc[m]);
+    }
+    if constexpr (TPR > 1) {
+#pragma unroll
+      for (int o = 1; o < TPR; o <<= 1)
+#pragma unroll
+        for (int m = 0; m < MMAX; m++) acc[m] += __shfl_xor(acc[m], o);
     }
     dispatch_act(act.kind, [&](auto kind_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
@@ -585,8 +597,8 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float *__restri
 #pragma unroll
       for (int m = 0; m < MMAX; m++) acc[m] = SM == 1 ? acc[m] / sum : acc[m] - ls;
     }
-    const int64_t row = tile * 256 + threadIdx.x;
-    if (row < rows) {
+    const int64_t row = tile * R + lrow;
+    if (row < rows && kg == 0) {
       float *y = Y + row * M;
       if (MMAX >= 4 && M == MMAX && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {  // whole quads, 16-byte aligned rows
 #pragma unroll
@@ -600,21 +612,28 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float *__restri
   }
 }
 
-static bool skinny_ok(int K, int M) { return K >= 1 && K <= 32 && M >= 1 && M <= 16; }
+// K <= 32 always; wider rows (up to 128 floats) when the 16x16x4 streaming kernel cannot take them (K % 16 != 0)
+static bool skinny_ok(int K, int M) { return M >= 1 && M <= 16 && K >= 1 && (K <= 32 || (K <= 128 && K % 16 != 0)); }
 
 static void launch_skinny(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
                           ActParam act, int softmax_mode) {
   const int mmax = M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : 16;
-  const size_t lds = (size_t(K) * mmax + mmax + 256 * size_t(K | 1)) * sizeof(float);
-  const int64_t ntiles = (rows + 255) / 256;
+  const bool wide = K > 32;  // 64 rows x 4 threads per row; else 256 rows, one thread each
+  const int R = wide ? 64 : 256;
+  const size_t lds = (size_t(K) * mmax + mmax + size_t(R) * size_t(K | 1)) * sizeof(float);
+  const int64_t ntiles = (rows + R - 1) / R;
   const unsigned grid = unsigned(std::min<int64_t>(ntiles, 256 * 8));
   const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
   auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, X, W, bias, Y, rows, K, M, act, aligned); };
+  auto by_r = [&](auto mm, auto smt) {
+    constexpr int MM = decltype(mm)::value, SMv = decltype(smt)::value;
+    if (wide) go(dense_skinny_kernel<MM, SMv, 64, 4>);
+    else go(dense_skinny_kernel<MM, SMv, 256, 1>);
+  };
   auto by_sm = [&](auto mm) {
-    constexpr int MM = decltype(mm)::value;
-    if (softmax_mode == 0) go(dense_skinny_kernel<MM, 0>);
-    else if (softmax_mode == 1) go(dense_skinny_kernel<MM, 1>);
-    else go(dense_skinny_kernel<MM, 2>);
+    if (softmax_mode == 0) by_r(mm, std::integral_constant<int, 0>{});
+    else if (softmax_mode == 1) by_r(mm, std::integral_constant<int, 1>{});
+    else by_r(mm, std::integral_constant<int, 2>{});
   };
   switch (mmax) {
     case 1: by_sm(std::integral_constant<int, 1>{}); break;

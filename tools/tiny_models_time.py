@@ -2,7 +2,7 @@ import os, sys, tempfile
 sys.path.insert(0, os.getcwd())
 from infera_amd import capi, onnx_writer as W
 d = tempfile.mkdtemp(); dev = capi.device_ordinal(0)
-for dims, sm in [((3, 1), False), ((13, 1), False), ((30, 1), False), ((4, 3), True), ((30, 2), True), ((100, 10), True), ((128, 10), True), ((64, 1), False), ((20, 16, 1), False), ((30, 8, 1), False)]:
+for dims, sm in [((3, 1), False), ((13, 1), False), ((30, 1), False), ((4, 3), True), ((30, 2), True), ((100, 10), True), ((128, 10), True), ((64, 1), False), ((20, 16, 1), False), ((30, 8, 1), False), ((50, 1), False), ((100, 1), False), ((77, 5), True)]:
     rows = 20_000_000
     name = "t" + "x".join(map(str, dims))
     capi.load_model(name, W.write(f"{d}/{name}.onnx", W.mlp(dims, final_softmax=sm)))
