@@ -2,6 +2,7 @@
 //
 // Fusions performed while walking the (topologically sorted) node list:
 //   MatMul + Add(const [M])            -> Dense with bias
+//   per-feature (x-mean)/std, x*s+t ... + MatMul/Gemm -> folded into the Dense weights and bias
 //   Gemm(transB, alpha, beta)          -> Dense (constants folded into W / bias)
 //   Dense|Conv|Binary|Affine + act     -> trailing activation fused into the producing step
 //   Conv + BatchNormalization          -> BN folded into conv weights/bias
@@ -139,12 +140,44 @@ struct Lowerer {
     const auto &w = cf32(n, b);
     int64_t K = tB ? b.shape[1] : b.shape[0], M = tB ? b.shape[0] : b.shape[1];
     if (a.shape[1] != K) unsupported(n, "inner dimensions differ: " + shape_str(a.shape) + " x " + shape_str(b.shape));
+    int in_buf = a.buf;
+    const std::vector<int64_t> a_shape = a.shape;
+    // Per-feature affine preprocessing in front of the layer -- (x - mean) / std, x * scale + shift: the sklearn
+    // StandardScaler / MinMaxScaler + linear model pipeline -- is folded into the weights:
+    //   ((x (op) c) . W + b)  ==  x . (s W) + (b + t . W)   with x' = s x + t composed over the chain,
+    // so the elementwise passes over the table disappear (exact algebra; rounding differs within the tolerance).
+    // Only when the preprocessing value has no other consumer and its steps are the last ones emitted.
+    std::vector<double> fs(size_t(K), 1.0), ft(size_t(K), 0.0);
+    bool folded = false;
+    std::string folded_origin;
+    for (;;) {
+      auto pit = producer.find(in_buf);
+      if (in_buf <= 0 || pit == producer.end() || pit->second != int(plan.steps.size()) - 1 || live_uses(in_buf) != 1) break;
+      const Step &p = plan.steps.back();
+      if (p.kind != StepKind::BinaryConst || p.act != Act::None || int64_t(p.cst.size()) != K) break;
+      if (p.bop != '+' && p.bop != '-' && p.bop != '*' && !(p.bop == '/' && !p.const_left)) break;
+      for (int64_t k = 0; k < K; k++) {
+        const double c = p.cst[size_t(k)], sk = fs[size_t(k)], tk = ft[size_t(k)];
+        switch (p.bop) {
+          case '+': ft[size_t(k)] = sk * c + tk; break;
+          case '-':
+            if (p.const_left) { fs[size_t(k)] = -sk; ft[size_t(k)] = sk * c + tk; }  // c - u
+            else ft[size_t(k)] = tk - sk * c;
+            break;
+          case '*': fs[size_t(k)] = sk * c; break;
+          default: fs[size_t(k)] = sk / c; break;
+        }
+      }
+      folded = true;
+      folded_origin = p.origin + (folded_origin.empty() ? "" : "+" + folded_origin);
+      in_buf = p.in0;
+      producer.erase(pit);
+      plan.steps.pop_back();
+    }
     // A wide layer over rows whose length is not a multiple of 4 floats (30 features, ...): copy the rows into a
     // zero-padded matrix first so the MFMA kernels can read them in 16-byte quads; the padded k carry zero weights.
     // (Narrow heads stream their input once and take any K.)
     const int64_t Kp = (M > 32 && K % 4 != 0) ? (K + 3) / 4 * 4 : K;
-    int in_buf = a.buf;
-    const std::vector<int64_t> a_shape = a.shape;
     if (Kp != K) {
       Step p;
       p.kind = StepKind::PadCols;
@@ -178,7 +211,19 @@ struct Lowerer {
         s.bias[size_t(j)] = beta == 1.f ? v : beta * v;
       }
     }
-    emit(std::move(s), n, {a_shape[0], M});
+    if (folded) {
+      std::vector<double> extra(size_t(M), 0.0);
+      for (int64_t k = 0; k < K; k++)
+        for (int64_t j = 0; j < M; j++) {
+          const double wkj = s.W[size_t(k * M + j)];
+          extra[size_t(j)] += ft[size_t(k)] * wkj;
+          s.W[size_t(k * M + j)] = float(fs[size_t(k)] * wkj);
+        }
+      if (s.bias.empty()) s.bias.assign(size_t(M), 0.f);
+      for (int64_t j = 0; j < M; j++) s.bias[size_t(j)] = float(double(s.bias[size_t(j)]) + extra[size_t(j)]);
+    }
+    Step &e = emit(std::move(s), n, {a_shape[0], M});
+    if (folded) e.origin = folded_origin + "+" + e.origin;
   }
 
   // Broadcast a constant against an activation's per-row shape; returns per_row floats.

@@ -320,6 +320,48 @@ def test_gpu_multi_input_split_slice(api, O, tmp_path):
     api.unload_model("wd")
 
 
+def _scaler_pipeline(tmp_path, k=30, m=1):
+    """sklearn-style Pipeline(StandardScaler, MinMax-ish rescale, LogisticRegression): Sub(mean) -> Div(std) -> Mul -> Add -> Gemm -> Sigmoid."""
+    rng = np.random.default_rng(21)
+    mean, std = rng.standard_normal(k).astype(np.float32), (0.5 + rng.random(k)).astype(np.float32)
+    sc, sh = (0.5 + rng.random(k)).astype(np.float32), rng.standard_normal(k).astype(np.float32) * 0.1
+    w, b = (rng.standard_normal((k, m)) * 0.3).astype(np.float32), rng.standard_normal(m).astype(np.float32)
+    nodes = [W.node("Sub", ["X", "mean"], ["c"]), W.node("Div", ["c", "std"], ["z"]), W.node("Mul", ["sc", "z"], ["u"]), W.node("Add", ["u", "sh"], ["v"]),
+             W.node("Gemm", ["v", "w", "b"], ["logit"]), W.node("Sigmoid", ["logit"], ["Y"])]
+    inits = [W.tensor("mean", mean), W.tensor("std", std), W.tensor("sc", sc), W.tensor("sh", sh), W.tensor("w", w), W.tensor("b", b)]
+    blob = W.model("scaler_logreg", nodes, inits, [W.value_info("X", ["N", k])], [W.value_info("Y", ["N", m])])
+
+    def ref(x):
+        v = ((x.astype(np.float64) - mean) / std) * sc + sh
+        return 1 / (1 + np.exp(-(v @ w + b)))
+
+    return W.write(str(tmp_path / "scaler_logreg.onnx"), blob), ref
+
+
+def test_scaler_pipeline_folds_into_the_linear_layer(O, built, tmp_path):
+    from infera_amd import capi
+
+    path, ref = _scaler_pipeline(tmp_path)
+    x = synth.table(41, 0, 64, 30)
+    assert_close(O.Model(path).predict(x), ref(x).astype(np.float32), rtol=2e-5, atol=2e-6)
+    capi.load_model("sp", path)
+    steps = capi.get_plan("sp")["plan"]["steps"]
+    assert [s["kind"] for s in steps] == ["Dense"], steps  # four elementwise passes over the table folded into W and b
+    assert steps[0]["origin"] == "Sub+Div+Mul+Add+Gemm+Sigmoid", steps[0]["origin"]
+    capi.unload_model("sp")
+
+
+@pytest.mark.gpu
+def test_gpu_scaler_pipeline(api, O, tmp_path):
+    path, ref = _scaler_pipeline(tmp_path)
+    x = synth.table(41, 0, 5003, 30)
+    api.load_model("sp", path)
+    got = api.predict("sp", x)
+    assert_close(got, O.Model(path).predict(x))
+    assert_close(got, ref(x).astype(np.float32), rtol=2e-5, atol=2e-6)
+    api.unload_model("sp")
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
