@@ -239,9 +239,19 @@ void schedule(LoadedModel &m) {
     // Dense + row Softmax over exactly its M outputs: softmax in the GEMM epilogue
     if (i + 1 < n && st[i].kind == StepKind::Dense && st[i + 1].kind == StepKind::Softmax && st[i + 1].in0 == st[i].out &&
         uses[size_t(st[i].out)] == 1 && st[i + 1].sm_outer == 1 && st[i + 1].sm_inner == 1 && st[i + 1].sm_len == st[i].M &&
-        st[i].M <= 64) {
+        st[i].M <= 64 && st[i + 1].sm_norm == 0) {
       m.exec[i] = ExecKind::DenseSoftmax;
       m.exec[i + 1] = ExecKind::Skipped;
+      i += 1;
+      continue;
+    }
+    // Dense + ArgMax over exactly its M scores (a classifier's label): the label is picked in the GEMM epilogue and
+    // the scores never reach memory.  Both buffers stay planned: the launch falls back to the two kernels when the
+    // input pointer it meets at run time cannot feed a kernel with that epilogue (dense_can_fuse_argmax).
+    if (i + 1 < n && st[i].kind == StepKind::Dense && st[i + 1].kind == StepKind::ArgMax && st[i + 1].in0 == st[i].out &&
+        uses[size_t(st[i].out)] == 1 && st[i + 1].K == st[i].M && st[i].M <= 16 &&
+        kern::dense_can_fuse_argmax(nullptr, int(st[i].K), int(st[i].M))) {
+      m.exec[i] = ExecKind::DenseArgMax;
       i += 1;
     }
   }
@@ -459,6 +469,13 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
             throw InferaError::onnx("fused MLP kernel launch failed: " + why);
           continue;
         }
+        case ExecKind::DenseArgMax:
+          if (kern::dense_can_fuse_argmax(buf(x.in0), int(x.K), int(x.M))) {
+            kern::dense(s, buf(x.in0), d.W, d.bias, buf(st[i + 1].out), nr, int(x.K), int(x.M), act_of(x), 3);
+            i += 1;  // the ArgMax step is done
+            continue;
+          }
+          break;  // as two kernels
         case ExecKind::DenseSoftmax:
           kern::dense(s, buf(x.in0), d.W, d.bias, buf(st[i + 1].out), nr, int(x.K), int(x.M), act_of(x),
                       st[i + 1].log_softmax ? 2 : 1);
@@ -501,7 +518,7 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           if (x.S > 1) kern::binary_gate(s, buf(x.in0), buf(x.in1), buf(x.out), nr, x.C, x.S, x.bop, act_of(x), m.cq_mode && x.in0 != 0);
           else kern::binary_act(s, buf(x.in0), buf(x.in1), buf(x.out), nr * p.buf_per_row[size_t(x.out)], x.bop, act_of(x));
           break;
-        case StepKind::Softmax: kern::softmax(s, buf(x.in0), buf(x.out), nr, x.sm_outer, x.sm_len, x.sm_inner, x.log_softmax); break;
+        case StepKind::Softmax: kern::softmax(s, buf(x.in0), buf(x.out), nr, x.sm_outer, x.sm_len, x.sm_inner, x.sm_norm ? 1 + x.sm_norm : int(x.log_softmax)); break;
         case StepKind::Conv2d: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
@@ -754,7 +771,7 @@ void sync_device(int device_ordinal) {
 hipStream_t thread_stream(int device_ordinal) { return ctx_for_slot(slot_of_ordinal(device_ordinal)).stream; }
 
 std::string LoadedModel::describe_json() const {
-  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch", "conv_depthwise", "dense_tiled"};
+  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch", "conv_depthwise", "dense_tiled", "dense_argmax"};
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";

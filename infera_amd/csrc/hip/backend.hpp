@@ -35,7 +35,7 @@ struct DeviceStep {
 };
 
 // How the executor runs a step.
-enum class ExecKind : int { Normal = 0, Skipped = 1, Mlp3Head = 2, DenseSoftmax = 3, ConvTiled = 4, ConvPatch = 5, ConvDepthwise = 6, DenseTiled = 7 };
+enum class ExecKind : int { Normal = 0, Skipped = 1, Mlp3Head = 2, DenseSoftmax = 3, ConvTiled = 4, ConvPatch = 5, ConvDepthwise = 6, DenseTiled = 7, DenseArgMax = 8 };
 
 struct DeviceModel {
   int device = -1;  // HIP ordinal

@@ -254,6 +254,29 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow_kernel(const float *_
 // latency of 40 cycles is hidden by alternating them).
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
+// ArgMax epilogue of the 16x16x4 kernels (SM == 3): the row's M scores live in v[0..3] of lanes n, n+16, n+32, n+48
+// (feature 4q+i).  Returns the index of the first maximum (ties -> lowest index, like the stand-alone kernel).
+__device__ __forceinline__ float argmax_over_quads(const f32x4 &v, int q, int M) {
+  float bv = -INFINITY;
+  int bi = 4 * q;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (4 * q + i < M && v[i] > bv) {
+      bv = v[i];
+      bi = 4 * q + i;
+    }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    const float ov = __shfl_xor(bv, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  return float(bi);
+}
+
 template <int SM>
 __global__ __launch_bounds__(WAVES * 64) void dense_narrow16_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                    const float *__restrict__ bias, float *__restrict__ Y,
@@ -320,7 +343,12 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16_kernel(const float 
 #pragma unroll
         for (int i = 0; i < 4; i++) v[i] = apply_act_c<KIND>(v[i] + bq[i], act.a, act.b);
       });
-      if constexpr (SM != 0) {  // the row's features live in lanes n, n+16, n+32, n+48
+      if constexpr (SM == 3) {  // label only: one float per row
+        const float label = argmax_over_quads(v, q, M);
+        if (valid[t] && q == 0) Y[row[t]] = label;
+        continue;
+      }
+      if constexpr (SM == 1 || SM == 2) {  // the row's features live in lanes n, n+16, n+32, n+48
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -445,7 +473,12 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16s_kernel(const float
 #pragma unroll
         for (int i = 0; i < 4; i++) v[i] = apply_act_c<KIND>(v[i] + bq[i], act.a, act.b);
       });
-      if constexpr (SM != 0) {  // the row's features live in lanes n, n+16, n+32, n+48
+      if constexpr (SM == 3) {  // label only: one float per row
+        const float label = argmax_over_quads(v, q, M);
+        if (row < rows && q == 0) Y[row] = label;
+        continue;
+      }
+      if constexpr (SM == 1 || SM == 2) {  // the row's features live in lanes n, n+16, n+32, n+48
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -495,66 +528,243 @@ static void launch_narrow16s(hipStream_t s, const float *X, const float *W, cons
   };
   if (softmax_mode == 0) go(dense_narrow16s_kernel<K, 0>);
   else if (softmax_mode == 1) go(dense_narrow16s_kernel<K, 1>);
-  else go(dense_narrow16s_kernel<K, 2>);
+  else if (softmax_mode == 2) go(dense_narrow16s_kernel<K, 2>);
+  else go(dense_narrow16s_kernel<K, 3>);
 }
 
-// ---- skinny layers: few features (K <= 32, or <= 128 when not a multiple of 16), M <= 16 outputs --------------
+// ---- any row length: the 16x16x4 kernel for tables whose rows are not 64/128/256 floats -------------------------
+// Real feature tables have 13, 30, 77, 100 columns: rows are not 16-byte aligned and K is no multiple of the MFMA's
+// k-group.  The table is still one contiguous run of floats, so a wave fetches its 32 rows (32*K floats, a 128*K-byte
+// aligned block) with perfectly coalesced 16-byte loads -- exactly as the bytes lie -- and scatters each float to
+// (row, column) of its LDS tile; the tile's rows are KP = 16*ceil(K/16) + 4 floats apart (KP/4 odd: the ds_read_b128
+// operand reads of 16 rows hit 16 different bank quads), columns K..16*ceil(K/16) are zeroed once and meet zero
+// weights.  From there on it is the narrow16s kernel: B = X[row n][16g+4q+j], A = W fragment-major in LDS, two
+// independent 16-row accumulators per wave, next tile's loads in flight during the MFMAs, epilogue in registers.
+// NL = 16-byte loads per lane per tile (ceil(K/8)), a compile-time bucket so the prefetch registers are static.
+template <int SM, int NL>
+__global__ __launch_bounds__(WAVES * 64) void dense_narrow16g_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                                    const float *__restrict__ bias, float *__restrict__ Y,
+                                                                    int64_t rows, int K, int M, ActParam act, bool x_aligned16) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [G][64][4] weights, then WAVES x [32 rows][KP] tiles
+  const int G = (K + 15) >> 4, KP = 16 * G + 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 15, q = lane >> 4;
+  for (int i = threadIdx.x; i < G * 256; i += WAVES * 64) {
+    const int g = i >> 8, l = (i >> 2) & 63, j = i & 3;
+    const int k = 16 * g + 4 * (l >> 4) + j, m = l & 15;
+    smem[i] = (m < M && k < K) ? W[int64_t(k) * M + m] : 0.f;
+  }
+  float *xs = smem + G * 256 + wave * (32 * KP);
+  for (int i = lane; i < 32 * (KP - K); i += 64) {  // the columns no table float ever lands in
+    const int r = i / (KP - K), c = K + i % (KP - K);
+    xs[r * KP + c] = 0.f;
+  }
+  __syncthreads();
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(smem) + lane;
+  float bq[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) bq[i] = (bias != nullptr && 4 * q + i < M) ? bias[4 * q + i] : 0.f;
+  // quad p = i*64 + lane of a tile holds floats 4p..4p+3 of its 32*K: where they go in the LDS tile.  Quads past the
+  // tile (the last load instruction is partly idle unless K % 8 == 0) re-read the tile's last quad and park it in the
+  // four never-read floats behind row 31, so neither the loads nor the LDS writes need a branch.
+  const int nq = 8 * K;
+  int slot[NL], col[NL], pq[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int p = i * 64 + lane, e = 4 * p, r = e / K;
+    pq[i] = min(p, nq - 1);
+    col[i] = p < nq ? e - r * K : 0;
+    slot[i] = p < nq ? r * KP + col[i] : 31 * KP + 16 * G;
+  }
+  const int64_t ntiles = (rows + 31) >> 5, total = rows * K;
+  const int64_t full_tiles = x_aligned16 ? rows >> 5 : 0;  // tiles that lie inside the table and start 16-byte aligned
+  const int64_t tstride = int64_t(gridDim.x) * WAVES;
+  auto fetch = [&](f32x4(&v)[NL], int64_t tile) {
+    if (tile < full_tiles) {  // wave-uniform: straight-line loads, all in flight together
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(X + tile * 32 * K);
+#pragma unroll
+      for (int i = 0; i < NL; i++) v[i] = src[pq[i]];
+      return;
+    }
+    const int64_t base = tile * 32 * K;  // ragged end of the table / unaligned base: element by element
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int64_t e = base + 4 * int64_t(pq[i]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[i][u] = e + u < total ? X[e + u] : 0.f;
+    }
+  };
+  f32x4 stage[NL];
+  int64_t tile = int64_t(blockIdx.x) * WAVES + wave;
+  if (tile < ntiles) fetch(stage, tile);
+  const float *x0p = xs + n * KP + 4 * q, *x1p = xs + (16 + n) * KP + 4 * q;
+  for (; tile < ntiles; tile += tstride) {
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) xs[slot[i] + u + (col[i] + u >= K ? KP - K : 0)] = stage[i][u];  // K >= 4: one wrap at most
+    if (tile + tstride < ntiles) fetch(stage, tile + tstride);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // operands of group g+1 are read while the eight MFMAs of group g run
+    f32x4 x0 = *reinterpret_cast<const f32x4 *>(x0p), x1 = *reinterpret_cast<const f32x4 *>(x1p), a0 = wq[0];
+    for (int g = 0; g < G; g++) {
+      const int gn = g + 1 < G ? g + 1 : g;
+      const f32x4 nx0 = *reinterpret_cast<const f32x4 *>(x0p + 16 * gn), nx1 = *reinterpret_cast<const f32x4 *>(x1p + 16 * gn);
+      const f32x4 na0 = wq[gn * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x1[j], acc[1], 0, 0, 0);
+      }
+      x0 = nx0;
+      x1 = nx1;
+      a0 = na0;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int64_t row = (tile << 5) + 16 * t + n;
+      f32x4 v = acc[t];
+      dispatch_act(act.kind, [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = apply_act_c<KIND>(v[i] + bq[i], act.a, act.b);
+      });
+      if constexpr (SM == 3) {  // label only: one float per row
+        const float label = argmax_over_quads(v, q, M);
+        if (row < rows && q == 0) Y[row] = label;
+        continue;
+      }
+      if constexpr (SM == 1 || SM == 2) {  // the row's features live in lanes n, n+16, n+32, n+48
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) mx = fmaxf(mx, v[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) {
+            const float e = expf(v[i] - mx);
+            sum += e;
+            v[i] = SM == 1 ? e : v[i] - mx;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float ls = logf(sum);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = SM == 1 ? v[i] / sum : v[i] - ls;
+      }
+      if (row < rows) {
+        float *yrow = Y + row * M + 4 * q;
+        if ((M & 1) == 0 && 4 * q + 3 < M) {  // row stride M*4 is 8-byte aligned: two 8-byte stores
+          *reinterpret_cast<f32x2 *>(yrow) = f32x2{v[0], v[1]};
+          *reinterpret_cast<f32x2 *>(yrow + 2) = f32x2{v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (4 * q + i < M) yrow[i] = v[i];
+        }
+      }
+    }
+  }
+}
+
+// Everything up to 128 columns that the 64/128-column kernel does not take, except the shortest rows with one or two
+// outputs (measured: the one-lane-per-row VALU kernel below is a few percent ahead for K <= 32, M <= 2).
+static bool narrow16g_ok(int K, int M) {
+  static const int min_m = getenv("INFERA_DENSE16G_MIN_M") ? atoi(getenv("INFERA_DENSE16G_MIN_M")) : 3;
+  return M >= 1 && M <= 16 && K >= 8 && K <= 128 && K != 64 && K != 128 && (K > 32 || M >= min_m);
+}
+
+static void launch_narrow16g(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
+                             ActParam act, int softmax_mode) {
+  const int G = (K + 15) / 16, KP = 16 * G + 4;
+  const int64_t ntiles = (rows + 31) / 32;
+  const size_t lds = (size_t(G) * 256 + size_t(WAVES) * 32 * KP) * sizeof(float);
+  const int per_cu = int(std::clamp<size_t>((160 * 1024) / lds, 1, 8));
+  const int64_t blocks = std::min<int64_t>((ntiles + WAVES - 1) / WAVES, 256 * per_cu);
+  const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  dim3 grid((unsigned)blocks), block(WAVES * 64);
+  auto go = [&](auto kernel) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, X, W, bias, Y, rows, K, M, act, aligned);
+  };
+  auto by_nl = [&](auto smt) {
+    constexpr int SMv = decltype(smt)::value;
+    if (K <= 32) go(dense_narrow16g_kernel<SMv, 4>);
+    else if (K <= 64) go(dense_narrow16g_kernel<SMv, 8>);
+    else go(dense_narrow16g_kernel<SMv, 16>);
+  };
+  if (softmax_mode == 0) by_nl(std::integral_constant<int, 0>{});
+  else if (softmax_mode == 1) by_nl(std::integral_constant<int, 1>{});
+  else if (softmax_mode == 2) by_nl(std::integral_constant<int, 2>{});
+  else by_nl(std::integral_constant<int, 3>{});
+}
+
+// ---- skinny layers: rows of at most 32 floats, M <= 16 outputs ----------------------------------------------------
 // The most common in-database models are a handful of multiply-adds per row: no matrix core can help, and the
 // MFMA kernels' 16-byte operand loads do not even apply (rows of 3, 13, 30 floats are not 16-byte aligned).
 // The table is streamed exactly as it lies in memory -- R rows = one contiguous R*K-float run, fetched with
 // perfectly coalesced loads into LDS (row stride K|1: conflict-free) -- and each lane then owns one row: a
 // k-ordered fmaf chain per output with the weights broadcast from LDS (the oracle's own summation order, so
-// results are bit-identical), bias, activation and the optional row softmax in registers.
-// TPR threads share a row (wider rows): thread g of a row takes k = g, g + TPR, ... and the partial sums meet in a
-// butterfly over the TPR adjacent lanes (a different summation order than the k-ordered chain; TPR = 1 keeps it).
-template <int MMAX, int SM, int R, int TPR>
-__global__ __launch_bounds__(R * TPR) void dense_skinny_kernel(const float *__restrict__ X, const float *__restrict__ W,
-                                                          const float *__restrict__ bias, float *__restrict__ Y, int64_t rows, int K,
-                                                          int M, ActParam act, bool x_aligned16) {
-  extern __shared__ __attribute__((aligned(16))) float sk[];  // [K][MMAX] weights (zero-padded), [MMAX] bias, [R][KS] rows
+// results are bit-identical), bias, activation and the optional row softmax / argmax in registers.
+template <int MMAX, int SM, int R>
+__global__ __launch_bounds__(R) void dense_skinny_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float *__restrict__ Y, int64_t rows, int K,
+                                                         int M, ActParam act, bool x_aligned16) {
+  extern __shared__ __attribute__((aligned(16))) float sk[];  // [K][MMAX] weights (zero-padded), [MMAX] bias, [R][KS] rows, 4 spare
   const int KS = K | 1;
   float *wl = sk, *bl = sk + K * MMAX, *xs = bl + MMAX;
-  constexpr int NT = R * TPR;
-  for (int i = threadIdx.x; i < K * MMAX; i += NT) {
+  for (int i = threadIdx.x; i < K * MMAX; i += R) {
     const int k = i / MMAX, m = i - k * MMAX;
     wl[i] = m < M ? W[k * M + m] : 0.f;
   }
   if (threadIdx.x < MMAX) bl[threadIdx.x] = (bias != nullptr && int(threadIdx.x) < M) ? bias[threadIdx.x] : 0.f;
   const int64_t ntiles = (rows + R - 1) / R, total = rows * K;
+  const int64_t full_tiles = x_aligned16 ? rows / R : 0;
   // A tile is R*K floats = R*K/4 quads (16-byte aligned: R*K*4 bytes per tile, R a multiple of 4); thread t fetches
-  // quads t, t+R, ... eight at a time (all in flight together), then scatters the four floats of each to (row, column).
-  const int nq = (R / 4) * K;
+  // quads t, t+R, ... (K <= 32: at most eight, all in flight together), then scatters the four floats of each to
+  // (row, column).  Threads past the tile's last quad re-read it and park it in the spare floats: no branches.
+  constexpr int NQ = 8;
+  const int nq = (R / 4) * K, nj = (K + 3) / 4;  // nj = load instructions a tile needs (wave-uniform)
+  int pq[NQ], r0[NQ], c0[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; j++) {
+    const int q = int(threadIdx.x) + j * R;
+    pq[j] = min(q, nq - 1);
+    r0[j] = (4 * q) / K;
+    c0[j] = 4 * q - r0[j] * K;
+    if (q >= nq) r0[j] = c0[j] = -8;  // parked: stays negative through the four column steps below
+  }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * R * K;
-    __syncthreads();  // weights visible (first trip) / previous tile's rows consumed
-    for (int q0 = 0; q0 < nq; q0 += 8 * NT) {
-      f32x4 v[8];
+    f32x4 v[NQ];
+    if (tile < full_tiles) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(X + base);
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int q = q0 + int(threadIdx.x) + j * NT;
-        const int64_t e = base + 4 * int64_t(q);
-        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (q < nq) {
-          if (x_aligned16 && e + 3 < total) v[j] = *reinterpret_cast<const f32x4 *>(X + e);
-          else
+      for (int j = 0; j < NQ; j++)
+        if (j < nj) v[j] = src[pq[j]];
+    } else {  // ragged end of the table / unaligned base
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-              if (e + u < total) v[j][u] = X[e + u];  // ragged end of the table / unaligned base
-        }
+      for (int j = 0; j < NQ; j++) {
+        if (j >= nj) break;
+        const int64_t e = base + 4 * int64_t(pq[j]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[j][u] = e + u < total ? X[e + u] : 0.f;
       }
+    }
+    __syncthreads();  // weights visible (first trip) / previous tile's rows consumed
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int q = q0 + int(threadIdx.x) + j * NT;
-        if (q < nq) {
-          int r = (4 * q) / K, c = 4 * q - r * K;
+    for (int j = 0; j < NQ; j++) {
+      if (j >= nj) break;
+      int r = r0[j], c = c0[j];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            xs[r * KS + c] = v[j][u];
-            if (++c == K) {
-              c = 0;
-              r++;
-            }
-          }
+      for (int u = 0; u < 4; u++) {
+        xs[c < 0 ? R * KS + u : r * KS + c] = v[j][u];
+        if (++c == K) {
+          c = 0;
+          r++;
         }
       }
     }
@@ -562,25 +772,32 @@ __global__ __launch_bounds__(R * TPR) void dense_skinny_kernel(const float *__re
     float acc[MMAX];
 #pragma unroll
     for (int m = 0; m < MMAX; m++) acc[m] = 0.f;
-    const int lrow = int(threadIdx.x) / TPR, kg = int(threadIdx.x) % TPR;
+    const int lrow = int(threadIdx.x);
     const float *xr = xs + lrow * KS;
-    for (int k = kg; k < K; k += TPR) {
+    for (int k = 0; k < K; k++) {
       const float x = xr[k];
 #pragma unroll
       for (int m = 0; m < MMAX; m++) acc[m] = fmaf(x, wl[k * MMAX + m], acc[m]);
-    }
-    if constexpr (TPR > 1) {
-#pragma unroll
-      for (int o = 1; o < TPR; o <<= 1)
-#pragma unroll
-        for (int m = 0; m < MMAX; m++) acc[m] += __shfl_xor(acc[m], o);
     }
     dispatch_act(act.kind, [&](auto kind_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
       for (int m = 0; m < MMAX; m++) acc[m] = apply_act_c<KIND>(acc[m] + bl[m], act.a, act.b);
     });
-    if constexpr (SM != 0) {
+    const int64_t row = tile * R + lrow;
+    if constexpr (SM == 3) {  // ArgMax over the M scores: the label is the only thing written
+      float best = acc[0];
+      int bi = 0;
+#pragma unroll
+      for (int m = 1; m < MMAX; m++)
+        if (m < M && acc[m] > best) {
+          best = acc[m];
+          bi = m;
+        }
+      if (row < rows) Y[row] = float(bi);
+      continue;
+    }
+    if constexpr (SM == 1 || SM == 2) {
       float mx = -INFINITY;
 #pragma unroll
       for (int m = 0; m < MMAX; m++)
@@ -597,8 +814,7 @@ __global__ __launch_bounds__(R * TPR) void dense_skinny_kernel(const float *__re
 #pragma unroll
       for (int m = 0; m < MMAX; m++) acc[m] = SM == 1 ? acc[m] / sum : acc[m] - ls;
     }
-    const int64_t row = tile * R + lrow;
-    if (row < rows && kg == 0) {
+    if (row < rows) {
       float *y = Y + row * M;
       if (MMAX >= 4 && M == MMAX && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {  // whole quads, 16-byte aligned rows
 #pragma unroll
@@ -612,28 +828,24 @@ __global__ __launch_bounds__(R * TPR) void dense_skinny_kernel(const float *__re
   }
 }
 
-// K <= 32 always; wider rows (up to 128 floats) when the 16x16x4 streaming kernel cannot take them (K % 16 != 0)
-static bool skinny_ok(int K, int M) { return M >= 1 && M <= 16 && K >= 1 && (K <= 32 || (K <= 128 && K % 16 != 0)); }
+// rows of up to 32 floats (wider ones go to the 16x16x4 kernels above)
+static bool skinny_ok(int K, int M) { return M >= 1 && M <= 16 && K >= 1 && K <= 32; }
 
 static void launch_skinny(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
                           ActParam act, int softmax_mode) {
   const int mmax = M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : 16;
-  const bool wide = K > 32;  // 64 rows x 4 threads per row; else 256 rows, one thread each
-  const int R = wide ? 64 : 256;
-  const size_t lds = (size_t(K) * mmax + mmax + size_t(R) * size_t(K | 1)) * sizeof(float);
+  constexpr int R = 256;  // rows per workgroup, one thread each
+  const size_t lds = (size_t(K) * mmax + mmax + size_t(R) * size_t(K | 1) + 4) * sizeof(float);
   const int64_t ntiles = (rows + R - 1) / R;
   const unsigned grid = unsigned(std::min<int64_t>(ntiles, 256 * 8));
   const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-  auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, X, W, bias, Y, rows, K, M, act, aligned); };
-  auto by_r = [&](auto mm, auto smt) {
-    constexpr int MM = decltype(mm)::value, SMv = decltype(smt)::value;
-    if (wide) go(dense_skinny_kernel<MM, SMv, 64, 4>);
-    else go(dense_skinny_kernel<MM, SMv, 256, 1>);
-  };
+  auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(R), lds, s, X, W, bias, Y, rows, K, M, act, aligned); };
   auto by_sm = [&](auto mm) {
-    if (softmax_mode == 0) by_r(mm, std::integral_constant<int, 0>{});
-    else if (softmax_mode == 1) by_r(mm, std::integral_constant<int, 1>{});
-    else by_r(mm, std::integral_constant<int, 2>{});
+    constexpr int MM = decltype(mm)::value;
+    if (softmax_mode == 0) go(dense_skinny_kernel<MM, 0, R>);
+    else if (softmax_mode == 1) go(dense_skinny_kernel<MM, 1, R>);
+    else if (softmax_mode == 2) go(dense_skinny_kernel<MM, 2, R>);
+    else go(dense_skinny_kernel<MM, 3, R>);
   };
   switch (mmax) {
     case 1: by_sm(std::integral_constant<int, 1>{}); break;
@@ -645,10 +857,15 @@ static void launch_skinny(hipStream_t s, const float *X, const float *W, const f
 }
 
 bool dense_can_fuse_softmax(int M) { return M <= 64; }
+// ArgMax epilogues (softmax_mode 3) exist in the skinny and the two 16x16x4 streaming kernels; the latter need 16-byte rows
+bool dense_can_fuse_argmax(const float *X, int K, int M) {
+  return narrow16g_ok(K, M) || skinny_ok(K, M) || (M <= 16 && K % 16 == 0 && K <= 1024 && (reinterpret_cast<uintptr_t>(X) & 15) == 0);
+}
 
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
            ActParam act, int softmax_mode) {
   if (rows <= 0) return;
+  if (narrow16g_ok(K, M)) return launch_narrow16g(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   if (skinny_ok(K, M)) return launch_skinny(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   static const bool staged16 = !(getenv("INFERA_DENSE16_STAGED") && atoi(getenv("INFERA_DENSE16_STAGED")) == 0);
   if (staged16 && M <= 16 && (K == 64 || K == 128 || K == 256) && rows >= 4096 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
@@ -665,9 +882,11 @@ void dense(hipStream_t s, const float *X, const float *W, const float *bias, flo
     dim3 grid((unsigned)blocks), block(WAVES * 64);
     if (softmax_mode == 0) hipLaunchKernelGGL((dense_narrow16_kernel<0>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
     else if (softmax_mode == 1) hipLaunchKernelGGL((dense_narrow16_kernel<1>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
-    else hipLaunchKernelGGL((dense_narrow16_kernel<2>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+    else if (softmax_mode == 2) hipLaunchKernelGGL((dense_narrow16_kernel<2>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+    else hipLaunchKernelGGL((dense_narrow16_kernel<3>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
     return;
   }
+  if (softmax_mode == 3) return;  // callers check dense_can_fuse_argmax first; nothing below has that epilogue
   if (M <= 32 && K % 8 == 0 && K <= 512 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
     const int64_t ntiles = (rows + 31) / 32;
     int64_t blocks = (ntiles + WAVES - 1) / WAVES;

@@ -81,12 +81,24 @@ __global__ __launch_bounds__(kBlock) void affine_channel_kernel(const float *__r
 // One lane per softmax vector when the vector is short (the common case here: 10 classes); the
 // vector's `len` elements are `inner` floats apart.  max / exp / sum / divide in the oracle's order.
 __global__ __launch_bounds__(kBlock) void softmax_small_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                              int64_t nvec, int64_t len, int64_t inner, bool logsm) {
+                                                              int64_t nvec, int64_t len, int64_t inner, int mode) {
   const int64_t stride = int64_t(gridDim.x) * kBlock;
+  const bool logsm = mode == 1;
   for (int64_t v = int64_t(blockIdx.x) * kBlock + threadIdx.x; v < nvec; v += stride) {
     const int64_t ou = v / inner, in = v % inner;
     const float *src = x + ou * len * inner + in;
     float *dst = y + ou * len * inner + in;
+    if (mode >= 2) {  // Normalizer: max|x| / sum|x| / sqrt(sum x^2), sequential like the oracle
+      float d = 0.f;
+      for (int64_t j = 0; j < len; j++) {
+        const float u = src[j * inner], a = fabsf(u);
+        d = mode == 2 ? fmaxf(d, a) : mode == 3 ? d + a : fmaf(u, u, d);
+      }
+      if (mode == 4) d = sqrtf(d);
+      d = fmaxf(d, 1e-30f);
+      for (int64_t j = 0; j < len; j++) dst[j * inner] = src[j * inner] / d;
+      continue;
+    }
     float mx = -INFINITY;
     for (int64_t j = 0; j < len; j++) mx = fmaxf(mx, src[j * inner]);
     float sum = 0.f;
@@ -103,13 +115,27 @@ __global__ __launch_bounds__(kBlock) void softmax_small_kernel(const float *__re
 // One wave per vector for long contiguous vectors (inner == 1): lanes stride the vector, the
 // reductions are wave shuffles over 64 lanes.  The sum is therefore tree-ordered, not sequential.
 __global__ __launch_bounds__(kBlock) void softmax_wave_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                             int64_t nvec, int64_t len, bool logsm) {
+                                                             int64_t nvec, int64_t len, int mode) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6;
   const int64_t nwaves = (int64_t(gridDim.x) * kBlock) >> 6;
+  const bool logsm = mode == 1;
   for (int64_t v = wave; v < nvec; v += nwaves) {
     const float *src = x + v * len;
     float *dst = y + v * len;
+    if (mode >= 2) {  // Normalizer
+      float d = 0.f;
+      for (int64_t j = lane; j < len; j += 64) {
+        const float u = src[j], a = fabsf(u);
+        d = mode == 2 ? fmaxf(d, a) : mode == 3 ? d + a : fmaf(u, u, d);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) d = mode == 2 ? fmaxf(d, __shfl_xor(d, o)) : d + __shfl_xor(d, o);
+      if (mode == 4) d = sqrtf(d);
+      d = fmaxf(d, 1e-30f);
+      for (int64_t j = lane; j < len; j += 64) dst[j] = src[j] / d;
+      continue;
+    }
     float mx = -INFINITY;
     for (int64_t j = lane; j < len; j += 64) mx = fmaxf(mx, src[j]);
 #pragma unroll
@@ -241,15 +267,14 @@ void affine_channel(hipStream_t s, const float *x, const float *scale, const flo
   hipLaunchKernelGGL(affine_channel_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, scale, shift, y, n, C, S, act, cq);
 }
 
-void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner,
-             bool log_softmax) {
+void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner, int mode) {
   const int64_t nvec = rows * outer * inner;
   if (nvec <= 0 || len <= 0) return;
   if (inner == 1 && len >= 256) {
-    hipLaunchKernelGGL(softmax_wave_kernel, dim3(grid_for(nvec * 64)), dim3(kBlock), 0, s, x, y, nvec, len, log_softmax);
+    hipLaunchKernelGGL(softmax_wave_kernel, dim3(grid_for(nvec * 64)), dim3(kBlock), 0, s, x, y, nvec, len, mode);
   } else {
     // vectors index as (row*outer + ou, in): flatten (row,outer) into the `ou` coordinate
-    hipLaunchKernelGGL(softmax_small_kernel, dim3(grid_for(nvec)), dim3(kBlock), 0, s, x, y, nvec, len, inner, log_softmax);
+    hipLaunchKernelGGL(softmax_small_kernel, dim3(grid_for(nvec)), dim3(kBlock), 0, s, x, y, nvec, len, inner, mode);
   }
 }
 

@@ -27,9 +27,9 @@ void binary_gate(hipStream_t s, const float *a, const float *gate, float *y, int
 // y[r, c, i] = act(x * scale[c] + shift[c]);  cq: activations in channel-quad planes [N][C/4][S][4] (conv.hip)
 void affine_channel(hipStream_t s, const float *x, const float *scale, const float *shift, float *y, int64_t rows,
                     int64_t C, int64_t S, ActParam act, bool cq);
-// softmax over `len` with element stride `inner`, repeated rows*outer*inner times
-void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner,
-             bool log_softmax);
+// row reduction + rescale over `len` with element stride `inner`, repeated rows*outer*inner times.
+// mode 0 softmax, 1 log-softmax; 2 / 3 / 4: divide by max|x| / sum|x| / sqrt(sum x^2) (ai.onnx.ml Normalizer, divisor floored at 1e-30)
+void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner, int mode);
 // dst[r, dst_off : dst_off+len] = src[r, src_off : src_off+len]  (Concat piece / Slice / Split); y[r] = float(argmax_j x[r, j])
 void copy_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t len, int64_t src_stride, int64_t src_off,
                int64_t dst_stride, int64_t dst_off);
@@ -45,8 +45,10 @@ void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_
 // Y[rows, M] = act(X[rows, K] . W[K, M] + bias[M]); W row-major, bias may be null.
 // softmax_fused: apply a row softmax over the M outputs in the epilogue (requires M <= 256).
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
-           ActParam act, int softmax_mode /*0 none,1 softmax,2 log-softmax*/);
+           ActParam act, int softmax_mode /*0 none,1 softmax,2 log-softmax,3 argmax (label only)*/);
 bool dense_can_fuse_softmax(int M);
+// softmax_mode 3: Y[rows] = float(index of the first maximum of the M scores) -- only where this returns true
+bool dense_can_fuse_argmax(const float *X, int K, int M);
 
 // ---- whole-chain fused MLP (mlp_fused.hip) -----------------------------------------------------
 // A chain D0 -> D1 -> D2 -> D3 evaluated in one persistent kernel; activations never leave

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <functional>
 #include <map>
+#include <set>
 #include <numeric>
 #include <sstream>
 
@@ -60,6 +61,7 @@ struct Lowerer {
   std::map<int, int> producer;  // buffer id -> index of the step that wrote it
   std::map<int, std::vector<std::string>> buf_names;  // value names that denote each buffer
   std::map<int, int> alias_edges;  // nodes folded away whose input AND output denote the buffer
+  std::set<int> int_bufs;  // buffers whose f32 values are whole numbers by construction (ArgMax, integer Cast, label arithmetic)
 
   explicit Lowerer(const onnx::Model &model) : m(model) {}
 
@@ -353,7 +355,11 @@ struct Lowerer {
     s.bop = op;
     s.const_left = const_left;
     s.cst = broadcast_const(n, cst, act_shape);
-    emit(std::move(s), n, act_shape);
+    const int src = act.buf;
+    const Step &e = emit(std::move(s), n, act_shape);
+    if (int_bufs.count(src) && (op == '+' || op == '-' || op == '*') &&
+        std::all_of(e.cst.begin(), e.cst.end(), [](float c) { return c == std::nearbyint(c); }))
+      int_bufs.insert(e.out);
   }
 
   // ---- constant folding of the integer (shape) sub-graphs exporters emit around Reshape ----
@@ -544,7 +550,7 @@ struct Lowerer {
     s.in0 = a.buf;
     s.act = Act::Trunc;
     std::vector<int64_t> shape = a.shape;
-    emit(std::move(s), n, shape);
+    int_bufs.insert(emit(std::move(s), n, shape).out);
   }
   void concat(const NodeDef &n) {
     if (n.inputs.empty()) unsupported(n, "no inputs");
@@ -627,7 +633,7 @@ struct Lowerer {
     s.K = a.shape[1];
     std::vector<int64_t> shape = {a.shape[0]};
     if (n.attr_i("keepdims", 1) != 0) shape.push_back(1);
-    emit(std::move(s), n, shape);
+    int_bufs.insert(emit(std::move(s), n, shape).out);
   }
 
   void unary(const NodeDef &n) {
@@ -916,6 +922,182 @@ struct Lowerer {
   }
 
   // ------------------------------------------------------------------------------------------
+  void lower_node(const NodeDef &n) {
+      const std::string &op = n.op;
+      if (op == "MatMul") dense(n, false);
+      else if (op == "Gemm") dense(n, true);
+      else if (op == "Add") binary(n, '+');
+      else if (op == "Sub") binary(n, '-');
+      else if (op == "Mul") binary(n, '*');
+      else if (op == "Div") binary(n, '/');
+      else if (op == "Min") binary(n, 'm');
+      else if (op == "Max") binary(n, 'M');
+      else if (op == "Pow") binary(n, '^');
+      else if (op == "PRelu") binary(n, 'p');
+      else if (op == "Relu" || op == "Sigmoid" || op == "Tanh" || op == "LeakyRelu" || op == "Clip" || op == "Exp" || op == "Log" ||
+               op == "Sqrt" || op == "Neg" || op == "Abs" || op == "Elu" || op == "Selu" || op == "Softplus" || op == "HardSigmoid" ||
+               op == "HardSwish" || op == "Erf" || op == "Gelu" || op == "Reciprocal" || op == "Floor" || op == "Ceil" ||
+               op == "Softsign" || op == "Round")
+        unary(n);
+      else if (op == "Shape") shape_op(n);
+      else if (op == "Gather") gather(n);
+      else if (op == "Slice") slice(n);
+      else if (op == "Split") split(n);
+      else if (op == "Cast") cast(n);
+      else if (op == "Concat") concat(n);
+      else if (op == "ReduceMean") reduce_mean(n);
+      else if (op == "ArgMax") argmax(n);
+      else if (op == "Identity" || op == "Dropout" || op == "Flatten" || op == "Reshape" || op == "Squeeze" || op == "Unsqueeze") reshape_like(n);
+      else if (op == "Softmax") softmax(n, false);
+      else if (op == "LogSoftmax") softmax(n, true);
+      else if (op == "Conv") conv(n);
+      else if (op == "BatchNormalization") batchnorm(n);
+      else if (op == "MaxPool") pool(n, true);
+      else if (op == "AveragePool") pool(n, false);
+      else if (op == "GlobalAveragePool") global_avgpool(n);
+      else if (op == "Constant") {
+        Val v;
+        v.is_const = true;
+        if (auto *a = n.attr("value"); a && a->t) {
+          v.c = a->t;
+        } else {  // scalar / 1-D attribute forms (opset 12+)
+          auto t = std::make_shared<TensorData>();
+          if (auto *f = n.attr("value_float")) { t->dtype = onnx::kFloat; t->f32 = {f->f}; }
+          else if (auto *i = n.attr("value_int")) { t->dtype = onnx::kInt64; t->i64 = {i->i}; }
+          else if (auto *is = n.attr_ints("value_ints")) { t->dtype = onnx::kInt64; t->i64 = *is; t->dims = {int64_t(is->size())}; }
+          else unsupported(n, "only the value / value_float / value_int / value_ints forms are supported");
+          v.c = t;
+        }
+        v.shape = v.c->dims;
+        vals[n.outputs[0]] = v;
+      } else {
+        unsupported(n, "unsupported operator");
+      }
+  }
+
+  // ---- ai.onnx.ml: the classical-ML nodes sklearn exporters write (tract-onnx 0.22 ops/ml is what serves them for
+  // the reference, engine.rs:49-56).  Each is rewritten into the standard operators above, so a Scaler folds into the
+  // linear model behind it and a LinearClassifier's scores go through the Dense (+Softmax) kernels; semantics follow
+  // the ONNX-ML operator specification (tract's sources are not in /root/reference).
+  Val const_f32(std::vector<float> v, std::vector<int64_t> dims) {
+    auto t = std::make_shared<TensorData>();
+    t->dtype = onnx::kFloat;
+    t->dims = std::move(dims);
+    t->f32 = std::move(v);
+    Val o;
+    o.is_const = true;
+    o.c = t;
+    o.shape = t->dims;
+    return o;
+  }
+  static NodeDef std_node(const NodeDef &from, const char *op, std::vector<std::string> in, std::string out) {
+    NodeDef d;
+    d.op = op;
+    d.name = from.name.empty() ? from.op : from.op + ":" + from.name;
+    d.inputs = std::move(in);
+    d.outputs = {std::move(out)};
+    return d;
+  }
+  static void set_i(NodeDef &d, const char *k, int64_t v) {
+    onnx::Attribute a;
+    a.name = k;
+    a.type = 2;
+    a.i = v;
+    d.attrs[k] = a;
+  }
+  bool wanted(const NodeDef &n, size_t i) const {
+    if (i >= n.outputs.size() || n.outputs[i].empty()) return false;
+    auto it = uses.find(n.outputs[i]);
+    return it != uses.end() && it->second > 0;
+  }
+  std::vector<float> ml_floats(const NodeDef &n, const char *k, int64_t want, float dflt, bool allow_scalar) {
+    const onnx::Attribute *a = n.attr(k);
+    std::vector<float> v = a ? a->floats : std::vector<float>{};
+    if (v.empty()) return std::vector<float>(size_t(want), dflt);
+    if (allow_scalar && v.size() == 1) return std::vector<float>(size_t(want), v[0]);
+    if (int64_t(v.size()) != want) unsupported(n, std::string(k) + " holds " + std::to_string(v.size()) + " values, expected " + std::to_string(want));
+    return v;
+  }
+  // post_transform over raw scores `raw` -> value `out`
+  void ml_post_transform(const NodeDef &n, const std::string &raw, const std::string &out) {
+    const std::string pt = n.attr_s("post_transform", "NONE");
+    if (pt == "NONE") lower_node(std_node(n, "Identity", {raw}, out));
+    else if (pt == "LOGISTIC") lower_node(std_node(n, "Sigmoid", {raw}, out));
+    else if (pt == "SOFTMAX") {
+      NodeDef d = std_node(n, "Softmax", {raw}, out);
+      set_i(d, "axis", 1);
+      lower_node(d);
+    } else unsupported(n, "post_transform " + pt);
+  }
+  void ml_node(const NodeDef &n) {
+    const Val &x = get(n, 0);
+    if (x.is_const || x.shape.size() != 2) unsupported(n, "only [rows, features] activations");
+    const int64_t F = x.shape[1];
+    const std::string tmp = n.outputs[0] + "\x01";
+    if (n.op == "Scaler") {
+      vals[tmp + "offset"] = const_f32(ml_floats(n, "offset", F, 0.f, true), {F});
+      vals[tmp + "scale"] = const_f32(ml_floats(n, "scale", F, 1.f, true), {F});
+      uses[tmp + "centered"] = 1;
+      lower_node(std_node(n, "Sub", {n.inputs[0], tmp + "offset"}, tmp + "centered"));
+      lower_node(std_node(n, "Mul", {tmp + "centered", tmp + "scale"}, n.outputs[0]));
+    } else if (n.op == "LinearRegressor" || n.op == "LinearClassifier") {
+      const bool cls = n.op == "LinearClassifier";
+      std::vector<int64_t> labels;
+      if (cls) {
+        if (n.attr("classlabels_strings")) unsupported(n, "string class labels cannot be returned as numbers");
+        if (auto *p = n.attr_ints("classlabels_ints")) labels = *p;
+        if (labels.size() < 2) unsupported(n, "needs at least two classlabels_ints");
+      }
+      const int64_t E = cls ? int64_t(labels.size()) : n.attr_i("targets", 1);
+      if (E < 1) unsupported(n, "targets must be positive");
+      vals[tmp + "coef"] = const_f32(ml_floats(n, "coefficients", E * F, 0.f, false), {E, F});
+      vals[tmp + "icpt"] = const_f32(ml_floats(n, "intercepts", E, 0.f, false), {E});
+      const bool want_label = cls && wanted(n, 0), want_scores = cls ? wanted(n, 1) : true;
+      const std::string raw = tmp + "raw";
+      uses[raw] = int(want_label) + int(want_scores);
+      NodeDef g = std_node(n, "Gemm", {n.inputs[0], tmp + "coef", tmp + "icpt"}, raw);
+      set_i(g, "transB", 1);
+      lower_node(g);
+      if (want_label) {
+        // label = classlabels_ints[argmax(raw scores)]; the class table must be an arithmetic progression
+        // (0..E-1, 1..E, {-1, 1}, ...), which is then one multiply-add on the index
+        const int64_t a0 = labels[0], step = labels[1] - labels[0];
+        for (size_t i = 0; i < labels.size(); i++)
+          if (labels[i] != a0 + step * int64_t(i)) unsupported(n, "classlabels_ints must be evenly spaced (label = a + b * index)");
+        std::string cur = (step == 1 && a0 == 0) ? n.outputs[0] : tmp + "index";
+        if (cur != n.outputs[0]) uses[cur] = 1;
+        NodeDef am = std_node(n, "ArgMax", {raw}, cur);
+        set_i(am, "axis", 1);
+        set_i(am, "keepdims", 0);
+        lower_node(am);
+        if (step != 1) {
+          vals[tmp + "step"] = const_f32({float(step)}, {});
+          const std::string nxt = a0 == 0 ? n.outputs[0] : tmp + "scaled";
+          if (nxt != n.outputs[0]) uses[nxt] = 1;
+          lower_node(std_node(n, "Mul", {cur, tmp + "step"}, nxt));
+          cur = nxt;
+        }
+        if (a0 != 0) {
+          vals[tmp + "first"] = const_f32({float(a0)}, {});
+          lower_node(std_node(n, "Add", {cur, tmp + "first"}, n.outputs[0]));
+        }
+      }
+      if (want_scores) ml_post_transform(n, raw, cls ? n.outputs[1] : n.outputs[0]);
+    } else if (n.op == "Normalizer") {
+      const std::string norm = n.attr_s("norm", "MAX");
+      Step s;
+      s.kind = StepKind::Softmax;
+      s.in0 = x.buf;
+      s.sm_norm = norm == "MAX" ? 1 : norm == "L1" ? 2 : norm == "L2" ? 3 : 0;
+      if (!s.sm_norm) unsupported(n, "norm " + norm);
+      s.sm_len = F;
+      std::vector<int64_t> shape = x.shape;
+      emit(std::move(s), n, shape);
+    } else {
+      unsupported(n, "unsupported operator");
+    }
+  }
+
   Plan run() {
     plan.opset = m.opset;
     const onnx::ValueDef &in = m.inputs[0];
@@ -998,57 +1180,9 @@ struct Lowerer {
       if (!live[ni]) continue;
       const auto &n = m.nodes[ni];
       if (n.outputs.empty()) throw InferaError::onnx("node " + n.op + " has no outputs");
-      if (!n.domain.empty() && n.domain != "ai.onnx") unsupported(n, "operator domain '" + n.domain + "'");
-      const std::string &op = n.op;
-      if (op == "MatMul") dense(n, false);
-      else if (op == "Gemm") dense(n, true);
-      else if (op == "Add") binary(n, '+');
-      else if (op == "Sub") binary(n, '-');
-      else if (op == "Mul") binary(n, '*');
-      else if (op == "Div") binary(n, '/');
-      else if (op == "Min") binary(n, 'm');
-      else if (op == "Max") binary(n, 'M');
-      else if (op == "Pow") binary(n, '^');
-      else if (op == "PRelu") binary(n, 'p');
-      else if (op == "Relu" || op == "Sigmoid" || op == "Tanh" || op == "LeakyRelu" || op == "Clip" || op == "Exp" || op == "Log" ||
-               op == "Sqrt" || op == "Neg" || op == "Abs" || op == "Elu" || op == "Selu" || op == "Softplus" || op == "HardSigmoid" ||
-               op == "HardSwish" || op == "Erf" || op == "Gelu" || op == "Reciprocal" || op == "Floor" || op == "Ceil" ||
-               op == "Softsign" || op == "Round")
-        unary(n);
-      else if (op == "Shape") shape_op(n);
-      else if (op == "Gather") gather(n);
-      else if (op == "Slice") slice(n);
-      else if (op == "Split") split(n);
-      else if (op == "Cast") cast(n);
-      else if (op == "Concat") concat(n);
-      else if (op == "ReduceMean") reduce_mean(n);
-      else if (op == "ArgMax") argmax(n);
-      else if (op == "Identity" || op == "Dropout" || op == "Flatten" || op == "Reshape" || op == "Squeeze" || op == "Unsqueeze") reshape_like(n);
-      else if (op == "Softmax") softmax(n, false);
-      else if (op == "LogSoftmax") softmax(n, true);
-      else if (op == "Conv") conv(n);
-      else if (op == "BatchNormalization") batchnorm(n);
-      else if (op == "MaxPool") pool(n, true);
-      else if (op == "AveragePool") pool(n, false);
-      else if (op == "GlobalAveragePool") global_avgpool(n);
-      else if (op == "Constant") {
-        Val v;
-        v.is_const = true;
-        if (auto *a = n.attr("value"); a && a->t) {
-          v.c = a->t;
-        } else {  // scalar / 1-D attribute forms (opset 12+)
-          auto t = std::make_shared<TensorData>();
-          if (auto *f = n.attr("value_float")) { t->dtype = onnx::kFloat; t->f32 = {f->f}; }
-          else if (auto *i = n.attr("value_int")) { t->dtype = onnx::kInt64; t->i64 = {i->i}; }
-          else if (auto *is = n.attr_ints("value_ints")) { t->dtype = onnx::kInt64; t->i64 = *is; t->dims = {int64_t(is->size())}; }
-          else unsupported(n, "only the value / value_float / value_int / value_ints forms are supported");
-          v.c = t;
-        }
-        v.shape = v.c->dims;
-        vals[n.outputs[0]] = v;
-      } else {
-        unsupported(n, "unsupported operator");
-      }
+      if (n.domain == "ai.onnx.ml") ml_node(n);
+      else if (!n.domain.empty() && n.domain != "ai.onnx") unsupported(n, "operator domain '" + n.domain + "'");
+      else lower_node(n);
     }
     // first output only (engine.rs:146-149)
     const onnx::ValueDef &out = m.outputs[0];
@@ -1058,9 +1192,7 @@ struct Lowerer {
     if (out.elem_type != 0 && out.elem_type != onnx::kFloat) {
       // integer outputs (ArgMax labels, Cast to int) are returned as f32 VALUES: the C ABI carries f32 only
       // (rust.h:28-49; the reference itself rejects non-f32 outputs at engine.rs:150-152)
-      auto pit = producer.find(it->second.buf);
-      const Step *ps = pit == producer.end() ? nullptr : &plan.steps[size_t(pit->second)];
-      const bool int_valued = ps && (ps->kind == StepKind::ArgMax || ps->act == Act::Trunc);
+      const bool int_valued = int_bufs.count(it->second.buf) > 0;
       if (!(int_valued && (out.elem_type == onnx::kInt64 || out.elem_type == onnx::kInt32)))
         throw InferaError::onnx("output '" + out.name + "' is not f32");
     }

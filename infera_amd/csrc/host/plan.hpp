@@ -60,6 +60,7 @@ struct Step {
   // Softmax
   int64_t sm_outer = 1, sm_len = 1, sm_inner = 1;
   bool log_softmax = false;
+  int sm_norm = 0;  // 0: softmax family; row normalisation instead (ai.onnx.ml Normalizer): 1 MAX, 2 L1, 3 L2
   // Conv2d / Pool2d / GlobalAvgPool geometry (per sample)
   int64_t C = 0, H = 0, Wd = 0, Mo = 0, OH = 0, OW = 0;
   int64_t kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0, dh = 1, dw = 1, groups = 1;

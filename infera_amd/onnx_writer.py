@@ -88,12 +88,26 @@ def attr_s(name: str, v: str) -> bytes:
     return _s(1, name) + _ld(4, v.encode()) + _vi(20, 3)
 
 
-def node(op: str, inputs: Sequence[str], outputs: Sequence[str], attrs: Sequence[bytes] = (), name: str = "") -> bytes:
+def attr_floats(name: str, vs: Iterable[float]) -> bytes:
+    return _s(1, name) + b"".join(_tag(7, 5) + struct.pack("<f", float(v)) for v in vs) + _vi(20, 6)
+
+
+def attr_strings(name: str, vs: Iterable[str]) -> bytes:
+    return _s(1, name) + b"".join(_ld(9, v.encode()) for v in vs) + _vi(20, 8)
+
+
+ML_DOMAIN = "ai.onnx.ml"
+
+
+def node(op: str, inputs: Sequence[str], outputs: Sequence[str], attrs: Sequence[bytes] = (), name: str = "",
+         domain: str = "") -> bytes:
     out = b"".join(_s(1, i) for i in inputs) + b"".join(_s(2, o) for o in outputs)
     if name:
         out += _s(3, name)
     out += _s(4, op)
     out += b"".join(_ld(5, a) for a in attrs)
+    if domain:
+        out += _s(7, domain)
     return out
 
 
@@ -107,12 +121,15 @@ def value_info(name: str, dims: Sequence[int | str], elem_type: int = FLOAT) -> 
 
 
 def model(graph_name: str, nodes: Sequence[bytes], inits: Sequence[bytes], inputs: Sequence[bytes],
-          outputs: Sequence[bytes], opset: int = 13, ir_version: int = 8, producer: str = "infera_amd") -> bytes:
+          outputs: Sequence[bytes], opset: int = 13, ir_version: int = 8, producer: str = "infera_amd",
+          ml_opset: int | None = None) -> bytes:
     g = b"".join(_ld(1, n) for n in nodes) + _s(2, graph_name)
     g += b"".join(_ld(5, t) for t in inits)
     g += b"".join(_ld(11, i) for i in inputs) + b"".join(_ld(12, o) for o in outputs)
-    opset_import = _s(1, "") + _vi(2, opset)
-    return _vi(1, ir_version) + _s(2, producer) + _ld(7, g) + _ld(8, opset_import)
+    opset_import = _ld(8, _s(1, "") + _vi(2, opset))
+    if ml_opset is not None:  # the classical-ML operator domain sklearn exporters use
+        opset_import += _ld(8, _s(1, ML_DOMAIN) + _vi(2, ml_opset))
+    return _vi(1, ir_version) + _s(2, producer) + _ld(7, g) + opset_import
 
 
 # ------------------------------------------------------------------------------------------
@@ -422,3 +439,37 @@ def write(path: str, blob: bytes) -> str:
     with open(path, "wb") as fh:
         fh.write(blob)
     return path
+
+
+def sklearn_pipeline(features: int = 30, classes: int = 3, kind: str = "classifier", post: str = "SOFTMAX",
+                     labels: Sequence[int] | None = None, normalizer: str | None = None, scaler: bool = True,
+                     output: str = "label", seed: int = 99) -> bytes:
+    """The graph skl2onnx writes for Pipeline(StandardScaler, LogisticRegression / LinearRegression): ai.onnx.ml
+    Scaler -> LinearClassifier (label, scores) [-> Normalizer] or -> LinearRegressor.  `output` picks which value
+    is graph output 0 -- the one the reference serves (engine.rs:146-149): "label" (int64 [N]), "scores" ([N,E])."""
+    ws = _WeightStream(seed)
+    nodes, x = [], "X"
+    if scaler:
+        off = ws.take((features,), 1)
+        sc = (1.0 + 0.5 * ws.take((features,), 1)).astype(np.float32)
+        nodes.append(node("Scaler", [x], ["Xs"], [attr_floats("offset", off), attr_floats("scale", sc)], domain=ML_DOMAIN))
+        x = "Xs"
+    coef = ws.take((classes, features), features)
+    icpt = ws.take((classes,), features)
+    if kind == "regressor":
+        nodes.append(node("LinearRegressor", [x], ["Y"],
+                          [attr_floats("coefficients", coef.ravel()), attr_floats("intercepts", icpt),
+                           attr_i("targets", classes), attr_s("post_transform", post)], domain=ML_DOMAIN))
+        outs = [value_info("Y", ["N", classes])]
+    else:
+        labels = list(labels) if labels is not None else list(range(classes))
+        nodes.append(node("LinearClassifier", [x], ["label", "scores"],
+                          [attr_floats("coefficients", coef.ravel()), attr_floats("intercepts", icpt),
+                           attr_ints("classlabels_ints", labels), attr_s("post_transform", post)], domain=ML_DOMAIN))
+        prob = "scores"
+        if normalizer:
+            nodes.append(node("Normalizer", ["scores"], ["probabilities"], [attr_s("norm", normalizer)], domain=ML_DOMAIN))
+            prob = "probabilities"
+        o_label, o_prob = value_info("label", ["N"], INT64), value_info(prob, ["N", classes])
+        outs = [o_label, o_prob] if output == "label" else [o_prob, o_label]
+    return model("sklearn_pipeline", nodes, [], [value_info("X", ["N", features])], outs, opset=13, ml_opset=1)

@@ -1089,6 +1089,131 @@ static int op_softmax(Exec *x, const Node *nd, int logsm) {
   return 0;
 }
 
+/* ---- ai.onnx.ml operators (the classical-ML nodes sklearn exporters emit; tract-onnx 0.22 ops/ml).
+ * tract's sources are not in /root/reference; these follow the published ONNX-ML operator specification
+ * (onnx/docs/Operators-ml.md) and the ONNX reference evaluator's arithmetic.  Parity for them is pinned on
+ * the spec text only -- stated in DESIGN.md. */
+static const char *attr_str(const Node *nd, const char *name, const char *dflt) {
+  const Attr *a = find_attr(nd, name);
+  return a && a->s ? a->s : dflt;
+}
+
+/* Scaler: Y = (X - offset) * scale, per feature (either attribute may hold one value for all features) */
+static int op_ml_scaler(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT || a->rank != 2) FAIL("Scaler: expects an f32 [N,F] input");
+  const Attr *off = find_attr(nd, "offset"), *sc = find_attr(nd, "scale");
+  size_t F = (size_t)a->dims[1], N = (size_t)a->dims[0];
+  if (off && off->nfloats != F && off->nfloats != 1) FAIL("Scaler: offset has %zu values for %zu features", off->nfloats, F);
+  if (sc && sc->nfloats != F && sc->nfloats != 1) FAIL("Scaler: scale has %zu values for %zu features", sc->nfloats, F);
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, 2, a->dims);
+  a = get_in(x, nd, 0);
+  for (size_t n = 0; n < N; n++)
+    for (size_t k = 0; k < F; k++) {
+      float of = off && off->nfloats ? off->floats[off->nfloats == 1 ? 0 : k] : 0.0f;
+      float s = sc && sc->nfloats ? sc->floats[sc->nfloats == 1 ? 0 : k] : 1.0f;
+      o->f[n * F + k] = (a->f[n * F + k] - of) * s;
+    }
+  return 0;
+}
+
+/* post_transform over a [N,E] score matrix, in place */
+static int ml_post_transform(Exec *x, const char *pt, float *s, size_t N, size_t E, const char *who) {
+  if (!strcmp(pt, "NONE")) return 0;
+  if (!strcmp(pt, "LOGISTIC")) {
+    for (size_t i = 0; i < N * E; i++) s[i] = 1.0f / (1.0f + expf(-s[i]));
+    return 0;
+  }
+  if (!strcmp(pt, "SOFTMAX")) {
+    for (size_t n = 0; n < N; n++) {
+      float *r = s + n * E, mx = -INFINITY, sum = 0.0f;
+      for (size_t j = 0; j < E; j++) mx = r[j] > mx ? r[j] : mx;
+      for (size_t j = 0; j < E; j++) { r[j] = expf(r[j] - mx); sum += r[j]; }
+      for (size_t j = 0; j < E; j++) r[j] = r[j] / sum;
+    }
+    return 0;
+  }
+  FAIL("%s: post_transform %s is not supported", who, pt);
+}
+
+/* scores[n][e] = sum_k X[n][k] * coef[e][k] + intercept[e]  (coefficients are [E, F] row-major) */
+static void ml_linear_scores(const float *X, const float *coef, const Attr *icpt, float *S, size_t N, size_t F, size_t E) {
+  for (size_t n = 0; n < N; n++)
+    for (size_t e = 0; e < E; e++) {
+      float acc = 0.0f;
+      for (size_t k = 0; k < F; k++) acc = fmaf(X[n * F + k], coef[e * F + k], acc);
+      S[n * E + e] = icpt && icpt->nfloats ? acc + icpt->floats[e] : acc;
+    }
+}
+
+/* LinearRegressor: Y = post_transform(X . coefficients^T + intercepts), `targets` rows of coefficients */
+static int op_ml_linear_regressor(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT || a->rank != 2) FAIL("LinearRegressor: expects an f32 [N,F] input");
+  const Attr *co = find_attr(nd, "coefficients"), *ic = find_attr(nd, "intercepts");
+  size_t N = (size_t)a->dims[0], F = (size_t)a->dims[1], E = (size_t)attr_i(nd, "targets", 1);
+  if (!co || E == 0 || co->nfloats != E * F) FAIL("LinearRegressor: coefficients must hold targets x features = %zu values", E * F);
+  if (ic && ic->nfloats && ic->nfloats != E) FAIL("LinearRegressor: intercepts must hold %zu values", E);
+  int64_t od[2] = {(int64_t)N, (int64_t)E};
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, 2, od);
+  a = get_in(x, nd, 0);
+  ml_linear_scores(a->f, co->floats, ic, o->f, N, F, E);
+  return ml_post_transform(x, attr_str(nd, "post_transform", "NONE"), o->f, N, E, "LinearRegressor");
+}
+
+/* LinearClassifier: outputs (label [N] int64, scores [N,E] f32).  label = classlabels_ints[argmax of the raw
+ * scores] (first maximum wins); scores = post_transform(raw).  One coefficient row per class label. */
+static int op_ml_linear_classifier(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT || a->rank != 2) FAIL("LinearClassifier: expects an f32 [N,F] input");
+  const Attr *co = find_attr(nd, "coefficients"), *ic = find_attr(nd, "intercepts"), *li = find_attr(nd, "classlabels_ints");
+  if (find_attr(nd, "classlabels_strings")) FAIL("LinearClassifier: string class labels cannot be returned as numbers");
+  if (!li || li->nints < 2) FAIL("LinearClassifier: needs at least two classlabels_ints");
+  size_t N = (size_t)a->dims[0], F = (size_t)a->dims[1], E = li->nints;
+  if (!co || co->nfloats != E * F) FAIL("LinearClassifier: coefficients must hold classes x features = %zu values", E * F);
+  if (ic && ic->nfloats && ic->nfloats != E) FAIL("LinearClassifier: intercepts must hold %zu values", E);
+  int64_t ld[1] = {(int64_t)N}, sd[2] = {(int64_t)N, (int64_t)E};
+  env_new(&x->env, nd->out[0], DT_INT64, 1, ld);
+  size_t li_idx = x->env.n - 1;
+  const char *sname = nd->nout > 1 && nd->out[1][0] ? nd->out[1] : "\x01ml_scores";
+  env_new(&x->env, sname, DT_FLOAT, 2, sd);
+  Tensor *lab = &x->env.v[li_idx], *sc = &x->env.v[x->env.n - 1];
+  a = get_in(x, nd, 0);
+  ml_linear_scores(a->f, co->floats, ic, sc->f, N, F, E);
+  for (size_t n = 0; n < N; n++) {
+    size_t best = 0;
+    for (size_t e = 1; e < E; e++)
+      if (sc->f[n * E + e] > sc->f[n * E + best]) best = e;
+    lab->i64[n] = li->ints[best];
+  }
+  return ml_post_transform(x, attr_str(nd, "post_transform", "NONE"), sc->f, N, E, "LinearClassifier");
+}
+
+/* Normalizer: each row divided by its max |x| (MAX, the default), sum |x| (L1) or sqrt(sum x^2) (L2); the divisor
+ * is floored at 1e-30 so an all-zero row stays zero (ONNX reference evaluator). */
+static int op_ml_normalizer(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT || a->rank != 2) FAIL("Normalizer: expects an f32 [N,F] input");
+  const char *norm = attr_str(nd, "norm", "MAX");
+  int mode = !strcmp(norm, "MAX") ? 0 : !strcmp(norm, "L1") ? 1 : !strcmp(norm, "L2") ? 2 : -1;
+  if (mode < 0) FAIL("Normalizer: norm %s is not supported", norm);
+  size_t N = (size_t)a->dims[0], F = (size_t)a->dims[1];
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, 2, a->dims);
+  a = get_in(x, nd, 0);
+  for (size_t n = 0; n < N; n++) {
+    const float *r = a->f + n * F;
+    float d = 0.0f;
+    for (size_t k = 0; k < F; k++) {
+      float v = fabsf(r[k]);
+      d = mode == 0 ? (v > d ? v : d) : mode == 1 ? d + v : fmaf(r[k], r[k], d);
+    }
+    if (mode == 2) d = sqrtf(d);
+    if (d < 1e-30f) d = 1e-30f;
+    for (size_t k = 0; k < F; k++) o->f[n * F + k] = r[k] / d;
+  }
+  return 0;
+}
+
 static int op_reshape_like(Exec *x, const Node *nd) {
   const Tensor *a = get_in(x, nd, 0);
   if (!a) FAIL("%s: missing input", nd->op);
@@ -1395,6 +1520,10 @@ static int run_node(Exec *x, const Node *nd) {
   if (!strcmp(op, "AveragePool")) return op_pool(x, nd, 0);
   if (!strcmp(op, "GlobalAveragePool")) return op_global_avgpool(x, nd);
   if (!strcmp(op, "Constant")) return op_constant(x, nd);
+  if (!strcmp(op, "Scaler")) return op_ml_scaler(x, nd);
+  if (!strcmp(op, "LinearRegressor")) return op_ml_linear_regressor(x, nd);
+  if (!strcmp(op, "LinearClassifier")) return op_ml_linear_classifier(x, nd);
+  if (!strcmp(op, "Normalizer")) return op_ml_normalizer(x, nd);
   FAIL("unsupported operator: %s", op);
 }
 

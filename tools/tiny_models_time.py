@@ -1,8 +1,13 @@
+"""Times small tabular models (single layers, softmax heads, two-layer MLPs) on a 20M-row table.
+usage (GPU box): python tools/tiny_models_time.py"""
 import os, sys, tempfile
 sys.path.insert(0, os.getcwd())
 from infera_amd import capi, onnx_writer as W
 d = tempfile.mkdtemp(); dev = capi.device_ordinal(0)
-for dims, sm in [((3, 1), False), ((13, 1), False), ((30, 1), False), ((4, 3), True), ((30, 2), True), ((100, 10), True), ((128, 10), True), ((64, 1), False), ((20, 16, 1), False), ((30, 8, 1), False), ((50, 1), False), ((100, 1), False), ((77, 5), True)]:
+CASES = [((3, 1), False), ((13, 1), False), ((30, 1), False), ((4, 3), True), ((30, 2), True), ((30, 3), True), ((30, 8), False),
+         ((100, 10), True), ((128, 10), True), ((64, 1), False), ((20, 16, 1), False), ((30, 8, 1), False), ((50, 1), False),
+         ((100, 1), False), ((77, 5), True), ((48, 10), True), ((96, 4), False), ((13, 3), True), ((120, 16), False)]
+for dims, sm in CASES:
     rows = 20_000_000
     name = "t" + "x".join(map(str, dims))
     capi.load_model(name, W.write(f"{d}/{name}.onnx", W.mlp(dims, final_softmax=sm)))
