@@ -187,6 +187,7 @@ std::vector<EffStep> effective_steps(const LoadedModel &m) {
       case ExecKind::Skipped: break;
       case ExecKind::Mlp3Head: out.push_back({int(i), {st[i].in0}, st[i + 2].out}); break;
       case ExecKind::DenseSoftmax: out.push_back({int(i), {st[i].in0}, st[i + 1].out}); break;
+      case ExecKind::ChainHead: out.push_back({int(i), {st[i].in0}, st[i + size_t(m.chain_at(i)->nsteps) - 1].out}); break;
       case ExecKind::ConvTiled:
         if (i < m.conv_fused_add.size() && m.conv_fused_add[i] >= 0)
           out.push_back({int(i), {st[i].in0, m.conv_residual_buf[i]}, st[size_t(m.conv_fused_add[i])].out});
@@ -235,6 +236,56 @@ void schedule(LoadedModel &m) {
         continue;
       }
       if (!why.empty()) log_msg(2, "model '" + m.name + "': Dense x3 chain stays layer-by-layer: " + why);
+    }
+    // A run of small Dense layers over a table of any width (optionally behind the PadCols the lowering put in front of
+    // a wide first layer, optionally ending in Softmax / ArgMax): one load-time specialised kernel reads the table once
+    // and writes only the last layer (chain_device.inc).  Single layers stay with the ahead-of-time kernels unless the
+    // chain also saves them the padding pass.
+    if (cfg.fused_mlp) {
+      size_t j = i;
+      int pad = 0;
+      if (st[j].kind == StepKind::PadCols && j + 1 < n && st[j + 1].kind == StepKind::Dense && st[j + 1].in0 == st[j].out &&
+          uses[size_t(st[j].out)] == 1 && m.exec[j + 1] == ExecKind::Normal) {
+        pad = 1;
+        j++;
+      }
+      kern::ChainShape sh;
+      sh.k0 = pad ? int(st[i].K) : int(st[j].K);
+      const size_t d0 = j;
+      while (j < n && st[j].kind == StepKind::Dense && m.exec[j] == ExecKind::Normal && int(st[j].act) <= kMaxMfmaFusedAct &&
+             st[j].K <= 128 && st[j].M <= 128 && (j == d0 || (st[j].in0 == st[j - 1].out && uses[size_t(st[j - 1].out)] == 1))) {
+        sh.dims.push_back(int(st[j].M));
+        sh.acts.push_back(int(st[j].act));
+        sh.pa.push_back(st[j].act_a);
+        sh.pb.push_back(st[j].act_b);
+        j++;
+      }
+      const size_t layers = j - d0;
+      if (layers >= 2 || (layers == 1 && pad)) {
+        if (j < n && st[j].in0 == st[j - 1].out && uses[size_t(st[j - 1].out)] == 1 && st[j - 1].M <= 16 && m.exec[j] == ExecKind::Normal) {
+          if (st[j].kind == StepKind::Softmax && st[j].sm_norm == 0 && st[j].sm_outer == 1 && st[j].sm_inner == 1 && st[j].sm_len == st[j - 1].M) {
+            sh.sm = st[j].log_softmax ? 2 : 1;
+            j++;
+          } else if (st[j].kind == StepKind::ArgMax && st[j].K == st[j - 1].M) {
+            sh.sm = 3;
+            j++;
+          }
+        }
+        std::string why;
+        if (kern::chain_supported(sh, &why)) {
+          LoadedModel::ChainRun run;
+          run.first = int(i);
+          run.nsteps = int(j - i);
+          run.pad = pad;
+          run.shape = sh;
+          m.chains.push_back(run);
+          m.exec[i] = ExecKind::ChainHead;
+          for (size_t k = i + 1; k < j; k++) m.exec[k] = ExecKind::Skipped;
+          i = j - 1;
+          continue;
+        }
+        log_msg(2, "model '" + m.name + "': Dense chain at step " + std::to_string(i) + " stays layer-by-layer: " + why);
+      }
     }
     // Dense + row Softmax over exactly its M outputs: softmax in the GEMM epilogue
     if (i + 1 < n && st[i].kind == StepKind::Dense && st[i + 1].kind == StepKind::Softmax && st[i + 1].in0 == st[i].out &&
@@ -370,6 +421,20 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       dm.mlp3_packed = upload(packed, us);
       continue;
     }
+    if (m.exec[i] == ExecKind::ChainHead) {
+      const LoadedModel::ChainRun &run = *m.chain_at(i);
+      std::vector<const float *> W, B;
+      for (size_t l = 0; l < run.shape.dims.size(); l++) {
+        const Step &ls = st[i + size_t(run.pad) + l];
+        W.push_back(ls.W.data());
+        B.push_back(ls.bias.empty() ? nullptr : ls.bias.data());
+      }
+      std::vector<float> packed(kern::chain_packed_floats(run.shape));
+      kern::chain_pack(run.shape, W, B, packed.data());
+      dm.chain_packed.resize(m.chains.size(), nullptr);
+      dm.chain_packed[size_t(&run - m.chains.data())] = upload(packed, us);
+      continue;
+    }
     if (m.exec[i] == ExecKind::ConvTiled) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
@@ -467,6 +532,14 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           std::string why;
           if (!kern::mlp3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_packed, buf(st[i + 2].out), nr, dm.num_cus, &why))
             throw InferaError::onnx("fused MLP kernel launch failed: " + why);
+          continue;
+        }
+        case ExecKind::ChainHead: {
+          const LoadedModel::ChainRun &run = *m.chain_at(i);
+          std::string why;
+          if (!kern::chain(s, run.shape, buf(x.in0), dm.chain_packed[size_t(&run - m.chains.data())],
+                           buf(st[i + size_t(run.nsteps) - 1].out), nr, dm.num_cus, &why))
+            throw InferaError::onnx("fused chain kernel launch failed: " + why);
           continue;
         }
         case ExecKind::DenseArgMax:
@@ -594,6 +667,8 @@ DeviceModel::~DeviceModel() {
       if (p) (void)hipFree(p);
   }
   if (mlp3_packed) (void)hipFree(mlp3_packed);
+  for (float *p : chain_packed)
+    if (p) (void)hipFree(p);
 }
 
 std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::string &path) {
@@ -771,7 +846,7 @@ void sync_device(int device_ordinal) {
 hipStream_t thread_stream(int device_ordinal) { return ctx_for_slot(slot_of_ordinal(device_ordinal)).stream; }
 
 std::string LoadedModel::describe_json() const {
-  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch", "conv_depthwise", "dense_tiled", "dense_argmax"};
+  static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch", "conv_depthwise", "dense_tiled", "dense_argmax", "chain_fused"};
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";
@@ -780,6 +855,11 @@ std::string LoadedModel::describe_json() const {
   o << "]";
   for (size_t i = 0; i < exec.size(); i++)
     if (exec[i] == ExecKind::Mlp3Head) o << ",\"fused_kernel\":" << json_str(kern::mlp3_kernel_name(mlp3_shape));
+  if (!chains.empty()) {
+    o << ",\"chain_kernels\":[";
+    for (size_t i = 0; i < chains.size(); i++) o << (i ? "," : "") << json_str(kern::chain_kernel_name(chains[i].shape));
+    o << "]";
+  }
   if (!device_error.empty()) o << ",\"device_error\":" << json_str(device_error);
   o << "}";
   return o.str();

@@ -35,13 +35,14 @@ struct DeviceStep {
 };
 
 // How the executor runs a step.
-enum class ExecKind : int { Normal = 0, Skipped = 1, Mlp3Head = 2, DenseSoftmax = 3, ConvTiled = 4, ConvPatch = 5, ConvDepthwise = 6, DenseTiled = 7, DenseArgMax = 8 };
+enum class ExecKind : int { Normal = 0, Skipped = 1, Mlp3Head = 2, DenseSoftmax = 3, ConvTiled = 4, ConvPatch = 5, ConvDepthwise = 6, DenseTiled = 7, DenseArgMax = 8, ChainHead = 9 };
 
 struct DeviceModel {
   int device = -1;  // HIP ordinal
   int num_cus = 0;
   std::vector<DeviceStep> steps;
   float *mlp3_packed = nullptr;
+  std::vector<float *> chain_packed;  // parameter block per LoadedModel::chains entry
   ~DeviceModel();
 };
 
@@ -53,6 +54,18 @@ class LoadedModel {
   // execution schedule (device independent)
   std::vector<ExecKind> exec;
   kern::Mlp3Shape mlp3_shape{};
+  // Runs of small Dense layers (optionally behind a PadCols, optionally ending in Softmax / ArgMax) executed by one
+  // load-time specialised kernel: steps [first, first + nsteps) of the plan; `pad` = 1 when the first one is a PadCols.
+  struct ChainRun {
+    int first = 0, nsteps = 0, pad = 0;
+    kern::ChainShape shape;
+  };
+  std::vector<ChainRun> chains;
+  const ChainRun *chain_at(size_t step) const {
+    for (const auto &c : chains)
+      if (size_t(c.first) == step) return &c;
+    return nullptr;
+  }
   // Convolutional plans keep every 4-D activation except the caller's input CHANNELS-LAST (NHWC) so
   // the implicit-GEMM gathers and stores are 16-byte vectors; decided per plan in schedule().
   bool cq_mode = false;

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 namespace infera_hip::kern {
 
@@ -68,6 +69,24 @@ void mlp3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const floa
 bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
           std::string *why = nullptr);
 std::string mlp3_kernel_name(const Mlp3Shape &sh);
+
+// ---- fused chain of small Dense layers over tables of any width (chain_device.inc, specialised with hipRTC) ----
+// k0 table columns; layer l maps dims[l-1] (dims[-1] = k0) -> dims[l] and applies acts[l] (plan.hpp Act 0..5) with
+// parameters pa/pb; sm: 0 plain, 1 softmax, 2 log-softmax, 3 argmax (label only) over the last layer's <= 16 outputs.
+struct ChainShape {
+  int k0 = 0;
+  std::vector<int> dims, acts;
+  std::vector<float> pa, pb;
+  int sm = 0;
+};
+// True once a kernel for the shape is compiled (first call compiles); `why` otherwise: limits, hipRTC missing, ...
+bool chain_supported(const ChainShape &s, std::string *why = nullptr);
+size_t chain_packed_floats(const ChainShape &s);
+// W[l] is [K_l, M_l] row-major, bias[l] has M_l floats or is null
+void chain_pack(const ChainShape &s, const std::vector<const float *> &W, const std::vector<const float *> &bias, float *out);
+bool chain(hipStream_t st, const ChainShape &s, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
+           std::string *why);
+std::string chain_kernel_name(const ChainShape &s);
 
 // ---- convolution / pooling (conv.hip) ----------------------------------------------------------
 struct ConvGeom {

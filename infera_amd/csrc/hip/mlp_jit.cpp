@@ -66,6 +66,57 @@ const Rtc &rtc() {
   return r;
 }
 
+
+}  // namespace
+
+bool jit_compile(const char *src, const char *file, const std::string &expr, std::vector<char> &code, std::string &lowered,
+                 std::string &why) {
+  const Rtc &r = rtc();
+  if (!r.ok) {
+    why = r.why;
+    return false;
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    why = "no HIP device to compile for";
+    return false;
+  }
+  // hipRTC pre-includes its own runtime header (threadIdx, __global__, device math); no #include needed
+  hiprtcProgram prog = nullptr;
+  if (r.CreateProgram(&prog, src, file, 0, nullptr, nullptr) != 0) {
+    why = "hiprtcCreateProgram failed";
+    return false;
+  }
+  r.AddNameExpression(prog, expr.c_str());
+  const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const char *opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+  const int rc = r.CompileProgram(prog, 3, opts);
+  if (rc != 0) {
+    size_t n = 0;
+    r.GetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) r.GetProgramLog(prog, log.data());
+    why = "hipRTC compile failed: " + log.substr(0, 600);
+    r.DestroyProgram(&prog);
+    return false;
+  }
+  const char *low = nullptr;
+  size_t n = 0;
+  if (r.GetLoweredName(prog, expr.c_str(), &low) != 0 || !low || r.GetCodeSize(prog, &n) != 0 || n == 0) {
+    why = "hipRTC produced no code object";
+    r.DestroyProgram(&prog);
+    return false;
+  }
+  lowered = low;
+  code.resize(n);
+  r.GetCode(prog, code.data());
+  r.DestroyProgram(&prog);
+  return true;
+}
+
+namespace {
+
 using Key = std::tuple<int, int, int, int, int, int, int>;
 Key key_of(const Mlp3Shape &s) { return {s.d0, s.d1, s.d2, s.d3, s.act1, s.act2, s.act3}; }
 
@@ -133,49 +184,7 @@ Compiled &compile_locked(const Mlp3Shape &s) {
   const Mlp3Layout L = mlp3_layout(s.d0, s.d1, s.d2, s.d3);
   if (!plan_kernel(s, L, c.expr, c.threads, c.why)) return c;
   c.lds_bytes = L.N_LDS * 4;
-  const Rtc &r = rtc();
-  if (!r.ok) {
-    c.why = r.why;
-    return c;
-  }
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-    c.why = "no HIP device to compile for";
-    return c;
-  }
-  // hipRTC pre-includes its own runtime header (threadIdx, __global__, device math); no #include needed
-  const std::string src = kMlpDeviceSrc;
-  hiprtcProgram prog = nullptr;
-  if (r.CreateProgram(&prog, src.c_str(), "infera_mlp_jit.hip", 0, nullptr, nullptr) != 0) {
-    c.why = "hiprtcCreateProgram failed";
-    return c;
-  }
-  r.AddNameExpression(prog, c.expr.c_str());
-  const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
-  const char *opts[] = {arch.c_str(), "-O3", "-std=c++17"};
-  const int rc = r.CompileProgram(prog, 3, opts);
-  if (rc != 0) {
-    size_t n = 0;
-    r.GetProgramLogSize(prog, &n);
-    std::string log(n, '\0');
-    if (n) r.GetProgramLog(prog, log.data());
-    c.why = "hipRTC compile failed: " + log.substr(0, 600);
-    r.DestroyProgram(&prog);
-    return c;
-  }
-  const char *low = nullptr;
-  size_t n = 0;
-  if (r.GetLoweredName(prog, c.expr.c_str(), &low) != 0 || !low || r.GetCodeSize(prog, &n) != 0 || n == 0) {
-    c.why = "hipRTC produced no code object";
-    r.DestroyProgram(&prog);
-    return c;
-  }
-  c.lowered = low;
-  c.code.resize(n);
-  r.GetCode(prog, c.code.data());
-  r.DestroyProgram(&prog);
-  c.ok = true;
+  c.ok = jit_compile(kMlpDeviceSrc, "infera_mlp_jit.hip", c.expr, c.code, c.lowered, c.why);
   return c;
 }
 

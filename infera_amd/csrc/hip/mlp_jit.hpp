@@ -6,10 +6,16 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "kernels.hpp"
 
 namespace infera_hip::kern {
+
+// Compiles `src` with hipRTC (dlopen'd) for the current device's architecture; returns the code object and the
+// lowered symbol of the name expression `expr`.  False + `why` when hipRTC is missing or the compile fails.
+bool jit_compile(const char *src, const char *file, const std::string &expr, std::vector<char> &code, std::string &lowered,
+                 std::string &why);
 
 // True if a kernel for `sh` is (or was just) compiled; on failure `why` says what went wrong (shape
 // constraints, hipRTC missing, compile error) and the caller falls back to layer-by-layer kernels.

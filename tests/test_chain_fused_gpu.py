@@ -1,0 +1,132 @@
+"""The load-time specialised chain kernel (csrc/hip/chain_device.inc): small MLPs over tables of any width, fused into one
+pass -- against the oracle, with the layer-by-layer kernels (INFERA_FUSED_MLP=0 in a child process) as a second opinion."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from infera_amd import onnx_writer as W
+from infera_amd import synth
+
+RTOL, ATOL = 1e-4, 1e-6
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def assert_close(got, want, rtol=RTOL, atol=ATOL):
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    bad = err > rtol * np.abs(want.astype(np.float64)) + atol
+    assert not bad.any(), f"{bad.sum()} / {bad.size} out of tolerance; worst err {err.max():.3e}"
+
+
+@pytest.fixture(scope="module")
+def O(built):
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def api(built):
+    from infera_amd import capi
+
+    assert capi.device_count() >= 1, capi.get_devices()
+    return capi
+
+
+# dims, activations, final softmax
+CHAINS = [
+    ((4, 10, 3), None, True),                 # iris-sized MLPClassifier
+    ((30, 100, 2), None, True),               # sklearn's default hidden layer on 30 features
+    ((13, 64, 32, 1), None, False),
+    ((20, 16, 1), ["Tanh", "Sigmoid"], False),
+    ((30, 8, 1), ["LeakyRelu", ""], False),
+    ((128, 128, 128, 16), ["Relu", "Sigmoid", ""], False),
+    ((1, 5, 1), None, False),
+    ((3, 3, 3, 3, 3), None, True),
+    ((100, 100, 100, 10), None, True),
+    ((77, 33, 17), ["Relu", "Relu"], False),  # 17 outputs: two output tiles, odd row length on the way out
+    ((64, 48, 20), None, False),
+    ((30, 100), None, False),                 # one wide layer behind a PadCols: fused to skip the padding pass
+    ((50, 12, 12), None, True),
+]
+
+
+def _name(c):
+    return "x".join(map(str, c[0])) + ("+sm" if c[2] else "")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 33, 4099])
+@pytest.mark.parametrize("case", CHAINS, ids=_name)
+def test_gpu_chain_vs_oracle(api, O, tmp_path, case, rows):
+    dims, acts, sm = case
+    path = W.write(str(tmp_path / "c.onnx"), W.mlp(dims, acts=acts, final_softmax=sm, seed=77))
+    x = synth.table(3, 0, rows, dims[0])
+    api.load_model("chain", path)
+    try:
+        plan = api.get_plan("chain")
+        if max(dims) < 100 or len(dims) <= 3:  # the widest chains exceed the LDS in one piece (or belong to the 32x32 kernel)
+            assert plan["exec"][0] == "chain_fused" and set(plan["exec"][1:]) <= {"skipped"}, plan["exec"]
+            assert plan["chain_kernels"][0].startswith("chain_kernel<" + "x".join(map(str, dims))), plan["chain_kernels"]
+        else:
+            assert {"chain_fused", "mlp3_fused"} & set(plan["exec"]), plan["exec"]
+        got = api.predict("chain", x)
+    finally:
+        api.unload_model("chain")
+    assert_close(got, O.Model(path).predict(x))
+
+
+@pytest.mark.gpu
+def test_gpu_chain_label_output_and_batch_invariance(api, O, tmp_path):
+    """classifier head: MLP -> ArgMax as the served output; and the same rows in one big scan or many small ones"""
+    ws = W._WeightStream(5)
+    k, h, e = 30, 24, 5
+    w1, b1, w2, b2 = ws.take((k, h), k), ws.take((h,), k), ws.take((h, e), h), ws.take((e,), h)
+    nodes = [W.node("Gemm", ["X", "w1", "b1"], ["h"]), W.node("Relu", ["h"], ["a"]), W.node("Gemm", ["a", "w2", "b2"], ["s"]),
+             W.node("ArgMax", ["s"], ["label"], [W.attr_i("axis", 1), W.attr_i("keepdims", 0)])]
+    inits = [W.tensor("w1", w1), W.tensor("b1", b1), W.tensor("w2", w2), W.tensor("b2", b2)]
+    path = W.write(str(tmp_path / "lab.onnx"),
+                   W.model("lab", nodes, inits, [W.value_info("X", ["N", k])], [W.value_info("label", ["N"], W.INT64)]))
+    x = synth.table(8, 0, 20000, k)
+    raw = np.maximum(x.astype(np.float64) @ w1 + b1, 0) @ w2.astype(np.float64) + b2
+    srt = np.sort(raw, axis=1)
+    ok = (srt[:, -1] - srt[:, -2]) > 1e-4
+    api.load_model("lab", path)
+    try:
+        plan = api.get_plan("lab")
+        assert plan["exec"] == ["chain_fused", "skipped", "skipped"] and plan["chain_kernels"][0].endswith("+argmax> [hipRTC]"), plan
+        whole = api.predict("lab", x).reshape(-1)
+        pieces = np.concatenate([api.predict("lab", x[i:i + 777]).reshape(-1) for i in range(0, len(x), 777)])
+    finally:
+        api.unload_model("lab")
+    assert np.array_equal(whole, pieces)
+    assert np.array_equal(whole[ok], np.argmax(raw, axis=1)[ok].astype(np.float32))
+    assert np.array_equal(whole[ok], O.Model(path).predict(x).reshape(-1)[ok])
+
+
+@pytest.mark.gpu
+def test_gpu_chain_agrees_with_layer_by_layer_kernels(api, tmp_path):
+    """same model, same rows, INFERA_FUSED_MLP=0 in a child process: the ahead-of-time kernels, one layer per pass"""
+    dims = (30, 100, 3)
+    path = W.write(str(tmp_path / "c.onnx"), W.mlp(dims, final_softmax=True, seed=5))
+    x = synth.table(4, 0, 5000, dims[0])
+    api.load_model("c", path)
+    try:
+        fused = api.predict("c", x)
+    finally:
+        api.unload_model("c")
+    np.save(tmp_path / "x.npy", x)
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from infera_amd import capi; "
+            "capi.load_model('c', %r); x = np.load(%r); y = capi.predict('c', x); np.save(%r, y); "
+            "print(json.dumps(capi.get_plan('c')['exec']))") % (ROOT, path, str(tmp_path / "x.npy"), str(tmp_path / "y.npy"))
+    env = dict(os.environ, INFERA_FUSED_MLP="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "chain_fused" not in json.loads(out.stdout.strip().splitlines()[-1])
+    assert_close(fused, np.load(tmp_path / "y.npy"), rtol=2e-5, atol=1e-6)
