@@ -1,6 +1,7 @@
 // chain_jit.cpp -- host side of the fused small-MLP chain (chain_device.inc): shape limits, the parameter block's
 // layout, load-time specialisation with hipRTC and the launch.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -16,7 +17,6 @@ namespace infera_hip::kern {
 
 namespace {
 
-constexpr int kWaves = 4;
 constexpr int kMaxWidth = 128;           // table columns and layer widths
 constexpr size_t kLdsBudget = 160 * 1024;
 
@@ -28,12 +28,20 @@ size_t layer_floats(const ChainShape &s, int l) { return size_t(groups(width(s, 
 int row_groups(const ChainShape &s) {
   int rt = std::clamp(6144 / (128 * s.k0), 1, 8);
   const size_t par = chain_packed_floats(s) * sizeof(float);
-  while (rt > 1 && par + size_t(kWaves) * 32 * rt * (16 * groups(s.k0) + 4) * sizeof(float) > 40 * 1024) rt--;
+  while (rt > 1 && par + size_t(4) * 32 * rt * (16 * groups(s.k0) + 4) * sizeof(float) > 40 * 1024) rt--;
   return rt;
 }
-size_t lds_bytes(const ChainShape &s) {
-  return (chain_packed_floats(s) + size_t(kWaves) * 32 * row_groups(s) * (16 * groups(s.k0) + 4)) * sizeof(float);
+size_t lds_bytes_with(const ChainShape &s, int waves) {
+  return (chain_packed_floats(s) + size_t(waves) * 32 * row_groups(s) * (16 * groups(s.k0) + 4)) * sizeof(float);
 }
+// Waves per workgroup: 4, or 8 when the parameter block is so big that only one 4-wave workgroup fits a CU (the eight
+// waves then share one copy of it and the CU still runs two waves per SIMD)
+int waves_of(const ChainShape &s) {
+  static const int forced = getenv("INFERA_CHAIN_WAVES") ? atoi(getenv("INFERA_CHAIN_WAVES")) : 0;
+  if (forced == 4 || forced == 8) return lds_bytes_with(s, forced) <= kLdsBudget ? forced : 4;
+  return (2 * lds_bytes_with(s, 4) > kLdsBudget && lds_bytes_with(s, 8) <= kLdsBudget) ? 8 : 4;
+}
+size_t lds_bytes(const ChainShape &s) { return lds_bytes_with(s, waves_of(s)); }
 
 int bits_of(float f) {
   int b;
@@ -52,7 +60,7 @@ std::string expr_of(const ChainShape &s) {
   for (float f : s.pa) pa.push_back(bits_of(f));
   for (float f : s.pb) pb.push_back(bits_of(f));
   return "infera_hip::kern::chaindev::chain_kernel<infera_hip::kern::chaindev::Cfg<" + std::to_string(s.k0) + "," + ints(s.dims) + "," +
-         ints(s.acts) + "," + ints(pa) + "," + ints(pb) + "," + std::to_string(s.sm) + "," + std::to_string(row_groups(s)) + ">>";
+         ints(s.acts) + "," + ints(pa) + "," + ints(pb) + "," + std::to_string(s.sm) + "," + std::to_string(row_groups(s)) + "," + std::to_string(waves_of(s)) + ">>";
 }
 
 struct Compiled {
@@ -168,10 +176,11 @@ bool chain(hipStream_t st, const ChainShape &s, const float *X, const float *pac
   if (rows <= 0) return true;
   const int64_t tile_rows = 32 * row_groups(s), ntiles = (rows + tile_rows - 1) / tile_rows;
   const int per_cu = int(std::min<size_t>(8, std::max<size_t>(1, kLdsBudget / size_t(lds))));
-  int64_t blocks = std::min<int64_t>((ntiles + kWaves - 1) / kWaves, int64_t(num_cus) * per_cu);
+  const int waves = waves_of(s);
+  int64_t blocks = std::min<int64_t>((ntiles + waves - 1) / waves, int64_t(num_cus) * per_cu);
   int aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0 ? 1 : 0;
   void *args[] = {(void *)&X, (void *)&packed, (void *)&Y, (void *)&rows, (void *)&aligned};
-  hipError_t e = hipModuleLaunchKernel(fn, unsigned(blocks), 1, 1, kWaves * 64, 1, 1, unsigned(lds), st, args, nullptr);
+  hipError_t e = hipModuleLaunchKernel(fn, unsigned(blocks), 1, 1, unsigned(waves) * 64, 1, 1, unsigned(lds), st, args, nullptr);
   if (e != hipSuccess) {
     if (why) *why = std::string("hipModuleLaunchKernel: ") + hipGetErrorString(e);
     return false;

@@ -544,7 +544,7 @@ struct Lowerer {
     }
     // activations are always f32 here: a float cast is an alias, an integer cast truncates toward zero and
     // the values stay in f32 storage (the C ABI returns f32, rust.h:28-49)
-    if (to_f) { alias(n, a.shape); return; }
+    if (to_f || int_bufs.count(a.buf)) { alias(n, a.shape); return; }  // (already whole numbers: ArgMax labels and the like)
     Step s;
     s.kind = StepKind::Unary;
     s.in0 = a.buf;
@@ -1029,7 +1029,51 @@ struct Lowerer {
       lower_node(d);
     } else unsupported(n, "post_transform " + pt);
   }
+  // ArrayFeatureExtractor: Y = X[..., indices].  Two forms occur in exported pipelines: a constant class table indexed
+  // by the ArgMax of the scores (label lookup; the table must be evenly spaced, then it is one multiply-add on the
+  // index), and a contiguous column range picked out of the feature matrix.
+  void array_feature_extractor(const NodeDef &n) {
+    const Val &x = get(n, 0);
+    const Val &ix = get(n, 1);
+    const std::string tmp = n.outputs[0] + "\x01";
+    if (x.is_const && !ix.is_const) {
+      if (!int_bufs.count(ix.buf)) unsupported(n, "indices must be whole numbers (an ArgMax output)");
+      if (x.shape.size() != 1) unsupported(n, "only a 1-D class table");
+      std::vector<double> tab;
+      if (x.c->dtype == onnx::kInt64) tab.assign(x.c->i64.begin(), x.c->i64.end());
+      else tab.assign(x.c->f32.begin(), x.c->f32.end());
+      if (tab.size() < 2) unsupported(n, "class table needs two entries");
+      const double a0 = tab[0], step = tab[1] - tab[0];
+      for (size_t i = 0; i < tab.size(); i++)
+        if (tab[i] != a0 + step * double(i)) unsupported(n, "class table must be evenly spaced (label = a + b * index)");
+      std::string cur = n.inputs[1];
+      if (step == 1.0 && a0 == 0.0) { lower_node(std_node(n, "Identity", {cur}, n.outputs[0])); return; }
+      if (step != 1.0) {
+        vals[tmp + "step"] = const_f32({float(step)}, {});
+        const std::string nxt = a0 == 0.0 ? n.outputs[0] : tmp + "scaled";
+        if (nxt != n.outputs[0]) uses[nxt] = 1;
+        lower_node(std_node(n, "Mul", {cur, tmp + "step"}, nxt));
+        cur = nxt;
+      }
+      if (a0 != 0.0) {
+        vals[tmp + "first"] = const_f32({float(a0)}, {});
+        lower_node(std_node(n, "Add", {cur, tmp + "first"}, n.outputs[0]));
+      }
+      return;
+    }
+    if (!x.is_const && ix.is_const && x.shape.size() == 2 && ix.c->dtype == onnx::kInt64 && !ix.c->i64.empty()) {
+      const auto &v = ix.c->i64;
+      for (size_t i = 1; i < v.size(); i++)
+        if (v[i] != v[0] + int64_t(i)) unsupported(n, "only a contiguous column range");
+      if (v[0] < 0 || v[0] + int64_t(v.size()) > x.shape[1]) unsupported(n, "column index out of range");
+      const Val src = x;
+      emit_slice_cols(n, src, v[0], v[0] + int64_t(v.size()), n.outputs[0]);
+      return;
+    }
+    unsupported(n, "only (constant table, index activation) or (activation, constant contiguous indices)");
+  }
   void ml_node(const NodeDef &n) {
+    if (n.op == "ArrayFeatureExtractor") return array_feature_extractor(n);
     const Val &x = get(n, 0);
     if (x.is_const || x.shape.size() != 2) unsupported(n, "only [rows, features] activations");
     const int64_t F = x.shape[1];

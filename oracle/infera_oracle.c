@@ -1214,6 +1214,35 @@ static int op_ml_normalizer(Exec *x, const Node *nd) {
   return 0;
 }
 
+/* ArrayFeatureExtractor: Y = X[..., indices] (gather along the last axis; indices int64 or whole-number f32).
+ * The output takes the indices' shape behind X's leading axes; a 1-D X indexed by [N] gives [N]. */
+static int op_ml_array_feature_extractor(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0), *ix = get_in(x, nd, 1);
+  if (!a || !ix || a->rank < 1) FAIL("ArrayFeatureExtractor: missing input");
+  size_t last = (size_t)a->dims[a->rank - 1], outer = a->n / (last ? last : 1), ni = ix->n;
+  int a_vec = a->rank == 1;
+  int64_t od[MAXRANK];
+  int r = 0;
+  if (a_vec) {
+    for (int i = 0; i < ix->rank; i++) od[r++] = ix->dims[i];
+    outer = 1;
+  } else {
+    for (int i = 0; i + 1 < a->rank; i++) od[r++] = a->dims[i];
+    od[r++] = (int64_t)ni;
+  }
+  Tensor *o = env_new(&x->env, nd->out[0], a->dtype, r, od);
+  a = get_in(x, nd, 0);
+  ix = get_in(x, nd, 1);
+  for (size_t u = 0; u < outer; u++)
+    for (size_t j = 0; j < ni; j++) {
+      int64_t k = ix->dtype == DT_INT64 ? ix->i64[j] : (int64_t)ix->f[j];
+      if (k < 0 || (size_t)k >= last) FAIL("ArrayFeatureExtractor: index %lld out of range", (long long)k);
+      if (a->dtype == DT_FLOAT) o->f[u * ni + j] = a->f[u * last + (size_t)k];
+      else o->i64[u * ni + j] = a->i64[u * last + (size_t)k];
+    }
+  return 0;
+}
+
 static int op_reshape_like(Exec *x, const Node *nd) {
   const Tensor *a = get_in(x, nd, 0);
   if (!a) FAIL("%s: missing input", nd->op);
@@ -1524,6 +1553,7 @@ static int run_node(Exec *x, const Node *nd) {
   if (!strcmp(op, "LinearRegressor")) return op_ml_linear_regressor(x, nd);
   if (!strcmp(op, "LinearClassifier")) return op_ml_linear_classifier(x, nd);
   if (!strcmp(op, "Normalizer")) return op_ml_normalizer(x, nd);
+  if (!strcmp(op, "ArrayFeatureExtractor")) return op_ml_array_feature_extractor(x, nd);
   FAIL("unsupported operator: %s", op);
 }
 

@@ -255,3 +255,66 @@ def test_gpu_label_ties_go_to_the_first_class(api, O, tmp_path, features, rows):
     ok = _decisive(raw)
     assert np.array_equal(got[ok], np.argmax(raw, axis=1)[ok].astype(np.float32))
     assert np.array_equal(got[ok], O.Model(path).predict(x).reshape(-1)[ok])
+
+
+def _mlp_classifier_export(tmp_path, classes_table, k=12, h=20):
+    """The graph skl2onnx writes for MLPClassifier: MatMul/Add/Relu, MatMul/Add, Softmax (probabilities, second output),
+    ArgMax -> ArrayFeatureExtractor(classes_, index) -> Cast(int64) (label, first output); a feature sub-range is picked
+    with ArrayFeatureExtractor first, as ColumnTransformer pipelines do."""
+    e = len(classes_table)
+    ws = W._WeightStream(21)
+    w1, b1, w2, b2 = ws.take((k - 2, h), k), ws.take((h,), k), ws.take((h, e), h), ws.take((e,), h)
+    nodes = [
+        W.node("ArrayFeatureExtractor", ["X", "cols"], ["Xsel"], domain=W.ML_DOMAIN),
+        W.node("MatMul", ["Xsel", "w1"], ["z1"]), W.node("Add", ["z1", "b1"], ["a1"]), W.node("Relu", ["a1"], ["h1"]),
+        W.node("MatMul", ["h1", "w2"], ["z2"]), W.node("Add", ["z2", "b2"], ["scores"]),
+        W.node("Softmax", ["scores"], ["probabilities"], [W.attr_i("axis", 1)]),
+        W.node("ArgMax", ["probabilities"], ["index"], [W.attr_i("axis", 1), W.attr_i("keepdims", 0)]),
+        W.node("ArrayFeatureExtractor", ["classes", "index"], ["picked"], domain=W.ML_DOMAIN),
+        W.node("Cast", ["picked"], ["label"], [W.attr_i("to", W.INT64)]),
+    ]
+    inits = [W.tensor("cols", np.arange(1, k - 1, dtype=np.int64)), W.tensor("w1", w1), W.tensor("b1", b1), W.tensor("w2", w2),
+             W.tensor("b2", b2), W.tensor("classes", np.asarray(classes_table, np.int64))]
+    blob = W.model("mlpc", nodes, inits, [W.value_info("X", ["N", k])],
+                   [W.value_info("label", ["N"], W.INT64), W.value_info("probabilities", ["N", e])], ml_opset=1)
+
+    def ref(x):
+        hid = np.maximum(x[:, 1:k - 1].astype(np.float64) @ w1 + b1, 0)
+        return hid @ w2.astype(np.float64) + b2
+
+    return W.write(str(tmp_path / "mlpc.onnx"), blob), ref
+
+
+@pytest.mark.parametrize("classes_table", [[0, 1, 2, 3], [3, 5, 7]])
+def test_exported_mlp_classifier_label_path(O, built, tmp_path, classes_table):
+    from infera_amd import capi
+
+    path, ref = _mlp_classifier_export(tmp_path, classes_table)
+    x = synth.table(2, 0, 300, 12)
+    raw = ref(x)
+    ok = _decisive(raw)
+    want = np.asarray(classes_table, np.float32)[np.argmax(raw, axis=1)]
+    got = O.Model(path).predict(x).reshape(-1)
+    assert np.array_equal(got[ok], want[ok])
+    capi.load_model("mlpc", path)
+    kinds = [s["kind"] for s in capi.get_plan("mlpc")["plan"]["steps"]]
+    capi.unload_model("mlpc")
+    # column pick, two layers, softmax (ArgMax reads the probabilities), label; Cast of whole numbers is an alias
+    extra = [] if classes_table[0] == 0 and classes_table[1] == 1 else ["BinaryConst", "BinaryConst"]
+    assert kinds == ["SliceCols", "Dense", "Dense", "Softmax", "ArgMax"] + extra, kinds
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classes_table", [[0, 1, 2, 3], [3, 5, 7]])
+def test_gpu_exported_mlp_classifier_label_path(api, O, tmp_path, classes_table):
+    path, ref = _mlp_classifier_export(tmp_path, classes_table)
+    x = synth.table(2, 0, 9001, 12)
+    raw = ref(x)
+    ok = _decisive(raw)
+    api.load_model("mlpc", path)
+    try:
+        got = api.predict("mlpc", x).reshape(-1)
+    finally:
+        api.unload_model("mlpc")
+    assert np.array_equal(got[ok], np.asarray(classes_table, np.float32)[np.argmax(raw, axis=1)][ok])
+    assert np.array_equal(got[ok], O.Model(path).predict(x).reshape(-1)[ok])

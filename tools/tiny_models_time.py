@@ -8,7 +8,8 @@ CASES = [((3, 1), False), ((13, 1), False), ((30, 1), False), ((4, 3), True), ((
          ((100, 10), True), ((128, 10), True), ((64, 1), False), ((20, 16, 1), False), ((30, 8, 1), False), ((50, 1), False),
          ((100, 1), False), ((77, 5), True), ((48, 10), True), ((96, 4), False), ((13, 3), True), ((120, 16), False),
          ((4, 10, 3), True), ((30, 100, 2), True), ((13, 64, 32, 1), False), ((30, 100), False), ((100, 100, 100, 10), True),
-         ((128, 128, 128, 16), False)]
+         ((128, 128, 128, 16), False),
+         ((30, 100, 100, 2), True), ((64, 100, 10), True), ((100, 50, 1), False), ((20, 64, 64, 64, 1), False)]
 for dims, sm in CASES:
     rows = 20_000_000
     name = "t" + "x".join(map(str, dims))
