@@ -130,3 +130,35 @@ def test_gpu_chain_agrees_with_layer_by_layer_kernels(api, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "chain_fused" not in json.loads(out.stdout.strip().splitlines()[-1])
     assert_close(fused, np.load(tmp_path / "y.npy"), rtol=2e-5, atol=1e-6)
+
+
+# dims, final softmax: one model per streaming kernel (skinny / any-width 16x16x4 / 64-128-column 16x16x4 / chain)
+UNALIGNED = [((13, 1), False), ((30, 2), True), ((30, 8), False), ((77, 5), True), ((100, 16), False), ((64, 10), True),
+             ((128, 3), False), ((4, 10, 3), True), ((30, 100, 2), True), ((50, 24, 12), False), ((30, 100), False)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", UNALIGNED, ids=lambda c: "x".join(map(str, c[0])))
+@pytest.mark.parametrize("rows", [5, 1000, 4133])
+def test_gpu_device_scan_from_unaligned_pointers(api, O, tmp_path, case, rows):
+    """infera_hip_predict_device on a table that starts 4 / 8 / 12 bytes past a 16-byte boundary (a column range of a
+    bigger allocation): the streaming kernels take their element-wise load path, results are the same"""
+    dims, sm = case
+    path = W.write(str(tmp_path / "u.onnx"), W.mlp(dims, final_softmax=sm, seed=11))
+    x = synth.table(6, 0, rows, dims[0])
+    want = O.Model(path).predict(x)
+    dev = api.device_ordinal(0)
+    api.load_model("u", path)
+    try:
+        for off_in, off_out in [(4, 0), (8, 4), (12, 12), (0, 8)]:
+            d_in = api.DeviceBuffer(dev, x.nbytes + 16)
+            d_out = api.DeviceBuffer(dev, want.nbytes + 16)
+            d_in.upload(np.concatenate([np.zeros(off_in // 4, np.float32), x.ravel()]))
+            r, c = api.predict_device("u", d_in, rows, dims[0], d_out, in_offset_bytes=off_in, out_offset_bytes=off_out)
+            assert (r, c) == want.shape
+            got = d_out.download(want.shape, offset_bytes=off_out)
+            assert_close(got, want)
+            d_in.free()
+            d_out.free()
+    finally:
+        api.unload_model("u")
