@@ -1,12 +1,19 @@
 #include "mlp_jit.hpp"
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
 
 #include <map>
 #include <mutex>
 #include <tuple>
 #include <vector>
 
+#include "../host/remote.hpp"
 #include "mlp_layout.hpp"
 
 // generated at build time from hip/mlp_device.inc (csrc/Makefile): `static const char kMlpDeviceSrc[] = R"..."`
@@ -29,6 +36,7 @@ struct Rtc {
   int (*GetProgramLogSize)(hiprtcProgram, size_t *) = nullptr;
   int (*GetProgramLog)(hiprtcProgram, char *) = nullptr;
   int (*DestroyProgram)(hiprtcProgram *) = nullptr;
+  int (*Version)(int *, int *) = nullptr;  // optional: part of the disk-cache key
   std::string why;
   bool ok = false;
 };
@@ -60,6 +68,7 @@ const Rtc &rtc() {
     SYM(GetProgramLog, "hiprtcGetProgramLog")
     SYM(DestroyProgram, "hiprtcDestroyProgram")
 #undef SYM
+    x.Version = reinterpret_cast<decltype(x.Version)>(dlsym(x.lib, "hiprtcVersion"));
     x.ok = true;
     return x;
   }();
@@ -67,6 +76,48 @@ const Rtc &rtc() {
 }
 
 
+}  // namespace
+
+// Code objects are kept on disk (INFERA_JIT_CACHE_DIR, default $TMPDIR/infera_jit_cache; "off" disables): the key is
+// sha256 over the device source, the name expression, the GPU architecture and the hipRTC version, so a second process
+// loading the same model shape skips the compile (0.5-3 s).  Files are written whole and renamed into place.
+namespace {
+std::string jit_cache_dir() {
+  const char *e = getenv("INFERA_JIT_CACHE_DIR");
+  if (e && (std::string(e) == "off" || std::string(e) == "0")) return "";
+  if (e && *e) return e;
+  const char *t = getenv("TMPDIR");
+  return std::string(t && *t ? t : "/tmp") + "/infera_jit_cache";
+}
+bool jit_cache_read(const std::string &path, std::vector<char> &code, std::string &lowered) {
+  std::ifstream f(path, std::ios::binary);
+  std::string magic, low;
+  size_t n = 0;
+  if (!f || !std::getline(f, magic) || magic != "INFERAJIT1" || !std::getline(f, low) || !(f >> n) || f.get() != '\n' || n == 0 ||
+      n > (size_t(1) << 30))
+    return false;
+  std::vector<char> buf(n);
+  if (!f.read(buf.data(), std::streamsize(n)) || f.peek() != EOF) return false;
+  code = std::move(buf);
+  lowered = low;
+  return true;
+}
+void jit_cache_write(const std::string &dir, const std::string &path, const std::vector<char> &code, const std::string &lowered) {
+  (void)::mkdir(dir.c_str(), 0755);
+  const std::string tmp = path + "." + std::to_string(long(::getpid())) + ".part";
+  {
+    std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+    if (!f) return;
+    f << "INFERAJIT1\n" << lowered << "\n" << code.size() << "\n";
+    f.write(code.data(), std::streamsize(code.size()));
+    if (!f.good()) {
+      f.close();
+      (void)::unlink(tmp.c_str());
+      return;
+    }
+  }
+  if (::rename(tmp.c_str(), path.c_str()) != 0) (void)::unlink(tmp.c_str());
+}
 }  // namespace
 
 bool jit_compile(const char *src, const char *file, const std::string &expr, std::vector<char> &code, std::string &lowered,
@@ -82,6 +133,12 @@ bool jit_compile(const char *src, const char *file, const std::string &expr, std
     why = "no HIP device to compile for";
     return false;
   }
+  int vmaj = 0, vmin = 0;
+  if (r.Version) (void)r.Version(&vmaj, &vmin);
+  const std::string dir = jit_cache_dir();
+  const std::string cached =
+      dir.empty() ? "" : dir + "/" + remote::sha256_hex(std::string(src) + '\n' + expr + '\n' + prop.gcnArchName + '\n' + std::to_string(vmaj) + "." + std::to_string(vmin)) + ".hsaco";
+  if (!cached.empty() && jit_cache_read(cached, code, lowered)) return true;
   // hipRTC pre-includes its own runtime header (threadIdx, __global__, device math); no #include needed
   hiprtcProgram prog = nullptr;
   if (r.CreateProgram(&prog, src, file, 0, nullptr, nullptr) != 0) {
@@ -112,6 +169,7 @@ bool jit_compile(const char *src, const char *file, const std::string &expr, std
   code.resize(n);
   r.GetCode(prog, code.data());
   r.DestroyProgram(&prog);
+  if (!cached.empty()) jit_cache_write(dir, cached, code, lowered);
   return true;
 }
 

@@ -162,3 +162,31 @@ def test_gpu_device_scan_from_unaligned_pointers(api, O, tmp_path, case, rows):
             d_out.free()
     finally:
         api.unload_model("u")
+
+
+@pytest.mark.gpu
+def test_gpu_jit_code_objects_are_cached_on_disk(tmp_path):
+    """a second process loading the same chain shape finds the code object under INFERA_JIT_CACHE_DIR (no recompile);
+    a truncated cache file is ignored and rewritten"""
+    path = W.write(str(tmp_path / "c.onnx"), W.mlp((9, 20, 4), final_softmax=True, seed=3))
+    cache = tmp_path / "jit"
+    code = ("import sys, time, json; sys.path.insert(0, %r); from infera_amd import capi; t = time.perf_counter(); "
+            "capi.load_model('c', %r); dt = time.perf_counter() - t; "
+            "import numpy as np; y = capi.predict('c', np.ones((3, 9), np.float32)); "
+            "print(json.dumps({'load_s': dt, 'exec': capi.get_plan('c')['exec'], 'y': y.tolist()}))") % (ROOT, path)
+    env = dict(os.environ, INFERA_JIT_CACHE_DIR=str(cache))
+
+    def run():
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    first = run()
+    files = sorted(cache.glob("*.hsaco"))
+    assert first["exec"][0] == "chain_fused" and len(files) == 1 and files[0].stat().st_size > 1000
+    second = run()
+    assert second["y"] == first["y"] and second["exec"] == first["exec"]
+    assert second["load_s"] < first["load_s"], (first["load_s"], second["load_s"])
+    files[0].write_bytes(files[0].read_bytes()[:500])  # corrupt: must be ignored, recompiled and replaced
+    third = run()
+    assert third["y"] == first["y"] and sorted(cache.glob("*.hsaco"))[0].stat().st_size > 1000
