@@ -34,6 +34,29 @@ __global__ __launch_bounds__(256) void read_write_kernel(const f32x4 *__restrict
   }
 }
 
+// the same traffic with the reads issued the way a real kernel can: a wave owns 32 consecutive rows (16 KB), every lane
+// has U 16-byte loads in flight, and the wave writes its 320 result floats as one contiguous run
+template <int U>
+__global__ __launch_bounds__(256) void read_write_tiled_kernel(const f32x4 *__restrict__ x, float *__restrict__ y, size_t rows) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t(blockIdx.x) * 256 + threadIdx.x) >> 6, nwaves = (size_t(gridDim.x) * 256) >> 6;
+  for (size_t t = wave; t * 32 + 31 < rows; t += nwaves) {
+    const f32x4 *src = x + t * 1024 + lane;  // 32 rows x 32 quads
+    float s = 0.f;
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += U) {
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = src[(i0 + u) * 64];
+#pragma unroll
+      for (int u = 0; u < U; u++) s += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+    }
+    float *dst = y + t * 320;
+#pragma unroll
+    for (int j = 0; j < 5; j++) dst[j * 64 + lane] = s + float(j);
+  }
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const f32x4 *__restrict__ x, f32x4 *__restrict__ y, size_t n4) {
   const size_t stride = size_t(gridDim.x) * 256;
   for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += stride) y[i] = x[i];
@@ -70,6 +93,10 @@ int main(int argc, char **argv) {
     double t8 = time_ms([&] { hipLaunchKernelGGL(read_kernel<8>, dim3(blocks), dim3(256), 0, 0, (const f32x4 *)x, y, n4); });
     double tc = time_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, 0, (const f32x4 *)x, (f32x4 *)y, n4 / 2); });
     double tw = time_ms([&] { hipLaunchKernelGGL(read_write_kernel, dim3(blocks), dim3(256), 0, 0, (const f32x4 *)x, y, rows); });
+    double t8w = time_ms([&] { hipLaunchKernelGGL(read_write_tiled_kernel<8>, dim3(blocks), dim3(256), 0, 0, (const f32x4 *)x, y, rows); });
+    double t16w = time_ms([&] { hipLaunchKernelGGL(read_write_tiled_kernel<16>, dim3(blocks), dim3(256), 0, 0, (const f32x4 *)x, y, rows); });
+    printf("blocks %5d: tiled read128+write10, 8 / 16 loads in flight per lane: %.2f / %.2f TB/s\n", blocks, (bytes + rows * 40.0) / t8w / 1e9,
+           (bytes + rows * 40.0) / t16w / 1e9);
     printf("blocks %5d: read x1 %.2f TB/s  x4 %.2f  x8 %.2f | copy %.2f TB/s (r+w) | read128+write10 %.2f TB/s\n", blocks, bytes / t1 / 1e9,
            bytes / t4 / 1e9, bytes / t8 / 1e9, bytes / tc / 1e9, (bytes + rows * 40.0) / tw / 1e9);
   }
