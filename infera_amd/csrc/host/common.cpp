@@ -14,6 +14,11 @@ void set_last_error(const std::string &text) {
   // CString::new fails on interior NULs (error.rs:79) -- in that case the slot keeps its old value.
   if (text.find('\0') != std::string::npos) return;
   g_last_error = text;
+  // Error texts quote names out of model files; a corrupted file can put arbitrary bytes there.  The reference's
+  // strings are Rust `String`s (always UTF-8) and DuckDB expects UTF-8: bytes of an invalid sequence become '?'.
+  if (!is_valid_utf8(g_last_error.c_str()))
+    for (auto &ch : g_last_error)
+      if (static_cast<unsigned char>(ch) >= 0x80) ch = '?';
   g_has_error = true;
 }
 

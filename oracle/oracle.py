@@ -83,7 +83,7 @@ class Model:
         err = C.create_string_buffer(512)
         self._h = lib().orc_load(os.fsencode(path), err, len(err))
         if not self._h:
-            raise OracleError(err.value.decode())
+            raise OracleError(err.value.decode(errors="replace"))
         self.input_shape = [lib().orc_input_shape(self._h)[i] for i in range(lib().orc_input_rank(self._h))]
         self.output_shape = [lib().orc_output_shape(self._h)[i] for i in range(lib().orc_output_rank(self._h))]
 
@@ -108,7 +108,7 @@ class Model:
         res, err = _Result(), C.create_string_buffer(512)
         rc = lib().orc_predict(self._h, x.ctypes.data, rows, cols, C.byref(res), err, len(err))
         if rc:
-            raise OracleError(err.value.decode())
+            raise OracleError(err.value.decode(errors="replace"))
         return self._take(res)
 
     def predict_blob(self, blob: bytes) -> np.ndarray:
@@ -116,7 +116,7 @@ class Model:
         res, err = _Result(), C.create_string_buffer(512)
         rc = lib().orc_predict_blob(self._h, buf, len(blob), C.byref(res), err, len(err))
         if rc:
-            raise OracleError(err.value.decode())
+            raise OracleError(err.value.decode(errors="replace"))
         return self._take(res)
 
     def bench_scan(self, rows: int, ncols: int, seed: int = 42, threads: int = 1, chunk_rows: int = 2048,
