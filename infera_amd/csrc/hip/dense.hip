@@ -702,6 +702,153 @@ static void launch_narrow16g(hipStream_t s, const float *X, const float *W, cons
   else by_nl(std::integral_constant<int, 3>{});
 }
 
+// ---- wide tables of any row length (K > 128 columns that the aligned kernels cannot take: 201, 300, 561, 1000) ----
+// Rows this long are contiguous runs of >= 516 bytes, so a wave reads them row by row: lane l takes column 64c + l of
+// each of its 32 rows -- 256 contiguous bytes per load instruction at whatever alignment the row has -- parks the
+// 32 x 64 chunk in LDS (row stride 68 floats: stride-1 writes, conflict-free ds_read_b128 operand reads) and runs the
+// four 16-column k-groups of the chunk on the 16x16x4 MFMA while the next chunk's 32 loads are in flight.  Loads are
+// clamped into the table and zeroed by select, never branched around.  Weights: fragment-major in LDS, zero-padded to
+// whole chunks.  WV waves share them (8 when they are too big for two 4-wave workgroups per CU).
+template <int SM, int WV>
+__global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                                 const float *__restrict__ bias, float *__restrict__ Y,
+                                                                 int64_t rows, int K, int M, ActParam act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4*NCH][64][4] weights, then WV x [32][68] chunks
+  constexpr int CS = 68;
+  const int NCH = (K + 63) >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = lane & 15, q = lane >> 4;
+  for (int i = threadIdx.x; i < NCH * 1024; i += WV * 64) {
+    const int g = i >> 8, l = (i >> 2) & 63, j = i & 3;
+    const int k = 16 * g + 4 * (l >> 4) + j, m = l & 15;
+    smem[i] = (m < M && k < K) ? W[int64_t(k) * M + m] : 0.f;
+  }
+  __syncthreads();
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(smem) + lane;
+  float *xs = smem + NCH * 1024 + wave * (32 * CS);
+  float bq[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) bq[i] = (bias != nullptr && 4 * q + i < M) ? bias[4 * q + i] : 0.f;
+  const int64_t ntiles = (rows + 31) >> 5;
+  const int64_t tstride = int64_t(gridDim.x) * WV;
+  // (tile, chunk) are wave-uniform: one scalar base per fetch, the per-lane offset walks down the rows by K.  (The
+  // opaque asm keeps hipcc from hoisting 32 row addresses per call site out of the tile loop -- it did, and spilled.)
+  auto fetch = [&](float(&v)[32], int64_t tile, int c) {
+    const int col = 64 * c + lane;
+    const bool col_ok = col < K;
+    int off = col_ok ? col : K - 1;
+    asm volatile("" : "+v"(off));
+    const float *base = X + (tile << 5) * K;
+    if ((tile << 5) + 32 <= rows) {
+#pragma unroll
+      for (int r = 0; r < 32; r++) {
+        const float u = base[off];
+        v[r] = col_ok ? u : 0.f;
+        off += K;
+      }
+    } else {  // last, partial tile
+      const int left = int(rows - (tile << 5));
+#pragma unroll
+      for (int r = 0; r < 32; r++) {
+        v[r] = (col_ok && r < left) ? base[off] : 0.f;
+        off += K;
+      }
+    }
+  };
+  float stage[32];
+  int64_t tile = int64_t(blockIdx.x) * WV + wave;
+  if (tile < ntiles) fetch(stage, tile, 0);
+  for (; tile < ntiles; tile += tstride) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int c = 0; c < NCH; c++) {
+#pragma unroll
+      for (int r = 0; r < 32; r++) xs[r * CS + lane] = stage[r];
+      if (c + 1 < NCH) fetch(stage, tile, c + 1);
+      else if (tile + tstride < ntiles) fetch(stage, tile + tstride, 0);
+#pragma unroll
+      for (int gg = 0; gg < 4; gg++) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + n * CS + 16 * gg + 4 * q);
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + (16 + n) * CS + 16 * gg + 4 * q);
+        const f32x4 a0 = wq[(4 * c + gg) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[j], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x1[j], acc[1], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int64_t row = (tile << 5) + 16 * t + n;
+      f32x4 v = acc[t];
+      dispatch_act(act.kind, [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = apply_act_c<KIND>(v[i] + bq[i], act.a, act.b);
+      });
+      if constexpr (SM == 3) {  // label only: one float per row
+        const float label = argmax_over_quads(v, q, M);
+        if (row < rows && q == 0) Y[row] = label;
+        continue;
+      }
+      if constexpr (SM == 1 || SM == 2) {  // the row's features live in lanes n, n+16, n+32, n+48
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) mx = fmaxf(mx, v[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) {
+            const float e = expf(v[i] - mx);
+            sum += e;
+            v[i] = SM == 1 ? e : v[i] - mx;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float ls = logf(sum);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = SM == 1 ? v[i] / sum : v[i] - ls;
+      }
+      if (row < rows) {
+        float *yrow = Y + row * M + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) yrow[i] = v[i];
+      }
+    }
+  }
+}
+
+static size_t narrow16w_lds(int K, int waves) { return (size_t((K + 63) / 64) * 1024 + size_t(waves) * 32 * 68) * sizeof(float); }
+static bool narrow16w_ok(int K, int M) { return M >= 1 && M <= 16 && K > 128 && narrow16w_lds(K, 4) <= 160 * 1024; }
+
+static void launch_narrow16w(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
+                             ActParam act, int softmax_mode) {
+  const bool eight = 2 * narrow16w_lds(K, 4) > 160 * 1024 && narrow16w_lds(K, 8) <= 160 * 1024;
+  const int waves = eight ? 8 : 4;
+  const size_t lds = narrow16w_lds(K, waves);
+  const int64_t ntiles = (rows + 31) / 32;
+  const int per_cu = int(std::clamp<size_t>((160 * 1024) / lds, 1, 8));
+  const int64_t blocks = std::min<int64_t>((ntiles + waves - 1) / waves, 256 * per_cu);
+  dim3 grid((unsigned)blocks), block(unsigned(waves) * 64);
+  auto go = [&](auto kernel) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
+  };
+  auto by_w = [&](auto smt) {
+    constexpr int SMv = decltype(smt)::value;
+    if (eight) go(dense_narrow16w_kernel<SMv, 8>);
+    else go(dense_narrow16w_kernel<SMv, 4>);
+  };
+  if (softmax_mode == 0) by_w(std::integral_constant<int, 0>{});
+  else if (softmax_mode == 1) by_w(std::integral_constant<int, 1>{});
+  else if (softmax_mode == 2) by_w(std::integral_constant<int, 2>{});
+  else by_w(std::integral_constant<int, 3>{});
+}
+
 // ---- skinny layers: rows of at most 32 floats, M <= 16 outputs ----------------------------------------------------
 // The most common in-database models are a handful of multiply-adds per row: no matrix core can help, and the
 // MFMA kernels' 16-byte operand loads do not even apply (rows of 3, 13, 30 floats are not 16-byte aligned).
@@ -859,12 +1006,15 @@ static void launch_skinny(hipStream_t s, const float *X, const float *W, const f
 bool dense_can_fuse_softmax(int M) { return M <= 64; }
 // ArgMax epilogues (softmax_mode 3) exist in the skinny and the two 16x16x4 streaming kernels; the latter need 16-byte rows
 bool dense_can_fuse_argmax(const float *X, int K, int M) {
-  return narrow16g_ok(K, M) || skinny_ok(K, M) || (M <= 16 && K % 16 == 0 && K <= 1024 && (reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  return narrow16g_ok(K, M) || skinny_ok(K, M) || narrow16w_ok(K, M) ||
+         (M <= 16 && K % 16 == 0 && K <= 1024 && (reinterpret_cast<uintptr_t>(X) & 15) == 0);
 }
 
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
            ActParam act, int softmax_mode) {
   if (rows <= 0) return;
+  static const int wide16 = getenv("INFERA_DENSE16W") ? atoi(getenv("INFERA_DENSE16W")) : 1;  // 0 off, 2 = also where aligned kernels exist (A/B)
+  if (wide16 == 2 && M <= 16 && K >= 64 && narrow16w_lds(K, 4) <= 160 * 1024) return launch_narrow16w(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   if (narrow16g_ok(K, M)) return launch_narrow16g(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   if (skinny_ok(K, M)) return launch_skinny(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   static const bool staged16 = !(getenv("INFERA_DENSE16_STAGED") && atoi(getenv("INFERA_DENSE16_STAGED")) == 0);
@@ -886,6 +1036,7 @@ void dense(hipStream_t s, const float *X, const float *W, const float *bias, flo
     else hipLaunchKernelGGL((dense_narrow16_kernel<3>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
     return;
   }
+  if (wide16 && narrow16w_ok(K, M)) return launch_narrow16w(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   if (softmax_mode == 3) return;  // callers check dense_can_fuse_argmax first; nothing below has that epilogue
   if (M <= 32 && K % 8 == 0 && K <= 512 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
     const int64_t ntiles = (rows + 31) / 32;

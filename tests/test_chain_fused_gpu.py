@@ -134,7 +134,7 @@ def test_gpu_chain_agrees_with_layer_by_layer_kernels(api, tmp_path):
 
 # dims, final softmax: one model per streaming kernel (skinny / any-width 16x16x4 / 64-128-column 16x16x4 / chain)
 UNALIGNED = [((13, 1), False), ((30, 2), True), ((30, 8), False), ((77, 5), True), ((100, 16), False), ((64, 10), True),
-             ((128, 3), False), ((4, 10, 3), True), ((30, 100, 2), True), ((50, 24, 12), False), ((30, 100), False)]
+             ((128, 3), False), ((201, 1), False), ((300, 10), True), ((561, 6), True), ((1000, 2), False), ((4, 10, 3), True), ((30, 100, 2), True), ((50, 24, 12), False), ((30, 100), False)]
 
 
 @pytest.mark.gpu
@@ -190,3 +190,18 @@ def test_gpu_jit_code_objects_are_cached_on_disk(tmp_path):
     files[0].write_bytes(files[0].read_bytes()[:500])  # corrupt: must be ignored, recompiled and replaced
     third = run()
     assert third["y"] == first["y"] and sorted(cache.glob("*.hsaco"))[0].stat().st_size > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,m,sm", [(129, 1, False), (201, 1, False), (300, 10, True), (561, 6, True), (1000, 16, False), (1984, 3, True)])
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 4100])
+def test_gpu_wide_tables_of_any_row_length(api, O, tmp_path, k, m, sm, rows):
+    """dense_narrow16w_kernel: 64-column chunks row by row, K not a multiple of anything, partial last chunk and tile"""
+    path = W.write(str(tmp_path / "w.onnx"), W.mlp((k, m), final_softmax=sm, seed=13))
+    x = synth.table(12, 0, rows, k)
+    api.load_model("w", path)
+    try:
+        got = api.predict("w", x)
+    finally:
+        api.unload_model("w")
+    assert_close(got, O.Model(path).predict(x))
