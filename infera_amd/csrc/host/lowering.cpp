@@ -156,6 +156,18 @@ struct Lowerer {
       auto pit = producer.find(in_buf);
       if (in_buf <= 0 || pit == producer.end() || pit->second != int(plan.steps.size()) - 1 || live_uses(in_buf) != 1) break;
       const Step &p = plan.steps.back();
+      if (p.kind == StepKind::AffineChannel && p.act == Act::None && p.S == 1 && p.C == K) {  // BatchNormalization of the features
+        for (int64_t k = 0; k < K; k++) {
+          ft[size_t(k)] += fs[size_t(k)] * double(p.shift[size_t(k)]);
+          fs[size_t(k)] *= double(p.scale[size_t(k)]);
+        }
+        folded = true;
+        folded_origin = p.origin + (folded_origin.empty() ? "" : "+" + folded_origin);
+        in_buf = p.in0;
+        producer.erase(pit);
+        plan.steps.pop_back();
+        continue;
+      }
       if (p.kind != StepKind::BinaryConst || p.act != Act::None || int64_t(p.cst.size()) != K) break;
       if (p.bop != '+' && p.bop != '-' && p.bop != '*' && !(p.bop == '/' && !p.const_left)) break;
       for (int64_t k = 0; k < K; k++) {
@@ -875,6 +887,15 @@ struct Lowerer {
           for (int64_t k = 0; k < per_m; k++) p->W[size_t(mo * per_m + k)] *= scale[size_t(mo)];
         if (p->bias.empty()) p->bias.assign(size_t(p->Mo), 0.f);
         for (int64_t mo = 0; mo < p->Mo; mo++) p->bias[size_t(mo)] = p->bias[size_t(mo)] * scale[size_t(mo)] + shift[size_t(mo)];
+        p->origin += "+BatchNormalization";
+        set_act(n, a.buf, shape, true);
+        return;
+      }
+      if (p->kind == StepKind::Dense && p->act == Act::None && a.shape.size() == 2 && p->M == C) {  // Dense -> BN (Keras MLPs)
+        for (int64_t k = 0; k < p->K; k++)
+          for (int64_t j = 0; j < C; j++) p->W[size_t(k * C + j)] *= scale[size_t(j)];
+        if (p->bias.empty()) p->bias.assign(size_t(C), 0.f);
+        for (int64_t j = 0; j < C; j++) p->bias[size_t(j)] = p->bias[size_t(j)] * scale[size_t(j)] + shift[size_t(j)];
         p->origin += "+BatchNormalization";
         set_act(n, a.buf, shape, true);
         return;

@@ -362,6 +362,60 @@ def test_gpu_scaler_pipeline(api, O, tmp_path):
     api.unload_model("sp")
 
 
+def _keras_bn_mlp(tmp_path, k=20, h=32, m=3):
+    """Keras-style tabular MLP: BatchNormalization(features) -> Dense -> BatchNormalization -> Relu -> Dense -> Softmax"""
+    rng = np.random.default_rng(5)
+
+    def bn(c, tag):
+        g, b = (0.5 + rng.random(c)).astype(np.float32), rng.standard_normal(c).astype(np.float32) * 0.2
+        mu, var = rng.standard_normal(c).astype(np.float32) * 0.3, (0.3 + rng.random(c)).astype(np.float32)
+        inits = [W.tensor(f"g{tag}", g), W.tensor(f"b{tag}", b), W.tensor(f"mu{tag}", mu), W.tensor(f"var{tag}", var)]
+        return inits, lambda x: (x - mu) / np.sqrt(var.astype(np.float64) + 1e-3) * g + b
+
+    i0, f0 = bn(k, "0")
+    i1, f1 = bn(h, "1")
+    w1, c1 = (rng.standard_normal((k, h)) * 0.3).astype(np.float32), rng.standard_normal(h).astype(np.float32) * 0.1
+    w2, c2 = (rng.standard_normal((h, m)) * 0.3).astype(np.float32), rng.standard_normal(m).astype(np.float32) * 0.1
+    eps = [W.attr_f("epsilon", 1e-3)]
+    nodes = [W.node("BatchNormalization", ["X", "g0", "b0", "mu0", "var0"], ["x0"], eps),
+             W.node("Gemm", ["x0", "w1", "c1"], ["z1"]),
+             W.node("BatchNormalization", ["z1", "g1", "b1", "mu1", "var1"], ["n1"], eps), W.node("Relu", ["n1"], ["a1"]),
+             W.node("Gemm", ["a1", "w2", "c2"], ["z2"]), W.node("Softmax", ["z2"], ["Y"], [W.attr_i("axis", 1)])]
+    inits = i0 + i1 + [W.tensor("w1", w1), W.tensor("c1", c1), W.tensor("w2", w2), W.tensor("c2", c2)]
+    blob = W.model("keras_bn", nodes, inits, [W.value_info("X", ["N", k])], [W.value_info("Y", ["N", m])])
+
+    def ref(x):
+        a = np.maximum(f1(f0(x.astype(np.float64)) @ w1 + c1), 0) @ w2 + c2
+        e = np.exp(a - a.max(axis=1, keepdims=True))
+        return e / e.sum(axis=1, keepdims=True)
+
+    return W.write(str(tmp_path / "keras_bn.onnx"), blob), ref
+
+
+def test_feature_batchnorm_folds_into_the_dense_layers(O, built, tmp_path):
+    from infera_amd import capi
+
+    path, ref = _keras_bn_mlp(tmp_path)
+    x = synth.table(43, 0, 64, 20)
+    assert_close(O.Model(path).predict(x), ref(x).astype(np.float32), rtol=3e-5, atol=2e-6)
+    capi.load_model("kbn", path)
+    steps = capi.get_plan("kbn")["plan"]["steps"]
+    capi.unload_model("kbn")
+    assert [s["kind"] for s in steps] == ["Dense", "Dense", "Softmax"], steps  # both BatchNormalizations are in W1 / b1
+    assert steps[0]["origin"] == "BatchNormalization+Gemm+BatchNormalization+Relu", steps[0]["origin"]
+
+
+@pytest.mark.gpu
+def test_gpu_feature_batchnorm_mlp(api, O, tmp_path):
+    path, ref = _keras_bn_mlp(tmp_path)
+    x = synth.table(43, 0, 5003, 20)
+    api.load_model("kbn", path)
+    got = api.predict("kbn", x)
+    api.unload_model("kbn")
+    assert_close(got, O.Model(path).predict(x))
+    assert_close(got, ref(x).astype(np.float32), rtol=3e-5, atol=2e-6)
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
