@@ -321,7 +321,8 @@ void schedule(LoadedModel &m) {
     // (CopyCols = channel concat: a contiguous per-row block in NCHW and in channel-quad planes alike)
     const bool layout_free = s.kind == StepKind::Conv2d || s.kind == StepKind::Pool2d || s.kind == StepKind::GlobalAvgPool ||
                              s.kind == StepKind::BinaryAct || s.kind == StepKind::Unary || s.kind == StepKind::AffineChannel ||
-                             s.kind == StepKind::CopyCols;
+                             s.kind == StepKind::CopyCols || s.kind == StepKind::SliceCols || s.kind == StepKind::LRN ||
+                             s.kind == StepKind::ChannelShuffle;
     for (int b : {s.in0, s.in1}) {
       if (b < 0) continue;
       if (b == 0 && is4d(0) && s.kind != StepKind::Conv2d) ok = false;  // the caller's NCHW input is read by convs only
@@ -604,13 +605,20 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
                        m.cq_mode && x.in0 != 0);
           break;
         case StepKind::GlobalAvgPool:
-          kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.cq_mode && x.in0 != 0);
+          kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.cq_mode && x.in0 != 0, x.is_max);
           break;
         case StepKind::CopyCols:
           kern::copy_cols(s, buf(x.in0), buf(x.out), nr, p.buf_per_row[size_t(x.in0)], p.buf_per_row[size_t(x.in0)], 0,
                           p.buf_per_row[size_t(x.out)], x.col_off);
           break;
         case StepKind::PadCols: kern::pad_cols(s, buf(x.in0), buf(x.out), nr, x.K, x.M); break;
+        case StepKind::LRN:
+          kern::lrn(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), int(x.lrn_size), x.lrn_alpha, x.lrn_beta, x.lrn_bias,
+                    m.cq_mode && x.in0 != 0);
+          break;
+        case StepKind::ChannelShuffle:
+          kern::channel_shuffle(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), int(x.groups), m.cq_mode && x.in0 != 0);
+          break;
         case StepKind::SliceCols:
           kern::copy_cols(s, buf(x.in0), buf(x.out), nr, x.K, p.buf_per_row[size_t(x.in0)], x.col_off, x.K, 0);
           break;

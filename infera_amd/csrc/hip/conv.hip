@@ -740,12 +740,23 @@ __global__ __launch_bounds__(kBlock) void pool2d_kernel(const float *__restrict_
 }
 
 // NCHW: one wave per (n, c) over S contiguous elements.  CQ: one lane per (n, channel quad), 16 bytes per step.
+// is_max: GlobalMaxPool (same traversal, max instead of mean).
 __global__ __launch_bounds__(kBlock) void global_avgpool_kernel(const float *__restrict__ X, float *__restrict__ Y,
-                                                               int64_t nc_total, int C, int S, bool cq) {
+                                                               int64_t nc_total, int C, int S, bool cq, bool is_max) {
   if (cq) {
     const int64_t stride = int64_t(gridDim.x) * kBlock, nq = nc_total >> 2;
     for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < nq; o += stride) {
       const f32x4 *src = reinterpret_cast<const f32x4 *>(X) + o * S;
+      if (is_max) {
+        f32x4 mx = src[0];
+        for (int i = 1; i < S; i++) {
+          const f32x4 v = src[i];
+#pragma unroll
+          for (int j = 0; j < 4; j++) mx[j] = fmaxf(mx[j], v[j]);
+        }
+        reinterpret_cast<f32x4 *>(Y)[o] = mx;
+        continue;
+      }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       for (int i = 0; i < S; i++) acc += src[i];
       reinterpret_cast<f32x4 *>(Y)[o] = acc / float(S);
@@ -757,11 +768,11 @@ __global__ __launch_bounds__(kBlock) void global_avgpool_kernel(const float *__r
   const int64_t nwaves = (int64_t(gridDim.x) * kBlock) >> 6;
   for (int64_t nc = wave; nc < nc_total; nc += nwaves) {
     const float *src = X + nc * S;
-    float acc = 0.f;
-    for (int i = lane; i < S; i += 64) acc += src[i];
+    float acc = is_max ? -INFINITY : 0.f;
+    for (int i = lane; i < S; i += 64) acc = is_max ? fmaxf(acc, src[i]) : acc + src[i];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) Y[nc] = acc / float(S);
+    for (int o = 32; o > 0; o >>= 1) acc = is_max ? fmaxf(acc, __shfl_xor(acc, o)) : acc + __shfl_xor(acc, o);
+    if (lane == 0) Y[nc] = is_max ? acc : acc / float(S);
   }
 }
 
@@ -985,10 +996,10 @@ void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H,
                      pl, dh, dw, is_max, count_pad);
 }
 
-void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool cq) {
+void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool cq, bool is_max) {
   const int64_t nc = rows * C;
   if (nc <= 0) return;
-  hipLaunchKernelGGL(global_avgpool_kernel, dim3(grid_for(cq ? nc / 4 : nc * 64)), dim3(kBlock), 0, s, X, Y, nc, C, S, cq);
+  hipLaunchKernelGGL(global_avgpool_kernel, dim3(grid_for(cq ? nc / 4 : nc * 64)), dim3(kBlock), 0, s, X, Y, nc, C, S, cq, is_max);
 }
 
 }  // namespace infera_hip::kern

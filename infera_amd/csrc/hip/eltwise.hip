@@ -296,6 +296,72 @@ void transpose_cm(hipStream_t s, const float *src, float *dst, int64_t rows, int
   hipLaunchKernelGGL(transpose_cm_kernel, dim3(unsigned((rows + 31) / 32), unsigned((ncols + 31) / 32)), dim3(kBlock), 0, s, src, dst, rows, ncols);
 }
 
+// Across-channel LRN, one lane per element.  Element (n, c, p) sits at ((n*C + c)*S + p) in NCHW and at
+// ((n*C/4 + c/4)*S + p)*4 + c%4 in channel-quad planes; the window walks channels at a fixed position p.
+__global__ __launch_bounds__(kBlock) void lrn_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n, int C, int S,
+                                                    int size, float alpha_over_size, float beta, float bias, bool cq) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  const int lo = (size - 1) / 2, hi = size - 1 - lo;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    int64_t img, p;
+    int c;
+    if (cq) {
+      const int64_t quad = i >> 2, plane = quad / S;  // plane = img * (C/4) + c/4
+      p = quad - plane * S;
+      img = plane / (C >> 2);
+      c = int(plane - img * (C >> 2)) * 4 + int(i & 3);
+    } else {
+      const int64_t nc = i / S;
+      p = i - nc * S;
+      img = nc / C;
+      c = int(nc - img * C);
+    }
+    const int c0 = max(c - lo, 0), c1 = min(c + hi, C - 1);
+    float sq = 0.f;
+    for (int k = c0; k <= c1; k++) {
+      const float v = cq ? x[((img * (C >> 2) + (k >> 2)) * S + p) * 4 + (k & 3)] : x[(img * C + k) * S + p];
+      sq = fmaf(v, v, sq);
+    }
+    y[i] = x[i] / powf(bias + alpha_over_size * sq, beta);
+  }
+}
+
+// Channel shuffle, one lane per output element: out channel j*g + i <- in channel i*(C/g) + j
+__global__ __launch_bounds__(kBlock) void channel_shuffle_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n, int C,
+                                                                int S, int g, bool cq) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  const int per = C / g;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    int64_t img, p;
+    int c;
+    if (cq) {
+      const int64_t quad = i >> 2, plane = quad / S;
+      p = quad - plane * S;
+      img = plane / (C >> 2);
+      c = int(plane - img * (C >> 2)) * 4 + int(i & 3);
+    } else {
+      const int64_t nc = i / S;
+      p = i - nc * S;
+      img = nc / C;
+      c = int(nc - img * C);
+    }
+    const int k = (c % g) * per + c / g;
+    y[i] = cq ? x[((img * (C >> 2) + (k >> 2)) * S + p) * 4 + (k & 3)] : x[(img * C + k) * S + p];
+  }
+}
+
+void lrn(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, int size, float alpha, float beta, float bias, bool cq) {
+  const int64_t n = rows * C * S;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(lrn_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, X, Y, n, C, S, size, alpha / float(size), beta, bias, cq);
+}
+
+void channel_shuffle(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, int groups, bool cq) {
+  const int64_t n = rows * C * S;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(channel_shuffle_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, X, Y, n, C, S, groups, cq);
+}
+
 void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t len) {
   if (rows <= 0 || len <= 0) return;
   hipLaunchKernelGGL(argmax_kernel, dim3(grid_for(rows)), dim3(kBlock), 0, s, x, y, rows, len);

@@ -122,6 +122,10 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
                   int64_t rows, const ConvGeom &g, ActParam act);
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
             int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq);
-void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool cq);
+// y[n,c,p] = x[n,c,p] / (bias + alpha/size * sum_{c' in window(c)} x[n,c',p]^2)^beta over [rows, C, S] (cq: channel-quad planes)
+void lrn(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, int size, float alpha, float beta, float bias, bool cq);
+// Y[n, j*g + i, p] = X[n, i*(C/g) + j, p]
+void channel_shuffle(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, int groups, bool cq);
+void global_avgpool(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, bool cq, bool is_max = false);
 
 }  // namespace infera_hip::kern

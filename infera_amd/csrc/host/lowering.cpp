@@ -35,6 +35,10 @@ struct Val {
   std::shared_ptr<TensorData> c;
   int buf = -1;
   std::vector<int64_t> shape;  // activations: dim0 = -1 (symbolic rows) or fixed batch
+  // zero padding (top, left, bottom, right) a Pad node asked for and the consuming Conv still has to apply; `shape`
+  // is the UNPADDED tensor that `buf` holds
+  int64_t pend[4] = {0, 0, 0, 0};
+  bool padded() const { return pend[0] || pend[1] || pend[2] || pend[3]; }
 };
 
 int64_t prod(const std::vector<int64_t> &v, size_t from = 0, size_t to = SIZE_MAX) {
@@ -444,27 +448,32 @@ struct Lowerer {
     }
   }
   // feature-axis slice of a [rows, K] activation: out = in[:, b:e]
+  // ... or a channel range of an [N,C,H,W] activation: channels [b, e) are one contiguous block of every sample, in
+  // NCHW and (whole quads) in the channel-quad layout alike
   void emit_slice_cols(const NodeDef &n, const Val &a, int64_t b, int64_t e, const std::string &out_name) {
+    const int64_t inner = prod(a.shape, 2);
+    std::vector<int64_t> oshape = a.shape;
+    oshape[1] = e - b;
     Step s;
     s.kind = StepKind::SliceCols;
     s.in0 = a.buf;
-    s.col_off = b;
-    s.K = e - b;
-    s.out = new_buf({a.shape[0], e - b});
+    s.col_off = b * inner;
+    s.K = (e - b) * inner;
+    s.out = new_buf(oshape);
     s.origin = n.op + (n.name.empty() ? "" : ":" + n.name);
     plan.steps.push_back(std::move(s));
     producer[plan.steps.back().out] = int(plan.steps.size()) - 1;
     Val v;
     v.buf = plan.steps.back().out;
-    v.shape = {a.shape[0], e - b};
+    v.shape = oshape;
     vals[out_name] = v;
     buf_names[v.buf].push_back(out_name);
   }
   void split(const NodeDef &n) {
     const Val &a = get(n, 0);
-    if (a.is_const || a.shape.size() != 2) unsupported(n, "only [rows, K] activations");
+    if (a.is_const || a.shape.size() < 2) unsupported(n, "only [rows, K] or [N,C,...] activations");
     int64_t axis = n.attr_i("axis", 0);
-    if (axis < 0) axis += 2;
+    if (axis < 0) axis += int64_t(a.shape.size());
     if (axis != 1) unsupported(n, "only axis 1 keeps rows independent");
     std::vector<int64_t> sizes;
     if (has_input(n, 1)) sizes = const_ints(n, 1, "split");
@@ -485,7 +494,7 @@ struct Lowerer {
   }
   void slice(const NodeDef &n) {
     const Val &d = get(n, 0);
-    if (!d.is_const && d.shape.size() == 2) {  // activation: feature-axis slice with step 1
+    if (!d.is_const && d.shape.size() >= 2) {  // activation: feature / channel axis slice with step 1
       std::vector<int64_t> st, en, ax, sp;
       if (has_input(n, 1)) {
         st = const_ints(n, 1, "starts");
@@ -498,8 +507,8 @@ struct Lowerer {
         if (auto *p = n.attr_ints("axes")) ax = *p;
       }
       if (st.size() != 1 || en.size() != 1 || ax.size() > 1 || (!sp.empty() && sp[0] != 1)) unsupported(n, "one axis, step 1");
-      const int64_t axis = ax.empty() ? 0 : (ax[0] < 0 ? ax[0] + 2 : ax[0]);
-      if (axis != 1) unsupported(n, "only axis 1 keeps rows independent");
+      const int64_t axis = ax.empty() ? 0 : (ax[0] < 0 ? ax[0] + int64_t(d.shape.size()) : ax[0]);
+      if (axis != 1) unsupported(n, "only axis 1 (features / channels)");
       const int64_t K = d.shape[1];
       int64_t b = st[0] < 0 ? st[0] + K : st[0], e = en[0] < 0 ? en[0] + K : en[0];
       b = std::clamp<int64_t>(b, 0, K);
@@ -811,7 +820,7 @@ struct Lowerer {
     emit(std::move(s), n, shape);
   }
 
-  void spatial(const NodeDef &n, Step &s, int64_t H, int64_t W) {
+  void spatial(const NodeDef &n, Step &s, int64_t H, int64_t W, const int64_t *extra_pad = nullptr) {
     s.sh = s.sw = s.dh = s.dw = 1;
     s.pt = s.pl = s.pb = s.pr = 0;
     if (auto *p = n.attr_ints("strides")) { if (p->size() != 2) unsupported(n, "only 2-D"); s.sh = (*p)[0]; s.sw = (*p)[1]; }
@@ -827,6 +836,10 @@ struct Lowerer {
       s.pt = up ? ph / 2 : ph - ph / 2; s.pb = ph - s.pt;
       s.pl = up ? pw / 2 : pw - pw / 2; s.pr = pw - s.pl;
     } else if (ap != "NOTSET") unsupported(n, "auto_pad " + ap);
+    if (extra_pad && (extra_pad[0] || extra_pad[1] || extra_pad[2] || extra_pad[3])) {  // a Pad node in front (TF exporters)
+      if (ap == "SAME_UPPER" || ap == "SAME_LOWER") unsupported(n, "auto_pad SAME behind an explicit Pad");
+      s.pt += extra_pad[0]; s.pl += extra_pad[1]; s.pb += extra_pad[2]; s.pr += extra_pad[3];
+    }
     // pooling only: ceil_mode=1 rounds the extent up, and a last window that would start beyond the input plus
     // its leading pad is dropped (ONNX MaxPool / AveragePool); the kernels already ignore out-of-image taps
     const bool ceil_mode = n.attr_i("ceil_mode", 0) != 0;
@@ -853,7 +866,7 @@ struct Lowerer {
     s.Mo = w.shape[0]; s.kh = w.shape[2]; s.kw = w.shape[3];
     s.groups = n.attr_i("group", 1);
     if (s.groups < 1 || s.C != w.shape[1] * s.groups || s.Mo % s.groups) unsupported(n, "channel/group mismatch");
-    spatial(n, s, s.H, s.Wd);
+    spatial(n, s, s.H, s.Wd, a.pend);
     s.W = cf32(n, w);
     if (has_input(n, 2)) {
       s.bias = cf32(n, get(n, 2));
@@ -929,11 +942,110 @@ struct Lowerer {
     emit(std::move(s), n, shape);
   }
 
-  void global_avgpool(const NodeDef &n) {
+  // Pad with zeros on the two spatial axes of an [N,C,H,W] activation: no kernel -- the value keeps its buffer and
+  // the Conv that consumes it widens its own padding (the form TF / Keras exporters write for 'same' convolutions).
+  void pad(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    if (a.is_const || a.shape.size() != 4) unsupported(n, "only [N,C,H,W] activations");
+    if (n.attr_s("mode", "constant") != "constant") unsupported(n, "only constant (zero) padding");
+    std::vector<int64_t> pads;
+    if (has_input(n, 1)) pads = const_ints(n, 1, "pads");
+    else if (auto *p = n.attr_ints("pads")) pads = *p;
+    if (pads.size() != 8) unsupported(n, "pads must hold 8 entries for a 4-D tensor");
+    float value = n.attr_f("value", 0.f);
+    if (has_input(n, 2)) {
+      const auto &cv = cf32(n, get(n, 2));
+      if (cv.size() != 1) unsupported(n, "constant_value must be a scalar");
+      value = cv[0];
+    }
+    if (value != 0.f) unsupported(n, "only zero padding folds into a convolution");
+    if (has_input(n, 3)) unsupported(n, "axes input");
+    if (pads[0] || pads[1] || pads[4] || pads[5]) unsupported(n, "padding of the batch / channel axes");
+    for (auto v : pads)
+      if (v < 0) unsupported(n, "negative pads (cropping)");
+    Val v = a;
+    v.pend[0] += pads[2]; v.pend[1] += pads[3]; v.pend[2] += pads[6]; v.pend[3] += pads[7];
+    vals[n.outputs[0]] = v;
+    buf_names[v.buf].push_back(n.outputs[0]);
+    alias_edges[v.buf]++;
+  }
+  void lrn(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    if (a.is_const || a.shape.size() < 3) unsupported(n, "only [N,C,...] activations");
+    Step s;
+    s.kind = StepKind::LRN;
+    s.in0 = a.buf;
+    s.C = a.shape[1];
+    s.S = prod(a.shape, 2);
+    s.lrn_size = n.attr_i("size", 0);
+    if (s.lrn_size < 1) unsupported(n, "size attribute required");
+    s.lrn_alpha = n.attr_f("alpha", 1e-4f);
+    s.lrn_beta = n.attr_f("beta", 0.75f);
+    s.lrn_bias = n.attr_f("bias", 1.f);
+    std::vector<int64_t> shape = a.shape;
+    emit(std::move(s), n, shape);
+  }
+  // Transpose: constants are folded (2-D weight matrices); on activations only the channel shuffle of ShuffleNet-style
+  // blocks -- Reshape [N,C,H,W] -> [N,g,C/g,H,W], Transpose(0,2,1,3,4), Reshape back -- which is a channel permutation.
+  void transpose(const NodeDef &n) {
+    const Val &a = get(n, 0);
+    const int64_t rank = int64_t(a.shape.size());
+    std::vector<int64_t> perm;
+    if (auto *p = n.attr_ints("perm")) perm = *p;
+    else for (int64_t i = rank; i-- > 0;) perm.push_back(i);
+    if (int64_t(perm.size()) != rank) unsupported(n, "perm length");
+    if (a.is_const) {
+      if (rank != 2 || a.c->dtype != onnx::kFloat) unsupported(n, "only 2-D f32 constants are folded");
+      if (perm[0] == 0 && perm[1] == 1) { vals[n.outputs[0]] = a; return; }
+      const int64_t R = a.shape[0], Cc = a.shape[1];
+      std::vector<float> t(size_t(R * Cc));
+      for (int64_t r = 0; r < R; r++)
+        for (int64_t c = 0; c < Cc; c++) t[size_t(c * R + r)] = a.c->f32[size_t(r * Cc + c)];
+      vals[n.outputs[0]] = const_f32(std::move(t), {Cc, R});
+      return;
+    }
+    const bool shuffle = rank >= 4 && perm[0] == 0 && perm[1] == 2 && perm[2] == 1 && [&] {
+      for (int64_t i = 3; i < rank; i++)
+        if (perm[size_t(i)] != i) return false;
+      return true;
+    }();
+    if (!shuffle) unsupported(n, "on activations only the channel shuffle (0,2,1,3,...) keeps rows independent and is supported");
+    Step s;
+    s.kind = StepKind::ChannelShuffle;
+    s.in0 = a.buf;
+    s.groups = a.shape[1];
+    s.C = a.shape[1] * a.shape[2];
+    s.S = prod(a.shape, 3);
+    // the buffer is registered as the [N,C,spatial...] tensor it is for the layout rules; the value carries the 5-D shape
+    std::vector<int64_t> bshape = {a.shape[0], s.C};
+    for (int64_t i = 3; i < rank; i++) bshape.push_back(a.shape[size_t(i)]);
+    std::vector<int64_t> vshape = a.shape;
+    std::swap(vshape[1], vshape[2]);
+    s.out = new_buf(bshape);
+    s.origin = n.op + (n.name.empty() ? "" : ":" + n.name);
+    plan.steps.push_back(std::move(s));
+    producer[plan.steps.back().out] = int(plan.steps.size()) - 1;
+    set_act(n, plan.steps.back().out, vshape);
+  }
+  // Sum of any number of equal-shaped activations: a chain of residual adds
+  void sum(const NodeDef &n) {
+    if (n.inputs.empty()) unsupported(n, "no inputs");
+    if (n.inputs.size() == 1) { lower_node(std_node(n, "Identity", {n.inputs[0]}, n.outputs[0])); return; }
+    std::string cur = n.inputs[0];
+    for (size_t i = 1; i < n.inputs.size(); i++) {
+      const bool last = i + 1 == n.inputs.size();
+      const std::string out = last ? n.outputs[0] : n.outputs[0] + "\x01sum" + std::to_string(i);
+      if (!last) uses[out] = 1;
+      lower_node(std_node(n, "Add", {cur, n.inputs[i]}, out));
+      cur = out;
+    }
+  }
+  void global_avgpool(const NodeDef &n, bool is_max) {
     const Val &a = get(n, 0);
     if (a.is_const || a.shape.size() < 3) unsupported(n, "bad input");
     Step s;
     s.kind = StepKind::GlobalAvgPool;
+    s.is_max = is_max;
     s.in0 = a.buf;
     s.C = a.shape[1];
     s.S = prod(a.shape, 2);
@@ -945,6 +1057,11 @@ struct Lowerer {
   // ------------------------------------------------------------------------------------------
   void lower_node(const NodeDef &n) {
       const std::string &op = n.op;
+      if (op != "Conv")
+        for (const auto &in_name : n.inputs) {
+          auto it = vals.find(in_name);
+          if (it != vals.end() && it->second.padded()) unsupported(n, "the output of a Pad node can only feed a Conv (its padding is folded into the convolution)");
+        }
       if (op == "MatMul") dense(n, false);
       else if (op == "Gemm") dense(n, true);
       else if (op == "Add") binary(n, '+');
@@ -975,7 +1092,12 @@ struct Lowerer {
       else if (op == "BatchNormalization") batchnorm(n);
       else if (op == "MaxPool") pool(n, true);
       else if (op == "AveragePool") pool(n, false);
-      else if (op == "GlobalAveragePool") global_avgpool(n);
+      else if (op == "GlobalAveragePool") global_avgpool(n, false);
+      else if (op == "GlobalMaxPool") global_avgpool(n, true);
+      else if (op == "Pad") pad(n);
+      else if (op == "Sum") sum(n);
+      else if (op == "LRN") lrn(n);
+      else if (op == "Transpose") transpose(n);
       else if (op == "Constant") {
         Val v;
         v.is_const = true;
@@ -1254,6 +1376,7 @@ struct Lowerer {
     auto it = vals.find(out.name);
     if (it == vals.end()) throw InferaError::onnx("output '" + out.name + "' is never produced");
     if (it->second.is_const) throw InferaError::onnx("output '" + out.name + "' is a constant; nothing to run");
+    if (it->second.padded()) throw InferaError::onnx("output '" + out.name + "' is a Pad result; padding is only folded into a following Conv");
     if (out.elem_type != 0 && out.elem_type != onnx::kFloat) {
       // integer outputs (ArgMax labels, Cast to int) are returned as f32 VALUES: the C ABI carries f32 only
       // (rust.h:28-49; the reference itself rejects non-f32 outputs at engine.rs:150-152)
@@ -1290,7 +1413,7 @@ double Plan::flops_per_row() const {
 }
 
 std::string Plan::describe_json() const {
-  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool", "CopyCols", "ArgMax", "SliceCols", "PadCols"};
+  static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool", "CopyCols", "ArgMax", "SliceCols", "PadCols", "LRN", "ChannelShuffle"};
   static const char *acts[] = {"", "Relu", "Sigmoid", "Tanh", "LeakyRelu", "Clip", "Exp", "Log", "Sqrt", "Neg", "Abs", "Elu", "Selu", "Softplus",
                                "HardSigmoid", "HardSwish", "Erf", "Gelu", "Reciprocal", "Floor", "Ceil", "Softsign", "Trunc", "Round"};
   std::ostringstream o;

@@ -36,6 +36,8 @@ enum class StepKind : int {
   CopyCols = 9,     // out[r, col_off : col_off+len] = in0[r, :]   (one piece of a Concat along the feature/channel axis)
   ArgMax = 10,      // out[r, 0] = float(index of the first maximum of in0[r, 0:len])   (labels as f32 values)
   SliceCols = 11,   // out[r, :] = in0[r, col_off : col_off+K]   (Slice / Split on the feature axis; one input of a multi-input model)
+  LRN = 13,         // across-channel local response normalisation: y = x / (act_b' ... see lrn_* fields) over [N,C,S]
+  ChannelShuffle = 14,  // out[n, j*g + i, p] = in0[n, i*(C/g) + j, p]   (Reshape [N,g,C/g,..] -> Transpose(0,2,1,..) -> Reshape; groups in `groups`)
   PadCols = 12,     // out[r, 0:K] = in0[r, :], zeros up to M columns   (row length -> multiple of 4 for the 16-byte loads of the MFMA kernels)
 };
 
@@ -65,6 +67,9 @@ struct Step {
   int64_t C = 0, H = 0, Wd = 0, Mo = 0, OH = 0, OW = 0;
   int64_t kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0, dh = 1, dw = 1, groups = 1;
   bool is_max = false, count_pad = false;
+  // LRN: window `lrn_size` channels, y = x / (lrn_bias + lrn_alpha / lrn_size * sum x^2)^lrn_beta
+  int64_t lrn_size = 0;
+  float lrn_alpha = 1e-4f, lrn_beta = 0.75f, lrn_bias = 1.f;
   std::string origin;  // ONNX node names/ops this step came from (diagnostics)
 };
 

@@ -435,6 +435,56 @@ def se_net(c: int = 16, hw: int = 10, classes: int = 6) -> bytes:
     return model("se_net", nodes, inits, [value_info("X", ["N", 4, hw, hw])], [value_info("Y", ["N", classes])], opset=14)
 
 
+def zoo_ops_net(hw: int = 16, classes: int = 7) -> tuple[bytes, dict]:
+    """One small network made of the operators the ONNX Model Zoo's vision models add to plain conv nets:
+    LRN (AlexNet / GoogLeNet), explicit asymmetric Pad in front of a VALID Conv (TF / Keras exporters), channel Split,
+    Concat and the Reshape -> Transpose -> Reshape channel shuffle (ShuffleNet), channel Slice, n-ary Sum and
+    GlobalMaxPool.  Returns (model bytes, weights by name) so a test can restate it in numpy."""
+    ws = _WeightStream(47)
+    inits, nodes, wts = [], [], {}
+
+    def conv(x, cin, cout, k, out, pads, stride=1, groups=1, act=None):
+        w, b = ws.take((cout, cin // groups, k, k), (cin // groups) * k * k), ws.take((cout,), cin * k * k)
+        wts[out] = (w, b)
+        inits.extend([tensor(out + "_w", w), tensor(out + "_b", b)])
+        nodes.append(node("Conv", [x, out + "_w", out + "_b"], [out if act is None else out + "_pre"],
+                          [attr_ints("kernel_shape", [k, k]), attr_ints("pads", pads), attr_ints("strides", [stride, stride]),
+                           attr_i("group", groups)]))
+        if act:
+            nodes.append(node(act, [out + "_pre"], [out]))
+        return out
+
+    conv("X", 3, 16, 3, "c1", [1, 1, 1, 1], act="Relu")
+    nodes.append(node("LRN", ["c1"], ["n1"], [attr_i("size", 5), attr_f("alpha", 0.05), attr_f("beta", 0.75), attr_f("bias", 1.5)]))
+    nodes.append(node("MaxPool", ["n1"], ["p1"], [attr_ints("kernel_shape", [2, 2]), attr_ints("strides", [2, 2])]))
+    h1 = hw // 2
+    inits.append(tensor("pads", np.array([0, 0, 0, 1, 0, 0, 2, 1], np.int64)))  # top 0, left 1, bottom 2, right 1
+    nodes.append(node("Pad", ["p1", "pads"], ["pp"]))
+    conv("pp", 16, 32, 3, "c2", [0, 0, 0, 0], stride=2, act="Relu")
+    h2 = (h1 + 2 - 3) // 2 + 1
+    nodes.append(node("Split", ["c2"], ["keep", "work"], [attr_i("axis", 1), attr_ints("split", [16, 16])]))
+    conv("work", 16, 16, 1, "b1", [0, 0, 0, 0], act="Relu")
+    conv("b1", 16, 16, 3, "b2", [1, 1, 1, 1], groups=16)
+    conv("b2", 16, 16, 1, "b3", [0, 0, 0, 0], act="Relu")
+    nodes.append(node("Concat", ["keep", "b3"], ["cat"], [attr_i("axis", 1)]))
+    inits += [tensor("shape5", np.array([0, 2, 16, h2, h2], np.int64)), tensor("shape4", np.array([0, 32, h2, h2], np.int64))]
+    nodes += [node("Reshape", ["cat", "shape5"], ["r5"]), node("Transpose", ["r5"], ["t5"], [attr_ints("perm", [0, 2, 1, 3, 4])]),
+              node("Reshape", ["t5", "shape4"], ["shuf"])]
+    inits += [tensor("s_st", np.array([8], np.int64)), tensor("s_en", np.array([24], np.int64)), tensor("s_ax", np.array([1], np.int64))]
+    nodes.append(node("Slice", ["shuf", "s_st", "s_en", "s_ax"], ["mid"]))
+    conv("mid", 16, 32, 1, "s1", [0, 0, 0, 0])
+    conv("shuf", 32, 32, 1, "s2", [0, 0, 0, 0])
+    nodes.append(node("Sum", ["s1", "s2", "shuf"], ["tot"]))
+    nodes.append(node("GlobalMaxPool", ["tot"], ["g"]))
+    nodes.append(node("Flatten", ["g"], ["f"], [attr_i("axis", 1)]))
+    w, b = ws.take((32, classes), 32), ws.take((classes,), 32)
+    wts["fc"] = (w, b)
+    inits += [tensor("fc_w", w), tensor("fc_b", b)]
+    nodes.append(node("Gemm", ["f", "fc_w", "fc_b"], ["Y"]))
+    blob = model("zoo_ops", nodes, inits, [value_info("X", ["N", 3, hw, hw])], [value_info("Y", ["N", classes])], opset=13)
+    return blob, wts
+
+
 def write(path: str, blob: bytes) -> str:
     with open(path, "wb") as fh:
         fh.write(blob)

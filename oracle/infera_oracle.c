@@ -1491,6 +1491,129 @@ static int op_global_avgpool(Exec *x, const Node *nd) {
   return 0;
 }
 
+static int op_global_maxpool(Exec *x, const Node *nd) {
+  const Tensor *in = get_in(x, nd, 0);
+  if (!in || in->rank < 3) FAIL("GlobalMaxPool: bad input");
+  int64_t od[MAXRANK];
+  for (int i = 0; i < in->rank; i++) od[i] = i < 2 ? in->dims[i] : 1;
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, in->rank, od);
+  in = get_in(x, nd, 0);
+  size_t NC = (size_t)(in->dims[0] * in->dims[1]), S = in->n / NC;
+  for (size_t i = 0; i < NC; i++) {
+    float mx = in->f[i * S];
+    for (size_t j = 1; j < S; j++) mx = in->f[i * S + j] > mx ? in->f[i * S + j] : mx;
+    o->f[i] = mx;
+  }
+  return 0;
+}
+
+/* Pad (mode constant): pads = [begin_0..begin_{r-1}, end_0..end_{r-1}], attribute (opset < 11) or input 1 */
+static int op_pad(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0), *tp = get_in(x, nd, 1), *tv = get_in(x, nd, 2);
+  if (!a || a->dtype != DT_FLOAT) FAIL("Pad: bad input");
+  const Attr *am = find_attr(nd, "mode");
+  if (am && am->s && strcmp(am->s, "constant")) FAIL("Pad: only constant mode");
+  int64_t pads[2 * MAXRANK];
+  const Attr *ap = find_attr(nd, "pads");
+  size_t np = tp ? tp->n : (ap ? ap->nints : 0);
+  if (np != (size_t)(2 * a->rank)) FAIL("Pad: pads must hold 2*rank entries");
+  for (size_t i = 0; i < np; i++) {
+    pads[i] = tp ? tp->i64[i] : ap->ints[i];
+    if (pads[i] < 0) FAIL("Pad: negative pads");
+  }
+  float value = tv ? tv->f[0] : attr_f(nd, "value", 0.0f);
+  int64_t od[MAXRANK];
+  const int rank = a->rank;
+  for (int i = 0; i < rank; i++) od[i] = a->dims[i] + pads[i] + pads[rank + i];
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, rank, od);
+  a = get_in(x, nd, 0);
+  for (size_t i = 0; i < o->n; i++) o->f[i] = value;
+  int64_t idx[MAXRANK] = {0};
+  for (size_t flat = 0; flat < a->n; flat++) {
+    size_t dst = 0;
+    for (int i = 0; i < rank; i++) dst = dst * (size_t)od[i] + (size_t)(idx[i] + pads[i]);
+    o->f[dst] = a->f[flat];
+    for (int i = rank - 1; i >= 0; i--) {
+      if (++idx[i] < a->dims[i]) break;
+      idx[i] = 0;
+    }
+  }
+  return 0;
+}
+
+/* Sum: elementwise sum of equal-shaped inputs, left to right */
+static int op_sum(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT) FAIL("Sum: bad input");
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, a->rank, a->dims);
+  a = get_in(x, nd, 0);
+  memcpy(o->f, a->f, a->n * 4);
+  for (size_t k = 1; k < nd->nin; k++) {
+    const Tensor *b = get_in(x, nd, k);
+    if (!b || b->n != o->n) FAIL("Sum: inputs must have equal shapes");
+    for (size_t i = 0; i < o->n; i++) o->f[i] = o->f[i] + b->f[i];
+  }
+  return 0;
+}
+
+/* LRN over the channel axis: y = x / (bias + alpha/size * sum_{c' in window} x[c']^2)^beta,
+ * window = [c - floor((size-1)/2), c + ceil((size-1)/2)] clipped to the channels */
+static int op_lrn(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT || a->rank < 3) FAIL("LRN: expects [N,C,...]");
+  const int64_t size = attr_i(nd, "size", 0);
+  if (size < 1) FAIL("LRN: size attribute required");
+  const float alpha = attr_f(nd, "alpha", 1e-4f), beta = attr_f(nd, "beta", 0.75f), bias = attr_f(nd, "bias", 1.0f);
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, a->rank, a->dims);
+  a = get_in(x, nd, 0);
+  const size_t N = (size_t)a->dims[0], C = (size_t)a->dims[1], S = a->n / (N * C);
+  const int64_t lo = (size - 1) / 2, hi = size - 1 - lo;
+  for (size_t n = 0; n < N; n++)
+    for (size_t c = 0; c < C; c++)
+      for (size_t p = 0; p < S; p++) {
+        int64_t c0 = (int64_t)c - lo, c1 = (int64_t)c + hi;
+        if (c0 < 0) c0 = 0;
+        if (c1 > (int64_t)C - 1) c1 = (int64_t)C - 1;
+        float sq = 0.0f;
+        for (int64_t k = c0; k <= c1; k++) {
+          const float v = a->f[(n * C + (size_t)k) * S + p];
+          sq = fmaf(v, v, sq);
+        }
+        o->f[(n * C + c) * S + p] = a->f[(n * C + c) * S + p] / powf(bias + alpha / (float)size * sq, beta);
+      }
+  return 0;
+}
+
+/* Transpose: out.dims[i] = in.dims[perm[i]] (default: reversed axes) */
+static int op_transpose(Exec *x, const Node *nd) {
+  const Tensor *a = get_in(x, nd, 0);
+  if (!a || a->dtype != DT_FLOAT) FAIL("Transpose: bad input");
+  const Attr *ap = find_attr(nd, "perm");
+  const int rank = a->rank;
+  int64_t perm[MAXRANK], od[MAXRANK], istr[MAXRANK];
+  if (ap && ap->nints != (size_t)rank) FAIL("Transpose: perm length");
+  for (int i = 0; i < rank; i++) perm[i] = ap ? ap->ints[i] : rank - 1 - i;
+  for (int i = 0; i < rank; i++) {
+    if (perm[i] < 0 || perm[i] >= rank) FAIL("Transpose: bad perm");
+    od[i] = a->dims[perm[i]];
+  }
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, rank, od);
+  a = get_in(x, nd, 0);
+  int64_t st = 1;
+  for (int i = rank - 1; i >= 0; i--) { istr[i] = st; st *= a->dims[i]; }
+  int64_t idx[MAXRANK] = {0};
+  for (size_t flat = 0; flat < o->n; flat++) {
+    size_t src = 0;
+    for (int i = 0; i < rank; i++) src += (size_t)(idx[i] * istr[perm[i]]);
+    o->f[flat] = a->f[src];
+    for (int i = rank - 1; i >= 0; i--) {
+      if (++idx[i] < od[i]) break;
+      idx[i] = 0;
+    }
+  }
+  return 0;
+}
+
 static int op_constant(Exec *x, const Node *nd) {
   const Attr *a = find_attr(nd, "value");
   if (a && a->t) {
@@ -1548,6 +1671,11 @@ static int run_node(Exec *x, const Node *nd) {
   if (!strcmp(op, "MaxPool")) return op_pool(x, nd, 1);
   if (!strcmp(op, "AveragePool")) return op_pool(x, nd, 0);
   if (!strcmp(op, "GlobalAveragePool")) return op_global_avgpool(x, nd);
+  if (!strcmp(op, "GlobalMaxPool")) return op_global_maxpool(x, nd);
+  if (!strcmp(op, "Pad")) return op_pad(x, nd);
+  if (!strcmp(op, "Sum")) return op_sum(x, nd);
+  if (!strcmp(op, "LRN")) return op_lrn(x, nd);
+  if (!strcmp(op, "Transpose")) return op_transpose(x, nd);
   if (!strcmp(op, "Constant")) return op_constant(x, nd);
   if (!strcmp(op, "Scaler")) return op_ml_scaler(x, nd);
   if (!strcmp(op, "LinearRegressor")) return op_ml_linear_regressor(x, nd);

@@ -416,6 +416,111 @@ def test_gpu_feature_batchnorm_mlp(api, O, tmp_path):
     assert_close(got, ref(x).astype(np.float32), rtol=3e-5, atol=2e-6)
 
 
+def np_zoo_ops(x, wts):
+    """float64 restatement of W.zoo_ops_net from the operator specifications"""
+    relu = lambda v: np.maximum(v, 0)
+    c = lambda name, v, **kw: np_conv2d(v, wts[name][0].astype(np.float64), wts[name][1].astype(np.float64), **kw)
+    a = relu(c("c1", x.astype(np.float64), pad=1))
+    sq = np.pad(a * a, ((0, 0), (2, 2), (0, 0), (0, 0)))
+    win = sum(sq[:, k:k + a.shape[1]] for k in range(5))  # channels c-2 .. c+2
+    a = a / (1.5 + 0.05 / 5 * win) ** 0.75
+    a = np_pool(a, 2, 2, 0, a.shape[2] // 2, True)
+    a = np.pad(a, ((0, 0), (0, 0), (0, 2), (1, 1)))
+    a = relu(c("c2", a, stride=2))
+    keep, work = a[:, :16], a[:, 16:]
+    b = relu(c("b1", work))
+    b = c("b2", b, pad=1, groups=16)
+    b = relu(c("b3", b))
+    cat = np.concatenate([keep, b], axis=1)
+    n, _, h, w = cat.shape
+    shuf = cat.reshape(n, 2, 16, h, w).transpose(0, 2, 1, 3, 4).reshape(n, 32, h, w)
+    tot = c("s1", shuf[:, 8:24]) + c("s2", shuf) + shuf
+    g = tot.max(axis=(2, 3))
+    return g @ wts["fc"][0].astype(np.float64) + wts["fc"][1]
+
+
+def test_model_zoo_operator_batch(O, built, tmp_path):
+    """LRN, Pad folded into a VALID Conv, channel Split / Slice, channel shuffle, Sum, GlobalMaxPool"""
+    from infera_amd import capi
+
+    blob, wts = W.zoo_ops_net()
+    path = W.write(str(tmp_path / "zoo_ops.onnx"), blob)
+    x = synth.table(77, 0, 5, 3 * 16 * 16)
+    assert_close(O.Model(path).predict_blob(x.tobytes()), np_zoo_ops(x.reshape(5, 3, 16, 16), wts).astype(np.float32), rtol=1e-4, atol=2e-6)
+    capi.load_model("zoo_ops", path)
+    steps = capi.get_plan("zoo_ops")["plan"]["steps"]
+    capi.unload_model("zoo_ops")
+    kinds = [s["kind"] for s in steps]
+    assert kinds.count("LRN") == 1 and kinds.count("ChannelShuffle") == 1 and kinds.count("SliceCols") == 3, kinds
+    assert "Pad" not in " ".join(s["origin"] for s in steps) and kinds.count("BinaryAct") == 2, kinds  # Pad is in c2's padding; Sum = two adds
+    bad = [W.node("Pad", ["X", "pads"], ["p"]), W.node("Relu", ["p"], ["Y"])]
+    p2 = W.write(str(tmp_path / "badpad.onnx"),
+                 W.model("badpad", bad, [W.tensor("pads", np.array([0, 0, 1, 1, 0, 0, 1, 1], np.int64))],
+                         [W.value_info("X", ["N", 3, 4, 4])], [W.value_info("Y", ["N", 3, 6, 6])]))
+    with pytest.raises(capi.InferaError, match="Pad node can only feed a Conv"):
+        capi.load_model("badpad", p2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 9, 130])
+def test_gpu_model_zoo_operator_batch(api, O, tmp_path, rows):
+    blob, wts = W.zoo_ops_net()
+    path = W.write(str(tmp_path / "zoo_ops.onnx"), blob)
+    x = synth.table(78, 0, rows, 3 * 16 * 16)
+    api.load_model("zoo_ops", path)
+    try:
+        assert api.get_plan("zoo_ops")["activation_layout"] == "NC/4HW4"
+        got = api.predict_from_blob("zoo_ops", x.tobytes())
+    finally:
+        api.unload_model("zoo_ops")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+    assert_close(got, np_zoo_ops(x.reshape(rows, 3, 16, 16), wts).astype(np.float32), rtol=1e-4, atol=2e-6)
+
+
+def _nchw_lrn_shuffle(tmp_path):
+    """6 channels (not whole quads): the plan stays NCHW, so LRN / channel shuffle / GlobalMaxPool run their NCHW paths"""
+    ws = W._WeightStream(9)
+    w, b = ws.take((6, 3, 3, 3), 27), ws.take((6,), 27)
+    fw, fb = ws.take((6, 4), 6), ws.take((4,), 6)
+    nodes = [W.node("Conv", ["X", "w", "b"], ["c"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("pads", [1, 1, 1, 1])]),
+             W.node("LRN", ["c"], ["l"], [W.attr_i("size", 3), W.attr_f("alpha", 0.1)]),
+             W.node("Reshape", ["l", "s5"], ["r5"]), W.node("Transpose", ["r5"], ["t5"], [W.attr_ints("perm", [0, 2, 1, 3, 4])]),
+             W.node("Reshape", ["t5", "s4"], ["sh"]), W.node("GlobalMaxPool", ["sh"], ["g"]), W.node("Flatten", ["g"], ["f"]),
+             W.node("Gemm", ["f", "fw", "fb"], ["Y"])]
+    inits = [W.tensor("w", w), W.tensor("b", b), W.tensor("fw", fw), W.tensor("fb", fb),
+             W.tensor("s5", np.array([0, 3, 2, 5, 5], np.int64)), W.tensor("s4", np.array([0, 6, 5, 5], np.int64))]
+    blob = W.model("nchw_ops", nodes, inits, [W.value_info("X", ["N", 3, 5, 5])], [W.value_info("Y", ["N", 4])])
+
+    def ref(x):
+        a = np_conv2d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), pad=1)
+        sq = np.pad(a * a, ((0, 0), (1, 1), (0, 0), (0, 0)))
+        a = a / (1.0 + 0.1 / 3 * sum(sq[:, k:k + 6] for k in range(3))) ** 0.75
+        a = a.reshape(-1, 3, 2, 5, 5).transpose(0, 2, 1, 3, 4).reshape(-1, 6, 5, 5)
+        return a.max(axis=(2, 3)) @ fw.astype(np.float64) + fb
+
+    return W.write(str(tmp_path / "nchw_ops.onnx"), blob), ref
+
+
+def test_oracle_nchw_lrn_shuffle_vs_numpy(O, tmp_path):
+    path, ref = _nchw_lrn_shuffle(tmp_path)
+    x = synth.table(5, 0, 4, 75)
+    assert_close(O.Model(path).predict_blob(x.tobytes()), ref(x.reshape(4, 3, 5, 5)).astype(np.float32), rtol=3e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_nchw_lrn_shuffle(api, O, tmp_path):
+    path, ref = _nchw_lrn_shuffle(tmp_path)
+    x = synth.table(5, 0, 300, 75)
+    api.load_model("nchw_ops", path)
+    try:
+        assert api.get_plan("nchw_ops")["activation_layout"] == "NCHW"
+        got = api.predict_from_blob("nchw_ops", x.tobytes())
+    finally:
+        api.unload_model("nchw_ops")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+    assert_close(got, ref(x.reshape(300, 3, 5, 5)).astype(np.float32), rtol=3e-5, atol=2e-6)
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
