@@ -316,6 +316,7 @@ void schedule(LoadedModel &m) {
   auto is4d = [&](int b) { return b >= 0 && m.plan.buf_shape[size_t(b)].size() == 4; };
   auto spatial = [&](int b) { return is4d(b) ? m.plan.buf_shape[size_t(b)][2] * m.plan.buf_shape[size_t(b)][3] : int64_t(1); };
   bool any_conv = false, ok = true;
+  std::vector<size_t> flat_dense;  // Dense layers fed by a flattened [C,H,W] activation
   for (const auto &s : st) {
     any_conv = any_conv || s.kind == StepKind::Conv2d;
     // (CopyCols = channel concat: a contiguous per-row block in NCHW and in channel-quad planes alike)
@@ -326,7 +327,13 @@ void schedule(LoadedModel &m) {
     for (int b : {s.in0, s.in1}) {
       if (b < 0) continue;
       if (b == 0 && is4d(0) && s.kind != StepKind::Conv2d) ok = false;  // the caller's NCHW input is read by convs only
-      if (!layout_free && spatial(b) > 1) ok = false;                    // e.g. Flatten(C,H,W) -> Gemm needs NCHW order
+      if (!layout_free && spatial(b) > 1) {
+        // Flatten(C,H,W) -> Gemm (VGG / AlexNet heads): the layer reads the channel-quad tensor as it lies and its
+        // weight rows are permuted to that order once, below.  Anything else that looks at flattened features in
+        // NCHW order keeps the whole plan NCHW.
+        if (s.kind == StepKind::Dense && b == s.in0 && b != 0 && s.K == m.plan.buf_per_row[size_t(b)]) flat_dense.push_back(&s - st.data());
+        else ok = false;
+      }
     }
   }
   if (spatial(m.plan.out_buf) > 1) ok = false;  // results leave in the caller's (NCHW) order
@@ -334,6 +341,18 @@ void schedule(LoadedModel &m) {
   for (size_t b = 1; b < m.plan.buf_shape.size(); b++)
     if (m.plan.buf_shape[b].size() == 4 && m.plan.buf_shape[b][1] % 4 != 0) ok = false;
   m.cq_mode = any_conv && ok;
+  if (m.cq_mode)
+    for (size_t i : flat_dense) {  // W rows: NCHW feature c*HW + p  ->  channel-quad feature ((c/4)*HW + p)*4 + c%4
+      Step &d = m.plan.steps[i];
+      const auto &bs = m.plan.buf_shape[size_t(d.in0)];
+      const int64_t C = bs[1], HW = bs[2] * bs[3], M = d.M;
+      std::vector<float> w(d.W.size());
+      for (int64_t c = 0; c < C; c++)
+        for (int64_t p = 0; p < HW; p++)
+          std::copy_n(d.W.begin() + (c * HW + p) * M, M, w.begin() + (((c >> 2) * HW + p) * 4 + (c & 3)) * M);
+      d.W = std::move(w);
+      d.origin += "[rows in channel-quad order]";
+    }
   if (m.cq_mode)
     for (size_t i = 0; i < n; i++) {
       const Step &s = st[i];

@@ -521,6 +521,59 @@ def test_gpu_nchw_lrn_shuffle(api, O, tmp_path):
     assert_close(got, ref(x.reshape(300, 3, 5, 5)).astype(np.float32), rtol=3e-5, atol=2e-6)
 
 
+def _vgg_like(tmp_path, hidden=40):
+    """VGG / AlexNet head: conv blocks -> Flatten(C,H,W) -> Gemm -> Relu -> Gemm (no global pooling before the classifier)"""
+    ws = W._WeightStream(61)
+    w1, b1 = ws.take((8, 3, 3, 3), 27), ws.take((8,), 27)
+    w2, b2 = ws.take((16, 8, 3, 3), 72), ws.take((16,), 72)
+    f1, g1 = ws.take((16 * 4 * 4, hidden), 256), ws.take((hidden,), 256)
+    f2, g2 = ws.take((hidden, 5), hidden), ws.take((5,), hidden)
+    cv = lambda x, w, b, o: W.node("Conv", [x, w, b], [o], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("pads", [1, 1, 1, 1])])
+    mp = lambda x, o: W.node("MaxPool", [x], [o], [W.attr_ints("kernel_shape", [2, 2]), W.attr_ints("strides", [2, 2])])
+    nodes = [cv("X", "w1", "b1", "c1"), W.node("Relu", ["c1"], ["r1"]), mp("r1", "p1"), cv("p1", "w2", "b2", "c2"), W.node("Relu", ["c2"], ["r2"]),
+             mp("r2", "p2"), W.node("Flatten", ["p2"], ["flat"], [W.attr_i("axis", 1)]), W.node("Gemm", ["flat", "f1", "g1"], ["h"]),
+             W.node("Relu", ["h"], ["hr"]), W.node("Gemm", ["hr", "f2", "g2"], ["Y"])]
+    inits = [W.tensor(k, v) for k, v in dict(w1=w1, b1=b1, w2=w2, b2=b2, f1=f1, g1=g1, f2=f2, g2=g2).items()]
+    blob = W.model("vgg_like", nodes, inits, [W.value_info("X", ["N", 3, 16, 16])], [W.value_info("Y", ["N", 5])])
+
+    def ref(x):
+        a = np.maximum(np_conv2d(x.astype(np.float64), w1.astype(np.float64), b1.astype(np.float64), pad=1), 0)
+        a = np_pool(a, 2, 2, 0, 8, True)
+        a = np.maximum(np_conv2d(a, w2.astype(np.float64), b2.astype(np.float64), pad=1), 0)
+        a = np_pool(a, 2, 2, 0, 4, True).reshape(len(x), -1)
+        return np.maximum(a @ f1.astype(np.float64) + g1, 0) @ f2.astype(np.float64) + g2
+
+    return W.write(str(tmp_path / f"vgg_like{hidden}.onnx"), blob), ref
+
+
+def test_flatten_into_gemm_keeps_the_conv_layout(O, built, tmp_path):
+    from infera_amd import capi
+
+    path, ref = _vgg_like(tmp_path)
+    x = synth.table(3, 0, 4, 768)
+    assert_close(O.Model(path).predict_blob(x.tobytes()), ref(x.reshape(4, 3, 16, 16)).astype(np.float32), rtol=3e-5, atol=2e-6)
+    capi.load_model("vgg", path)
+    plan = capi.get_plan("vgg")
+    capi.unload_model("vgg")
+    assert plan["activation_layout"] == "NC/4HW4", plan["activation_layout"]  # the classifier's weight rows were permuted instead
+    assert any("channel-quad order" in s["origin"] for s in plan["plan"]["steps"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [8, 40, 100])  # narrow / chain-or-tiled first classifier layers
+def test_gpu_flatten_into_gemm(api, O, tmp_path, hidden):
+    path, ref = _vgg_like(tmp_path, hidden)
+    x = synth.table(3, 0, 70, 768)
+    api.load_model("vgg", path)
+    try:
+        assert api.get_plan("vgg")["activation_layout"] == "NC/4HW4"
+        got = api.predict_from_blob("vgg", x.tobytes())
+    finally:
+        api.unload_model("vgg")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+    assert_close(got, ref(x.reshape(70, 3, 16, 16)).astype(np.float32), rtol=3e-5, atol=2e-6)
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi

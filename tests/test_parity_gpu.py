@@ -508,22 +508,27 @@ def test_tiled_conv_feature_tile_variants(api, tmp_path):
 
 
 def test_conv_plan_falls_back_to_nchw_when_flatten_needs_it(api, tmp_path):
-    """Conv -> Flatten(C*H*W) -> Gemm consumes the feature map in NCHW order: the plan must stay NCHW."""
+    """Conv -> Flatten(C*H*W) -> MatMul reads the feature map through the layer's permuted weight rows (the conv layout
+    stays); a Softmax over the flattened features looks at them in NCHW order: that plan must stay NCHW."""
     from infera_amd import onnx_writer as W
     from oracle import oracle
 
     rng = np.random.default_rng(3)
     w = rng.standard_normal((8, 3, 3, 3)).astype(np.float32) * 0.2
     fc = rng.standard_normal((8 * 6 * 6, 5)).astype(np.float32) * 0.1
-    nodes = [W.node("Conv", ["X", "w"], ["c"], [W.attr_ints("kernel_shape", [3, 3])]), W.node("Relu", ["c"], ["r"]),
-             W.node("Flatten", ["r"], ["f"], [W.attr_i("axis", 1)]), W.node("MatMul", ["f", "fc"], ["Y"])]
-    blob = W.model("convfc", nodes, [W.tensor("w", w), W.tensor("fc", fc)], [W.value_info("X", ["N", 3, 8, 8])], [W.value_info("Y", ["N", 5])])
-    path = W.write(str(tmp_path / "convfc.onnx"), blob)
-    api.load_model("convfc", path)
-    assert api.get_plan("convfc")["activation_layout"] == "NCHW"
     x = rng.standard_normal((4, 3, 8, 8)).astype(np.float32)
-    assert_close(api.predict_from_blob("convfc", x.tobytes()), oracle.Model(path).predict_blob(x.tobytes()))
-    api.unload_model("convfc")
+    for softmax, layout in [(False, "NC/4HW4"), (True, "NCHW")]:
+        nodes = [W.node("Conv", ["X", "w"], ["c"], [W.attr_ints("kernel_shape", [3, 3])]), W.node("Relu", ["c"], ["r"]),
+                 W.node("Flatten", ["r"], ["f"], [W.attr_i("axis", 1)])]
+        if softmax:
+            nodes.append(W.node("Softmax", ["f"], ["s"], [W.attr_i("axis", 1)]))
+        nodes.append(W.node("MatMul", ["s" if softmax else "f", "fc"], ["Y"]))
+        blob = W.model("convfc", nodes, [W.tensor("w", w), W.tensor("fc", fc)], [W.value_info("X", ["N", 3, 8, 8])], [W.value_info("Y", ["N", 5])])
+        path = W.write(str(tmp_path / f"convfc{int(softmax)}.onnx"), blob)
+        api.load_model("convfc", path)
+        assert api.get_plan("convfc")["activation_layout"] == layout
+        assert_close(api.predict_from_blob("convfc", x.tobytes()), oracle.Model(path).predict_blob(x.tobytes()))
+        api.unload_model("convfc")
 
 
 def test_empty_and_multi_pass_host_inputs(api, models):
