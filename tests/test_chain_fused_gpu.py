@@ -205,3 +205,50 @@ def test_gpu_wide_tables_of_any_row_length(api, O, tmp_path, k, m, sm, rows):
     finally:
         api.unload_model("w")
     assert_close(got, O.Model(path).predict(x))
+
+
+# one model per compute kernel family: a poisoned row (NaN / Inf features) must stay that row's problem
+ISOLATION = [((128, 256, 64, 1), False), ((128, 10), True), ((30, 100, 2), True), ((4, 10, 3), True), ((13, 1), False),
+             ((30, 8), False), ((77, 5), True), ((300, 10), True), ((64, 96, 1), False), ((200, 160, 40), False), ((561, 6), False)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ISOLATION, ids=lambda c: "x".join(map(str, c[0])))
+def test_gpu_rows_are_independent_even_when_one_is_poisoned(api, tmp_path, case):
+    """table rows are independent records: NaN / Inf in one row may not leak into its neighbours through tile padding,
+    zero-weight lanes or shared LDS staging (0 * NaN is NaN) -- every other row's result is bit-identical"""
+    dims, sm = case
+    path = W.write(str(tmp_path / "iso.onnx"), W.mlp(dims, final_softmax=sm, seed=19))
+    rows = 2500
+    x = synth.table(31, 0, rows, dims[0])
+    bad = x.copy()
+    poisoned = [0, 31, 32, 1000, 1777, rows - 1]
+    for i, r in enumerate(poisoned):
+        bad[r, (7 * i) % dims[0]] = [np.nan, np.inf, -np.inf][i % 3]
+    api.load_model("iso", path)
+    try:
+        clean, dirty = api.predict("iso", x), api.predict("iso", bad)
+    finally:
+        api.unload_model("iso")
+    keep = np.ones(rows, bool)
+    keep[poisoned] = False
+    assert np.isfinite(clean).all()
+    assert np.array_equal(clean[keep], dirty[keep]), np.nonzero((clean != dirty).any(axis=1) & keep)[0][:10]
+
+
+@pytest.mark.gpu
+def test_gpu_images_are_independent_even_when_one_is_poisoned(api, tmp_path):
+    blob, _ = W.zoo_ops_net()
+    path = W.write(str(tmp_path / "iso_img.onnx"), blob)
+    n = 40
+    x = synth.table(32, 0, n, 3 * 16 * 16)
+    bad = x.copy()
+    bad[3, 100], bad[17, 5], bad[n - 1, 700] = np.nan, np.inf, -np.inf
+    api.load_model("iso_img", path)
+    try:
+        clean, dirty = api.predict_from_blob("iso_img", x.tobytes()), api.predict_from_blob("iso_img", bad.tobytes())
+    finally:
+        api.unload_model("iso_img")
+    keep = np.ones(n, bool)
+    keep[[3, 17, n - 1]] = False
+    assert np.isfinite(clean).all() and np.array_equal(clean[keep], dirty[keep])
