@@ -458,7 +458,22 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
     if (m.exec[i] == ExecKind::ConvTiled) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
-      std::vector<float> packed(kern::conv2d_tiled_packed_floats(g));
+      const kern::ConvGeom gp = kern::conv2d_tiled_geom(g);
+      std::vector<float> packed(kern::conv2d_tiled_packed_floats(gp));
+      if (gp.padc) {  // channel counts padded to 32: zero weights and zero bias beyond the real ones
+        const size_t taps = size_t(g.kh) * g.kw;
+        std::vector<float> wt(size_t(gp.M) * gp.C * taps, 0.f);
+        for (int mo = 0; mo < g.M; mo++)
+          std::copy_n(s.W.begin() + size_t(mo) * g.C * taps, size_t(g.C) * taps, wt.begin() + size_t(mo) * gp.C * taps);
+        kern::conv2d_tiled_pack(gp, wt.data(), packed.data());
+        d.W = upload(packed, us);
+        if (!s.bias.empty()) {
+          std::vector<float> bp(size_t(gp.M), 0.f);
+          std::copy(s.bias.begin(), s.bias.end(), bp.begin());
+          d.bias = upload(bp, us);
+        }
+        continue;
+      }
       kern::conv2d_tiled_pack(g, s.W.data(), packed.data());
       d.W = upload(packed, us);
     } else if (m.exec[i] == ExecKind::ConvDepthwise) {
@@ -577,8 +592,9 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
           const int fj = m.conv_fused_add[i];
-          if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, g, act_of(st[size_t(fj)]));
-          else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, g, act_of(x));
+          const kern::ConvGeom gp = kern::conv2d_tiled_geom(g);
+          if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]));
+          else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, gp, act_of(x));
           continue;
         }
         case ExecKind::DenseTiled:

@@ -163,10 +163,14 @@ __device__ unsigned long long g_conv_stamps[2][12];
 // DENSE: a fully connected layer as a 1x1 convolution over 1x1 images (the channel-quad layout of a 1x1 image is the
 // row-major matrix).  g.C / g.M are padded to multiples of 32; the input rows are g.kvalid floats long (a multiple
 // of 4: whole quads past the end read the zero page), the output rows g.mvalid (any length: stores are guarded).
-template <int MT, int S, int PROBE = 0, bool DENSE = false>
+// MODE 2 (PADC): a convolution whose channel counts are whole quads but no multiples of 32: g.C / g.M are padded as for
+// DENSE (zero weights / bias), the tensors hold g.kvalid / g.mvalid channels -- channel-quad planes past the real ones
+// read the zero page on the way in and are not stored on the way out.
+template <int MT, int S, int PROBE = 0, int MODE = 0>
 __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                              const float *__restrict__ bias, const float *__restrict__ residual,
                                                              float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
+  constexpr bool DENSE = MODE == 1, PADC = MODE == 2;
   constexpr int NB = 4 * S;   // B fragments (16 B per lane) per stage
   constexpr int U = NB * MT;  // units per stage
   constexpr int P = 3;        // A-fragment ring depth (2 and 4 measured identical)
@@ -192,7 +196,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
   // receptive-field corner of this lane's pixel (may lie outside the image; masked taps never dereference it)
   const int HW4 = g.H * g.W * 4;  // floats per channel-quad plane
-  const float *xc = DENSE ? X + n * g.kvalid + 4 * h : X + n * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
+  const float *xc = DENSE ? X + n * g.kvalid + 4 * h
+                          : X + n * g.H * g.W * (PADC ? g.kvalid : g.C) + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
   const float *zp = g_zero_page + 4 * h;
   uint64_t okmask = 0;
   if (pvalid) {
@@ -214,10 +219,18 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   // consecutive stages read the same channel planes shifted by one tap, i.e. mostly the same cache lines while
   // they are still in L2 (with taps outermost the shifted re-read came C/(32 S) stages -- several MB of other
   // planes per XCD -- later and went back to HBM: 49 GB of reads per 1024-image pass against ~15 GB of tensors).
-  int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0;
+  int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0, n_plane = 0;
   auto gather = [&](f32x4(&b)[NB]) {
     const bool ok = (okmask >> n_tap) & 1;
-    if constexpr (DENSE) {
+    if constexpr (PADC) {
+      // group q of this channel block is plane n_plane + 2q + h; planes >= kvalid / 4 do not exist
+      const int planes = g.kvalid >> 2;
+#pragma unroll
+      for (int q = 0; q < NB; q++) {
+        const bool in = ok && n_plane + 2 * q + h < planes;
+        b[q] = *reinterpret_cast<const f32x4 *>(in ? xc + n_off + q * 2 * int64_t(HW4) : zp);
+      }
+    } else if constexpr (DENSE) {
       // this lane's quad of group q starts at column n_off + 8q + 4h; columns >= kvalid do not exist
 #pragma unroll
       for (int q = 0; q < NB; q++) {
@@ -242,6 +255,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
       n_tap = 0;
       n_base += 2 * NB * HW4;
       n_off = n_base;
+      n_plane += 2 * NB;
     }
   };
   // This block's MT tiles of one 32-channel chunk are contiguous in the packed blob (MT*1024 floats); they go
@@ -352,7 +366,9 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   // epilogue: lane (r,h) holds pixel `pix`, channels 32*(mt0+t) + 8*q + 4h + j -> one 16-byte NHWC store per quad
   // (optional residual: the block's skip tensor, same NHWC layout -- the Add of a ResNet block is fused here)
   const int64_t OHW4 = int64_t(OHW) * 4;
-  const int64_t yoff = DENSE ? n * g.mvalid + (8 * mt0 + h) * 4 : n * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+  const int64_t yoff = DENSE ? n * g.mvalid + (8 * mt0 + h) * 4
+                             : n * OHW * (PADC ? g.mvalid : g.M) + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+  const int oplanes = g.mvalid >> 2;  // PADC: output planes that exist
   float *yp = Y + yoff;
   const float *rp = residual ? residual + yoff : nullptr;
   const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
@@ -362,7 +378,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
-      rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool there = !PADC || 8 * (mt0 + t) + 2 * q + h < oplanes;
+      rv[q] = (rp && there) ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   dispatch_act(act.kind, [&](auto kind_tag) {
@@ -393,6 +410,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
             for (int j = 0; j < 4; j++)
               if (f0 + j < g.mvalid) dst[j] = v[j];
           }
+        } else if constexpr (PADC) {
+          if (8 * (mt0 + t) + 2 * q + h < oplanes) *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
         } else {
           *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
         }
@@ -894,9 +913,21 @@ void conv2d_depthwise(hipStream_t s, const float *X, const float *packed, const 
   hipLaunchKernelGGL(conv2d_depthwise_cq_kernel, dim3(grid_for(total4)), dim3(kBlock), 0, s, X, packed, bias, Y, total4, g, act);
 }
 
+// C and M multiples of 32, or (channel-quad tensors) of 4: those run with zero-padded weights, see conv2d_tiled_geom
 bool conv2d_tiled_supported(const ConvGeom &g) {
-  return g.groups == 1 && g.C % 32 == 0 && g.M % 32 == 0 && g.kh * g.kw <= 64 /* per-lane tap mask */ &&
+  return g.groups == 1 && g.C % 4 == 0 && g.M % 4 == 0 && g.kh * g.kw <= 64 /* per-lane tap mask */ &&
          int64_t(g.H) * g.W * g.C < (int64_t(1) << 30);
+}
+
+ConvGeom conv2d_tiled_geom(const ConvGeom &real) {
+  ConvGeom g = real;
+  if (real.mvalid > 0 || (real.C % 32 == 0 && real.M % 32 == 0)) return g;  // dense layers arrive padded already
+  g.C = (real.C + 31) / 32 * 32;
+  g.M = (real.M + 31) / 32 * 32;
+  g.kvalid = real.C;
+  g.mvalid = real.M;
+  g.padc = 1;
+  return g;
 }
 
 size_t conv2d_tiled_packed_floats(const ConvGeom &g) { return size_t(g.kh) * g.kw * g.C * g.M; }
@@ -969,11 +1000,18 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
     }
   }
 #endif
+  if (g.padc) {  // channel counts padded to 32 (g = conv2d_tiled_geom(real))
+    if (wide) deep ? launch(conv2d_tiled_kernel<4, 2, 0, 2>, 4) : launch(conv2d_tiled_kernel<4, 1, 0, 2>, 4);
+    else if (mt_pick == 3) deep ? launch(conv2d_tiled_kernel<3, 2, 0, 2>, 3) : launch(conv2d_tiled_kernel<3, 1, 0, 2>, 3);
+    else if (mt_pick == 2) deep ? launch(conv2d_tiled_kernel<2, 2, 0, 2>, 2) : launch(conv2d_tiled_kernel<2, 1, 0, 2>, 2);
+    else deep ? launch(conv2d_tiled_kernel<1, 2, 0, 2>, 1) : launch(conv2d_tiled_kernel<1, 1, 0, 2>, 1);
+    return;
+  }
   if (g.mvalid > 0) {  // dense layer
-    if (wide) deep ? launch(conv2d_tiled_kernel<4, 2, 0, true>, 4) : launch(conv2d_tiled_kernel<4, 1, 0, true>, 4);
-    else if (mt_pick == 3) deep ? launch(conv2d_tiled_kernel<3, 2, 0, true>, 3) : launch(conv2d_tiled_kernel<3, 1, 0, true>, 3);
-    else if (mt_pick == 2) deep ? launch(conv2d_tiled_kernel<2, 2, 0, true>, 2) : launch(conv2d_tiled_kernel<2, 1, 0, true>, 2);
-    else deep ? launch(conv2d_tiled_kernel<1, 2, 0, true>, 1) : launch(conv2d_tiled_kernel<1, 1, 0, true>, 1);
+    if (wide) deep ? launch(conv2d_tiled_kernel<4, 2, 0, 1>, 4) : launch(conv2d_tiled_kernel<4, 1, 0, 1>, 4);
+    else if (mt_pick == 3) deep ? launch(conv2d_tiled_kernel<3, 2, 0, 1>, 3) : launch(conv2d_tiled_kernel<3, 1, 0, 1>, 3);
+    else if (mt_pick == 2) deep ? launch(conv2d_tiled_kernel<2, 2, 0, 1>, 2) : launch(conv2d_tiled_kernel<2, 1, 0, 1>, 2);
+    else deep ? launch(conv2d_tiled_kernel<1, 2, 0, 1>, 1) : launch(conv2d_tiled_kernel<1, 1, 0, 1>, 1);
     return;
   }
   if (wide && deep) launch(conv2d_tiled_kernel<4, 2>, 4);

@@ -94,7 +94,12 @@ struct ConvGeom {
   // Dense layers on the tiled kernel (H = W = 1): C and M are the PADDED sizes (multiples of 32, zero weights / bias
   // beyond the real ones); the real row lengths of the input and output matrices.  0 = not a dense layer.
   int kvalid = 0, mvalid = 0;
+  // Convolutions whose channel counts are whole quads but no multiples of 32 (MobileNet's 16 / 24 / 144, ...): C and M
+  // are the PADDED sizes as above, kvalid / mvalid the real ones (the tensors' plane counts are kvalid/4 and mvalid/4).
+  int padc = 0;
 };
+// the geometry the tiled kernel runs for a convolution step: channels padded to 32 when they are not (padc = 1)
+ConvGeom conv2d_tiled_geom(const ConvGeom &real);
 // Generic implicit-GEMM convolution: any geometry / groups; Wk = conv2d_generic_pack() of the ONNX
 // weights ([group][k][M/g], k = (c, ky, kx)); activations NCHW or channel-quad planes (CQ) per flag.
 bool conv2d_generic_supported(const ConvGeom &g);  // (C/g)*kh*kw <= 8192 (the per-k offset table lives in LDS)
