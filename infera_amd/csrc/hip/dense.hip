@@ -709,23 +709,33 @@ static void launch_narrow16g(hipStream_t s, const float *X, const float *W, cons
 // four 16-column k-groups of the chunk on the 16x16x4 MFMA while the next chunk's 32 loads are in flight.  Loads are
 // clamped into the table and zeroed by select, never branched around.  Weights: fragment-major in LDS, zero-padded to
 // whole chunks.  WV waves share them (8 when they are too big for two 4-wave workgroups per CU).
-template <int SM, int WV>
+// BIGK (rows longer than ~1500 floats: 2048- / 4096-dimensional embeddings): the weights no longer fit the LDS in one
+// piece, so the workgroup keeps a window of 16 chunks (1024 columns, 64 KB) and restages it as its waves move along
+// the row together -- two barriers per window; every wave of the block runs the same number of tile trips for that.
+template <int SM, int WV, bool BIGK = false>
 __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                  const float *__restrict__ bias, float *__restrict__ Y,
                                                                  int64_t rows, int K, int M, ActParam act) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [4*NCH][64][4] weights, then WV x [32][68] chunks
   constexpr int CS = 68;
+  constexpr int WIN = 16;  // chunks per weight window (BIGK)
   const int NCH = (K + 63) >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = lane & 15, q = lane >> 4;
-  for (int i = threadIdx.x; i < NCH * 1024; i += WV * 64) {
-    const int g = i >> 8, l = (i >> 2) & 63, j = i & 3;
-    const int k = 16 * g + 4 * (l >> 4) + j, m = l & 15;
-    smem[i] = (m < M && k < K) ? W[int64_t(k) * M + m] : 0.f;
+  // fragment-major weights of chunks [c0, c0 + count) into the front of the LDS
+  auto stage_weights = [&](int c0, int count) {
+    for (int i = threadIdx.x; i < count * 1024; i += WV * 64) {
+      const int g = 4 * c0 + (i >> 8), l = (i >> 2) & 63, j = i & 3;
+      const int k = 16 * g + 4 * (l >> 4) + j, m = l & 15;
+      smem[i] = (m < M && k < K) ? W[int64_t(k) * M + m] : 0.f;
+    }
+  };
+  if constexpr (!BIGK) {
+    stage_weights(0, NCH);
+    __syncthreads();
   }
-  __syncthreads();
   const f32x4 *wq = reinterpret_cast<const f32x4 *>(smem) + lane;
-  float *xs = smem + NCH * 1024 + wave * (32 * CS);
+  float *xs = smem + (BIGK ? WIN : NCH) * 1024 + wave * (32 * CS);
   float bq[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) bq[i] = (bias != nullptr && 4 * q + i < M) ? bias[4 * q + i] : 0.f;
@@ -758,9 +768,20 @@ __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *_
   float stage[32];
   int64_t tile = int64_t(blockIdx.x) * WV + wave;
   if (tile < ntiles) fetch(stage, tile, 0);
-  for (; tile < ntiles; tile += tstride) {
+  // BIGK: every wave of the workgroup makes the same number of trips (those past the table only meet the barriers)
+  const int64_t first = int64_t(blockIdx.x) * WV;
+  for (; BIGK ? first + (tile - first - wave) < ntiles : tile < ntiles; tile += tstride) {
+    const bool live = tile < ntiles;
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int c = 0; c < NCH; c++) {
+      if constexpr (BIGK) {
+        if (c % WIN == 0) {
+          __syncthreads();  // everyone is done with the previous window
+          stage_weights(c, min(WIN, NCH - c));
+          __syncthreads();
+        }
+        if (!live) continue;
+      }
 #pragma unroll
       for (int r = 0; r < 32; r++) xs[r * CS + lane] = stage[r];
       if (c + 1 < NCH) fetch(stage, tile, c + 1);
@@ -769,7 +790,7 @@ __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *_
       for (int gg = 0; gg < 4; gg++) {
         const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + n * CS + 16 * gg + 4 * q);
         const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + (16 + n) * CS + 16 * gg + 4 * q);
-        const f32x4 a0 = wq[(4 * c + gg) * 64];
+        const f32x4 a0 = wq[(4 * (BIGK ? c % WIN : c) + gg) * 64];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[j], acc[0], 0, 0, 0);
@@ -777,6 +798,7 @@ __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *_
         }
       }
     }
+    if (BIGK && !live) continue;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const int64_t row = (tile << 5) + 16 * t + n;
@@ -823,13 +845,15 @@ __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *_
 }
 
 static size_t narrow16w_lds(int K, int waves) { return (size_t((K + 63) / 64) * 1024 + size_t(waves) * 32 * 68) * sizeof(float); }
-static bool narrow16w_ok(int K, int M) { return M >= 1 && M <= 16 && K > 128 && narrow16w_lds(K, 4) <= 160 * 1024; }
+static size_t narrow16w_big_lds(int waves) { return (size_t(16) * 1024 + size_t(waves) * 32 * 68) * sizeof(float); }
+static bool narrow16w_ok(int K, int M) { return M >= 1 && M <= 16 && K > 128 && K <= (1 << 20); }
 
 static void launch_narrow16w(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
                              ActParam act, int softmax_mode) {
-  const bool eight = 2 * narrow16w_lds(K, 4) > 160 * 1024 && narrow16w_lds(K, 8) <= 160 * 1024;
+  const bool big = narrow16w_lds(K, 8) > 160 * 1024;  // weights in 1024-column windows
+  const bool eight = big || (2 * narrow16w_lds(K, 4) > 160 * 1024);
   const int waves = eight ? 8 : 4;
-  const size_t lds = narrow16w_lds(K, waves);
+  const size_t lds = big ? narrow16w_big_lds(waves) : narrow16w_lds(K, waves);
   const int64_t ntiles = (rows + 31) / 32;
   const int per_cu = int(std::clamp<size_t>((160 * 1024) / lds, 1, 8));
   const int64_t blocks = std::min<int64_t>((ntiles + waves - 1) / waves, 256 * per_cu);
@@ -840,7 +864,8 @@ static void launch_narrow16w(hipStream_t s, const float *X, const float *W, cons
   };
   auto by_w = [&](auto smt) {
     constexpr int SMv = decltype(smt)::value;
-    if (eight) go(dense_narrow16w_kernel<SMv, 8>);
+    if (big) go(dense_narrow16w_kernel<SMv, 8, true>);
+    else if (eight) go(dense_narrow16w_kernel<SMv, 8>);
     else go(dense_narrow16w_kernel<SMv, 4>);
   };
   if (softmax_mode == 0) by_w(std::integral_constant<int, 0>{});
@@ -1014,7 +1039,7 @@ void dense(hipStream_t s, const float *X, const float *W, const float *bias, flo
            ActParam act, int softmax_mode) {
   if (rows <= 0) return;
   static const int wide16 = getenv("INFERA_DENSE16W") ? atoi(getenv("INFERA_DENSE16W")) : 1;  // 0 off, 2 = also where aligned kernels exist (A/B)
-  if (wide16 == 2 && M <= 16 && K >= 64 && narrow16w_lds(K, 4) <= 160 * 1024) return launch_narrow16w(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
+  if (wide16 == 2 && M <= 16 && K >= 64) return launch_narrow16w(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   if (narrow16g_ok(K, M)) return launch_narrow16g(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   if (skinny_ok(K, M)) return launch_skinny(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   static const bool staged16 = !(getenv("INFERA_DENSE16_STAGED") && atoi(getenv("INFERA_DENSE16_STAGED")) == 0);
