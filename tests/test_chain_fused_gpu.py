@@ -53,6 +53,7 @@ CHAINS = [
     ((77, 33, 17), ["Relu", "Relu"], False),  # 17 outputs: two output tiles, odd row length on the way out
     ((64, 48, 20), None, False),
     ((30, 100), None, False),                 # one wide layer behind a PadCols: fused to skip the padding pass
+    ((100, 20), None, False),                 # 17..32 outputs over rows no aligned kernel reads: one-layer chain
     ((50, 12, 12), None, True),
 ]
 
