@@ -292,7 +292,7 @@ void schedule(LoadedModel &m) {
     // Dense + row Softmax over exactly its M outputs: softmax in the GEMM epilogue
     if (i + 1 < n && st[i].kind == StepKind::Dense && st[i + 1].kind == StepKind::Softmax && st[i + 1].in0 == st[i].out &&
         uses[size_t(st[i].out)] == 1 && st[i + 1].sm_outer == 1 && st[i + 1].sm_inner == 1 && st[i + 1].sm_len == st[i].M &&
-        st[i].M <= 64 && st[i + 1].sm_norm == 0) {
+        kern::dense_can_fuse_softmax(int(st[i].K), int(st[i].M)) && st[i + 1].sm_norm == 0) {
       m.exec[i] = ExecKind::DenseSoftmax;
       m.exec[i + 1] = ExecKind::Skipped;
       i += 1;

@@ -1028,7 +1028,7 @@ static void launch_skinny(hipStream_t s, const float *X, const float *W, const f
   }
 }
 
-bool dense_can_fuse_softmax(int M) { return M <= 64; }
+bool dense_can_fuse_softmax(int K, int M) { return M <= 16 || (M <= 32 && K % 8 == 0 && K <= 512); }
 // ArgMax epilogues (softmax_mode 3) exist in the skinny and the two 16x16x4 streaming kernels; the latter need 16-byte rows
 bool dense_can_fuse_argmax(const float *X, int K, int M) {
   return narrow16g_ok(K, M) || skinny_ok(K, M) || narrow16w_ok(K, M) ||

@@ -4,6 +4,8 @@
 // grid capped at 256 CUs x 8 blocks (cdna_hip_programming.md Guideline 11).
 #include "device_common.hpp"
 
+#include <cstdlib>
+
 namespace infera_hip::kern {
 
 namespace {
@@ -149,6 +151,69 @@ __global__ __launch_bounds__(kBlock) void softmax_wave_kernel(const float *__res
   }
 }
 
+// Contiguous vectors of 5..1024 elements (class scores, inner == 1): LPR lanes share a vector and hold it in registers
+// (EPL elements each, element j of lane l is l + LPR*j: consecutive lanes read consecutive floats), so the vector is
+// read once and written once; max / sum meet in a butterfly over the LPR lanes.  (One lane per vector -- the kernel
+// above -- walks 100 floats of its own row while its 63 neighbours do the same 400 bytes away: 15x slower at len 100.)
+template <int LPR, int EPL>
+__global__ __launch_bounds__(kBlock) void softmax_rows_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t nvec, int len,
+                                                             int mode) {
+  constexpr int VPW = 64 / LPR;  // vectors per wave
+  const int lane = threadIdx.x & 63, sub = lane % LPR, slot = lane / LPR;
+  const int64_t wave = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * kBlock) >> 6;
+  for (int64_t v0 = wave * VPW; v0 < nvec; v0 += nwaves * VPW) {
+    const int64_t v = v0 + slot;
+    const bool live = v < nvec;
+    const float *src = x + (live ? v : nvec - 1) * len;
+    float e[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; j++) {
+      const int k = sub + LPR * j;
+      e[j] = k < len ? src[k] : 0.f;
+    }
+    float red = mode >= 2 ? 0.f : -INFINITY;  // softmax: max; Normalizer: max|x| / sum|x| / sum x^2
+#pragma unroll
+    for (int j = 0; j < EPL; j++)
+      if (sub + LPR * j < len) {
+        const float u = e[j], a = fabsf(u);
+        red = mode < 2 ? fmaxf(red, u) : mode == 2 ? fmaxf(red, a) : mode == 3 ? red + a : fmaf(u, u, red);
+      }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) {
+      const float other = __shfl_xor(red, o);
+      red = (mode < 2 || mode == 2) ? fmaxf(red, other) : red + other;
+    }
+    if (mode >= 2) {
+      if (mode == 4) red = sqrtf(red);
+      red = fmaxf(red, 1e-30f);
+#pragma unroll
+      for (int j = 0; j < EPL; j++) e[j] = e[j] / red;
+    } else {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPL; j++)
+        if (sub + LPR * j < len) {
+          const float t = expf(e[j] - red);
+          sum += t;
+          e[j] = mode == 0 ? t : e[j] - red;
+        }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float ls = logf(sum);
+#pragma unroll
+      for (int j = 0; j < EPL; j++) e[j] = mode == 0 ? e[j] / sum : e[j] - ls;
+    }
+    if (live) {
+      float *dst = y + v * len;
+#pragma unroll
+      for (int j = 0; j < EPL; j++) {
+        const int k = sub + LPR * j;
+        if (k < len) dst[k] = e[j];
+      }
+    }
+  }
+}
+
 // Column-block copy between row-major matrices: dst[r, dst_off : dst_off+len] = src[r, src_off : src_off+len].
 // One piece of a Concat along the feature / channel axis (src is a whole row) or a Slice / Split / one input of a
 // multi-input model (dst is a whole row).  16-byte moves when every offset and stride is a multiple of 4 floats.
@@ -270,7 +335,17 @@ void affine_channel(hipStream_t s, const float *x, const float *scale, const flo
 void softmax(hipStream_t s, const float *x, float *y, int64_t rows, int64_t outer, int64_t len, int64_t inner, int mode) {
   const int64_t nvec = rows * outer * inner;
   if (nvec <= 0 || len <= 0) return;
-  if (inner == 1 && len >= 256) {
+  static const bool rows_kernel = !(getenv("INFERA_SOFTMAX_ROWS") && atoi(getenv("INFERA_SOFTMAX_ROWS")) == 0);
+  if (rows_kernel && inner == 1 && len >= 5 && len <= 1024) {
+    auto go = [&](auto kernel, int lpr) {
+      hipLaunchKernelGGL(kernel, dim3(grid_for((nvec + 64 / lpr - 1) / (64 / lpr) * 64)), dim3(kBlock), 0, s, x, y, nvec, int(len), mode);
+    };
+    if (len <= 16) go(softmax_rows_kernel<16, 1>, 16);
+    else if (len <= 64) go(softmax_rows_kernel<16, 4>, 16);
+    else if (len <= 128) go(softmax_rows_kernel<32, 4>, 32);
+    else if (len <= 256) go(softmax_rows_kernel<64, 4>, 64);
+    else go(softmax_rows_kernel<64, 16>, 64);
+  } else if (inner == 1 && len >= 256) {
     hipLaunchKernelGGL(softmax_wave_kernel, dim3(grid_for(nvec * 64)), dim3(kBlock), 0, s, x, y, nvec, len, mode);
   } else {
     // vectors index as (row*outer + ou, in): flatten (row,outer) into the `ou` coordinate

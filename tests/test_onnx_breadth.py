@@ -674,3 +674,24 @@ def test_gpu_mobilenet_v2_vs_oracle(api, O, paths):
     assert got.shape == (5, 20)
     assert_close(got, want)
     api.unload_model("mnv2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("length", [3, 5, 16, 17, 64, 65, 100, 128, 129, 256, 257, 1000, 1024, 1025, 3000])
+@pytest.mark.parametrize("op", ["Softmax", "LogSoftmax", "NormL1", "NormL2", "NormMAX"])
+def test_gpu_row_reductions_at_every_kernel_boundary(api, O, tmp_path, op, length):
+    """Softmax / LogSoftmax / Normalizer over contiguous rows: one lane per row (short), 16 / 32 / 64 lanes per row with the
+    row held in registers, one wave per row in three passes (long) -- lengths on both sides of every switch"""
+    if op.startswith("Norm"):
+        nd = W.node("Normalizer", ["X"], ["Y"], [W.attr_s("norm", op[4:])], domain=W.ML_DOMAIN)
+        blob = W.model("rr", [nd], [], [W.value_info("X", ["N", length])], [W.value_info("Y", ["N", length])], ml_opset=1)
+    else:
+        blob = W.model("rr", [W.node(op, ["X"], ["Y"], [W.attr_i("axis", 1)])], [], [W.value_info("X", ["N", length])], [W.value_info("Y", ["N", length])])
+    path = W.write(str(tmp_path / "rr.onnx"), blob)
+    x = synth.table(length, 0, 333, length) * 4.0
+    api.load_model("rr", path)
+    try:
+        got = api.predict("rr", x)
+    finally:
+        api.unload_model("rr")
+    assert_close(got, O.Model(path).predict(x), rtol=1e-4, atol=1e-6)
