@@ -261,7 +261,7 @@ __device__ __forceinline__ float argmax_over_quads(const f32x4 &v, int q, int M)
   int bi = 4 * q;
 #pragma unroll
   for (int i = 0; i < 4; i++)
-    if (4 * q + i < M && v[i] > bv) {
+    if (4 * q + i < M && (4 * q + i == 0 || v[i] > bv)) {  // score 0 starts the scan whatever it is (the sequential rule)
       bv = v[i];
       bi = 4 * q + i;
     }

@@ -437,8 +437,49 @@ void channel_shuffle(hipStream_t s, const float *X, float *Y, int64_t rows, int 
   hipLaunchKernelGGL(channel_shuffle_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, X, Y, n, C, S, groups, cq);
 }
 
+// Longer rows: LPR lanes share a row (consecutive lanes read consecutive floats), each keeps the first maximum of its
+// elements, then a butterfly over the LPR lanes picks the winner (ties -> lowest index, like the sequential scan).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void argmax_rows_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t rows, int len) {
+  constexpr int VPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR, slot = lane / LPR;
+  const int64_t wave = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * kBlock) >> 6;
+  for (int64_t r0 = wave * VPW; r0 < rows; r0 += nwaves * VPW) {
+    const int64_t r = r0 + slot;
+    const float *src = x + (r < rows ? r : rows - 1) * len;
+    float best = -INFINITY;
+    int bi = len;  // lanes without an element never win a tie
+    for (int k = sub; k < len; k += LPR) {
+      const float u = src[k];
+      if (k == 0 || u > best) {  // element 0 starts the scan whatever it is (NaN included), like the sequential kernel
+        best = u;
+        bi = k;
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (oi < len && (bi == len || ov > best || (ov == best && oi < bi))) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (r < rows && sub == 0) y[r] = float(bi);
+  }
+}
+
 void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t len) {
   if (rows <= 0 || len <= 0) return;
+  if (len >= 8 && len <= (1 << 30)) {
+    auto go = [&](auto kernel, int lpr) {
+      hipLaunchKernelGGL(kernel, dim3(grid_for((rows + 64 / lpr - 1) / (64 / lpr) * 64)), dim3(kBlock), 0, s, x, y, rows, int(len));
+    };
+    if (len <= 64) go(argmax_rows_kernel<16>, 16);
+    else if (len <= 256) go(argmax_rows_kernel<32>, 32);
+    else go(argmax_rows_kernel<64>, 64);
+    return;
+  }
   hipLaunchKernelGGL(argmax_kernel, dim3(grid_for(rows)), dim3(kBlock), 0, s, x, y, rows, len);
 }
 

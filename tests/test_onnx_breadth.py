@@ -695,3 +695,29 @@ def test_gpu_row_reductions_at_every_kernel_boundary(api, O, tmp_path, op, lengt
     finally:
         api.unload_model("rr")
     assert_close(got, O.Model(path).predict(x), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("length", [2, 7, 8, 64, 65, 100, 256, 257, 1000, 5000])
+def test_gpu_argmax_rows_at_every_kernel_boundary(api, O, tmp_path, length):
+    """stand-alone ArgMax: ties go to the first index, NaN never wins unless it is element 0 (the sequential scan's rule)"""
+    blob = W.model("am", [W.node("ArgMax", ["X"], ["Y"], [W.attr_i("axis", 1), W.attr_i("keepdims", 0)])], [],
+                   [W.value_info("X", ["N", length])], [W.value_info("Y", ["N"], W.INT64)])
+    path = W.write(str(tmp_path / "am.onnx"), blob)
+    rng = np.random.default_rng(length)
+    x = np.round(synth.table(length, 0, 500, length) * 3.0)  # few distinct values: plenty of ties
+    x[7, :] = -np.inf
+    x[8, min(3, length - 1)] = np.nan
+    x[9, 0] = np.nan
+    x[10, length - 1] = np.inf
+    api.load_model("am", path)
+    try:
+        got = api.predict("am", x.astype(np.float32)).reshape(-1)
+    finally:
+        api.unload_model("am")
+    want = O.Model(path).predict(x.astype(np.float32)).reshape(-1)
+    assert np.array_equal(got, want)
+    ok = np.ones(500, bool)
+    ok[[8, 9]] = False  # numpy's argmax treats NaN as the maximum
+    assert np.array_equal(got[ok], np.argmax(x[ok], axis=1).astype(np.float32))
+    assert got[9] == 0.0 and got[7] == 0.0
