@@ -365,6 +365,44 @@ struct Lowerer {
         return;
       }
     }
+    // Per-feature affine arithmetic on a [rows, K] table (x - mean, / std, * scale, + shift ...) is one multiply-add
+    // per element however many nodes spell it: consecutive ones compose into a single AffineChannel pass (and the
+    // Dense fold above still finds it).
+    if (act_shape.size() == 2 && (op == '+' || op == '-' || op == '*' || (op == '/' && !const_left))) {
+      const std::vector<float> cv = broadcast_const(n, cst, act_shape);
+      const size_t C = cv.size();
+      std::vector<double> sc(C, 1.0), sh(C, 0.0);
+      for (size_t k = 0; k < C; k++) {
+        const double c = cv[k];
+        if (op == '+') sh[k] = c;
+        else if (op == '-') { sc[k] = const_left ? -1.0 : 1.0; sh[k] = const_left ? c : -c; }
+        else if (op == '*') sc[k] = c;
+        else sc[k] = 1.0 / c;
+      }
+      Step *p = fusable_producer(n, const_left ? 1 : 0);
+      if (p && p->kind == StepKind::AffineChannel && p->act == Act::None && p->S == 1 && size_t(p->C) == C) {
+        for (size_t k = 0; k < C; k++) {
+          p->shift[k] = float(sc[k] * double(p->shift[k]) + sh[k]);
+          p->scale[k] = float(sc[k] * double(p->scale[k]));
+        }
+        p->origin += "+" + n.op + (n.name.empty() ? "" : ":" + n.name);
+        set_act(n, act.buf, act_shape, true);
+        return;
+      }
+      Step a;
+      a.kind = StepKind::AffineChannel;
+      a.in0 = act.buf;
+      a.C = int64_t(C);
+      a.S = 1;
+      a.scale.resize(C);
+      a.shift.resize(C);
+      for (size_t k = 0; k < C; k++) {
+        a.scale[k] = float(sc[k]);
+        a.shift[k] = float(sh[k]);
+      }
+      emit(std::move(a), n, act_shape);
+      return;
+    }
     Step s;
     s.kind = StepKind::BinaryConst;
     s.in0 = act.buf;
