@@ -255,3 +255,38 @@ def test_gpu_images_are_independent_even_when_one_is_poisoned(api, tmp_path):
     keep = np.ones(n, bool)
     keep[[3, 17, n - 1]] = False
     assert np.isfinite(clean).all() and np.array_equal(clean[keep], dirty[keep])
+
+
+@pytest.mark.gpu
+def test_gpu_concurrent_load_predict_unload_of_jit_models(api, O, tmp_path):
+    """eight threads load / run / unload models that need load-time compiled kernels (five shapes, shared code-object
+    cache, per-thread streams): every result matches the oracle's, nothing deadlocks"""
+    import threading
+
+    shapes = [((9, 12, 3), True), ((30, 100, 2), True), ((17, 40), False), ((5, 8, 8, 1), False), ((32, 64, 32, 1), False)]
+    models = []
+    for i, (dims, sm) in enumerate(shapes):
+        path = W.write(str(tmp_path / f"cc{i}.onnx"), W.mlp(dims, final_softmax=sm, seed=40 + i))
+        x = synth.table(50 + i, 0, 777, dims[0])
+        models.append((path, x, O.Model(path).predict(x)))
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(25):
+                path, x, want = models[(t + it) % len(models)]
+                name = f"cc_t{t}"
+                api.load_model(name, path)
+                got = api.predict(name, x)
+                api.unload_model(name)
+                assert_close(got, want)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=240)
+    assert not any(th.is_alive() for th in threads), "a worker is stuck"
+    assert not errors, errors[:3]
