@@ -36,9 +36,47 @@ __global__ __launch_bounds__(kBlock) void unary_kernel(const float *__restrict__
 __global__ __launch_bounds__(kBlock) void binary_const_kernel(const float *__restrict__ x, const float *__restrict__ c,
                                                              float *__restrict__ y, int64_t n, int64_t per_row, char op,
                                                              bool const_left, ActParam act) {
-  const int64_t stride = int64_t(gridDim.x) * kBlock;
-  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
-    y[i] = apply_act(apply_bop(x[i], c[i % per_row], op, const_left), act);
+  // the position inside the row advances by (stride mod per_row) per trip: one 64-bit modulo per thread, not per element
+  const int64_t stride = int64_t(gridDim.x) * kBlock, i0 = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t step = stride % per_row;
+  int64_t j = i0 % per_row;
+  for (int64_t i = i0; i < n; i += stride) {
+    y[i] = apply_act(apply_bop(x[i], c[j], op, const_left), act);
+    j += step;
+    if (j >= per_row) j -= per_row;
+  }
+}
+
+// Per-feature x*scale + shift on a [rows, C] table (S == 1): as above without the per-element division, and in
+// 16-byte pieces when the rows are whole quads.
+__global__ __launch_bounds__(kBlock) void affine_rows_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, float *__restrict__ y, int64_t n,
+                                                            int64_t C, ActParam act, bool vec4) {
+  const int64_t stride = int64_t(gridDim.x) * kBlock, i0 = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (vec4) {
+    const int64_t n4 = n >> 2, C4 = C >> 2, step = stride % C4;
+    int64_t j = i0 % C4;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x), *sc4 = reinterpret_cast<const f32x4 *>(scale),
+                *sh4 = reinterpret_cast<const f32x4 *>(shift);
+    f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+    for (int64_t i = i0; i < n4; i += stride) {
+      const f32x4 u = x4[i], a = sc4[j], b = sh4[j];
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; e++) r[e] = apply_act(u[e] * a[e] + b[e], act);
+      y4[i] = r;
+      j += step;
+      if (j >= C4) j -= C4;
+    }
+    return;
+  }
+  const int64_t step = stride % C;
+  int64_t j = i0 % C;
+  for (int64_t i = i0; i < n; i += stride) {
+    y[i] = apply_act(x[i] * scale[j] + shift[j], act);
+    j += step;
+    if (j >= C) j -= C;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void binary_act_kernel(const float *__restrict__ a, const float *__restrict__ b,
@@ -329,6 +367,11 @@ void affine_channel(hipStream_t s, const float *x, const float *scale, const flo
                     int64_t C, int64_t S, ActParam act, bool cq) {
   const int64_t n = rows * C * S;
   if (n <= 0) return;
+  if (S == 1) {  // a table: no layout to respect
+    const bool vec4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    hipLaunchKernelGGL(affine_rows_kernel, dim3(grid_for(vec4 ? n / 4 : n)), dim3(kBlock), 0, s, x, scale, shift, y, n, C, act, vec4);
+    return;
+  }
   hipLaunchKernelGGL(affine_channel_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, scale, shift, y, n, C, S, act, cq);
 }
 
