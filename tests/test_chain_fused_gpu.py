@@ -54,6 +54,9 @@ CHAINS = [
     ((64, 48, 20), None, False),
     ((30, 100), None, False),                 # one wide layer behind a PadCols: fused to skip the padding pass
     ((100, 20), None, False),                 # 17..32 outputs over rows no aligned kernel reads: one-layer chain
+    ((30, 100), None, True),                  # wide softmax heads: scores never leave the registers
+    ((64, 50), None, True),
+    ((13, 20, 128), None, True),
     ((50, 12, 12), None, True),
 ]
 

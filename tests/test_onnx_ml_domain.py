@@ -208,13 +208,14 @@ def _classifier(tmp_path, features, coef, icpt):
 
 # (features, classes, rows, expected exec of the Dense step): the label is picked in the epilogue of the skinny kernel
 # (few / odd features), of the two 16x16x4 streaming kernels (staged for big scans, direct below 4096 rows), and by the
-# wide-table kernel (rows longer than 128 floats of any alignment), and by the stand-alone ArgMax kernel behind every
-# other Dense kernel
+# wide-table kernel (rows longer than 128 floats of any alignment), of the one-layer chain kernel (17..128 classes over up
+# to 128 columns), and by the stand-alone ArgMax kernel behind every other Dense kernel
 ARGMAX_CASES = [(30, 3, 5001, "dense_argmax"), (5, 2, 257, "dense_argmax"), (100, 16, 3000, "dense_argmax"),
                 (64, 10, 20011, "dense_argmax"), (128, 7, 9000, "dense_argmax"), (256, 16, 4099, "dense_argmax"),
                 (64, 10, 1000, "dense_argmax"), (48, 5, 7001, "dense_argmax"), (1024, 3, 513, "dense_argmax"),
                 (200, 6, 2500, "dense_argmax"), (561, 6, 3001, "dense_argmax"), (301, 16, 777, "dense_argmax"),
-                (2000, 4, 600, "dense_argmax"), (64, 20, 2500, "normal"), (32, 40, 2500, "dense_tiled")]
+                (2000, 4, 600, "dense_argmax"), (64, 20, 2500, "chain_fused"), (32, 40, 2500, "chain_fused"), (100, 128, 1500, "chain_fused"),
+                (300, 40, 2500, "dense_tiled")]
 
 
 @pytest.mark.gpu
