@@ -710,23 +710,24 @@ static void launch_narrow16g(hipStream_t s, const float *X, const float *W, cons
 // clamped into the table and zeroed by select, never branched around.  Weights: fragment-major in LDS, zero-padded to
 // whole chunks.  WV waves share them (8 when they are too big for two 4-wave workgroups per CU).
 // BIGK (rows longer than ~1500 floats: 2048- / 4096-dimensional embeddings): the weights no longer fit the LDS in one
-// piece, so the workgroup keeps a window of 16 chunks (1024 columns, 64 KB) and restages it as its waves move along
-// the row together -- two barriers per window; every wave of the block runs the same number of tile trips for that.
-template <int SM, int WV, bool BIGK = false>
+// piece, so the workgroup keeps a window of WIN chunks (64 KB) and restages it as its waves move along the row
+// together -- two barriers per window; every wave of the block runs the same number of tile trips for that.
+// MT = 16-wide output tiles (1: M <= 16, 2: M <= 32 -- 20 / 26 / 32-class heads).
+template <int SM, int WV, bool BIGK, int MT>
 __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                  const float *__restrict__ bias, float *__restrict__ Y,
                                                                  int64_t rows, int K, int M, ActParam act) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4*NCH][64][4] weights, then WV x [32][68] chunks
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4*NCH][MT][64][4] weights (or a window), then WV x [32][68] chunks
   constexpr int CS = 68;
-  constexpr int WIN = 16;  // chunks per weight window (BIGK)
+  constexpr int WIN = 16 / MT;  // chunks per weight window (BIGK)
   const int NCH = (K + 63) >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = lane & 15, q = lane >> 4;
-  // fragment-major weights of chunks [c0, c0 + count) into the front of the LDS
+  // fragment-major weights of chunks [c0, c0 + count) into the front of the LDS: [group][mt][lane][j]
   auto stage_weights = [&](int c0, int count) {
-    for (int i = threadIdx.x; i < count * 1024; i += WV * 64) {
-      const int g = 4 * c0 + (i >> 8), l = (i >> 2) & 63, j = i & 3;
-      const int k = 16 * g + 4 * (l >> 4) + j, m = l & 15;
+    for (int i = threadIdx.x; i < count * 1024 * MT; i += WV * 64) {
+      const int j = i & 3, l = (i >> 2) & 63, mt = (i >> 8) % MT, g = 4 * c0 + (i >> 8) / MT;
+      const int k = 16 * g + 4 * (l >> 4) + j, m = 16 * mt + (l & 15);
       smem[i] = (m < M && k < K) ? W[int64_t(k) * M + m] : 0.f;
     }
   };
@@ -735,10 +736,12 @@ __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *_
     __syncthreads();
   }
   const f32x4 *wq = reinterpret_cast<const f32x4 *>(smem) + lane;
-  float *xs = smem + (BIGK ? WIN : NCH) * 1024 + wave * (32 * CS);
-  float bq[4];
+  float *xs = smem + (BIGK ? WIN : NCH) * 1024 * MT + wave * (32 * CS);
+  float bq[MT][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) bq[i] = (bias != nullptr && 4 * q + i < M) ? bias[4 * q + i] : 0.f;
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) bq[mt][i] = (bias != nullptr && 16 * mt + 4 * q + i < M) ? bias[16 * mt + 4 * q + i] : 0.f;
   const int64_t ntiles = (rows + 31) >> 5;
   const int64_t tstride = int64_t(gridDim.x) * WV;
   // (tile, chunk) are wave-uniform: one scalar base per fetch, the per-lane offset walks down the rows by K.  (The
@@ -772,7 +775,9 @@ __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *_
   const int64_t first = int64_t(blockIdx.x) * WV;
   for (; BIGK ? first + (tile - first - wave) < ntiles : tile < ntiles; tile += tstride) {
     const bool live = tile < ntiles;
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[0][mt] = acc[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < NCH; c++) {
       if constexpr (BIGK) {
         if (c % WIN == 0) {
@@ -790,11 +795,14 @@ __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *_
       for (int gg = 0; gg < 4; gg++) {
         const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + n * CS + 16 * gg + 4 * q);
         const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + (16 + n) * CS + 16 * gg + 4 * q);
-        const f32x4 a0 = wq[(4 * (BIGK ? c % WIN : c) + gg) * 64];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[j], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x1[j], acc[1], 0, 0, 0);
+        for (int mt = 0; mt < MT; mt++) {
+          const f32x4 a0 = wq[((4 * (BIGK ? c % WIN : c) + gg) * MT + mt) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[j], acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x1[j], acc[1][mt], 0, 0, 0);
+          }
         }
       }
     }
@@ -802,58 +810,92 @@ __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *_
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const int64_t row = (tile << 5) + 16 * t + n;
-      f32x4 v = acc[t];
+      f32x4 v[MT];
       dispatch_act(act.kind, [&](auto kind_tag) {
         constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = apply_act_c<KIND>(v[i] + bq[i], act.a, act.b);
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[mt][i] = apply_act_c<KIND>(acc[t][mt][i] + bq[mt][i], act.a, act.b);
       });
-      if constexpr (SM == 3) {  // label only: one float per row
-        const float label = argmax_over_quads(v, q, M);
-        if (row < rows && q == 0) Y[row] = label;
+      if constexpr (SM == 3) {  // label only: this lane's scores 16mt + 4q + i in ascending order, then the four q groups
+        float bv = -INFINITY;
+        int bi = M;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int f = 16 * mt + 4 * q + i;
+            if (f < M && (f == 0 || v[mt][i] > bv)) {  // score 0 starts the scan whatever it is (the sequential rule)
+              bv = v[mt][i];
+              bi = f;
+            }
+          }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float ov = __shfl_xor(bv, o);
+          const int oi = __shfl_xor(bi, o);
+          if (oi < M && (bi == M || ov > bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+          }
+        }
+        if (row < rows && q == 0) Y[row] = float(bi);
         continue;
       }
-      if constexpr (SM == 1 || SM == 2) {  // the row's features live in lanes n, n+16, n+32, n+48
+      if constexpr (SM == 1 || SM == 2) {  // the row's scores live in this lane's MT quads and in lanes n+16, n+32, n+48
         float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (4 * q + i < M) mx = fmaxf(mx, v[i]);
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (16 * mt + 4 * q + i < M) mx = fmaxf(mx, v[mt][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (4 * q + i < M) {
-            const float e = expf(v[i] - mx);
-            sum += e;
-            v[i] = SM == 1 ? e : v[i] - mx;
-          }
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (16 * mt + 4 * q + i < M) {
+              const float e = expf(v[mt][i] - mx);
+              sum += e;
+              v[mt][i] = SM == 1 ? e : v[mt][i] - mx;
+            }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float ls = logf(sum);
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = SM == 1 ? v[i] / sum : v[i] - ls;
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[mt][i] = SM == 1 ? v[mt][i] / sum : v[mt][i] - ls;
       }
       if (row < rows) {
-        float *yrow = Y + row * M + 4 * q;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (4 * q + i < M) yrow[i] = v[i];
+        for (int mt = 0; mt < MT; mt++) {
+          float *yrow = Y + row * M + 16 * mt + 4 * q;
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (16 * mt + 4 * q + i < M) yrow[i] = v[mt][i];
+        }
       }
     }
   }
 }
 
-static size_t narrow16w_lds(int K, int waves) { return (size_t((K + 63) / 64) * 1024 + size_t(waves) * 32 * 68) * sizeof(float); }
+static size_t narrow16w_lds(int K, int waves, int mt) {
+  return (size_t((K + 63) / 64) * 1024 * mt + size_t(waves) * 32 * 68) * sizeof(float);
+}
 static size_t narrow16w_big_lds(int waves) { return (size_t(16) * 1024 + size_t(waves) * 32 * 68) * sizeof(float); }
-static bool narrow16w_ok(int K, int M) { return M >= 1 && M <= 16 && K > 128 && K <= (1 << 20); }
+static bool narrow16w_ok(int K, int M) { return M >= 1 && M <= 32 && K > 128 && K <= (1 << 20); }
 
 static void launch_narrow16w(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
                              ActParam act, int softmax_mode) {
-  const bool big = narrow16w_lds(K, 8) > 160 * 1024;  // weights in 1024-column windows
-  const bool eight = big || (2 * narrow16w_lds(K, 4) > 160 * 1024);
+  const int mt = M <= 16 ? 1 : 2;
+  const bool big = narrow16w_lds(K, 8, mt) > 160 * 1024;  // weights in 64 KB windows
+  const bool eight = big || (2 * narrow16w_lds(K, 4, mt) > 160 * 1024);
   const int waves = eight ? 8 : 4;
-  const size_t lds = big ? narrow16w_big_lds(waves) : narrow16w_lds(K, waves);
+  const size_t lds = big ? narrow16w_big_lds(waves) : narrow16w_lds(K, waves, mt);
   const int64_t ntiles = (rows + 31) / 32;
   const int per_cu = int(std::clamp<size_t>((160 * 1024) / lds, 1, 8));
   const int64_t blocks = std::min<int64_t>((ntiles + waves - 1) / waves, 256 * per_cu);
@@ -862,16 +904,20 @@ static void launch_narrow16w(hipStream_t s, const float *X, const float *W, cons
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     hipLaunchKernelGGL(kernel, grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
   };
-  auto by_w = [&](auto smt) {
-    constexpr int SMv = decltype(smt)::value;
-    if (big) go(dense_narrow16w_kernel<SMv, 8, true>);
-    else if (eight) go(dense_narrow16w_kernel<SMv, 8>);
-    else go(dense_narrow16w_kernel<SMv, 4>);
+  auto by_w = [&](auto smt, auto mtt) {
+    constexpr int SMv = decltype(smt)::value, MTv = decltype(mtt)::value;
+    if (big) go(dense_narrow16w_kernel<SMv, 8, true, MTv>);
+    else if (eight) go(dense_narrow16w_kernel<SMv, 8, false, MTv>);
+    else go(dense_narrow16w_kernel<SMv, 4, false, MTv>);
   };
-  if (softmax_mode == 0) by_w(std::integral_constant<int, 0>{});
-  else if (softmax_mode == 1) by_w(std::integral_constant<int, 1>{});
-  else if (softmax_mode == 2) by_w(std::integral_constant<int, 2>{});
-  else by_w(std::integral_constant<int, 3>{});
+  auto by_mt = [&](auto smt) {
+    if (mt == 1) by_w(smt, std::integral_constant<int, 1>{});
+    else by_w(smt, std::integral_constant<int, 2>{});
+  };
+  if (softmax_mode == 0) by_mt(std::integral_constant<int, 0>{});
+  else if (softmax_mode == 1) by_mt(std::integral_constant<int, 1>{});
+  else if (softmax_mode == 2) by_mt(std::integral_constant<int, 2>{});
+  else by_mt(std::integral_constant<int, 3>{});
 }
 
 // ---- skinny layers: rows of at most 32 floats, M <= 16 outputs ----------------------------------------------------
@@ -1028,7 +1074,7 @@ static void launch_skinny(hipStream_t s, const float *X, const float *W, const f
   }
 }
 
-bool dense_can_fuse_softmax(int K, int M) { return M <= 16 || (M <= 32 && K % 8 == 0 && K <= 512); }
+bool dense_can_fuse_softmax(int K, int M) { return M <= 16 || (M <= 32 && ((K % 8 == 0 && K <= 512) || K > 128)); }
 // ArgMax epilogues (softmax_mode 3) exist in the skinny and the two 16x16x4 streaming kernels; the latter need 16-byte rows
 bool dense_can_fuse_argmax(const float *X, int K, int M) {
   return narrow16g_ok(K, M) || skinny_ok(K, M) || narrow16w_ok(K, M) ||
