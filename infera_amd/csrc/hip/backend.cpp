@@ -305,7 +305,7 @@ void schedule(LoadedModel &m) {
     // the scores never reach memory.  Both buffers stay planned: the launch falls back to the two kernels when the
     // input pointer it meets at run time cannot feed a kernel with that epilogue (dense_can_fuse_argmax).
     if (i + 1 < n && st[i].kind == StepKind::Dense && st[i + 1].kind == StepKind::ArgMax && st[i + 1].in0 == st[i].out &&
-        uses[size_t(st[i].out)] == 1 && st[i + 1].K == st[i].M && st[i].M <= 32 &&
+        uses[size_t(st[i].out)] == 1 && st[i + 1].K == st[i].M && st[i].M <= 64 &&
         kern::dense_can_fuse_argmax(nullptr, int(st[i].K), int(st[i].M))) {
       m.exec[i] = ExecKind::DenseArgMax;
       i += 1;

@@ -712,7 +712,7 @@ static void launch_narrow16g(hipStream_t s, const float *X, const float *W, cons
 // BIGK (rows longer than ~1500 floats: 2048- / 4096-dimensional embeddings): the weights no longer fit the LDS in one
 // piece, so the workgroup keeps a window of WIN chunks (64 KB) and restages it as its waves move along the row
 // together -- two barriers per window; every wave of the block runs the same number of tile trips for that.
-// MT = 16-wide output tiles (1: M <= 16, 2: M <= 32 -- 20 / 26 / 32-class heads).
+// MT = 16-wide output tiles (1: M <= 16, 2: M <= 32 -- 20 / 26 / 32-class heads, 4: M <= 64).
 template <int SM, int WV, bool BIGK, int MT>
 __global__ __launch_bounds__(WV * 64) void dense_narrow16w_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                  const float *__restrict__ bias, float *__restrict__ Y,
@@ -887,11 +887,11 @@ static size_t narrow16w_lds(int K, int waves, int mt) {
   return (size_t((K + 63) / 64) * 1024 * mt + size_t(waves) * 32 * 68) * sizeof(float);
 }
 static size_t narrow16w_big_lds(int waves) { return (size_t(16) * 1024 + size_t(waves) * 32 * 68) * sizeof(float); }
-static bool narrow16w_ok(int K, int M) { return M >= 1 && M <= 32 && K > 128 && K <= (1 << 20); }
+static bool narrow16w_ok(int K, int M) { return M >= 1 && M <= 64 && K > 128 && K <= (1 << 20); }
 
 static void launch_narrow16w(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
                              ActParam act, int softmax_mode) {
-  const int mt = M <= 16 ? 1 : 2;
+  const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4;
   const bool big = narrow16w_lds(K, 8, mt) > 160 * 1024;  // weights in 64 KB windows
   const bool eight = big || (2 * narrow16w_lds(K, 4, mt) > 160 * 1024);
   const int waves = eight ? 8 : 4;
@@ -912,7 +912,8 @@ static void launch_narrow16w(hipStream_t s, const float *X, const float *W, cons
   };
   auto by_mt = [&](auto smt) {
     if (mt == 1) by_w(smt, std::integral_constant<int, 1>{});
-    else by_w(smt, std::integral_constant<int, 2>{});
+    else if (mt == 2) by_w(smt, std::integral_constant<int, 2>{});
+    else by_w(smt, std::integral_constant<int, 4>{});
   };
   if (softmax_mode == 0) by_mt(std::integral_constant<int, 0>{});
   else if (softmax_mode == 1) by_mt(std::integral_constant<int, 1>{});
@@ -1074,7 +1075,7 @@ static void launch_skinny(hipStream_t s, const float *X, const float *W, const f
   }
 }
 
-bool dense_can_fuse_softmax(int K, int M) { return M <= 16 || (M <= 32 && ((K % 8 == 0 && K <= 512) || K > 128)); }
+bool dense_can_fuse_softmax(int K, int M) { return M <= 16 || (M <= 32 && K % 8 == 0 && K <= 512) || (M <= 64 && K > 128); }
 // ArgMax epilogues (softmax_mode 3) exist in the skinny and the two 16x16x4 streaming kernels; the latter need 16-byte rows
 bool dense_can_fuse_argmax(const float *X, int K, int M) {
   return narrow16g_ok(K, M) || skinny_ok(K, M) || narrow16w_ok(K, M) ||

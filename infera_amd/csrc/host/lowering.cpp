@@ -195,7 +195,8 @@ struct Lowerer {
     // A wide layer over rows whose length is not a multiple of 4 floats (30 features, ...): copy the rows into a
     // zero-padded matrix first so the MFMA kernels can read them in 16-byte quads; the padded k carry zero weights.
     // (Narrow heads stream their input once and take any K.)
-    const int64_t Kp = (M > 32 && K % 4 != 0) ? (K + 3) / 4 * 4 : K;
+    // (up to 64 outputs over more than 128 columns the wide-table kernel reads the rows as they are)
+    const int64_t Kp = (M > 32 && K % 4 != 0 && !(K > 128 && M <= 64)) ? (K + 3) / 4 * 4 : K;
     if (Kp != K) {
       Step p;
       p.kind = StepKind::PadCols;

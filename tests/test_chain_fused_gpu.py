@@ -199,7 +199,8 @@ def test_gpu_jit_code_objects_are_cached_on_disk(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,m,sm", [(129, 1, False), (201, 1, False), (300, 10, True), (561, 6, True), (1000, 16, False), (1984, 3, True),
                                     (2048, 10, True), (2049, 3, False), (3000, 5, True), (4096, 16, False),
-                                    (300, 20, True), (561, 32, False), (1000, 26, True), (2048, 17, True), (4099, 32, False)])
+                                    (300, 20, True), (561, 32, False), (1000, 26, True), (2048, 17, True), (4099, 32, False),
+                                    (561, 50, True), (300, 64, False), (2048, 64, True), (1001, 33, False)])
 @pytest.mark.parametrize("rows", [1, 31, 32, 33, 4100])
 def test_gpu_wide_tables_of_any_row_length(api, O, tmp_path, k, m, sm, rows):
     """dense_narrow16w_kernel: 64-column chunks row by row, K not a multiple of anything, partial last chunk and tile;

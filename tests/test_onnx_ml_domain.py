@@ -215,7 +215,7 @@ ARGMAX_CASES = [(30, 3, 5001, "dense_argmax"), (5, 2, 257, "dense_argmax"), (100
                 (64, 10, 1000, "dense_argmax"), (48, 5, 7001, "dense_argmax"), (1024, 3, 513, "dense_argmax"),
                 (200, 6, 2500, "dense_argmax"), (561, 6, 3001, "dense_argmax"), (301, 16, 777, "dense_argmax"),
                 (2000, 4, 600, "dense_argmax"), (64, 20, 2500, "chain_fused"), (32, 40, 2500, "chain_fused"), (100, 128, 1500, "chain_fused"),
-                (300, 40, 2500, "dense_tiled"), (300, 26, 2500, "dense_argmax"), (2050, 32, 700, "dense_argmax")]
+                (300, 40, 2500, "dense_argmax"), (301, 40, 2500, "dense_argmax"), (561, 64, 900, "dense_argmax"), (300, 100, 2500, "dense_tiled"), (300, 26, 2500, "dense_argmax"), (2050, 32, 700, "dense_argmax")]
 
 
 @pytest.mark.gpu
