@@ -626,3 +626,35 @@ print("ok")
 ''' % (root, models["linear"], models["linear_dyn"], models["linear_dyn"])
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, INFERA_BATCH_SPLIT="1"), capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
+
+
+def test_many_more_caller_threads_than_admitted_submissions(api, models):
+    """64 caller threads (a DuckDB scan on a many-core host) against the default admission limit of 12 in-flight calls per
+    GPU: every chunk's result is right, nobody starves or deadlocks"""
+    import threading
+
+    from infera_amd import synth
+    from oracle import oracle
+
+    api.load_model("mlp", models["mlp"])
+    x = synth.table(77, 0, 2048, 128)
+    want = oracle.Model(models["mlp"]).predict(x)
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(12):
+                lo = (37 * t + 101 * it) % 1500
+                got = api.predict("mlp", x[lo:lo + 500])
+                assert_close(got, want[lo:lo + 500])
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(64)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in threads), "a caller is stuck behind the admission gate"
+    assert not errors, errors[:3]
+    api.unload_model("mlp")

@@ -14,13 +14,19 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=4_000_000)
 ap.add_argument("--threads", default="1,2,4,8,16,32,64")
 ap.add_argument("--workload", default="mlp")
+ap.add_argument("--dims", default="", help="custom MLP instead of a named workload, e.g. 30,100,2 (first = table columns)")
+ap.add_argument("--softmax", action="store_true")
 a = ap.parse_args()
 tmp = tempfile.mkdtemp()
-blob = onnx_writer.mlp() if a.workload == "mlp" else onnx_writer.logreg_softmax()
-fn = "infera_predict" if a.workload == "mlp" else "infera_predict_array"
+if a.dims:
+    dims = tuple(int(x) for x in a.dims.split(","))
+    blob, cols, fn = onnx_writer.mlp(dims, final_softmax=a.softmax), dims[0], "infera_predict" if dims[-1] == 1 else "infera_predict_array"
+else:
+    blob = onnx_writer.mlp() if a.workload == "mlp" else onnx_writer.logreg_softmax()
+    cols, fn = 128, "infera_predict" if a.workload == "mlp" else "infera_predict_array"
 capi.load_model("m", onnx_writer.write(os.path.join(tmp, "m.onnx"), blob))
-sqlmock.bench_scan(fn, "m", 2048 * 64, 128, 4)  # warm
-print(f"devices={capi.device_count()} workload={a.workload} rows={a.rows}")
+sqlmock.bench_scan(fn, "m", 2048 * 64, cols, 4)  # warm
+print(f"devices={capi.device_count()} workload={a.dims or a.workload} rows={a.rows} exec={capi.get_plan('m')['exec']}")
 for t in [int(x) for x in a.threads.split(",")]:
-    sec, cs = sqlmock.bench_scan(fn, "m", a.rows, 128, t)
-    print(f"threads={t:>3}  {a.rows / sec / 1e6:>9.2f} M rows/s  ({a.rows * 512 / sec / 1e9:.2f} GB/s of features)  checksum={cs:.4f}")
+    sec, cs = sqlmock.bench_scan(fn, "m", a.rows, cols, t)
+    print(f"threads={t:>3}  {a.rows / sec / 1e6:>9.2f} M rows/s  ({a.rows * cols * 4 / sec / 1e9:.2f} GB/s of features)  checksum={cs:.4f}")
