@@ -144,6 +144,63 @@ ThreadCtx &ctx_for_slot(int slot) {
   return *c;
 }
 
+// Host-ABI calls do not own a context per caller thread: a DuckDB scan on a 256-thread host would pin 256 sets of
+// staging buffers and per-model scratch (ResNet-18: ~1 GB each) and create 256 streams, for no throughput -- the path
+// saturates at ~16 callers per GPU.  They lease one of at most INFERA_HOST_CONTEXTS (default 24) contexts per GPU for
+// the duration of the call; the rest wait.  (The device-resident entry points keep the caller thread's own stream.)
+struct HostPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<ThreadCtx *> free;
+  int created = 0;
+};
+HostPool &host_pool(int slot) {
+  static HostPool pools[64];
+  return pools[size_t(slot) % 64];
+}
+struct HostLease {
+  HostPool &pool;
+  ThreadCtx *c = nullptr;
+  explicit HostLease(int slot) : pool(host_pool(slot)) {
+    const auto &ds = devices();
+    HIP_TRY(hipSetDevice(ds.ids[size_t(slot)]));
+    const int cap = Config::get().host_contexts;
+    {
+      std::unique_lock<std::mutex> lk(pool.mu);
+      pool.cv.wait(lk, [&] { return !pool.free.empty() || pool.created < cap; });
+      if (!pool.free.empty()) {
+        c = pool.free.back();
+        pool.free.pop_back();
+        return;
+      }
+      pool.created++;
+    }
+    auto *n = new ThreadCtx();
+    n->device = ds.ids[size_t(slot)];
+    const hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete n;
+      {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        pool.created--;
+      }
+      pool.cv.notify_one();
+      hip_fail(e, "hipStreamCreateWithFlags");
+    }
+    c = n;
+  }
+  ~HostLease() {
+    if (!c) return;
+    {
+      std::lock_guard<std::mutex> lk(pool.mu);
+      pool.free.push_back(c);
+    }
+    pool.cv.notify_one();
+  }
+  HostLease(const HostLease &) = delete;
+  HostLease &operator=(const HostLease &) = delete;
+};
+
 int home_slot() {
   if (t_holder.home_slot < 0) t_holder.home_slot = int(g_next_home.fetch_add(1) % unsigned(devices().ids.size()));
   return t_holder.home_slot;
@@ -788,7 +845,8 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
   if (rows <= 0) return;
   const int slot = home_slot();
-  ThreadCtx &ctx = ctx_for_slot(slot);
+  HostLease lease(slot);
+  ThreadCtx &ctx = *lease.c;
   const DeviceModel &dm = device_model(m, slot);
   const size_t in_row = size_t(m.plan.in_per_row()) * 4, out_row = size_t(m.plan.out_per_row()) * 4;
   const size_t widest = std::max(in_row, out_row);

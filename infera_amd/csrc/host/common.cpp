@@ -1,5 +1,6 @@
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -86,6 +87,7 @@ const Config &Config::get() {
     }
     c.use_hipgraph = env_flag("INFERA_HIPGRAPH", false);
     c.max_inflight = int(env_u64("INFERA_MAX_INFLIGHT", 12));
+    c.host_contexts = std::max(1, int(env_u64("INFERA_HOST_CONTEXTS", 24)));
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);
     c.max_rows_per_pass = env_u64("INFERA_MAX_ROWS_PER_PASS", 1ull << 18);
     c.batch_split = env_flag("INFERA_BATCH_SPLIT", false);

@@ -87,6 +87,7 @@ struct Config {
   uint64_t http_retry_delay_ms;       // INFERA_HTTP_RETRY_DELAY    (default 1000, multiplied by the attempt number)
   // MI355X backend knobs (new; same style)
   std::vector<int> devices;           // INFERA_DEVICES="0,1,.."  (default: all visible)
+  int host_contexts;                  // INFERA_HOST_CONTEXTS=n   staging contexts (stream + pinned / device buffers + scratch) per GPU that host-ABI calls lease
   int max_inflight;                   // INFERA_MAX_INFLIGHT=n    host-ABI calls per GPU between their first H2D and their sync (0 = no limit)
   bool use_hipgraph;                  // INFERA_HIPGRAPH=0|1      replay a per-(model,rows) hipGraph {H2D,kernels,D2H} per
                                       //   host-path chunk.  Default 0: measured SLOWER than three direct stream
