@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -64,13 +65,14 @@ std::string expr_of(const ChainShape &s) {
 }
 
 struct Compiled {
+  std::mutex mu;  // compile + per-device module load of THIS shape; other shapes' launches never wait on it
   bool ok = false;
   std::string why, expr, lowered;
   std::vector<char> code;
   std::map<int, hipFunction_t> fn_by_device;
 };
-std::mutex g_mu;
-std::map<std::string, Compiled> g_cache;  // keyed by the name expression (it spells out the whole shape)
+std::mutex g_mu;  // the map only
+std::map<std::string, std::shared_ptr<Compiled>> g_cache;  // keyed by the name expression (it spells out the whole shape)
 
 bool shape_ok(const ChainShape &s, std::string &why) {
   const size_t L = s.dims.size();
@@ -103,9 +105,18 @@ bool shape_ok(const ChainShape &s, std::string &why) {
   return true;
 }
 
-Compiled &compile_locked(const ChainShape &s) {
+// entry of the shape, compiled (or failed) on return; the caller holds c.mu
+Compiled &compile_locked(const ChainShape &s, std::unique_lock<std::mutex> &held) {
   const std::string expr = expr_of(s);
-  Compiled &c = g_cache[expr];
+  std::shared_ptr<Compiled> entry;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto &slot = g_cache[expr];
+    if (!slot) slot = std::make_shared<Compiled>();
+    entry = slot;  // entries are never erased: the reference stays valid
+  }
+  Compiled &c = *entry;
+  held = std::unique_lock<std::mutex>(c.mu);
   if (c.ok || !c.why.empty()) return c;
   c.expr = expr;
   if (!shape_ok(s, c.why)) return c;
@@ -138,8 +149,8 @@ void chain_pack(const ChainShape &s, const std::vector<const float *> &W, const 
 }
 
 bool chain_supported(const ChainShape &s, std::string *why) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  Compiled &c = compile_locked(s);
+  std::unique_lock<std::mutex> lk;
+  Compiled &c = compile_locked(s, lk);
   if (!c.ok && why) *why = c.why;
   return c.ok;
 }
@@ -149,8 +160,8 @@ bool chain(hipStream_t st, const ChainShape &s, const float *X, const float *pac
   hipFunction_t fn = nullptr;
   const int lds = int(lds_bytes(s));
   {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Compiled &c = compile_locked(s);
+    std::unique_lock<std::mutex> lk;
+    Compiled &c = compile_locked(s, lk);
     if (!c.ok) {
       if (why) *why = c.why;
       return false;

@@ -9,6 +9,7 @@
 #include <fstream>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -179,6 +180,7 @@ using Key = std::tuple<int, int, int, int, int, int, int>;
 Key key_of(const Mlp3Shape &s) { return {s.d0, s.d1, s.d2, s.d3, s.act1, s.act2, s.act3}; }
 
 struct Compiled {
+  std::mutex mu;  // compile + per-device module load of THIS shape
   bool ok = false;
   std::string why, expr, lowered;
   std::vector<char> code;
@@ -186,8 +188,8 @@ struct Compiled {
   std::map<int, hipFunction_t> fn_by_device;
 };
 
-std::mutex g_mu;
-std::map<Key, Compiled> g_cache;
+std::mutex g_mu;  // the map only
+std::map<Key, std::shared_ptr<Compiled>> g_cache;
 
 // Picks the kernel template and its tuning parameters for a shape; returns the name expression.
 bool plan_kernel(const Mlp3Shape &s, const Mlp3Layout &L, std::string &expr, int &threads, std::string &why) {
@@ -236,8 +238,17 @@ bool plan_kernel(const Mlp3Shape &s, const Mlp3Layout &L, std::string &expr, int
   return false;
 }
 
-Compiled &compile_locked(const Mlp3Shape &s) {
-  Compiled &c = g_cache[key_of(s)];
+// entry of the shape, compiled (or failed) on return; the caller holds c.mu (other shapes' launches never wait on it)
+Compiled &compile_locked(const Mlp3Shape &s, std::unique_lock<std::mutex> &held) {
+  std::shared_ptr<Compiled> entry;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto &slot = g_cache[key_of(s)];
+    if (!slot) slot = std::make_shared<Compiled>();
+    entry = slot;  // entries are never erased
+  }
+  Compiled &c = *entry;
+  held = std::unique_lock<std::mutex>(c.mu);
   if (c.ok || !c.why.empty()) return c;
   const Mlp3Layout L = mlp3_layout(s.d0, s.d1, s.d2, s.d3);
   if (!plan_kernel(s, L, c.expr, c.threads, c.why)) return c;
@@ -249,8 +260,8 @@ Compiled &compile_locked(const Mlp3Shape &s) {
 }  // namespace
 
 bool mlp3_jit_prepare(const Mlp3Shape &sh, std::string *why) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  Compiled &c = compile_locked(sh);
+  std::unique_lock<std::mutex> lk;
+  Compiled &c = compile_locked(sh, lk);
   if (!c.ok && why) *why = c.why;
   return c.ok;
 }
@@ -260,8 +271,8 @@ bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const f
   hipFunction_t fn = nullptr;
   int threads = 256, lds = 0;
   {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Compiled &c = compile_locked(sh);
+    std::unique_lock<std::mutex> lk;
+    Compiled &c = compile_locked(sh, lk);
     if (!c.ok) {
       if (why) *why = c.why;
       return false;
@@ -301,9 +312,15 @@ bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const f
 }
 
 std::string mlp3_jit_kernel_name(const Mlp3Shape &sh) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_cache.find(key_of(sh));
-  return it != g_cache.end() && it->second.ok ? it->second.expr + " [hipRTC]" : std::string();
+  std::shared_ptr<Compiled> entry;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.find(key_of(sh));
+    if (it == g_cache.end()) return std::string();
+    entry = it->second;
+  }
+  std::lock_guard<std::mutex> el(entry->mu);
+  return entry->ok ? entry->expr + " [hipRTC]" : std::string();
 }
 
 }  // namespace infera_hip::kern
