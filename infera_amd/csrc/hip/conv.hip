@@ -672,69 +672,69 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
 // (Tried for 3x3: one thread per strip of four outputs with the shared input quads held in registers and branch-free
 // clamped loads -- strips along a row: 4.39 ms, strips down a column: 4.20 ms, this kernel: 4.03 ms for the
 // MobileNetV2 topology at 256 images.  Fewer load instructions did not pay for a quarter of the threads.)
-__global__ __launch_bounds__(kBlock) void conv2d_depthwise_cq_kernel(const float *__restrict__ X, const float *__restrict__ Wd,
-                                                                    const float *__restrict__ bias, float *__restrict__ Y,
-                                                                    int64_t total4, ConvGeom g, ActParam act) {
-  const int64_t stride = int64_t(gridDim.x) * kBlock;
-  const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X), *w4 = reinterpret_cast<const f32x4 *>(Wd);
-  f32x4 *y4 = reinterpret_cast<f32x4 *>(Y);
-  const int C4 = g.C >> 2, ntaps = g.kh * g.kw;
-  for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < total4; o += stride) {
-    const int ow = int(o % g.OW);
-    const int oh = int((o / g.OW) % g.OH);
-    const int64_t plane = o / (int64_t(g.OW) * g.OH);  // n * C/4 + c/4
-    const int c4 = int(plane % C4);
-    f32x4 acc = bias ? reinterpret_cast<const f32x4 *>(bias)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 *wq = w4 + int64_t(c4) * ntaps;
-    for (int ky = 0; ky < g.kh; ky++) {
-      const int iy = oh * g.sh - g.pt + ky * g.dh;
-      if (iy < 0 || iy >= g.H) continue;
-      for (int kx = 0; kx < g.kw; kx++) {
-        const int ix = ow * g.sw - g.pl + kx * g.dw;
-        if (ix < 0 || ix >= g.W) continue;
-        const f32x4 v = x4[(plane * g.H + iy) * g.W + ix], w = wq[ky * g.kw + kx];
+// Grid: x = plane (n * C/4 + c/4), y = blocks of BS positions inside the plane -- the plane, its channel quad and its
+// weights are scalar (per workgroup), the position costs one 32-bit division; the first version decomposed a flat
+// 64-bit index per thread (four 64-bit divisions, ~160 VALU instructions per output quad, more than the 36 FMAs).
+template <int BS>
+__global__ __launch_bounds__(BS) void conv2d_depthwise_cq_kernel(const float *__restrict__ X, const float *__restrict__ Wd,
+                                                                 const float *__restrict__ bias, float *__restrict__ Y,
+                                                                 ConvGeom g, ActParam act) {
+  const int pos = int(blockIdx.y) * BS + int(threadIdx.x), ohw = g.OH * g.OW;
+  if (pos >= ohw) return;
+  const int64_t plane = blockIdx.x;
+  const int c4 = int(plane % (g.C >> 2)), ntaps = g.kh * g.kw;
+  const int oh = pos / g.OW, ow = pos - oh * g.OW;
+  const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X) + plane * g.H * g.W;
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(Wd) + int64_t(c4) * ntaps;
+  f32x4 acc = bias ? reinterpret_cast<const f32x4 *>(bias)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int iy0 = oh * g.sh - g.pt, ix0 = ow * g.sw - g.pl;
+  for (int ky = 0; ky < g.kh; ky++) {
+    const int iy = iy0 + ky * g.dh;
+    if (iy < 0 || iy >= g.H) continue;
+    for (int kx = 0; kx < g.kw; kx++) {
+      const int ix = ix0 + kx * g.dw;
+      if (ix < 0 || ix >= g.W) continue;
+      const f32x4 v = x4[iy * g.W + ix], w = wq[ky * g.kw + kx];
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc[e] = fmaf(v[e], w[e], acc[e]);
-      }
+      for (int e = 0; e < 4; e++) acc[e] = fmaf(v[e], w[e], acc[e]);
     }
-#pragma unroll
-    for (int e = 0; e < 4; e++) acc[e] = apply_act(acc[e], act);
-    y4[o] = acc;
   }
+#pragma unroll
+  for (int e = 0; e < 4; e++) acc[e] = apply_act(acc[e], act);
+  reinterpret_cast<f32x4 *>(Y)[plane * ohw + pos] = acc;
 }
 
 // CQ pooling: one thread per (n, channel quad, oh, ow) -- 16 bytes per tap, consecutive lanes walk a plane row.
-__global__ __launch_bounds__(kBlock) void pool2d_cq_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total4,
-                                                          int H, int W, int OH, int OW, int kh, int kw, int sh, int sw, int pt,
-                                                          int pl, int dh, int dw, bool is_max, bool count_pad) {
-  const int64_t stride = int64_t(gridDim.x) * kBlock;
-  const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X);
-  f32x4 *y4 = reinterpret_cast<f32x4 *>(Y);
-  for (int64_t o = int64_t(blockIdx.x) * kBlock + threadIdx.x; o < total4; o += stride) {
-    const int ow = int(o % OW);
-    const int oh = int((o / OW) % OH);
-    const int64_t plane = o / (int64_t(OW) * OH);  // n * C/4 + c/4
-    f32x4 acc = is_max ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
-    int cnt = 0;
-    for (int i = 0; i < kh; i++) {
-      const int iy = oh * sh - pt + i * dh;
-      if (iy < 0 || iy >= H) continue;
-      for (int j = 0; j < kw; j++) {
-        const int ix = ow * sw - pl + j * dw;
-        if (ix < 0 || ix >= W) continue;
-        const f32x4 v = x4[(plane * H + iy) * W + ix];
+template <int BS>
+__global__ __launch_bounds__(BS) void pool2d_cq_kernel(const float *__restrict__ X, float *__restrict__ Y, int H, int W, int OH, int OW,
+                                                       int kh, int kw, int sh, int sw, int pt, int pl, int dh, int dw, bool is_max,
+                                                       bool count_pad) {
+  // grid: x = plane (n * C/4 + c/4), y = blocks of BS positions (see the depthwise kernel)
+  const int pos = int(blockIdx.y) * BS + int(threadIdx.x), ohw = OH * OW;
+  if (pos >= ohw) return;
+  const int64_t plane = blockIdx.x;
+  const int oh = pos / OW, ow = pos - oh * OW;
+  const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X) + plane * H * W;
+  f32x4 acc = is_max ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;
+  for (int i = 0; i < kh; i++) {
+    const int iy = oh * sh - pt + i * dh;
+    if (iy < 0 || iy >= H) continue;
+    for (int j = 0; j < kw; j++) {
+      const int ix = ow * sw - pl + j * dw;
+      if (ix < 0 || ix >= W) continue;
+      const f32x4 v = x4[iy * W + ix];
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc[e] = is_max ? fmaxf(acc[e], v[e]) : acc[e] + v[e];
-        cnt++;
-      }
+      for (int e = 0; e < 4; e++) acc[e] = is_max ? fmaxf(acc[e], v[e]) : acc[e] + v[e];
+      cnt++;
     }
-    if (!is_max) {
-      const float d = float(count_pad ? kh * kw : (cnt ? cnt : 1));
-#pragma unroll
-      for (int e = 0; e < 4; e++) acc[e] = acc[e] / d;
-    }
-    y4[o] = acc;
   }
+  if (!is_max) {
+    const float d = float(count_pad ? kh * kw : (cnt ? cnt : 1));
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc[e] = acc[e] / d;
+  }
+  reinterpret_cast<f32x4 *>(Y)[plane * ohw + pos] = acc;
 }
 
 __global__ __launch_bounds__(kBlock) void pool2d_kernel(const float *__restrict__ X, float *__restrict__ Y, int64_t total,
@@ -911,9 +911,11 @@ void conv2d_depthwise_pack(const ConvGeom &g, const float *Wt, float *packed) {
 
 void conv2d_depthwise(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                       const ConvGeom &g, ActParam act) {
-  const int64_t total4 = rows * (g.C / 4) * g.OH * g.OW;
-  if (total4 <= 0) return;
-  hipLaunchKernelGGL(conv2d_depthwise_cq_kernel, dim3(grid_for(total4)), dim3(kBlock), 0, s, X, packed, bias, Y, total4, g, act);
+  const int64_t planes = rows * (g.C / 4);
+  const int ohw = g.OH * g.OW;
+  if (planes <= 0 || ohw <= 0) return;
+  if (ohw <= 64) hipLaunchKernelGGL(conv2d_depthwise_cq_kernel<64>, dim3(unsigned(planes), unsigned((ohw + 63) / 64)), dim3(64), 0, s, X, packed, bias, Y, g, act);
+  else hipLaunchKernelGGL(conv2d_depthwise_cq_kernel<256>, dim3(unsigned(planes), unsigned((ohw + 255) / 256)), dim3(256), 0, s, X, packed, bias, Y, g, act);
 }
 
 // C and M multiples of 32, or (channel-quad tensors) of 4: those run with zero-padded weights, see conv2d_tiled_geom
@@ -1029,8 +1031,10 @@ void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H,
   const int64_t total = rows * C * OH * OW;
   if (total <= 0) return;
   if (cq) {  // the plan guarantees C % 4 == 0 in CQ mode
-    hipLaunchKernelGGL(pool2d_cq_kernel, dim3(grid_for(total / 4)), dim3(kBlock), 0, s, X, Y, total / 4, H, W, OH, OW, kh, kw, sh, sw,
-                       pt, pl, dh, dw, is_max, count_pad);
+    const int64_t planes = rows * (C / 4);
+    const int ohw = OH * OW;
+    if (ohw <= 64) hipLaunchKernelGGL(pool2d_cq_kernel<64>, dim3(unsigned(planes), unsigned((ohw + 63) / 64)), dim3(64), 0, s, X, Y, H, W, OH, OW, kh, kw, sh, sw, pt, pl, dh, dw, is_max, count_pad);
+    else hipLaunchKernelGGL(pool2d_cq_kernel<256>, dim3(unsigned(planes), unsigned((ohw + 255) / 256)), dim3(256), 0, s, X, Y, H, W, OH, OW, kh, kw, sh, sw, pt, pl, dh, dw, is_max, count_pad);
     return;
   }
   hipLaunchKernelGGL(pool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, X, Y, total, C, H, W, OH, OW, kh, kw, sh, sw, pt,
