@@ -96,6 +96,48 @@ __global__ __launch_bounds__(kBlock) void binary_act_kernel(const float *__restr
     y[i] = apply_act(apply_bop(a[i], b[i], op, false), act);
 }
 
+// Per-channel work on [N,C,S] tensors with a (plane, position block) grid: the plane -- n*C + c, or n*C/4 + c/4 in
+// channel-quad planes -- is the workgroup's, so its scale / shift / gate values are scalar loads and no thread divides a
+// flat 64-bit index (that decomposition was ~100 VALU instructions per element on kernels that move 8 bytes per element).
+template <bool CQ>
+__global__ __launch_bounds__(kBlock) void affine_planes_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, float *__restrict__ y, int C, int S,
+                                                              ActParam act) {
+  const int pos = int(blockIdx.y) * kBlock + int(threadIdx.x);
+  if (pos >= S) return;
+  const int64_t plane = blockIdx.x;
+  if constexpr (CQ) {
+    const int c4 = int(plane % (C >> 2));
+    const f32x4 sc = reinterpret_cast<const f32x4 *>(scale)[c4], sh = reinterpret_cast<const f32x4 *>(shift)[c4];
+    const f32x4 u = reinterpret_cast<const f32x4 *>(x)[plane * S + pos];
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; e++) r[e] = apply_act(u[e] * sc[e] + sh[e], act);
+    reinterpret_cast<f32x4 *>(y)[plane * S + pos] = r;
+  } else {
+    const int c = int(plane % C);
+    y[plane * S + pos] = apply_act(x[plane * S + pos] * scale[c] + shift[c], act);
+  }
+}
+
+template <bool CQ>
+__global__ __launch_bounds__(kBlock) void gate_planes_kernel(const float *__restrict__ a, const float *__restrict__ gate,
+                                                            float *__restrict__ y, int C, int S, char op, ActParam act) {
+  const int pos = int(blockIdx.y) * kBlock + int(threadIdx.x);
+  if (pos >= S) return;
+  const int64_t plane = blockIdx.x;  // the gate tensor [N,C] is exactly one value per NCHW plane / one quad per CQ plane
+  if constexpr (CQ) {
+    const f32x4 g = reinterpret_cast<const f32x4 *>(gate)[plane];
+    const f32x4 u = reinterpret_cast<const f32x4 *>(a)[plane * S + pos];
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; e++) r[e] = apply_act(apply_bop(u[e], g[e], op, false), act);
+    reinterpret_cast<f32x4 *>(y)[plane * S + pos] = r;
+  } else {
+    y[plane * S + pos] = apply_act(apply_bop(a[plane * S + pos], gate[plane], op, false), act);
+  }
+}
+
 // y[r, c, s] = act(a[r, c, s] (op) gate[r, c])   (squeeze-and-excitation style per-channel gate)
 __global__ __launch_bounds__(kBlock) void binary_gate_kernel(const float *__restrict__ a, const float *__restrict__ gate,
                                                             float *__restrict__ y, int64_t n, int64_t C, int64_t S, char op, ActParam act,
@@ -360,6 +402,12 @@ void binary_gate(hipStream_t s, const float *a, const float *gate, float *y, int
                  bool cq) {
   const int64_t n = rows * C * S;
   if (n <= 0) return;
+  if (S <= 65535LL * kBlock && (!cq || C % 4 == 0)) {
+    const dim3 grid(unsigned(cq ? rows * C / 4 : rows * C), unsigned((S + kBlock - 1) / kBlock));
+    if (cq) hipLaunchKernelGGL(gate_planes_kernel<true>, grid, dim3(kBlock), 0, s, a, gate, y, int(C), int(S), op, act);
+    else hipLaunchKernelGGL(gate_planes_kernel<false>, grid, dim3(kBlock), 0, s, a, gate, y, int(C), int(S), op, act);
+    return;
+  }
   hipLaunchKernelGGL(binary_gate_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, a, gate, y, n, C, S, op, act, cq);
 }
 
@@ -370,6 +418,12 @@ void affine_channel(hipStream_t s, const float *x, const float *scale, const flo
   if (S == 1) {  // a table: no layout to respect
     const bool vec4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     hipLaunchKernelGGL(affine_rows_kernel, dim3(grid_for(vec4 ? n / 4 : n)), dim3(kBlock), 0, s, x, scale, shift, y, n, C, act, vec4);
+    return;
+  }
+  if (S <= 65535LL * kBlock && (!cq || C % 4 == 0)) {
+    const dim3 grid(unsigned(cq ? rows * C / 4 : rows * C), unsigned((S + kBlock - 1) / kBlock));
+    if (cq) hipLaunchKernelGGL(affine_planes_kernel<true>, grid, dim3(kBlock), 0, s, x, scale, shift, y, int(C), int(S), act);
+    else hipLaunchKernelGGL(affine_planes_kernel<false>, grid, dim3(kBlock), 0, s, x, scale, shift, y, int(C), int(S), act);
     return;
   }
   hipLaunchKernelGGL(affine_channel_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, scale, shift, y, n, C, S, act, cq);
