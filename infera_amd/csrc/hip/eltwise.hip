@@ -528,9 +528,39 @@ void lrn(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, in
   hipLaunchKernelGGL(lrn_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, X, Y, n, C, S, size, alpha / float(size), beta, bias, cq);
 }
 
+// (plane, position block) grid as for the other per-channel kernels: the four source channels of an output quad are
+// scalar; NCHW planes are plain contiguous copies.
+template <bool CQ>
+__global__ __launch_bounds__(kBlock) void channel_shuffle_planes_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int S, int g) {
+  const int pos = int(blockIdx.y) * kBlock + int(threadIdx.x);
+  if (pos >= S) return;
+  const int64_t plane = blockIdx.x;
+  const int per = C / g;
+  if constexpr (CQ) {
+    const int C4 = C >> 2, cq = int(plane % C4);
+    const int64_t img = plane / C4;
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = 4 * cq + e, k = (c % g) * per + c / g;
+      r[e] = x[((img * C4 + (k >> 2)) * S + pos) * 4 + (k & 3)];
+    }
+    reinterpret_cast<f32x4 *>(y)[plane * S + pos] = r;
+  } else {
+    const int c = int(plane % C), k = (c % g) * per + c / g;
+    y[plane * S + pos] = x[(plane - c + k) * S + pos];
+  }
+}
+
 void channel_shuffle(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int S, int groups, bool cq) {
   const int64_t n = rows * C * S;
   if (n <= 0) return;
+  if (S <= 65535LL * kBlock && (!cq || C % 4 == 0)) {
+    const dim3 grid(unsigned(cq ? rows * C / 4 : rows * C), unsigned((S + kBlock - 1) / kBlock));
+    if (cq) hipLaunchKernelGGL(channel_shuffle_planes_kernel<true>, grid, dim3(kBlock), 0, s, X, Y, C, S, groups);
+    else hipLaunchKernelGGL(channel_shuffle_planes_kernel<false>, grid, dim3(kBlock), 0, s, X, Y, C, S, groups);
+    return;
+  }
   hipLaunchKernelGGL(channel_shuffle_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, X, Y, n, C, S, groups, cq);
 }
 
