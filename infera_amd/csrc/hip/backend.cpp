@@ -374,7 +374,7 @@ void schedule(LoadedModel &m) {
   // one weight per lane per MFMA from L2 and measured 13-16 TFLOP/s; narrow heads keep their streaming kernels)
   for (size_t i = 0; i < n; i++)
     if (m.exec[i] == ExecKind::Normal && st[i].kind == StepKind::Dense && st[i].M > 32 && st[i].K % 4 == 0 &&
-        int(st[i].act) <= kMaxMfmaFusedAct && kern::conv2d_tiled_supported(dense_as_conv(st[i])))
+        mfma_fusable(st[i].act) && kern::conv2d_tiled_supported(dense_as_conv(st[i])))
       m.exec[i] = ExecKind::DenseTiled;
   // ---- layout decision for convolutional plans ----
   auto is4d = [&](int b) { return b >= 0 && m.plan.buf_shape[size_t(b)].size() == 4; };
@@ -441,7 +441,7 @@ void schedule(LoadedModel &m) {
     for (size_t j = 0; j < n; j++) {
       const Step &a = st[j];
       if (m.exec[j] != ExecKind::Normal || a.kind != StepKind::BinaryAct || a.bop != '+' || !is4d(a.out) || a.S > 1) continue;
-      if (int(a.act) > kMaxMfmaFusedAct) continue;  // the conv epilogue resolves only the MFMA-fusable kinds
+      if (!mfma_fusable(a.act)) continue;  // the conv epilogue resolves only the MFMA-fusable kinds
       const int pa = prod[size_t(a.in0)], pb = prod[size_t(a.in1)];
       const int late = std::max(pa, pb);
       if (late < 0 || a.in0 == a.in1) continue;

@@ -39,6 +39,7 @@ __device__ __forceinline__ float apply_act_c(float v, float a, float b) {
   if constexpr (KIND == 21) return v / (1.0f + fabsf(v));                            // Softsign
   if constexpr (KIND == 22) return truncf(v);
   if constexpr (KIND == 23) return rintf(v);                                         // Round: half to even
+  if constexpr (KIND == 24) return v / (1.0f + expf(-v));                            // Swish = x * sigmoid(x)
   return v;
 }
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ float apply_act(float v, const ActParam &p) {
     INFERA_ACT_CASE(1) INFERA_ACT_CASE(2) INFERA_ACT_CASE(3) INFERA_ACT_CASE(4) INFERA_ACT_CASE(5) INFERA_ACT_CASE(6)
     INFERA_ACT_CASE(7) INFERA_ACT_CASE(8) INFERA_ACT_CASE(9) INFERA_ACT_CASE(10) INFERA_ACT_CASE(11) INFERA_ACT_CASE(12)
     INFERA_ACT_CASE(13) INFERA_ACT_CASE(14) INFERA_ACT_CASE(15) INFERA_ACT_CASE(16) INFERA_ACT_CASE(17) INFERA_ACT_CASE(18)
-    INFERA_ACT_CASE(19) INFERA_ACT_CASE(20) INFERA_ACT_CASE(21) INFERA_ACT_CASE(22) INFERA_ACT_CASE(23)
+    INFERA_ACT_CASE(19) INFERA_ACT_CASE(20) INFERA_ACT_CASE(21) INFERA_ACT_CASE(22) INFERA_ACT_CASE(23) INFERA_ACT_CASE(24)
 #undef INFERA_ACT_CASE
     default: return v;
   }
@@ -69,6 +70,9 @@ __device__ __forceinline__ void dispatch_act(int kind, F &&f) {
     case 3: f(std::integral_constant<int, 3>{}); break;
     case 4: f(std::integral_constant<int, 4>{}); break;
     case 5: f(std::integral_constant<int, 5>{}); break;
+    case 14: f(std::integral_constant<int, 14>{}); break;  // HardSigmoid, HardSwish, Swish: the gates of mobile nets
+    case 15: f(std::integral_constant<int, 15>{}); break;
+    case 24: f(std::integral_constant<int, 24>{}); break;
     default: f(std::integral_constant<int, 0>{}); break;
   }
 }

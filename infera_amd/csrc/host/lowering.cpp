@@ -307,6 +307,22 @@ struct Lowerer {
       vals[n.outputs[0]] = v;
       return;
     }
+    if (!a.is_const && !b.is_const && op == '*' && a.shape == b.shape) {
+      // x * Sigmoid(x) (Swish / SiLU as exporters spell it): the Sigmoid pass and the multiply become ONE activation on x,
+      // which then folds into the epilogue of the convolution / layer that produced x when nothing else reads it
+      for (int side = 0; side < 2; side++) {
+        const Val &x = side ? b : a, &sg = side ? a : b;
+        auto pit = producer.find(sg.buf);
+        if (sg.buf <= 0 || pit == producer.end() || pit->second != int(plan.steps.size()) - 1 || live_uses(sg.buf) != 1) continue;
+        const Step &ps = plan.steps.back();
+        if (ps.kind != StepKind::Unary || ps.act != Act::Sigmoid || ps.in0 != x.buf) continue;
+        producer.erase(pit);
+        plan.steps.pop_back();
+        alias_edges[x.buf]++;  // the Sigmoid node no longer consumes x
+        apply_unary(n, side ? 1 : 0, Act::Swish, 0.f, 0.f, "Swish");
+        return;
+      }
+    }
     if (!a.is_const && !b.is_const) {
       // per-channel gate: [N,C,H,W] (op) [N,C,1,1]  (squeeze-and-excitation blocks); either order for + * min max
       auto is_gate = [](const Val &big, const Val &small) {
@@ -723,18 +739,23 @@ struct Lowerer {
       if (has_input(n, 1)) { const Val &v = get(n, 1); if (cf32(n, v).size() == 1) pa = v.c->f32[0]; }
       if (has_input(n, 2)) { const Val &v = get(n, 2); if (cf32(n, v).size() == 1) pb = v.c->f32[0]; }
     }
-    const Val &a = get(n, 0);
+    apply_unary(n, 0, act, pa, pb, n.op);
+  }
+  // activation `act` on input `idx` of node n: into the epilogue of the step that produced it when that step takes one
+  // and nothing else reads the value, else an elementwise pass
+  void apply_unary(const NodeDef &n, size_t idx, Act act, float pa, float pb, const std::string &label) {
+    const Val &a = get(n, idx);
     if (a.is_const) unsupported(n, "activation of a constant");
     std::vector<int64_t> shape = a.shape;
-    if (Step *p = fusable_producer(n, 0)) {
+    if (Step *p = fusable_producer(n, idx)) {
       const bool mfma_step = p->kind == StepKind::Dense || p->kind == StepKind::Conv2d;
       const bool takes_act = p->kind == StepKind::Dense || p->kind == StepKind::Conv2d || p->kind == StepKind::AffineChannel ||
                              p->kind == StepKind::BinaryConst || p->kind == StepKind::BinaryAct;
-      if (p->act == Act::None && takes_act && (!mfma_step || int(act) <= kMaxMfmaFusedAct)) {
+      if (p->act == Act::None && takes_act && (!mfma_step || mfma_fusable(act))) {
         p->act = act;
         p->act_a = pa;
         p->act_b = pb;
-        p->origin += "+" + n.op;
+        p->origin += "+" + label;
         set_act(n, a.buf, shape, true);
         return;
       }
@@ -1454,7 +1475,7 @@ double Plan::flops_per_row() const {
 std::string Plan::describe_json() const {
   static const char *kinds[] = {"Dense", "Unary", "AffineChannel", "BinaryConst", "BinaryAct", "Softmax", "Conv2d", "Pool2d", "GlobalAvgPool", "CopyCols", "ArgMax", "SliceCols", "PadCols", "LRN", "ChannelShuffle"};
   static const char *acts[] = {"", "Relu", "Sigmoid", "Tanh", "LeakyRelu", "Clip", "Exp", "Log", "Sqrt", "Neg", "Abs", "Elu", "Selu", "Softplus",
-                               "HardSigmoid", "HardSwish", "Erf", "Gelu", "Reciprocal", "Floor", "Ceil", "Softsign", "Trunc", "Round"};
+                               "HardSigmoid", "HardSwish", "Erf", "Gelu", "Reciprocal", "Floor", "Ceil", "Softsign", "Trunc", "Round", "Swish"};
   std::ostringstream o;
   o << "{\"input_shape\":" << json_int_array(input_shape) << ",\"output_shape\":" << json_int_array(output_shape)
     << ",\"flops_per_row\":" << (long long)flops_per_row() << ",\"steps\":[";

@@ -20,8 +20,11 @@ enum class Act : int {
   None = 0, Relu = 1, Sigmoid = 2, Tanh = 3, LeakyRelu = 4, Clip = 5,
   Exp = 6, Log = 7, Sqrt = 8, Neg = 9, Abs = 10, Elu = 11, Selu = 12, Softplus = 13, HardSigmoid = 14, HardSwish = 15,
   Erf = 16, Gelu = 17, Reciprocal = 18, Floor = 19, Ceil = 20, Softsign = 21, Trunc = 22, Round = 23,
+  Swish = 24,  // x * sigmoid(x): recognised from Mul(x, Sigmoid(x)) (EfficientNet / YOLO exports)
 };
-constexpr int kMaxMfmaFusedAct = 5;
+constexpr int kMaxMfmaFusedAct = 5;  // the load-time specialised chain kernels resolve kinds 0..5
+// what the ahead-of-time MFMA epilogues resolve (device_common.hpp dispatch_act): the above + the mobile-net gates
+inline bool mfma_fusable(Act a) { return int(a) <= kMaxMfmaFusedAct || a == Act::HardSigmoid || a == Act::HardSwish || a == Act::Swish; }
 
 enum class StepKind : int {
   Dense = 0,        // Y[rows,M] = act(X[rows,K] . W[K,M] + bias[M])       (MatMul / Gemm [+Add] [+act])

@@ -574,6 +574,60 @@ def test_gpu_flatten_into_gemm(api, O, tmp_path, hidden):
     assert_close(got, ref(x.reshape(70, 3, 16, 16)).astype(np.float32), rtol=3e-5, atol=2e-6)
 
 
+def _swish_net(tmp_path):
+    """EfficientNet-style block: Conv -> x*Sigmoid(x) -> depthwise Conv -> HardSwish -> 1x1 Conv -> Sigmoid*x (other operand
+    order) -> GAP -> Gemm -> x*Sigmoid(x) -> Gemm"""
+    ws = W._WeightStream(71)
+    inits, nodes = [], []
+
+    def conv(x, cin, cout, k, out, groups=1):
+        w, b = ws.take((cout, cin // groups, k, k), (cin // groups) * k * k), ws.take((cout,), cin * k * k)
+        inits.extend([W.tensor(out + "_w", w), W.tensor(out + "_b", b)])
+        nodes.append(W.node("Conv", [x, out + "_w", out + "_b"], [out], [W.attr_ints("kernel_shape", [k, k]), W.attr_ints("pads", [k // 2] * 4),
+                                                                        W.attr_i("group", groups)]))
+        return out
+
+    conv("X", 3, 32, 3, "c1")
+    nodes += [W.node("Sigmoid", ["c1"], ["s1"]), W.node("Mul", ["c1", "s1"], ["a1"])]
+    conv("a1", 32, 32, 3, "dw", groups=32)
+    nodes.append(W.node("HardSwish", ["dw"], ["a2"]))
+    conv("a2", 32, 64, 1, "pw")
+    nodes += [W.node("Sigmoid", ["pw"], ["s3"]), W.node("Mul", ["s3", "pw"], ["a3"])]
+    nodes += [W.node("GlobalAveragePool", ["a3"], ["g"]), W.node("Flatten", ["g"], ["f"])]
+    f1, g1, f2, g2 = ws.take((64, 48), 64), ws.take((48,), 64), ws.take((48, 5), 48), ws.take((5,), 48)
+    inits += [W.tensor("f1", f1), W.tensor("g1", g1), W.tensor("f2", f2), W.tensor("g2", g2)]
+    nodes += [W.node("Gemm", ["f", "f1", "g1"], ["h"]), W.node("Sigmoid", ["h"], ["hs"]), W.node("Mul", ["h", "hs"], ["ha"]),
+              W.node("Gemm", ["ha", "f2", "g2"], ["Y"])]
+    blob = W.model("swish_net", nodes, inits, [W.value_info("X", ["N", 3, 12, 12])], [W.value_info("Y", ["N", 5])], opset=14)
+    return W.write(str(tmp_path / "swish_net.onnx"), blob)
+
+
+def test_swish_and_hardswish_fold_into_the_producing_layers(O, built, tmp_path):
+    from infera_amd import capi
+
+    path = _swish_net(tmp_path)
+    capi.load_model("sw", path)
+    steps = capi.get_plan("sw")["plan"]["steps"]
+    capi.unload_model("sw")
+    assert [s["kind"] for s in steps] == ["Conv2d", "Conv2d", "Conv2d", "GlobalAvgPool", "Dense", "Dense"], steps
+    assert [s.get("act", "") for s in steps] == ["Swish", "HardSwish", "Swish", "", "Swish", ""], steps
+    x = synth.table(9, 0, 3, 3 * 12 * 12)
+    assert np.isfinite(O.Model(path).predict_blob(x.tobytes())).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 50])
+def test_gpu_swish_net(api, O, tmp_path, rows):
+    path = _swish_net(tmp_path)
+    x = synth.table(9, 0, rows, 3 * 12 * 12)
+    api.load_model("sw", path)
+    try:
+        got = api.predict_from_blob("sw", x.tobytes())
+    finally:
+        api.unload_model("sw")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
