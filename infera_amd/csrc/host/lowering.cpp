@@ -1116,66 +1116,66 @@ struct Lowerer {
 
   // ------------------------------------------------------------------------------------------
   void lower_node(const NodeDef &n) {
-      const std::string &op = n.op;
-      if (op != "Conv")
-        for (const auto &in_name : n.inputs) {
-          auto it = vals.find(in_name);
-          if (it != vals.end() && it->second.padded()) unsupported(n, "the output of a Pad node can only feed a Conv (its padding is folded into the convolution)");
-        }
-      if (op == "MatMul") dense(n, false);
-      else if (op == "Gemm") dense(n, true);
-      else if (op == "Add") binary(n, '+');
-      else if (op == "Sub") binary(n, '-');
-      else if (op == "Mul") binary(n, '*');
-      else if (op == "Div") binary(n, '/');
-      else if (op == "Min") binary(n, 'm');
-      else if (op == "Max") binary(n, 'M');
-      else if (op == "Pow") binary(n, '^');
-      else if (op == "PRelu") binary(n, 'p');
-      else if (op == "Relu" || op == "Sigmoid" || op == "Tanh" || op == "LeakyRelu" || op == "Clip" || op == "Exp" || op == "Log" ||
-               op == "Sqrt" || op == "Neg" || op == "Abs" || op == "Elu" || op == "Selu" || op == "Softplus" || op == "HardSigmoid" ||
-               op == "HardSwish" || op == "Erf" || op == "Gelu" || op == "Reciprocal" || op == "Floor" || op == "Ceil" ||
-               op == "Softsign" || op == "Round")
-        unary(n);
-      else if (op == "Shape") shape_op(n);
-      else if (op == "Gather") gather(n);
-      else if (op == "Slice") slice(n);
-      else if (op == "Split") split(n);
-      else if (op == "Cast") cast(n);
-      else if (op == "Concat") concat(n);
-      else if (op == "ReduceMean") reduce_mean(n);
-      else if (op == "ArgMax") argmax(n);
-      else if (op == "Identity" || op == "Dropout" || op == "Flatten" || op == "Reshape" || op == "Squeeze" || op == "Unsqueeze") reshape_like(n);
-      else if (op == "Softmax") softmax(n, false);
-      else if (op == "LogSoftmax") softmax(n, true);
-      else if (op == "Conv") conv(n);
-      else if (op == "BatchNormalization") batchnorm(n);
-      else if (op == "MaxPool") pool(n, true);
-      else if (op == "AveragePool") pool(n, false);
-      else if (op == "GlobalAveragePool") global_avgpool(n, false);
-      else if (op == "GlobalMaxPool") global_avgpool(n, true);
-      else if (op == "Pad") pad(n);
-      else if (op == "Sum") sum(n);
-      else if (op == "LRN") lrn(n);
-      else if (op == "Transpose") transpose(n);
-      else if (op == "Constant") {
-        Val v;
-        v.is_const = true;
-        if (auto *a = n.attr("value"); a && a->t) {
-          v.c = a->t;
-        } else {  // scalar / 1-D attribute forms (opset 12+)
-          auto t = std::make_shared<TensorData>();
-          if (auto *f = n.attr("value_float")) { t->dtype = onnx::kFloat; t->f32 = {f->f}; }
-          else if (auto *i = n.attr("value_int")) { t->dtype = onnx::kInt64; t->i64 = {i->i}; }
-          else if (auto *is = n.attr_ints("value_ints")) { t->dtype = onnx::kInt64; t->i64 = *is; t->dims = {int64_t(is->size())}; }
-          else unsupported(n, "only the value / value_float / value_int / value_ints forms are supported");
-          v.c = t;
-        }
-        v.shape = v.c->dims;
-        vals[n.outputs[0]] = v;
-      } else {
-        unsupported(n, "unsupported operator");
+    const std::string &op = n.op;
+    if (op != "Conv")
+      for (const auto &in_name : n.inputs) {
+        auto it = vals.find(in_name);
+        if (it != vals.end() && it->second.padded()) unsupported(n, "the output of a Pad node can only feed a Conv (its padding is folded into the convolution)");
       }
+    if (op == "MatMul") dense(n, false);
+    else if (op == "Gemm") dense(n, true);
+    else if (op == "Add") binary(n, '+');
+    else if (op == "Sub") binary(n, '-');
+    else if (op == "Mul") binary(n, '*');
+    else if (op == "Div") binary(n, '/');
+    else if (op == "Min") binary(n, 'm');
+    else if (op == "Max") binary(n, 'M');
+    else if (op == "Pow") binary(n, '^');
+    else if (op == "PRelu") binary(n, 'p');
+    else if (op == "Relu" || op == "Sigmoid" || op == "Tanh" || op == "LeakyRelu" || op == "Clip" || op == "Exp" || op == "Log" ||
+             op == "Sqrt" || op == "Neg" || op == "Abs" || op == "Elu" || op == "Selu" || op == "Softplus" || op == "HardSigmoid" ||
+             op == "HardSwish" || op == "Erf" || op == "Gelu" || op == "Reciprocal" || op == "Floor" || op == "Ceil" ||
+             op == "Softsign" || op == "Round")
+      unary(n);
+    else if (op == "Shape") shape_op(n);
+    else if (op == "Gather") gather(n);
+    else if (op == "Slice") slice(n);
+    else if (op == "Split") split(n);
+    else if (op == "Cast") cast(n);
+    else if (op == "Concat") concat(n);
+    else if (op == "ReduceMean") reduce_mean(n);
+    else if (op == "ArgMax") argmax(n);
+    else if (op == "Identity" || op == "Dropout" || op == "Flatten" || op == "Reshape" || op == "Squeeze" || op == "Unsqueeze") reshape_like(n);
+    else if (op == "Softmax") softmax(n, false);
+    else if (op == "LogSoftmax") softmax(n, true);
+    else if (op == "Conv") conv(n);
+    else if (op == "BatchNormalization") batchnorm(n);
+    else if (op == "MaxPool") pool(n, true);
+    else if (op == "AveragePool") pool(n, false);
+    else if (op == "GlobalAveragePool") global_avgpool(n, false);
+    else if (op == "GlobalMaxPool") global_avgpool(n, true);
+    else if (op == "Pad") pad(n);
+    else if (op == "Sum") sum(n);
+    else if (op == "LRN") lrn(n);
+    else if (op == "Transpose") transpose(n);
+    else if (op == "Constant") {
+      Val v;
+      v.is_const = true;
+      if (auto *a = n.attr("value"); a && a->t) {
+        v.c = a->t;
+      } else {  // scalar / 1-D attribute forms (opset 12+)
+        auto t = std::make_shared<TensorData>();
+        if (auto *f = n.attr("value_float")) { t->dtype = onnx::kFloat; t->f32 = {f->f}; }
+        else if (auto *i = n.attr("value_int")) { t->dtype = onnx::kInt64; t->i64 = {i->i}; }
+        else if (auto *is = n.attr_ints("value_ints")) { t->dtype = onnx::kInt64; t->i64 = *is; t->dims = {int64_t(is->size())}; }
+        else unsupported(n, "only the value / value_float / value_int / value_ints forms are supported");
+        v.c = t;
+      }
+      v.shape = v.c->dims;
+      vals[n.outputs[0]] = v;
+    } else {
+      unsupported(n, "unsupported operator");
+    }
   }
 
   // ---- ai.onnx.ml: the classical-ML nodes sklearn exporters write (tract-onnx 0.22 ops/ml is what serves them for
