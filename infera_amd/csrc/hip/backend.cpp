@@ -381,6 +381,12 @@ void schedule(LoadedModel &m) {
   auto spatial = [&](int b) { return is4d(b) ? m.plan.buf_shape[size_t(b)][2] * m.plan.buf_shape[size_t(b)][3] : int64_t(1); };
   bool any_conv = false, ok = true;
   std::vector<size_t> flat_dense;  // Dense layers fed by a flattened [C,H,W] activation
+  // buffers that keep the caller's NCHW order: the input, and elementwise preprocessing of it (in-graph normalisation)
+  m.nchw_buf.assign(m.plan.buf_shape.size(), 0);
+  m.nchw_buf[0] = 1;
+  auto elementwise = [](const Step &s) { return s.kind == StepKind::Unary || s.kind == StepKind::BinaryConst || s.kind == StepKind::AffineChannel; };
+  for (const auto &s : st)
+    if (elementwise(s) && s.in0 >= 0 && m.nchw_buf[size_t(s.in0)] && is4d(s.out) && s.out != m.plan.out_buf) m.nchw_buf[size_t(s.out)] = 1;
   for (const auto &s : st) {
     any_conv = any_conv || s.kind == StepKind::Conv2d;
     // (CopyCols = channel concat: a contiguous per-row block in NCHW and in channel-quad planes alike)
@@ -390,7 +396,10 @@ void schedule(LoadedModel &m) {
                              s.kind == StepKind::ChannelShuffle;
     for (int b : {s.in0, s.in1}) {
       if (b < 0) continue;
-      if (b == 0 && is4d(0) && s.kind != StepKind::Conv2d) ok = false;  // the caller's NCHW input is read by convs only
+      if (m.nchw_buf[size_t(b)] && is4d(b)) {  // NCHW tensors are read by convolutions and by their own elementwise chain only
+        if (!(s.kind == StepKind::Conv2d || (elementwise(s) && b == s.in0 && m.nchw_buf[size_t(s.out)]))) ok = false;
+        continue;
+      }
       if (!layout_free && spatial(b) > 1) {
         // Flatten(C,H,W) -> Gemm (VGG / AlexNet heads): the layer reads the channel-quad tensor as it lies and its
         // weight rows are permuted to that order once, below.  Anything else that looks at flattened features in
@@ -403,7 +412,7 @@ void schedule(LoadedModel &m) {
   if (spatial(m.plan.out_buf) > 1) ok = false;  // results leave in the caller's (NCHW) order
   // channel-quad planes need whole quads in every internal 4-D tensor (the caller's input stays NCHW)
   for (size_t b = 1; b < m.plan.buf_shape.size(); b++)
-    if (m.plan.buf_shape[b].size() == 4 && m.plan.buf_shape[b][1] % 4 != 0) ok = false;
+    if (m.plan.buf_shape[b].size() == 4 && m.plan.buf_shape[b][1] % 4 != 0 && !m.nchw_buf[b]) ok = false;
   m.cq_mode = any_conv && ok;
   if (m.cq_mode)
     for (size_t i : flat_dense) {  // W rows: NCHW feature c*HW + p  ->  channel-quad feature ((c/4)*HW + p)*4 + c%4
@@ -423,7 +432,7 @@ void schedule(LoadedModel &m) {
       if (m.exec[i] != ExecKind::Normal || s.kind != StepKind::Conv2d) continue;
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
-      if (s.in0 == 0) {  // the caller's NCHW blob: few channels -> LDS patch kernel
+      if (m.nchw_buf[size_t(s.in0)]) {  // the caller's NCHW blob (or its normalised copy): few channels -> LDS patch kernel
         if (kern::conv2d_patch_supported(g)) m.exec[i] = ExecKind::ConvPatch;
         continue;
       }
@@ -682,29 +691,29 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case StepKind::Dense: kern::dense(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, int(x.K), int(x.M), act_of(x), 0); break;
         case StepKind::Unary: kern::unary(s, buf(x.in0), buf(x.out), nr * p.buf_per_row[size_t(x.out)], act_of(x)); break;
         case StepKind::AffineChannel:
-          kern::affine_channel(s, buf(x.in0), d.scale, d.shift, buf(x.out), nr, x.C, x.S, act_of(x), m.cq_mode && x.in0 != 0);
+          kern::affine_channel(s, buf(x.in0), d.scale, d.shift, buf(x.out), nr, x.C, x.S, act_of(x), m.cq_mode && !m.nchw_buf[size_t(x.in0)]);
           break;
         case StepKind::BinaryConst:
           kern::binary_const(s, buf(x.in0), d.cst, buf(x.out), nr, p.buf_per_row[size_t(x.out)], x.bop, x.const_left, act_of(x));
           break;
         case StepKind::BinaryAct:
-          if (x.S > 1) kern::binary_gate(s, buf(x.in0), buf(x.in1), buf(x.out), nr, x.C, x.S, x.bop, act_of(x), m.cq_mode && x.in0 != 0);
+          if (x.S > 1) kern::binary_gate(s, buf(x.in0), buf(x.in1), buf(x.out), nr, x.C, x.S, x.bop, act_of(x), m.cq_mode && !m.nchw_buf[size_t(x.in0)]);
           else kern::binary_act(s, buf(x.in0), buf(x.in1), buf(x.out), nr * p.buf_per_row[size_t(x.out)], x.bop, act_of(x));
           break;
         case StepKind::Softmax: kern::softmax(s, buf(x.in0), buf(x.out), nr, x.sm_outer, x.sm_len, x.sm_inner, x.sm_norm ? 1 + x.sm_norm : int(x.log_softmax)); break;
         case StepKind::Conv2d: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
-          kern::conv2d(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), m.cq_mode && x.in0 != 0, m.cq_mode);
+          kern::conv2d(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), m.cq_mode && !m.nchw_buf[size_t(x.in0)], m.cq_mode);
           break;
         }
         case StepKind::Pool2d:
           kern::pool2d(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.H), int(x.Wd), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                        int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), x.is_max, x.count_pad,
-                       m.cq_mode && x.in0 != 0);
+                       m.cq_mode && !m.nchw_buf[size_t(x.in0)]);
           break;
         case StepKind::GlobalAvgPool:
-          kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.cq_mode && x.in0 != 0, x.is_max);
+          kern::global_avgpool(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), m.cq_mode && !m.nchw_buf[size_t(x.in0)], x.is_max);
           break;
         case StepKind::CopyCols:
           kern::copy_cols(s, buf(x.in0), buf(x.out), nr, p.buf_per_row[size_t(x.in0)], p.buf_per_row[size_t(x.in0)], 0,
@@ -713,10 +722,10 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case StepKind::PadCols: kern::pad_cols(s, buf(x.in0), buf(x.out), nr, x.K, x.M); break;
         case StepKind::LRN:
           kern::lrn(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), int(x.lrn_size), x.lrn_alpha, x.lrn_beta, x.lrn_bias,
-                    m.cq_mode && x.in0 != 0);
+                    m.cq_mode && !m.nchw_buf[size_t(x.in0)]);
           break;
         case StepKind::ChannelShuffle:
-          kern::channel_shuffle(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), int(x.groups), m.cq_mode && x.in0 != 0);
+          kern::channel_shuffle(s, buf(x.in0), buf(x.out), nr, int(x.C), int(x.S), int(x.groups), m.cq_mode && !m.nchw_buf[size_t(x.in0)]);
           break;
         case StepKind::SliceCols:
           kern::copy_cols(s, buf(x.in0), buf(x.out), nr, x.K, p.buf_per_row[size_t(x.in0)], x.col_off, x.K, 0);

@@ -69,6 +69,9 @@ class LoadedModel {
   // Convolutional plans keep every 4-D activation except the caller's input CHANNELS-LAST (NHWC) so
   // the implicit-GEMM gathers and stores are 16-byte vectors; decided per plan in schedule().
   bool cq_mode = false;
+  // ... except the caller's input and what elementwise preprocessing makes of it (x/255, (x - mean) / std in the graph):
+  // those few-channel tensors stay NCHW and the first convolution reads them with the patch kernel.
+  std::vector<char> nchw_buf;
   // A ConvTiled step that absorbed the residual Add (+ activation) following it: per conv step, the
   // index of the fused BinaryAct step (-1: none) and which of its operands is the skip tensor.
   std::vector<int> conv_fused_add;

@@ -628,6 +628,57 @@ def test_gpu_swish_net(api, O, tmp_path, rows):
     assert_close(got, O.Model(path).predict_blob(x.tobytes()))
 
 
+def _normalised_input_net(tmp_path, variant):
+    """in-graph input normalisation in front of the first convolution: (x - mean) / std per channel (torchvision-style
+    transforms exported with the model), x * (1/255) (Keras Rescaling), or a BatchNormalization of the input"""
+    ws = W._WeightStream(81)
+    w1, b1 = ws.take((32, 3, 3, 3), 27), ws.take((32,), 27)
+    w2, b2 = ws.take((32, 32, 3, 3), 288), ws.take((32,), 288)
+    fw, fb = ws.take((32, 6), 32), ws.take((6,), 32)
+    inits = [W.tensor(k, v) for k, v in dict(w1=w1, b1=b1, w2=w2, b2=b2, fw=fw, fb=fb).items()]
+    if variant == "meanstd":
+        inits += [W.tensor("mean", np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 3, 1, 1)),
+                  W.tensor("std", np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 3, 1, 1))]
+        pre = [W.node("Sub", ["X", "mean"], ["xc"]), W.node("Div", ["xc", "std"], ["xn"])]
+    elif variant == "rescale":
+        inits += [W.tensor("k", np.array(1.0 / 255.0, np.float32))]
+        pre = [W.node("Mul", ["X", "k"], ["xn"])]
+    else:
+        inits += [W.tensor("g", np.array([1.1, 0.9, 1.3], np.float32)), W.tensor("b", np.array([0.1, -0.2, 0.0], np.float32)),
+                  W.tensor("mu", np.array([0.2, 0.1, -0.1], np.float32)), W.tensor("var", np.array([0.5, 1.5, 1.0], np.float32))]
+        pre = [W.node("BatchNormalization", ["X", "g", "b", "mu", "var"], ["xn"])]
+    cv = lambda x, w, b, o, s=1: W.node("Conv", [x, w, b], [o], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("pads", [1, 1, 1, 1]), W.attr_ints("strides", [s, s])])
+    nodes = pre + [cv("xn", "w1", "b1", "c1", 2), W.node("Relu", ["c1"], ["r1"]), cv("r1", "w2", "b2", "c2"), W.node("Relu", ["c2"], ["r2"]),
+                   W.node("GlobalAveragePool", ["r2"], ["g2"]), W.node("Flatten", ["g2"], ["f"]), W.node("Gemm", ["f", "fw", "fb"], ["Y"])]
+    blob = W.model("norm_in", nodes, inits, [W.value_info("X", ["N", 3, 20, 20])], [W.value_info("Y", ["N", 6])])
+    return W.write(str(tmp_path / f"norm_in_{variant}.onnx"), blob)
+
+
+@pytest.mark.parametrize("variant", ["meanstd", "rescale", "bn"])
+def test_input_normalisation_does_not_cost_the_conv_layout(built, tmp_path, variant):
+    from infera_amd import capi
+
+    capi.load_model("ni", _normalised_input_net(tmp_path, variant))
+    plan = capi.get_plan("ni")
+    capi.unload_model("ni")
+    assert plan["activation_layout"] == "NC/4HW4", (variant, plan["activation_layout"])
+    convs = [e for e, s in zip(plan["exec"], plan["plan"]["steps"]) if s["kind"] == "Conv2d"]
+    assert convs == ["conv_patch", "conv_tiled_cq"], convs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["meanstd", "rescale", "bn"])
+def test_gpu_input_normalisation_net(api, O, tmp_path, variant):
+    path = _normalised_input_net(tmp_path, variant)
+    x = synth.table(19, 0, 37, 3 * 20 * 20) * (100.0 if variant == "rescale" else 1.0)
+    api.load_model("ni", path)
+    try:
+        got = api.predict_from_blob("ni", x.tobytes())
+    finally:
+        api.unload_model("ni")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+
+
 # ---- CPU: the product's lowering (no GPU needed to load and lower) ---------------------------------------------
 def test_lowering_of_breadth_models(built, paths):
     from infera_amd import capi
