@@ -396,7 +396,7 @@ void schedule(LoadedModel &m) {
                              s.kind == StepKind::ChannelShuffle;
     for (int b : {s.in0, s.in1}) {
       if (b < 0) continue;
-      if (m.nchw_buf[size_t(b)] && is4d(b)) {  // NCHW tensors are read by convolutions and by their own elementwise chain only
+      if (m.nchw_buf[size_t(b)] && is4d(b) && spatial(b) > 1) {  // NCHW tensors are read by convolutions and by their own elementwise chain only
         if (!(s.kind == StepKind::Conv2d || (elementwise(s) && b == s.in0 && m.nchw_buf[size_t(s.out)]))) ok = false;
         continue;
       }
@@ -412,7 +412,11 @@ void schedule(LoadedModel &m) {
   if (spatial(m.plan.out_buf) > 1) ok = false;  // results leave in the caller's (NCHW) order
   // channel-quad planes need whole quads in every internal 4-D tensor (the caller's input stays NCHW)
   for (size_t b = 1; b < m.plan.buf_shape.size(); b++)
-    if (m.plan.buf_shape[b].size() == 4 && m.plan.buf_shape[b][1] % 4 != 0 && !m.nchw_buf[b]) ok = false;
+    if (m.plan.buf_shape[b].size() == 4 && m.plan.buf_shape[b][1] % 4 != 0 && !m.nchw_buf[b]) {
+      // a [N,C,1,1] tensor has no layout to speak of (a conv head with 10 classes behind the global pool): plain order
+      if (spatial(int(b)) == 1) m.nchw_buf[b] = 1;
+      else ok = false;
+    }
   m.cq_mode = any_conv && ok;
   if (m.cq_mode)
     for (size_t i : flat_dense) {  // W rows: NCHW feature c*HW + p  ->  channel-quad feature ((c/4)*HW + p)*4 + c%4
@@ -704,7 +708,8 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case StepKind::Conv2d: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
-          kern::conv2d(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), m.cq_mode && !m.nchw_buf[size_t(x.in0)], m.cq_mode);
+          kern::conv2d(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), m.cq_mode && !m.nchw_buf[size_t(x.in0)],
+                       m.cq_mode && !m.nchw_buf[size_t(x.out)]);
           break;
         }
         case StepKind::Pool2d:

@@ -826,3 +826,39 @@ def test_gpu_argmax_rows_at_every_kernel_boundary(api, O, tmp_path, length):
     ok[[8, 9]] = False  # numpy's argmax treats NaN as the maximum
     assert np.array_equal(got[ok], np.argmax(x[ok], axis=1).astype(np.float32))
     assert got[9] == 0.0 and got[7] == 0.0
+
+
+def _conv_head_net(tmp_path, classes=10):
+    """global pool -> 1x1 Conv to `classes` (not a multiple of 4) -> Flatten -> Softmax: a fully-convolutional head"""
+    ws = W._WeightStream(91)
+    w1, b1 = ws.take((32, 3, 3, 3), 27), ws.take((32,), 27)
+    w2, b2 = ws.take((classes, 32, 1, 1), 32), ws.take((classes,), 32)
+    nodes = [W.node("Conv", ["X", "w1", "b1"], ["c1"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("pads", [1, 1, 1, 1])]),
+             W.node("Relu", ["c1"], ["r1"]), W.node("GlobalAveragePool", ["r1"], ["g"]),
+             W.node("Conv", ["g", "w2", "b2"], ["logits"], [W.attr_ints("kernel_shape", [1, 1])]),
+             W.node("Flatten", ["logits"], ["f"]), W.node("Softmax", ["f"], ["Y"], [W.attr_i("axis", 1)])]
+    blob = W.model("conv_head", nodes, [W.tensor("w1", w1), W.tensor("b1", b1), W.tensor("w2", w2), W.tensor("b2", b2)],
+                   [W.value_info("X", ["N", 3, 12, 12])], [W.value_info("Y", ["N", classes])])
+    return W.write(str(tmp_path / "conv_head.onnx"), blob)
+
+
+def test_conv_head_with_odd_class_count_keeps_the_conv_layout(built, tmp_path):
+    from infera_amd import capi
+
+    capi.load_model("ch", _conv_head_net(tmp_path))
+    plan = capi.get_plan("ch")
+    capi.unload_model("ch")
+    assert plan["activation_layout"] == "NC/4HW4", plan["activation_layout"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classes", [10, 7, 12])
+def test_gpu_conv_head_with_odd_class_count(api, O, tmp_path, classes):
+    path = _conv_head_net(tmp_path, classes)
+    x = synth.table(29, 0, 41, 3 * 12 * 12)
+    api.load_model("ch", path)
+    try:
+        got = api.predict_from_blob("ch", x.tobytes())
+    finally:
+        api.unload_model("ch")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
