@@ -382,43 +382,61 @@ struct Lowerer {
         return;
       }
     }
-    // Per-feature affine arithmetic on a [rows, K] table (x - mean, / std, * scale, + shift ...) is one multiply-add
-    // per element however many nodes spell it: consecutive ones compose into a single AffineChannel pass (and the
-    // Dense fold above still finds it).
-    if (act_shape.size() == 2 && (op == '+' || op == '-' || op == '*' || (op == '/' && !const_left))) {
+    // Per-feature affine arithmetic on a [rows, K] table (x - mean, / std, * scale, + shift ...) or per-channel on an
+    // [N,C,H,W] tensor (a bias Add / scale Mul an exporter left behind a convolution, in-graph pixel normalisation) is
+    // one multiply-add per element however many nodes spell it: consecutive ones compose into a single AffineChannel
+    // pass, fold into the convolution that produced the tensor, and the Dense fold above still finds them.
+    if (act_shape.size() >= 2 && (op == '+' || op == '-' || op == '*' || (op == '/' && !const_left))) {
       const std::vector<float> cv = broadcast_const(n, cst, act_shape);
-      const size_t C = cv.size();
-      std::vector<double> sc(C, 1.0), sh(C, 0.0);
-      for (size_t k = 0; k < C; k++) {
-        const double c = cv[k];
-        if (op == '+') sh[k] = c;
-        else if (op == '-') { sc[k] = const_left ? -1.0 : 1.0; sh[k] = const_left ? c : -c; }
-        else if (op == '*') sc[k] = c;
-        else sc[k] = 1.0 / c;
-      }
-      Step *p = fusable_producer(n, const_left ? 1 : 0);
-      if (p && p->kind == StepKind::AffineChannel && p->act == Act::None && p->S == 1 && size_t(p->C) == C) {
+      const size_t C = size_t(act_shape[1]), S = size_t(prod(act_shape, 2));
+      bool per_channel = cv.size() == C * S;
+      for (size_t c = 0; per_channel && c < C; c++)
+        for (size_t q = 1; q < S; q++)
+          if (cv[c * S + q] != cv[c * S]) { per_channel = false; break; }
+      if (per_channel) {
+        std::vector<double> sc(C, 1.0), sh(C, 0.0);
         for (size_t k = 0; k < C; k++) {
-          p->shift[k] = float(sc[k] * double(p->shift[k]) + sh[k]);
-          p->scale[k] = float(sc[k] * double(p->scale[k]));
+          const double c = cv[k * S];
+          if (op == '+') sh[k] = c;
+          else if (op == '-') { sc[k] = const_left ? -1.0 : 1.0; sh[k] = const_left ? c : -c; }
+          else if (op == '*') sc[k] = c;
+          else sc[k] = 1.0 / c;
         }
-        p->origin += "+" + n.op + (n.name.empty() ? "" : ":" + n.name);
-        set_act(n, act.buf, act_shape, true);
+        const std::string label = n.op + (n.name.empty() ? "" : ":" + n.name);
+        Step *p = fusable_producer(n, const_left ? 1 : 0);
+        if (p && p->kind == StepKind::AffineChannel && p->act == Act::None && size_t(p->S) == S && size_t(p->C) == C) {
+          for (size_t k = 0; k < C; k++) {
+            p->shift[k] = float(sc[k] * double(p->shift[k]) + sh[k]);
+            p->scale[k] = float(sc[k] * double(p->scale[k]));
+          }
+          p->origin += "+" + label;
+          set_act(n, act.buf, act_shape, true);
+          return;
+        }
+        if (p && p->kind == StepKind::Conv2d && p->act == Act::None && size_t(p->Mo) == C) {  // into the conv's weights and bias
+          const size_t per_m = size_t(p->K);
+          for (size_t mo = 0; mo < C; mo++)
+            for (size_t k = 0; k < per_m; k++) p->W[mo * per_m + k] = float(sc[mo] * double(p->W[mo * per_m + k]));
+          if (p->bias.empty()) p->bias.assign(C, 0.f);
+          for (size_t mo = 0; mo < C; mo++) p->bias[mo] = float(sc[mo] * double(p->bias[mo]) + sh[mo]);
+          p->origin += "+" + label;
+          set_act(n, act.buf, act_shape, true);
+          return;
+        }
+        Step a;
+        a.kind = StepKind::AffineChannel;
+        a.in0 = act.buf;
+        a.C = int64_t(C);
+        a.S = int64_t(S);
+        a.scale.resize(C);
+        a.shift.resize(C);
+        for (size_t k = 0; k < C; k++) {
+          a.scale[k] = float(sc[k]);
+          a.shift[k] = float(sh[k]);
+        }
+        emit(std::move(a), n, act_shape);
         return;
       }
-      Step a;
-      a.kind = StepKind::AffineChannel;
-      a.in0 = act.buf;
-      a.C = int64_t(C);
-      a.S = 1;
-      a.scale.resize(C);
-      a.shift.resize(C);
-      for (size_t k = 0; k < C; k++) {
-        a.scale[k] = float(sc[k]);
-        a.shift[k] = float(sh[k]);
-      }
-      emit(std::move(a), n, act_shape);
-      return;
     }
     Step s;
     s.kind = StepKind::BinaryConst;

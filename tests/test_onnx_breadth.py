@@ -862,3 +862,48 @@ def test_gpu_conv_head_with_odd_class_count(api, O, tmp_path, classes):
     finally:
         api.unload_model("ch")
     assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+
+
+def _tf_style_bias_net(tmp_path):
+    """what TF / Keras converters leave behind: Conv without bias -> Add(bias [1,C,1,1]) -> Mul(scale [C,1,1]) -> Relu, and a
+    per-channel Mul / Add pair behind a pooling layer (no convolution to fold into)"""
+    ws = W._WeightStream(97)
+    w1, w2 = ws.take((32, 3, 3, 3), 27), ws.take((64, 32, 3, 3), 288)
+    fw, fb = ws.take((64, 5), 64), ws.take((5,), 64)
+    rng = np.random.default_rng(4)
+    b1, s1 = rng.standard_normal((1, 32, 1, 1)).astype(np.float32) * 0.1, (0.5 + rng.random((32, 1, 1))).astype(np.float32)
+    b2 = rng.standard_normal((1, 64, 1, 1)).astype(np.float32) * 0.1
+    ps, pb = (0.5 + rng.random((1, 64, 1, 1))).astype(np.float32), rng.standard_normal((64, 1, 1)).astype(np.float32) * 0.1
+    cv = lambda x, w, o: W.node("Conv", [x, w], [o], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("pads", [1, 1, 1, 1])])
+    nodes = [cv("X", "w1", "c1"), W.node("Add", ["c1", "b1"], ["a1"]), W.node("Mul", ["a1", "s1"], ["m1"]), W.node("Relu", ["m1"], ["r1"]),
+             cv("r1", "w2", "c2"), W.node("Add", ["b2", "c2"], ["a2"]), W.node("Relu", ["a2"], ["r2"]),
+             W.node("MaxPool", ["r2"], ["p"], [W.attr_ints("kernel_shape", [2, 2]), W.attr_ints("strides", [2, 2])]),
+             W.node("Mul", ["p", "ps"], ["q"]), W.node("Add", ["q", "pb"], ["t"]),
+             W.node("GlobalAveragePool", ["t"], ["g"]), W.node("Flatten", ["g"], ["f"]), W.node("Gemm", ["f", "fw", "fb"], ["Y"])]
+    inits = [W.tensor(k, v) for k, v in dict(w1=w1, w2=w2, fw=fw, fb=fb, b1=b1, s1=s1, b2=b2, ps=ps, pb=pb).items()]
+    blob = W.model("tf_bias", nodes, inits, [W.value_info("X", ["N", 3, 12, 12])], [W.value_info("Y", ["N", 5])])
+    return W.write(str(tmp_path / "tf_bias.onnx"), blob)
+
+
+def test_per_channel_constants_fold_into_convolutions(built, tmp_path):
+    from infera_amd import capi
+
+    capi.load_model("tfb", _tf_style_bias_net(tmp_path))
+    plan = capi.get_plan("tfb")
+    capi.unload_model("tfb")
+    kinds = [s["kind"] for s in plan["plan"]["steps"]]
+    assert kinds == ["Conv2d", "Conv2d", "Pool2d", "AffineChannel", "GlobalAvgPool", "Dense"], kinds
+    assert plan["plan"]["steps"][0]["origin"].startswith("Conv+Add+Mul+Relu"), plan["plan"]["steps"][0]["origin"]
+    assert plan["activation_layout"] == "NC/4HW4"
+
+
+@pytest.mark.gpu
+def test_gpu_per_channel_constants_net(api, O, tmp_path):
+    path = _tf_style_bias_net(tmp_path)
+    x = synth.table(33, 0, 29, 3 * 12 * 12)
+    api.load_model("tfb", path)
+    try:
+        got = api.predict_from_blob("tfb", x.tobytes())
+    finally:
+        api.unload_model("tfb")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
