@@ -393,7 +393,8 @@ void schedule(LoadedModel &m) {
     const bool layout_free = s.kind == StepKind::Conv2d || s.kind == StepKind::Pool2d || s.kind == StepKind::GlobalAvgPool ||
                              s.kind == StepKind::BinaryAct || s.kind == StepKind::Unary || s.kind == StepKind::AffineChannel ||
                              s.kind == StepKind::CopyCols || s.kind == StepKind::SliceCols || s.kind == StepKind::LRN ||
-                             s.kind == StepKind::ChannelShuffle;
+                             s.kind == StepKind::ChannelShuffle ||
+                             s.kind == StepKind::BinaryConst;  // (its per-row constant is permuted to channel-quad order below)
     for (int b : {s.in0, s.in1}) {
       if (b < 0) continue;
       if (m.nchw_buf[size_t(b)] && is4d(b) && spatial(b) > 1) {  // NCHW tensors are read by convolutions and by their own elementwise chain only
@@ -429,6 +430,18 @@ void schedule(LoadedModel &m) {
           std::copy_n(d.W.begin() + (c * HW + p) * M, M, w.begin() + (((c >> 2) * HW + p) * 4 + (c & 3)) * M);
       d.W = std::move(w);
       d.origin += "[rows in channel-quad order]";
+    }
+  if (m.cq_mode)
+    for (size_t i = 0; i < n; i++) {  // PRelu slopes, Min / Max / Pow constants on channel-quad tensors: same permutation
+      Step &b = m.plan.steps[i];
+      if (b.kind != StepKind::BinaryConst || !is4d(b.in0) || m.nchw_buf[size_t(b.in0)] || spatial(b.in0) <= 1) continue;
+      const auto &bs = m.plan.buf_shape[size_t(b.in0)];
+      const int64_t C = bs[1], HW = bs[2] * bs[3];
+      if (int64_t(b.cst.size()) != C * HW) continue;
+      std::vector<float> c2(b.cst.size());
+      for (int64_t c = 0; c < C; c++)
+        for (int64_t p = 0; p < HW; p++) c2[size_t((((c >> 2) * HW + p) << 2) + (c & 3))] = b.cst[size_t(c * HW + p)];
+      b.cst = std::move(c2);
     }
   if (m.cq_mode)
     for (size_t i = 0; i < n; i++) {

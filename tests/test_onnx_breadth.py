@@ -907,3 +907,41 @@ def test_gpu_per_channel_constants_net(api, O, tmp_path):
     finally:
         api.unload_model("tfb")
     assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+
+
+def _prelu_net(tmp_path):
+    """per-channel PRelu slopes and a Max / Min clamp by constants between convolutions (face / older detection nets)"""
+    ws = W._WeightStream(101)
+    w1, b1 = ws.take((32, 3, 3, 3), 27), ws.take((32,), 27)
+    w2, b2 = ws.take((32, 32, 3, 3), 288), ws.take((32,), 288)
+    fw, fb = ws.take((32, 4), 32), ws.take((4,), 32)
+    slope = (0.05 + 0.3 * np.random.default_rng(6).random((32, 1, 1))).astype(np.float32)
+    cv = lambda x, w, b, o: W.node("Conv", [x, w, b], [o], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("pads", [1, 1, 1, 1])])
+    nodes = [cv("X", "w1", "b1", "c1"), W.node("PRelu", ["c1", "slope"], ["p1"]), cv("p1", "w2", "b2", "c2"),
+             W.node("Max", ["c2", "lo"], ["m1"]), W.node("Min", ["m1", "hi"], ["m2"]),
+             W.node("GlobalAveragePool", ["m2"], ["g"]), W.node("Flatten", ["g"], ["f"]), W.node("Gemm", ["f", "fw", "fb"], ["Y"])]
+    inits = [W.tensor(k, v) for k, v in dict(w1=w1, b1=b1, w2=w2, b2=b2, fw=fw, fb=fb, slope=slope,
+                                             lo=np.array(-0.2, np.float32), hi=np.array(0.3, np.float32)).items()]
+    blob = W.model("prelu_net", nodes, inits, [W.value_info("X", ["N", 3, 10, 10])], [W.value_info("Y", ["N", 4])])
+    return W.write(str(tmp_path / "prelu_net.onnx"), blob)
+
+
+def test_prelu_and_clamps_keep_the_conv_layout(built, tmp_path):
+    from infera_amd import capi
+
+    capi.load_model("pr", _prelu_net(tmp_path))
+    plan = capi.get_plan("pr")
+    capi.unload_model("pr")
+    assert plan["activation_layout"] == "NC/4HW4", plan["activation_layout"]
+
+
+@pytest.mark.gpu
+def test_gpu_prelu_net(api, O, tmp_path):
+    path = _prelu_net(tmp_path)
+    x = synth.table(35, 0, 31, 3 * 10 * 10)
+    api.load_model("pr", path)
+    try:
+        got = api.predict_from_blob("pr", x.tobytes())
+    finally:
+        api.unload_model("pr")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
