@@ -380,6 +380,11 @@ void schedule(LoadedModel &m) {
   auto is4d = [&](int b) { return b >= 0 && m.plan.buf_shape[size_t(b)].size() == 4; };
   auto spatial = [&](int b) { return is4d(b) ? m.plan.buf_shape[size_t(b)][2] * m.plan.buf_shape[size_t(b)][3] : int64_t(1); };
   bool any_conv = false, ok = true;
+  std::string nchw_reason;  // first thing that keeps a convolutional plan out of the channel-quad layout (logged: it costs ~10x)
+  auto refuse = [&](const std::string &why) {
+    if (ok) nchw_reason = why;
+    ok = false;
+  };
   std::vector<size_t> flat_dense;  // Dense layers fed by a flattened [C,H,W] activation
   // buffers that keep the caller's NCHW order: the input, and elementwise preprocessing of it (in-graph normalisation)
   m.nchw_buf.assign(m.plan.buf_shape.size(), 0);
@@ -398,7 +403,8 @@ void schedule(LoadedModel &m) {
     for (int b : {s.in0, s.in1}) {
       if (b < 0) continue;
       if (m.nchw_buf[size_t(b)] && is4d(b) && spatial(b) > 1) {  // NCHW tensors are read by convolutions and by their own elementwise chain only
-        if (!(s.kind == StepKind::Conv2d || (elementwise(s) && b == s.in0 && m.nchw_buf[size_t(s.out)]))) ok = false;
+        if (!(s.kind == StepKind::Conv2d || (elementwise(s) && b == s.in0 && m.nchw_buf[size_t(s.out)])))
+          refuse("'" + s.origin + "' reads the NCHW input tensor and is neither a convolution nor elementwise preprocessing");
         continue;
       }
       if (!layout_free && spatial(b) > 1) {
@@ -406,19 +412,21 @@ void schedule(LoadedModel &m) {
         // weight rows are permuted to that order once, below.  Anything else that looks at flattened features in
         // NCHW order keeps the whole plan NCHW.
         if (s.kind == StepKind::Dense && b == s.in0 && b != 0 && s.K == m.plan.buf_per_row[size_t(b)]) flat_dense.push_back(&s - st.data());
-        else ok = false;
+        else refuse("'" + s.origin + "' looks at a [C,H,W] tensor in NCHW element order");
       }
     }
   }
-  if (spatial(m.plan.out_buf) > 1) ok = false;  // results leave in the caller's (NCHW) order
+  if (spatial(m.plan.out_buf) > 1) refuse("the served output is a [C,H,W] tensor (results leave in the caller's NCHW order)");
   // channel-quad planes need whole quads in every internal 4-D tensor (the caller's input stays NCHW)
   for (size_t b = 1; b < m.plan.buf_shape.size(); b++)
     if (m.plan.buf_shape[b].size() == 4 && m.plan.buf_shape[b][1] % 4 != 0 && !m.nchw_buf[b]) {
       // a [N,C,1,1] tensor has no layout to speak of (a conv head with 10 classes behind the global pool): plain order
       if (spatial(int(b)) == 1) m.nchw_buf[b] = 1;
-      else ok = false;
+      else refuse("an internal [N,C,H,W] tensor has " + std::to_string(m.plan.buf_shape[b][1]) + " channels (not whole quads)");
     }
   m.cq_mode = any_conv && ok;
+  if (any_conv && !ok)
+    log_msg(1, "model '" + m.name + "': convolutional plan stays in NCHW (generic kernels, roughly 10x slower): " + nchw_reason);
   if (m.cq_mode)
     for (size_t i : flat_dense) {  // W rows: NCHW feature c*HW + p  ->  channel-quad feature ((c/4)*HW + p)*4 + c%4
       Step &d = m.plan.steps[i];
