@@ -458,7 +458,7 @@ void schedule(LoadedModel &m) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
       if (m.nchw_buf[size_t(s.in0)]) {  // the caller's NCHW blob (or its normalised copy): few channels -> LDS patch kernel
-        if (kern::conv2d_patch_supported(g)) m.exec[i] = ExecKind::ConvPatch;
+        if (kern::conv2d_patch_supported(kern::conv2d_patch_geom(g))) m.exec[i] = ExecKind::ConvPatch;
         continue;
       }
       if (kern::conv2d_tiled_supported(g)) m.exec[i] = ExecKind::ConvTiled;
@@ -599,7 +599,20 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
     } else if (m.exec[i] == ExecKind::ConvPatch) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
-      std::vector<float> packed(kern::conv2d_patch_packed_floats(g));
+      const kern::ConvGeom gp = kern::conv2d_patch_geom(g);
+      std::vector<float> packed(kern::conv2d_patch_packed_floats(gp));
+      if (gp.mvalid > 0) {  // output features padded to whole tiles: zero weights and bias beyond the real ones
+        std::vector<float> wt(size_t(gp.M) * g.C * g.kh * g.kw, 0.f);
+        std::copy(s.W.begin(), s.W.end(), wt.begin());
+        kern::conv2d_patch_pack(gp, wt.data(), packed.data());
+        d.W = upload(packed, us);
+        if (!s.bias.empty()) {
+          std::vector<float> bp(size_t(gp.M), 0.f);
+          std::copy(s.bias.begin(), s.bias.end(), bp.begin());
+          d.bias = upload(bp, us);
+        }
+        continue;
+      }
       kern::conv2d_patch_pack(g, s.W.data(), packed.data());
       d.W = upload(packed, us);
     } else if (s.kind == StepKind::Conv2d) {
@@ -707,7 +720,7 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case ExecKind::ConvPatch: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
-          kern::conv2d_patch(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, g, act_of(x), dm.num_cus);
+          kern::conv2d_patch(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, kern::conv2d_patch_geom(g), act_of(x), dm.num_cus);
           continue;
         }
         default: break;

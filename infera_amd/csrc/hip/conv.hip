@@ -642,7 +642,9 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
     tile_origin(tile, img, oy0, ox0);
     const int oy = oy0 + py, ox = ox0 + px;
     if (oy < g.OH && ox < g.OW) {
-      float *yp = Y + img * OHW * g.M + (int64_t(h) * OHW + oy * g.OW + ox) * 4;
+      // g.mvalid > 0: M was padded to whole 32-feature tiles (stems with 16 / 24 outputs); planes past mvalid/4 do not exist
+      const int mreal = g.mvalid > 0 ? g.mvalid : g.M;
+      float *yp = Y + img * OHW * mreal + (int64_t(h) * OHW + oy * g.OW + ox) * 4;
       const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias) + h : nullptr;
       dispatch_act(act.kind, [&](auto kind_tag) {
         constexpr int KIND = decltype(kind_tag)::value;
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>(acc[t][4 * q + j] + bv[q][j], act.a, act.b);
-            *reinterpret_cast<f32x4 *>(yp + int64_t(8 * t + 2 * q) * OHW * 4) = v;
+            if (4 * (8 * t + 2 * q + h) < mreal) *reinterpret_cast<f32x4 *>(yp + int64_t(8 * t + 2 * q) * OHW * 4) = v;
           }
         }
       });
@@ -841,8 +843,18 @@ void conv2d(hipStream_t s, const float *X, const float *Wk, const float *bias, f
   }
 }
 
+ConvGeom conv2d_patch_geom(const ConvGeom &real) {
+  ConvGeom g = real;
+  if (real.M % 32 != 0) {
+    g.M = (real.M + 31) / 32 * 32;
+    g.mvalid = real.M;
+  }
+  return g;
+}
+
+// (pass the padded geometry: conv2d_patch_geom)
 bool conv2d_patch_supported(const ConvGeom &g) {
-  if (g.groups != 1 || g.M % 32 != 0 || g.M > 128 || g.C > 8) return false;
+  if (g.groups != 1 || g.M % 32 != 0 || g.M > 128 || g.C > 8 || (g.mvalid > 0 && g.mvalid % 4 != 0)) return false;
   if (int64_t(g.C) * g.H * g.W >= (int64_t(1) << 30)) return false;
   const PatchGeom p = patch_geom(g);
   return p.NE <= kPatchMaxE && p.PR < 32768 && p.PC < 65536 && patch_lds_bytes(g, p) <= 160 * 1024;

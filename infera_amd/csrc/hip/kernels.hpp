@@ -101,6 +101,8 @@ struct ConvGeom {
 };
 // the geometry the tiled kernel runs for a convolution step: channels padded to 32 when they are not (padc = 1)
 ConvGeom conv2d_tiled_geom(const ConvGeom &real);
+// the same for the stem's patch kernel: M padded to whole 32-feature tiles (mvalid = the real count) for stems with 16 / 24 outputs
+ConvGeom conv2d_patch_geom(const ConvGeom &real);
 // Generic implicit-GEMM convolution: any geometry / groups; Wk = conv2d_generic_pack() of the ONNX
 // weights ([group][k][M/g], k = (c, ky, kx)); activations NCHW or channel-quad planes (CQ) per flag.
 bool conv2d_generic_supported(const ConvGeom &g);  // (C/g)*kh*kw <= 8192 (the per-k offset table lives in LDS)

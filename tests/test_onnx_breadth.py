@@ -945,3 +945,43 @@ def test_gpu_prelu_net(api, O, tmp_path):
     finally:
         api.unload_model("pr")
     assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+
+
+def _narrow_stem_net(tmp_path, stem):
+    """stems with 16 / 24 output channels (MobileNetV3, ShuffleNet): 7x7 or 3x3 stride-2 convolution over the NCHW image"""
+    ws = W._WeightStream(111 + stem)
+    k = 7 if stem == 24 else 3
+    w1, b1 = ws.take((stem, 3, k, k), 3 * k * k), ws.take((stem,), 3 * k * k)
+    w2, b2 = ws.take((32, stem, 3, 3), stem * 9), ws.take((32,), stem * 9)
+    fw, fb = ws.take((32, 3), 32), ws.take((3,), 32)
+    nodes = [W.node("Conv", ["X", "w1", "b1"], ["c1"], [W.attr_ints("kernel_shape", [k, k]), W.attr_ints("pads", [k // 2] * 4), W.attr_ints("strides", [2, 2])]),
+             W.node("HardSwish", ["c1"], ["a1"]),
+             W.node("Conv", ["a1", "w2", "b2"], ["c2"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("pads", [1, 1, 1, 1])]), W.node("Relu", ["c2"], ["a2"]),
+             W.node("GlobalAveragePool", ["a2"], ["g"]), W.node("Flatten", ["g"], ["f"]), W.node("Gemm", ["f", "fw", "fb"], ["Y"])]
+    inits = [W.tensor(n, v) for n, v in dict(w1=w1, b1=b1, w2=w2, b2=b2, fw=fw, fb=fb).items()]
+    blob = W.model("narrow_stem", nodes, inits, [W.value_info("X", ["N", 3, 18, 18])], [W.value_info("Y", ["N", 3])], opset=14)
+    return W.write(str(tmp_path / f"narrow_stem{stem}.onnx"), blob)
+
+
+@pytest.mark.parametrize("stem", [16, 24, 32])
+def test_narrow_stems_run_on_the_patch_kernel(built, tmp_path, stem):
+    from infera_amd import capi
+
+    capi.load_model("ns", _narrow_stem_net(tmp_path, stem))
+    plan = capi.get_plan("ns")
+    capi.unload_model("ns")
+    assert plan["activation_layout"] == "NC/4HW4" and plan["exec"][:2] == ["conv_patch", "conv_tiled_cq"], plan["exec"]
+    assert plan["plan"]["steps"][0].get("act") == "HardSwish", plan["plan"]["steps"][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stem", [16, 24, 32])
+def test_gpu_narrow_stems(api, O, tmp_path, stem):
+    path = _narrow_stem_net(tmp_path, stem)
+    x = synth.table(37, 0, 33, 3 * 18 * 18)
+    api.load_model("ns", path)
+    try:
+        got = api.predict_from_blob("ns", x.tobytes())
+    finally:
+        api.unload_model("ns")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
