@@ -70,7 +70,8 @@ struct Lowerer {
   explicit Lowerer(const onnx::Model &model) : m(model) {}
 
   int new_buf(const std::vector<int64_t> &shape) {
-    plan.buf_shape.push_back(shape);
+    // [N,C,L] tensors (1-D convolutional nets) are laid out and scheduled as [N,C,1,L]; values keep their 3-D shape
+    plan.buf_shape.push_back(shape.size() == 3 ? std::vector<int64_t>{shape[0], shape[1], 1, shape[2]} : shape);
     plan.buf_per_row.push_back(prod(shape, 1));
     return int(plan.buf_shape.size()) - 1;
   }
@@ -901,9 +902,14 @@ struct Lowerer {
   void spatial(const NodeDef &n, Step &s, int64_t H, int64_t W, const int64_t *extra_pad = nullptr) {
     s.sh = s.sw = s.dh = s.dw = 1;
     s.pt = s.pl = s.pb = s.pr = 0;
-    if (auto *p = n.attr_ints("strides")) { if (p->size() != 2) unsupported(n, "only 2-D"); s.sh = (*p)[0]; s.sw = (*p)[1]; }
-    if (auto *p = n.attr_ints("dilations")) { if (p->size() != 2) unsupported(n, "only 2-D"); s.dh = (*p)[0]; s.dw = (*p)[1]; }
-    if (auto *p = n.attr_ints("pads")) { if (p->size() != 4) unsupported(n, "only 2-D"); s.pt = (*p)[0]; s.pl = (*p)[1]; s.pb = (*p)[2]; s.pr = (*p)[3]; }
+    // (1-D operators run as [N,C,1,L]: one stride / dilation, two pads, all on the W axis)
+    if (auto *p = n.attr_ints("strides")) { if (p->size() == 1) s.sw = (*p)[0]; else if (p->size() != 2) unsupported(n, "only 1-D / 2-D"); else { s.sh = (*p)[0]; s.sw = (*p)[1]; } }
+    if (auto *p = n.attr_ints("dilations")) { if (p->size() == 1) s.dw = (*p)[0]; else if (p->size() != 2) unsupported(n, "only 1-D / 2-D"); else { s.dh = (*p)[0]; s.dw = (*p)[1]; } }
+    if (auto *p = n.attr_ints("pads")) {
+      if (p->size() == 2) { s.pl = (*p)[0]; s.pr = (*p)[1]; }
+      else if (p->size() != 4) unsupported(n, "only 1-D / 2-D");
+      else { s.pt = (*p)[0]; s.pl = (*p)[1]; s.pb = (*p)[2]; s.pr = (*p)[3]; }
+    }
     std::string ap = n.attr_s("auto_pad", "NOTSET");
     if (ap == "VALID") s.pt = s.pl = s.pb = s.pr = 0;
     else if (ap == "SAME_UPPER" || ap == "SAME_LOWER") {
@@ -935,13 +941,14 @@ struct Lowerer {
   void conv(const NodeDef &n) {
     const Val &a = get(n, 0);
     const Val &w = get(n, 1);
-    if (a.is_const || a.shape.size() != 4) unsupported(n, "only 2-D NCHW activations");
-    if (!w.is_const || w.shape.size() != 4) unsupported(n, "weights must be a constant [M,C/g,kh,kw]");
+    const bool one_d = a.shape.size() == 3 && w.shape.size() == 3;  // Conv1d: [N,C,L] as [N,C,1,L], kernel [M,C/g,k] as [M,C/g,1,k]
+    if (a.is_const || (a.shape.size() != 4 && !one_d)) unsupported(n, "only [N,C,L] / [N,C,H,W] activations");
+    if (!w.is_const || (w.shape.size() != 4 && !one_d)) unsupported(n, "weights must be a constant [M,C/g,kh,kw] (or [M,C/g,k])");
     Step s;
     s.kind = StepKind::Conv2d;
     s.in0 = a.buf;
-    s.C = a.shape[1]; s.H = a.shape[2]; s.Wd = a.shape[3];
-    s.Mo = w.shape[0]; s.kh = w.shape[2]; s.kw = w.shape[3];
+    s.C = a.shape[1]; s.H = one_d ? 1 : a.shape[2]; s.Wd = one_d ? a.shape[2] : a.shape[3];
+    s.Mo = w.shape[0]; s.kh = one_d ? 1 : w.shape[2]; s.kw = one_d ? w.shape[2] : w.shape[3];
     s.groups = n.attr_i("group", 1);
     if (s.groups < 1 || s.C != w.shape[1] * s.groups || s.Mo % s.groups) unsupported(n, "channel/group mismatch");
     spatial(n, s, s.H, s.Wd, a.pend);
@@ -953,6 +960,7 @@ struct Lowerer {
     s.K = (s.C / s.groups) * s.kh * s.kw;
     s.M = s.Mo;
     std::vector<int64_t> shape = {a.shape[0], s.Mo, s.OH, s.OW};
+    if (one_d) shape = {a.shape[0], s.Mo, s.OW};
     emit(std::move(s), n, shape);
   }
 
@@ -1004,19 +1012,21 @@ struct Lowerer {
 
   void pool(const NodeDef &n, bool is_max) {
     const Val &a = get(n, 0);
-    if (a.is_const || a.shape.size() != 4) unsupported(n, "only 2-D NCHW activations");
+    const bool one_d = a.shape.size() == 3;
+    if (a.is_const || (a.shape.size() != 4 && !one_d)) unsupported(n, "only [N,C,L] / [N,C,H,W] activations");
     auto *ks = n.attr_ints("kernel_shape");
-    if (!ks || ks->size() != 2) unsupported(n, "kernel_shape must have 2 entries");
+    if (!ks || ks->size() != (one_d ? 1u : 2u)) unsupported(n, "kernel_shape must have one entry per spatial axis");
     Step s;
     s.kind = StepKind::Pool2d;
     s.in0 = a.buf;
     s.is_max = is_max;
     s.count_pad = n.attr_i("count_include_pad", 0) != 0;
     if (!is_max && s.count_pad && n.attr_i("ceil_mode", 0) != 0) unsupported(n, "ceil_mode=1 with count_include_pad=1");
-    s.C = a.shape[1]; s.H = a.shape[2]; s.Wd = a.shape[3];
-    s.kh = (*ks)[0]; s.kw = (*ks)[1];
+    s.C = a.shape[1]; s.H = one_d ? 1 : a.shape[2]; s.Wd = one_d ? a.shape[2] : a.shape[3];
+    s.kh = one_d ? 1 : (*ks)[0]; s.kw = one_d ? (*ks)[0] : (*ks)[1];
     spatial(n, s, s.H, s.Wd);
     std::vector<int64_t> shape = {a.shape[0], s.C, s.OH, s.OW};
+    if (one_d) shape = {a.shape[0], s.C, s.OW};
     emit(std::move(s), n, shape);
   }
 

@@ -1341,6 +1341,10 @@ static int spatial_attrs(Exec *x, const Node *nd, int64_t kh, int64_t kw, int64_
   if ((a = find_attr(nd, "strides")) && a->nints == 2) { s->sh = a->ints[0]; s->sw = a->ints[1]; }
   if ((a = find_attr(nd, "dilations")) && a->nints == 2) { s->dh = a->ints[0]; s->dw = a->ints[1]; }
   if ((a = find_attr(nd, "pads")) && a->nints == 4) { s->pt = a->ints[0]; s->pl = a->ints[1]; s->pb = a->ints[2]; s->pr = a->ints[3]; }
+  /* 1-D operators ([N,C,L] tensors run as [N,C,1,L]): one entry per attribute, two pads */
+  if ((a = find_attr(nd, "strides")) && a->nints == 1) s->sw = a->ints[0];
+  if ((a = find_attr(nd, "dilations")) && a->nints == 1) s->dw = a->ints[0];
+  if ((a = find_attr(nd, "pads")) && a->nints == 2) { s->pl = a->ints[0]; s->pr = a->ints[1]; }
   if ((a = find_attr(nd, "auto_pad")) && a->s && strcmp(a->s, "NOTSET") != 0) {
     if (!strcmp(a->s, "VALID")) { s->pt = s->pl = s->pb = s->pr = 0; }
     else if (!strcmp(a->s, "SAME_UPPER") || !strcmp(a->s, "SAME_LOWER")) {
@@ -1370,9 +1374,10 @@ static int64_t pool_extent(int64_t in, int64_t p0, int64_t p1, int64_t k, int64_
 static int op_conv(Exec *x, const Node *nd) {
   const Tensor *in = get_in(x, nd, 0), *w = get_in(x, nd, 1), *bias = get_in(x, nd, 2);
   if (!in || !w) FAIL("Conv: missing input");
-  if (in->rank != 4 || w->rank != 4) FAIL("Conv: only 2-D NCHW supported");
-  int64_t N = in->dims[0], C = in->dims[1], H = in->dims[2], W = in->dims[3];
-  int64_t M = w->dims[0], Cg = w->dims[1], kh = w->dims[2], kw = w->dims[3];
+  const int one_d = in->rank == 3 && w->rank == 3; /* Conv1d: [N,C,L] as [N,C,1,L], kernel [M,C/g,k] as [M,C/g,1,k] */
+  if (!one_d && (in->rank != 4 || w->rank != 4)) FAIL("Conv: only 1-D / 2-D convolutions supported");
+  int64_t N = in->dims[0], C = in->dims[1], H = one_d ? 1 : in->dims[2], W = one_d ? in->dims[2] : in->dims[3];
+  int64_t M = w->dims[0], Cg = w->dims[1], kh = one_d ? 1 : w->dims[2], kw = one_d ? w->dims[2] : w->dims[3];
   int64_t G = attr_i(nd, "group", 1);
   if (G < 1 || C != Cg * G || M % G) FAIL("Conv: channel/group mismatch");
   Spatial s;
@@ -1381,7 +1386,8 @@ static int op_conv(Exec *x, const Node *nd) {
   int64_t OW = (W + s.pl + s.pr - (s.dw * (kw - 1) + 1)) / s.sw + 1;
   if (OH <= 0 || OW <= 0) FAIL("Conv: empty output");
   int64_t od[4] = {N, M, OH, OW};
-  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, 4, od);
+  if (one_d) od[2] = OW;
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, one_d ? 3 : 4, od);
   in = get_in(x, nd, 0);
   w = get_in(x, nd, 1);
   bias = get_in(x, nd, 2);
@@ -1438,19 +1444,21 @@ static int op_batchnorm(Exec *x, const Node *nd) {
 
 static int op_pool(Exec *x, const Node *nd, int is_max) {
   const Tensor *in = get_in(x, nd, 0);
-  if (!in || in->rank != 4) FAIL("%s: only 2-D NCHW supported", nd->op);
+  const int one_d = in && in->rank == 3;
+  if (!in || (in->rank != 4 && !one_d)) FAIL("%s: only 1-D / 2-D pooling supported", nd->op);
   const Attr *ks = find_attr(nd, "kernel_shape");
-  if (!ks || ks->nints != 2) FAIL("%s: kernel_shape required", nd->op);
-  int64_t N = in->dims[0], C = in->dims[1], H = in->dims[2], W = in->dims[3];
+  if (!ks || ks->nints != (one_d ? 1u : 2u)) FAIL("%s: kernel_shape required", nd->op);
+  int64_t N = in->dims[0], C = in->dims[1], H = one_d ? 1 : in->dims[2], W = one_d ? in->dims[2] : in->dims[3];
   Spatial s;
-  if (spatial_attrs(x, nd, ks->ints[0], ks->ints[1], H, W, &s)) return -1;
+  if (spatial_attrs(x, nd, one_d ? 1 : ks->ints[0], one_d ? ks->ints[0] : ks->ints[1], H, W, &s)) return -1;
   int ceil_mode = attr_i(nd, "ceil_mode", 0) != 0;
   int count_pad = (int)attr_i(nd, "count_include_pad", 0);
   if (ceil_mode && count_pad && !is_max) FAIL("%s: ceil_mode=1 with count_include_pad=1 unsupported", nd->op);
   int64_t OH = pool_extent(H, s.pt, s.pb, s.kh, s.dh, s.sh, ceil_mode);
   int64_t OW = pool_extent(W, s.pl, s.pr, s.kw, s.dw, s.sw, ceil_mode);
   int64_t od[4] = {N, C, OH, OW};
-  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, 4, od);
+  if (one_d) od[2] = OW;
+  Tensor *o = env_new(&x->env, nd->out[0], DT_FLOAT, one_d ? 3 : 4, od);
   in = get_in(x, nd, 0);
   for (int64_t nc = 0; nc < N * C; nc++) {
     const float *src = in->f + (size_t)nc * (size_t)(H * W);

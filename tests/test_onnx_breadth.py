@@ -985,3 +985,67 @@ def test_gpu_narrow_stems(api, O, tmp_path, stem):
     finally:
         api.unload_model("ns")
     assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+
+
+def _conv1d_net(tmp_path, in_ch=4):
+    """1-D CNN over [N, C, L] sequences (sensor / ECG windows): Conv1d k5 -> Relu -> MaxPool1d -> Conv1d k3 s2 d1 ->
+    BatchNormalization -> Relu -> AveragePool1d -> GlobalAveragePool -> Gemm"""
+    ws = W._WeightStream(131)
+    w1, b1 = ws.take((32, in_ch, 5), in_ch * 5), ws.take((32,), in_ch * 5)
+    w2, b2 = ws.take((64, 32, 3), 96), ws.take((64,), 96)
+    fw, fb = ws.take((64, 3), 64), ws.take((3,), 64)
+    rng = np.random.default_rng(8)
+    bn = dict(g=(0.5 + rng.random(64)).astype(np.float32), b=(rng.standard_normal(64) * 0.1).astype(np.float32),
+              mu=(rng.standard_normal(64) * 0.1).astype(np.float32), var=(0.5 + rng.random(64)).astype(np.float32))
+    nodes = [W.node("Conv", ["X", "w1", "b1"], ["c1"], [W.attr_ints("kernel_shape", [5]), W.attr_ints("pads", [2, 2])]), W.node("Relu", ["c1"], ["r1"]),
+             W.node("MaxPool", ["r1"], ["p1"], [W.attr_ints("kernel_shape", [2]), W.attr_ints("strides", [2])]),
+             W.node("Conv", ["p1", "w2", "b2"], ["c2"], [W.attr_ints("kernel_shape", [3]), W.attr_ints("pads", [1, 1]), W.attr_ints("strides", [2])]),
+             W.node("BatchNormalization", ["c2", "g", "b", "mu", "var"], ["n2"]), W.node("Relu", ["n2"], ["r2"]),
+             W.node("AveragePool", ["r2"], ["p2"], [W.attr_ints("kernel_shape", [3]), W.attr_ints("strides", [1]), W.attr_ints("pads", [1, 1])]),
+             W.node("GlobalAveragePool", ["p2"], ["gp"]), W.node("Flatten", ["gp"], ["f"]), W.node("Gemm", ["f", "fw", "fb"], ["Y"])]
+    inits = [W.tensor(k, v) for k, v in dict(w1=w1, b1=b1, w2=w2, b2=b2, fw=fw, fb=fb, **bn).items()]
+    blob = W.model("conv1d", nodes, inits, [W.value_info("X", ["N", in_ch, 64])], [W.value_info("Y", ["N", 3])])
+
+    def ref(x):
+        xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (2, 2)))
+        win = np.lib.stride_tricks.sliding_window_view(xp, 5, axis=2)  # n c l k
+        a = np.maximum(np.einsum("nclk,mck->nml", win, w1.astype(np.float64)) + b1[None, :, None], 0)
+        a = a.reshape(a.shape[0], 32, 32, 2).max(axis=3)
+        ap = np.pad(a, ((0, 0), (0, 0), (1, 1)))
+        win = np.lib.stride_tricks.sliding_window_view(ap, 3, axis=2)[:, :, ::2]
+        c = np.einsum("nclk,mck->nml", win, w2.astype(np.float64)) + b2[None, :, None]
+        c = (c - bn["mu"][None, :, None]) / np.sqrt(bn["var"].astype(np.float64) + 1e-5)[None, :, None] * bn["g"][None, :, None] + bn["b"][None, :, None]
+        c = np.maximum(c, 0)
+        L = c.shape[2]
+        cp = np.pad(c, ((0, 0), (0, 0), (1, 1)))
+        cnt = np.array([min(i + 2, L) - max(i - 1, 0) for i in range(L)], np.float64)
+        p = np.lib.stride_tricks.sliding_window_view(cp, 3, axis=2).sum(axis=3) / cnt
+        return p.mean(axis=2) @ fw.astype(np.float64) + fb
+
+    return W.write(str(tmp_path / f"conv1d_{in_ch}.onnx"), blob), ref
+
+
+def test_oracle_conv1d_net_vs_numpy(O, built, tmp_path):
+    from infera_amd import capi
+
+    path, ref = _conv1d_net(tmp_path)
+    x = synth.table(45, 0, 6, 4 * 64)
+    assert_close(O.Model(path).predict_blob(x.tobytes()), ref(x.reshape(6, 4, 64)).astype(np.float32), rtol=3e-5, atol=2e-6)
+    capi.load_model("c1d", path)
+    plan, info = capi.get_plan("c1d"), capi.get_model_info("c1d")
+    capi.unload_model("c1d")
+    assert info["input_shape"] == [-1, 4, 64] and plan["activation_layout"] == "NC/4HW4", (info, plan["activation_layout"])
+    assert plan["exec"][0] == "conv_patch" and "conv_tiled_cq" in plan["exec"], plan["exec"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_ch", [4, 12])
+def test_gpu_conv1d_net(api, O, tmp_path, in_ch):
+    path, _ = _conv1d_net(tmp_path, in_ch)
+    x = synth.table(45, 0, 300, in_ch * 64)
+    api.load_model("c1d", path)
+    try:
+        got = api.predict_from_blob("c1d", x.tobytes())
+    finally:
+        api.unload_model("c1d")
+    assert_close(got, O.Model(path).predict_blob(x.tobytes()))
