@@ -321,10 +321,10 @@ void schedule(LoadedModel &m) {
       }
       const size_t layers = j - d0;
       // a single layer with 17..32 outputs over rows the aligned kernels cannot read would fall to the generic kernel
-      const bool tail_next = j < n && st[j].in0 == st[j - 1].out && uses[size_t(st[j - 1].out)] == 1 &&
+      const bool tail_next = layers >= 1 && j < n && st[j].in0 == st[j - 1].out && uses[size_t(st[j - 1].out)] == 1 &&
                              (st[j].kind == StepKind::Softmax || st[j].kind == StepKind::ArgMax);
       // ... and a single 17..128-wide layer whose Softmax / ArgMax would otherwise cost two more passes over its scores
-      const bool lone_gap = layers == 1 && !pad && st[d0].M > 16 && ((st[d0].M <= 32 && st[d0].K % 8 != 0) || tail_next);
+      const bool lone_gap = layers == 1 && !pad && st[d0].M > 16 && ((st[d0].M <= 32 && st[d0].K % 8 != 0) || tail_next);  // (layers == 1: d0 is a Dense step)
       if (layers >= 2 || (layers == 1 && pad) || lone_gap) {
         if (j < n && st[j].in0 == st[j - 1].out && uses[size_t(st[j - 1].out)] == 1 && m.exec[j] == ExecKind::Normal) {
           if (st[j].kind == StepKind::Softmax && st[j].sm_norm == 0 && st[j].sm_outer == 1 && st[j].sm_inner == 1 && st[j].sm_len == st[j - 1].M) {
