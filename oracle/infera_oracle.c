@@ -537,7 +537,10 @@ typedef struct {
   size_t n, cap;
 } Env;
 
-static Tensor *env_new(Env *e, const char *name, int dtype, int rank, const int64_t *dims) {
+static Tensor *env_new(Env *e, const char *name, int dtype, int rank, const int64_t *dims_in) {
+  /* callers pass an input tensor's own dims, which live in e->v: copy them before the array may move */
+  int64_t dims[MAXRANK];
+  memcpy(dims, dims_in, sizeof(int64_t) * (size_t)rank);
   if (e->n == e->cap) {
     e->cap = e->cap ? e->cap * 2 : 64;
     e->v = realloc(e->v, e->cap * sizeof(Tensor));
