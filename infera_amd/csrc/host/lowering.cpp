@@ -497,6 +497,25 @@ struct Lowerer {
   void gather(const NodeDef &n) {
     const Val &d = get(n, 0);
     const Val &ix = get(n, 1);
+    // column pick out of a [rows, K] activation (the probability of one class, a feature subset): a contiguous range
+    if (!d.is_const && d.shape.size() == 2 && ix.is_const && ix.c->dtype == onnx::kInt64 && !ix.c->i64.empty() && ix.shape.size() <= 1) {
+      int64_t axis = n.attr_i("axis", 0);
+      if (axis < 0) axis += 2;
+      if (axis != 1) unsupported(n, "only axis 1 keeps rows independent");
+      std::vector<int64_t> v = ix.c->i64;
+      for (auto &i : v)
+        if (i < 0) i += d.shape[1];
+      for (size_t i = 1; i < v.size(); i++)
+        if (v[i] != v[0] + int64_t(i)) unsupported(n, "only a contiguous column range");
+      if (v[0] < 0 || v[0] + int64_t(v.size()) > d.shape[1]) unsupported(n, "column index out of range");
+      const Val src = d;
+      emit_slice_cols(n, src, v[0], v[0] + int64_t(v.size()), n.outputs[0]);
+      if (ix.shape.empty()) {  // scalar index: the axis disappears ([rows] instead of [rows, 1])
+        Val &o = vals[n.outputs[0]];
+        o.shape = {src.shape[0]};
+      }
+      return;
+    }
     if (!d.is_const || !ix.is_const || ix.c->dtype != onnx::kInt64) unsupported(n, "only constant data with constant indices is folded");
     if (d.shape.size() > 1 || n.attr_i("axis", 0) != 0) unsupported(n, "only 1-D data / axis 0");
     const int64_t len = d.c->dtype == onnx::kInt64 ? int64_t(d.c->i64.size()) : int64_t(d.c->f32.size());

@@ -765,20 +765,36 @@ static int op_shape(Exec *x, const Node *nd) {
   return 0;
 }
 
+/* Gather along `axis`: out.shape = data.shape[:axis] + indices.shape + data.shape[axis+1:] */
 static int op_gather(Exec *x, const Node *nd) {
   const Tensor *d = get_in(x, nd, 0), *ix = get_in(x, nd, 1);
   if (!d || !ix || ix->dtype != DT_INT64) FAIL("Gather: needs data and int64 indices");
-  if (d->rank > 1 || attr_i(nd, "axis", 0) != 0) FAIL("Gather: only 1-D data / axis 0");
-  Tensor *o = env_new(&x->env, nd->out[0], d->dtype, ix->rank, ix->dims);
+  int64_t axis = attr_i(nd, "axis", 0);
+  if (axis < 0) axis += d->rank;
+  if (d->rank < 1 || axis < 0 || axis >= d->rank) FAIL("Gather: axis out of range");
+  if (d->rank - 1 + ix->rank > MAXRANK) FAIL("Gather: rank too high");
+  int64_t od[MAXRANK];
+  int r = 0;
+  size_t outer = 1, inner = 1;
+  for (int i = 0; i < axis; i++) { od[r++] = d->dims[i]; outer *= (size_t)d->dims[i]; }
+  for (int i = 0; i < ix->rank; i++) od[r++] = ix->dims[i];
+  for (int i = (int)axis + 1; i < d->rank; i++) { od[r++] = d->dims[i]; inner *= (size_t)d->dims[i]; }
+  const size_t len = (size_t)d->dims[axis], ni = ix->n;
+  const int dtype = d->dtype;
+  Tensor *o = env_new(&x->env, nd->out[0], dtype, r, od);
   d = get_in(x, nd, 0);
   ix = get_in(x, nd, 1);
-  for (size_t i = 0; i < o->n; i++) {
-    int64_t k = ix->i64[i];
-    if (k < 0) k += (int64_t)d->n;
-    if (k < 0 || (size_t)k >= d->n) FAIL("Gather: index out of range");
-    if (d->dtype == DT_FLOAT) o->f[i] = d->f[k];
-    else o->i64[i] = d->i64[k];
-  }
+  for (size_t u = 0; u < outer; u++)
+    for (size_t j = 0; j < ni; j++) {
+      int64_t k = ix->i64[j];
+      if (k < 0) k += (int64_t)len;
+      if (k < 0 || (size_t)k >= len) FAIL("Gather: index out of range");
+      for (size_t v = 0; v < inner; v++) {
+        const size_t src = (u * len + (size_t)k) * inner + v, dst = (u * ni + j) * inner + v;
+        if (dtype == DT_FLOAT) o->f[dst] = d->f[src];
+        else o->i64[dst] = d->i64[src];
+      }
+    }
   return 0;
 }
 

@@ -1049,3 +1049,44 @@ def test_gpu_conv1d_net(api, O, tmp_path, in_ch):
     finally:
         api.unload_model("c1d")
     assert_close(got, O.Model(path).predict_blob(x.tobytes()))
+
+
+@pytest.mark.parametrize("index,shape", [(np.array(1, np.int64), ["N"]), (np.array([2, 3], np.int64), ["N", 2]), (np.array([-1], np.int64), ["N", 1])])
+def test_gather_of_class_columns(O, built, tmp_path, index, shape):
+    """Gather(axis=1) with constant indices behind a classifier: the probability of one class / a column range"""
+    from infera_amd import capi
+
+    ws = W._WeightStream(141)
+    w, b = ws.take((9, 4), 9), ws.take((4,), 9)
+    nodes = [W.node("Gemm", ["X", "w", "b"], ["s"]), W.node("Softmax", ["s"], ["p"], [W.attr_i("axis", 1)]),
+             W.node("Gather", ["p", "idx"], ["Y"], [W.attr_i("axis", 1)])]
+    blob = W.model("gat", nodes, [W.tensor("w", w), W.tensor("b", b), W.tensor("idx", index)], [W.value_info("X", ["N", 9])], [W.value_info("Y", shape)])
+    path = W.write(str(tmp_path / "gat.onnx"), blob)
+    x = synth.table(3, 0, 50, 9)
+    z = x.astype(np.float64) @ w + b
+    p = np.exp(z - z.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    want = p[:, index] if index.ndim else p[:, int(index)]
+    got = O.Model(path).predict(x)
+    assert_close(got.reshape(want.shape), want.astype(np.float32), rtol=3e-5, atol=2e-6)
+    capi.load_model("gat", path)
+    kinds = [s["kind"] for s in capi.get_plan("gat")["plan"]["steps"]]
+    capi.unload_model("gat")
+    assert kinds[-1] == "SliceCols", kinds
+
+
+@pytest.mark.gpu
+def test_gpu_gather_of_class_columns(api, O, tmp_path):
+    ws = W._WeightStream(141)
+    w, b = ws.take((9, 4), 9), ws.take((4,), 9)
+    nodes = [W.node("Gemm", ["X", "w", "b"], ["s"]), W.node("Softmax", ["s"], ["p"], [W.attr_i("axis", 1)]),
+             W.node("Gather", ["p", "idx"], ["Y"], [W.attr_i("axis", 1)])]
+    blob = W.model("gat", nodes, [W.tensor("w", w), W.tensor("b", b), W.tensor("idx", np.array(1, np.int64))], [W.value_info("X", ["N", 9])], [W.value_info("Y", ["N"])])
+    path = W.write(str(tmp_path / "gat.onnx"), blob)
+    x = synth.table(3, 0, 3001, 9)
+    api.load_model("gat", path)
+    try:
+        got = api.predict("gat", x)
+    finally:
+        api.unload_model("gat")
+    assert_close(got, O.Model(path).predict(x))
