@@ -638,7 +638,12 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
 int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
   if (m.scratch_per_row <= 0 || m.plan.out_buf == 0) return rows;
   int64_t by_budget = int64_t(kScratchBudgetBytes / (size_t(m.scratch_per_row) * 4));
-  int64_t rows_pass = std::min<int64_t>(rows, std::max<int64_t>(1, std::min<int64_t>(by_budget, int64_t(Config::get().max_rows_per_pass))));
+  // INFERA_MAX_ROWS_PER_PASS (2^18) bounds the scratch of plans with wide intermediates; plans whose intermediates are a
+  // few floats per row (a linear model + Softmax + Normalizer) take passes of up to 256 MB of scratch instead -- 77 passes
+  // of 262k rows over a 20M-row table were launch-bound (three ~10 us kernels each)
+  const int64_t by_size = int64_t((256ull << 20) / (size_t(m.scratch_per_row) * 4));
+  const int64_t cap = std::max<int64_t>(int64_t(Config::get().max_rows_per_pass), by_size);
+  int64_t rows_pass = std::min<int64_t>(rows, std::max<int64_t>(1, std::min<int64_t>(by_budget, cap)));
   ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass) * size_t(m.scratch_per_row) * 4);
   return rows_pass;
 }
