@@ -23,7 +23,12 @@ constexpr size_t kLdsBudget = 160 * 1024;
 
 int groups(int d) { return (d + 15) / 16; }
 int width(const ChainShape &s, int l) { return l == 0 ? s.k0 : s.dims[size_t(l - 1)]; }
-size_t layer_floats(const ChainShape &s, int l) { return size_t(groups(width(s, l - 1))) * groups(width(s, l)) * 256 + 16 * size_t(groups(width(s, l))); }
+// the last layer of a chain of >= 2 with at most 4 outputs runs on the VALU (chain_device.inc, VH)
+bool vhead(const ChainShape &s) { return s.dims.size() >= 2 && s.dims.back() <= 4; }
+size_t layer_floats(const ChainShape &s, int l) {
+  if (vhead(s) && l == int(s.dims.size())) return size_t(groups(width(s, l - 1))) * 16 * size_t(width(s, l)) + 4;
+  return size_t(groups(width(s, l - 1))) * groups(width(s, l)) * 256 + 16 * size_t(groups(width(s, l)));
+}
 // 32-row groups per trip: about 6 KB of table per wave in flight, as long as the tiles leave room for four workgroups
 // per CU beside the parameters
 int row_groups(const ChainShape &s) {
@@ -61,7 +66,7 @@ std::string expr_of(const ChainShape &s) {
   for (float f : s.pa) pa.push_back(bits_of(f));
   for (float f : s.pb) pb.push_back(bits_of(f));
   return "infera_hip::kern::chaindev::chain_kernel<infera_hip::kern::chaindev::Cfg<" + std::to_string(s.k0) + "," + ints(s.dims) + "," +
-         ints(s.acts) + "," + ints(pa) + "," + ints(pb) + "," + std::to_string(s.sm) + "," + std::to_string(row_groups(s)) + "," + std::to_string(waves_of(s)) + ">>";
+         ints(s.acts) + "," + ints(pa) + "," + ints(pb) + "," + std::to_string(s.sm) + "," + std::to_string(row_groups(s)) + "," + std::to_string(waves_of(s)) + "," + (vhead(s) ? "1" : "0") + ">>";
 }
 
 struct Compiled {
@@ -137,6 +142,17 @@ void chain_pack(const ChainShape &s, const std::vector<const float *> &W, const 
   for (int l = 1; l <= int(s.dims.size()); l++) {
     const int kin = width(s, l - 1), mout = width(s, l), G = groups(kin), MT = groups(mout);
     const float *w = W[size_t(l - 1)], *b = bias[size_t(l - 1)];
+    if (vhead(s) && l == int(s.dims.size())) {  // [g][q][j][m], zero past the real input width; then 4 bias slots
+      for (int g = 0; g < G; g++)
+        for (int q = 0; q < 4; q++)
+          for (int j = 0; j < 4; j++)
+            for (int m = 0; m < mout; m++) {
+              const int k = 16 * g + 4 * q + j;
+              *out++ = k < kin ? w[size_t(k) * mout + m] : 0.f;
+            }
+      for (int m = 0; m < 4; m++) *out++ = (b != nullptr && m < mout) ? b[m] : 0.f;
+      continue;
+    }
     for (int g = 0; g < G; g++)
       for (int mt = 0; mt < MT; mt++)
         for (int lane = 0; lane < 64; lane++)
