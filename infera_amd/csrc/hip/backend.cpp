@@ -644,6 +644,9 @@ int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
   const int64_t by_size = int64_t((256ull << 20) / (size_t(m.scratch_per_row) * 4));
   const int64_t cap = std::max<int64_t>(int64_t(Config::get().max_rows_per_pass), by_size);
   int64_t rows_pass = std::min<int64_t>(rows, std::max<int64_t>(1, std::min<int64_t>(by_budget, cap)));
+  // equal passes (2000 images at 1783 per pass run as 1000 + 1000, not 1783 + 217: the short tail would leave the chip half empty)
+  const int64_t npass = (rows + rows_pass - 1) / rows_pass;
+  rows_pass = (rows + npass - 1) / npass;
   ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass) * size_t(m.scratch_per_row) * 4);
   return rows_pass;
 }
