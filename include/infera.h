@@ -40,8 +40,9 @@ extern "C" {
 
 /* replaces rust.h:77-78 (lib.rs:38-64).  Parses `path`, lowers the graph to HIP kernels, uploads
  * weights to every selected GPU, registers under `name` (same name silently replaces,
- * engine.rs:74-80).  Paths starting with "http" are a remote fetch in the reference; this build
- * has no network stack and fails them with "HTTP request failed: ...". 0 / -1. */
+ * engine.rs:74-80).  Paths starting with "http" are fetched into the on-disk model cache first, as in
+ * the reference (lib.rs:47-58 -> http.rs:179-335: sha256(url) cache key, ETag revalidation, LRU eviction
+ * under INFERA_CACHE_SIZE_LIMIT, retries); failures read "HTTP request failed: ...". 0 / -1. */
 int32_t infera_load_model(const char *name, const char *path);
 
 /* replaces rust.h:97 (lib.rs:81-102).  -1 + "Model not found: <name>" if absent. */

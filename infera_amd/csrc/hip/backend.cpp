@@ -400,6 +400,12 @@ void schedule(LoadedModel &m) {
                              s.kind == StepKind::CopyCols || s.kind == StepKind::SliceCols || s.kind == StepKind::LRN ||
                              s.kind == StepKind::ChannelShuffle ||
                              s.kind == StepKind::BinaryConst;  // (its per-row constant is permuted to channel-quad order below)
+    // A channel slice is one contiguous block per sample in channel-quad planes only when it starts on a quad
+    // boundary (its length is covered by the whole-quads check on the output tensor below): channels 2..5 of an
+    // 8-channel tensor are NOT floats [2HW, 6HW) of the interleaved buffer.
+    if (s.kind == StepKind::SliceCols && is4d(s.in0) && spatial(s.in0) > 1 && !m.nchw_buf[size_t(s.in0)] &&
+        s.col_off % (4 * spatial(s.in0)) != 0)
+      refuse("'" + s.origin + "' slices channels from an offset that is not a whole quad");
     for (int b : {s.in0, s.in1}) {
       if (b < 0) continue;
       if (m.nchw_buf[size_t(b)] && is4d(b) && spatial(b) > 1) {  // NCHW tensors are read by convolutions and by their own elementwise chain only

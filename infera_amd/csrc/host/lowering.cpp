@@ -42,10 +42,16 @@ struct Val {
 };
 
 int64_t prod(const std::vector<int64_t> &v, size_t from = 0, size_t to = SIZE_MAX) {
+  // Shapes come from a model file: a product that leaves int64 is an error, not a wrapped number.
   int64_t p = 1;
-  for (size_t i = from; i < std::min(to, v.size()); i++) p *= v[i];
+  for (size_t i = from; i < std::min(to, v.size()); i++)
+    if (__builtin_mul_overflow(p, v[i], &p)) throw InferaError::onnx("tensor shape too large");
   return p;
 }
+
+// Largest activation row the planner accepts (elements): 2^31 floats = 8 GiB per table row is beyond anything the
+// staging or scratch sizing could serve, and keeping per-row counts in 31 bits keeps rows*per_row inside int64.
+constexpr int64_t kMaxPerRow = int64_t(1) << 31;
 
 std::string shape_str(const std::vector<int64_t> &s) {
   std::string o = "[";
@@ -72,7 +78,9 @@ struct Lowerer {
   int new_buf(const std::vector<int64_t> &shape) {
     // [N,C,L] tensors (1-D convolutional nets) are laid out and scheduled as [N,C,1,L]; values keep their 3-D shape
     plan.buf_shape.push_back(shape.size() == 3 ? std::vector<int64_t>{shape[0], shape[1], 1, shape[2]} : shape);
-    plan.buf_per_row.push_back(prod(shape, 1));
+    const int64_t per_row = prod(shape, 1);
+    if (per_row < 0 || per_row > kMaxPerRow) throw InferaError::onnx("activation of " + std::to_string(per_row) + " elements per row is too large");
+    plan.buf_per_row.push_back(per_row);
     return int(plan.buf_shape.size()) - 1;
   }
 
@@ -721,7 +729,11 @@ struct Lowerer {
     else if (auto *p = n.attr_ints("axes")) axes = *p;
     const int64_t rank = int64_t(a.shape.size());
     std::vector<bool> red(size_t(rank), false);
-    for (auto ax : axes) red[size_t(ax < 0 ? ax + rank : ax)] = true;
+    for (auto ax : axes) {
+      const int64_t na = ax < 0 ? ax + rank : ax;
+      if (na < 0 || na >= rank) unsupported(n, "axis " + std::to_string(ax) + " is out of range for rank " + std::to_string(rank));
+      red[size_t(na)] = true;
+    }
     for (int64_t i = 0; i < rank; i++)
       if (red[size_t(i)] != (i >= 2)) unsupported(n, "axes must be exactly the spatial axes");
     Step s;
@@ -774,8 +786,8 @@ struct Lowerer {
       pb = INFINITY;
       if (auto *a = n.attr("min")) pa = a->f;
       if (auto *a = n.attr("max")) pb = a->f;
-      if (has_input(n, 1)) { const Val &v = get(n, 1); if (cf32(n, v).size() == 1) pa = v.c->f32[0]; }
-      if (has_input(n, 2)) { const Val &v = get(n, 2); if (cf32(n, v).size() == 1) pb = v.c->f32[0]; }
+      if (has_input(n, 1)) { const Val &v = get(n, 1); if (cf32(n, v).size() != 1) unsupported(n, "min must be a scalar constant"); pa = v.c->f32[0]; }
+      if (has_input(n, 2)) { const Val &v = get(n, 2); if (cf32(n, v).size() != 1) unsupported(n, "max must be a scalar constant"); pb = v.c->f32[0]; }
     }
     apply_unary(n, 0, act, pa, pb, n.op);
   }
@@ -888,8 +900,10 @@ struct Lowerer {
           bool ins = false;
           for (auto ax : axes) if ((ax < 0 ? ax + nr : ax) == i) ins = true;
           if (ins && i == 0) unsupported(n, "cannot insert an axis before the row axis");
+          if (!ins && src >= a.shape.size()) unsupported(n, "axes out of range");
           out.push_back(ins ? 1 : a.shape[src++]);
         }
+        if (src != a.shape.size()) unsupported(n, "axes out of range");
       }
     }
     alias(n, out);
@@ -943,6 +957,15 @@ struct Lowerer {
       if (ap == "SAME_UPPER" || ap == "SAME_LOWER") unsupported(n, "auto_pad SAME behind an explicit Pad");
       s.pt += extra_pad[0]; s.pl += extra_pad[1]; s.pb += extra_pad[2]; s.pr += extra_pad[3];
     }
+    // A model file is untrusted input: attributes that would divide by zero or index backwards are rejected here
+    // (the reference's parser returns an error for them; it must never take the host process down).
+    if (s.sh < 1 || s.sw < 1) unsupported(n, "strides must be >= 1");
+    if (s.dh < 1 || s.dw < 1) unsupported(n, "dilations must be >= 1");
+    if (s.kh < 1 || s.kw < 1) unsupported(n, "kernel extents must be >= 1");
+    if (s.pt < 0 || s.pl < 0 || s.pb < 0 || s.pr < 0) unsupported(n, "negative pads");
+    const int64_t lim = int64_t(1) << 20;  // keeps every extent product below far inside int64
+    if (s.sh > lim || s.sw > lim || s.dh > lim || s.dw > lim || s.kh > lim || s.kw > lim || s.pt > lim || s.pl > lim || s.pb > lim || s.pr > lim)
+      unsupported(n, "spatial attribute out of range");
     // pooling only: ceil_mode=1 rounds the extent up, and a last window that would start beyond the input plus
     // its leading pad is dropped (ONNX MaxPool / AveragePool); the kernels already ignore out-of-image taps
     const bool ceil_mode = n.attr_i("ceil_mode", 0) != 0;
@@ -1086,6 +1109,7 @@ struct Lowerer {
     s.S = prod(a.shape, 2);
     s.lrn_size = n.attr_i("size", 0);
     if (s.lrn_size < 1) unsupported(n, "size attribute required");
+    if (s.lrn_size > (int64_t(1) << 20)) unsupported(n, "size out of range");  // the kernels carry it as int
     s.lrn_alpha = n.attr_f("alpha", 1e-4f);
     s.lrn_beta = n.attr_f("beta", 0.75f);
     s.lrn_bias = n.attr_f("bias", 1.f);

@@ -146,13 +146,21 @@ std::shared_ptr<TensorData> read_tensor(Wire w) {
   if (external) throw InferaError::onnx("tensor '" + t->name + "' uses external data, which is not supported");
   for (auto d : t->dims)
     if (d < 0) throw InferaError::onnx("tensor '" + t->name + "' has a negative dimension");
-  const size_t n = t->count();
   auto size_err = [&] { return InferaError::onnx("tensor '" + t->name + "': element count does not match dims"); };
+  // Element count with overflow detection: dims such as [4, 2^62] wrap a plain product to 0 and would
+  // pass every size comparison below.  The count is then compared with the payload that is really in the
+  // file BEFORE anything is allocated, so no declared shape can make the loader reserve more than it read.
+  size_t n = 1;
+  for (auto d : t->dims)
+    if (__builtin_mul_overflow(n, size_t(d), &n)) throw size_err();
+  if (n == 0)  // an empty tensor must not smuggle an absurd extent past the payload check either
+    for (auto d : t->dims)
+      if (d > (int64_t(1) << 31)) throw size_err();
   switch (dtype) {
     case kFloat:
       t->dtype = kFloat;
       if (raw) {
-        if (rawlen != n * 4) throw size_err();
+        if (rawlen / 4 != n || rawlen % 4) throw size_err();
         t->f32.resize(n);
         std::memcpy(t->f32.data(), raw, rawlen);
       } else {
@@ -162,9 +170,9 @@ std::shared_ptr<TensorData> read_tensor(Wire w) {
       break;
     case kDouble:
       t->dtype = kFloat;  // narrowed: the whole path computes in f32
-      t->f32.resize(n);
       if (raw) {
-        if (rawlen != n * 8) throw size_err();
+        if (rawlen / 8 != n || rawlen % 8) throw size_err();
+        t->f32.resize(n);
         for (size_t i = 0; i < n; i++) {
           double d;
           std::memcpy(&d, raw + i * 8, 8);
@@ -172,16 +180,17 @@ std::shared_ptr<TensorData> read_tensor(Wire w) {
         }
       } else {
         if (ddata.size() != n) throw size_err();
+        t->f32.resize(n);
         for (size_t i = 0; i < n; i++) t->f32[i] = float(ddata[i]);
       }
       break;
     case kInt64:
     case kInt32:
       t->dtype = kInt64;
-      t->i64.resize(n);
       if (raw) {
         const size_t es = dtype == kInt64 ? 8 : 4;
-        if (rawlen != n * es) throw size_err();
+        if (rawlen / es != n || rawlen % es) throw size_err();
+        t->i64.resize(n);
         for (size_t i = 0; i < n; i++) {
           if (es == 8) {
             int64_t v;

@@ -22,11 +22,9 @@ struct TensorData {
   std::vector<int64_t> dims;
   std::vector<float> f32;
   std::vector<int64_t> i64;
-  size_t count() const {
-    size_t n = 1;
-    for (auto d : dims) n *= (size_t)d;
-    return n;
-  }
+  // Element count = payload length.  The decoder has verified it equals Π dims (overflow-checked), so a
+  // declared shape can never claim more elements than the file holds.
+  size_t count() const { return dtype == kInt64 ? i64.size() : f32.size(); }
 };
 
 struct Attribute {

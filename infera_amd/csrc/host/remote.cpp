@@ -12,6 +12,7 @@
 #include <utime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
@@ -113,6 +114,7 @@ void evict_if_needed(const std::string &dir, uint64_t required) {
   for (const auto &f : files) {
     if (current - freed <= target) break;
     if (::unlink(f.path.c_str()) != 0) throw InferaError::io(std::strerror(errno));
+    ::unlink((f.path.substr(0, f.path.size() - 5) + ".etag").c_str());  // its revalidation tag goes with it
     freed += f.size;
   }
 }
@@ -244,6 +246,8 @@ enum class Fetch { NotModified, Downloaded };
 
 // http.rs:303-337 (download_file): GET with optional If-None-Match; 304 -> NotModified; other non-2xx -> error;
 // body streamed to `dest`.  `etag_out` receives the response's ETag ("" if none).
+Fetch download_file_curl(const std::string &url, const std::string &dest, uint64_t timeout_secs, const std::string *etag, std::string &etag_out);
+
 Fetch download_file(const std::string &url_in, const std::string &dest, uint64_t timeout_secs, const std::string *etag, std::string &etag_out) {
   std::string url = url_in;
   const auto deadline = Clock::now() + std::chrono::seconds(timeout_secs ? timeout_secs : 1);
@@ -281,6 +285,8 @@ Fetch download_file(const std::string &url_in, const std::string &dest, uint64_t
     if (status == 304) return Fetch::NotModified;
     if (status >= 300 && status < 400 && !location.empty()) {  // reqwest follows redirects
       url = location.rfind("http", 0) == 0 ? location : "http://" + u.host + (u.port == "80" ? "" : ":" + u.port) + location;
+      // a hop to https leaves this client: hand the rest of the chain to the TLS-capable backend
+      if (url.rfind("https://", 0) == 0) return download_file_curl(url, dest, timeout_secs, etag, etag_out);
       continue;
     }
     if (status < 200 || status >= 300) {
@@ -300,8 +306,15 @@ Fetch download_file(const std::string &url_in, const std::string &dest, uint64_t
     };
     if (chunked) {
       for (;;) {
+        // chunk-size line: 1..16 hex digits, optionally followed by ";extensions".  Anything else (an empty line
+        // where the connection died, garbage) must not read as "0 = end of body" and commit a truncated file.
         const std::string szl = c.read_line();
-        const uint64_t n = std::strtoull(szl.c_str(), nullptr, 16);
+        size_t nd = 0;
+        while (nd < szl.size() && std::isxdigit(static_cast<unsigned char>(szl[nd]))) nd++;
+        size_t rest = nd;
+        while (rest < szl.size() && (szl[rest] == ' ' || szl[rest] == '\t')) rest++;
+        if (nd == 0 || nd > 16 || (rest < szl.size() && szl[rest] != ';')) throw InferaError::io("unexpected end of file");
+        const uint64_t n = std::strtoull(szl.substr(0, nd).c_str(), nullptr, 16);
         if (n == 0) break;
         uint64_t left = n;
         while (left) {

@@ -36,3 +36,12 @@ def models(tmp_path_factory, built):
         "identity_dyn": W.write(str(d / "identity_dyn.onnx"), W.identity(4)),
     }
     return out
+
+
+@pytest.fixture(scope="session")
+def gpu_api(built):
+    """The ctypes mirror of the C ABI, on a box where the HIP backend sees a GPU (for `-m gpu` tests)."""
+    from infera_amd import capi
+
+    assert capi.device_count() >= 1, capi.get_devices()
+    return capi

@@ -66,6 +66,11 @@ class H(http.server.BaseHTTPRequestHandler):
                 c = LINEAR[i:i + 37]
                 self.wfile.write(b"%x\r\n" % len(c) + c + b"\r\n")
             self.wfile.write(b"0\r\n\r\n")
+        elif p in ("/badchunk.onnx", "/emptychunk.onnx"):  # a chunk-size line that is not hex / is empty: truncated body, not "end of body"
+            self.send_response(200); self.send_header("Transfer-Encoding", "chunked"); self.send_header("Connection", "close"); self.end_headers()
+            self.wfile.write(b"%x\r\n" % 37 + LINEAR[:37] + b"\r\n")
+            self.wfile.write(b"zz\r\n\r\n" if p == "/badchunk.onnx" else b"\r\n\r\n")
+        elif p.startswith("/bigtag"): send(200, BIG, [("ETag", "t" + p[7])])
         elif p == "/redir.onnx": send(302, headers=[("Location", "/ok.onnx")])
         elif p.startswith("/big"): send(200, BIG)
         else: send(404, b"nope")
@@ -105,7 +110,7 @@ out["etag200_second"] = capi.get_model_info("r3")["input_shape"]
 out["etag200_tag"] = open(os.path.join(CACHE, key(u) + ".etag")).read().strip()
 
 # failures leave nothing behind (http.rs:346-459)
-for name in ("err500", "short", "drop", "missing"):
+for name in ("err500", "short", "drop", "missing", "badchunk", "emptychunk"):
     u = base + f"/{name}.onnx"
     try:
         capi.load_model("bad", u)
@@ -141,6 +146,14 @@ capi.load_model("big2", urls[2])                 # 8192 + 4096 > 10000 -> evict 
 out["present_after_evict"] = [os.path.exists(cached(u)) for u in urls]
 out["big0_hits"] = hits["/big0.onnx"]
 out["info_after"] = capi.get_cache_info()
+# eviction takes the entry's .etag along (no orphan revalidation tags)
+capi.clear_cache()
+turls = [base + f"/bigtag{i}.onnx" for i in range(3)]
+for i in range(3):
+    capi.load_model(f"bt{i}", turls[i])
+    os.utime(cached(turls[i]), (2000 + i, 2000 + i))
+out["etag_files_after_evict"] = sorted(f for f in os.listdir(CACHE) if f.endswith(".etag"))
+out["etag_expected"] = sorted(key(u) + ".etag" for u in turls[1:])
 os.makedirs(os.path.join(CACHE, "subdir"), exist_ok=True)
 open(os.path.join(CACHE, "subdir", "x.tmp"), "w").write("x")
 capi.clear_cache()
@@ -186,6 +199,9 @@ def test_remote_fetch_and_lru_cache(built, tmp_path, backend):
     assert (out["drop"].startswith("IO error: ") or out["drop"].startswith("HTTP request failed: ")) and out["drop_clean"]
     assert out["missing"].startswith("HTTP request failed: HTTP status client error (404") and out["missing_clean"]
     assert out["chunked_ok"] and out["redir_ok"]
+    for name in ("badchunk", "emptychunk"):  # a malformed chunk-size line is a failed download, never a cached truncated file
+        assert (out[name].startswith("IO error: ") or out[name].startswith("HTTP request failed: ")) and out[name + "_clean"], out[name]
+    assert out["etag_files_after_evict"] == out["etag_expected"]
     assert out["https"].startswith("HTTP request failed: ")  # refused by the socket client / connection refused through curl
     assert out["info_before"]["cache_dir"] == str(cache) and out["info_before"]["file_count"] >= 5
     assert out["info_before"]["size_limit_bytes"] == 10000
