@@ -100,6 +100,11 @@ int32_t infera_gather_columns(const InferaColumn *columns, uintptr_t ncols, uint
 struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_name, const uint8_t *const *blobs,
                                                             const uintptr_t *lens, uintptr_t n);
 
+/* The product's own output-shape rule, exposed so it can be pinned on the reference's unit-test table without a GPU
+ * (engine.rs:19-29 shape_rows_cols, table at engine.rs:321-328): [] -> (1,1); [n] -> (n,1); [d0,...] ->
+ * (d0, max(prod(rest),1)).  infera_predict* report rows/cols of every result through exactly this function. */
+void infera_hip_shape_rows_cols(const uint64_t *shape, uintptr_t rank, uint64_t *rows, uint64_t *cols);
+
 /* sha256(data) as 64 lower-case hex characters: the key under which infera_load_model("http://...") caches a
  * remote model (`<cache_dir>/<sha256(url)>.onnx`, reference http.rs:186-190).  Free with infera_free. */
 char *infera_hip_sha256_hex(const char *data, uintptr_t len);

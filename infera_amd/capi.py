@@ -28,7 +28,7 @@ EXTENSION_SYMBOLS = [
     "infera_hip_predict_device", "infera_hip_sync", "infera_hip_time_predict_device", "infera_hip_malloc",
     "infera_hip_free", "infera_hip_memcpy_h2d", "infera_hip_memcpy_d2h", "infera_hip_synth_fill",
     "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch", "infera_gather_columns",
-    "infera_hip_sha256_hex",
+    "infera_hip_sha256_hex", "infera_hip_shape_rows_cols",
 ]
 
 
@@ -117,6 +117,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.infera_gather_columns.restype = C.c_int32
     L.infera_predict_from_blob_batch.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t]
     L.infera_predict_from_blob_batch.restype = InferaInferenceResult
+    L.infera_hip_shape_rows_cols.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.infera_hip_shape_rows_cols.restype = None
     _lib = L
     return L
 
@@ -205,6 +207,14 @@ def set_autoload_dir(path: str) -> dict:
 
 
 # ---- additive MI355X entry points ----------------------------------------------------------------
+
+def shape_rows_cols(shape: Sequence[int]) -> tuple[int, int]:
+    """The product's engine.rs:19-29 rule (what every result's rows/cols come from)."""
+    arr = (C.c_uint64 * max(len(shape), 1))(*shape)
+    r, c = C.c_uint64(), C.c_uint64()
+    load_library().infera_hip_shape_rows_cols(arr, len(shape), C.byref(r), C.byref(c))
+    return r.value, c.value
+
 
 def device_count() -> int:
     return int(load_library().infera_hip_device_count())

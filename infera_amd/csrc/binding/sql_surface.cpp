@@ -528,4 +528,92 @@ double infera_sql_bench_scan(const char *function, const char *model, uint64_t r
   return sec;
 }
 
+// ---- table scan over a MATERIALISED columnar table (the measurement of SURVEY.md 8d) --------------------------
+// Layout = DuckDB's storage shape: row groups of INFERA_SQL_ROW_GROUP rows, inside a group one contiguous run per
+// column.  Value (row, col) sits at  table[g*RG*ncols + col*rows_in_group(g) + (row - g*RG)].
+
+uint64_t infera_sql_table_floats(uint64_t rows, uint32_t ncols) { return rows * uint64_t(ncols); }
+
+void infera_sql_synth_table(float *table, uint64_t seed, uint64_t rows, uint32_t ncols, int32_t threads) {
+  if (threads < 1) threads = 1;
+  const uint64_t RG = INFERA_SQL_ROW_GROUP;
+  const uint64_t ngroups = (rows + RG - 1) / RG;
+  std::atomic<uint64_t> next{0};
+  auto worker = [&] {
+    for (;;) {
+      const uint64_t task = next.fetch_add(1, std::memory_order_relaxed);  // one (group, column) run per task
+      if (task >= ngroups * ncols) break;
+      const uint64_t g = task / ncols, c = task % ncols;
+      const uint64_t r0 = g * RG, gr = std::min<uint64_t>(RG, rows - r0);
+      float *dst = table + r0 * ncols + c * gr;
+      for (uint64_t r = 0; r < gr; r++) {
+        const uint64_t u = splitmix64(seed ^ ((r0 + r) * ncols + c));
+        dst[r] = float(u >> 40) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; t++) th.emplace_back(worker);
+  for (auto &x : th) x.join();
+}
+
+int32_t infera_sql_bench_scan_table(const char *function, const char *model, const float *table, uint64_t rows, uint32_t ncols,
+                                    int32_t threads, int32_t reps, double *secs, double *checksum, char *err, uint64_t errlen) {
+  if (threads < 1) threads = 1;
+  const size_t CH = INFERA_SQL_VECTOR_SIZE;
+  const uint64_t RG = INFERA_SQL_ROW_GROUP;
+  static_assert(INFERA_SQL_ROW_GROUP % INFERA_SQL_VECTOR_SIZE == 0, "chunks never straddle a row group");
+  const uint64_t nchunks = (rows + CH - 1) / CH;
+  const std::string fn = function ? function : "infera_predict";
+  std::string first_error;
+  std::mutex mu;
+  for (int rep = 0; rep < reps; rep++) {
+    std::atomic<uint64_t> next{0};
+    double total = 0.0;
+    auto worker = [&] {
+      std::vector<InferaSqlVector> args(ncols + 1);
+      const uint8_t *name_ptr = reinterpret_cast<const uint8_t *>(model);
+      uint64_t name_len = std::strlen(model);
+      args[0] = InferaSqlVector{INFERA_SQL_VARCHAR, 1, &name_ptr, &name_len, nullptr};
+      double local = 0.0;
+      for (;;) {
+        const uint64_t c = next.fetch_add(1, std::memory_order_relaxed);
+        if (c >= nchunks) break;
+        const uint64_t row0 = c * CH, g = row0 / RG, g0 = g * RG, gr = std::min<uint64_t>(RG, rows - g0);
+        const size_t nr = size_t(std::min<uint64_t>(CH, rows - row0));
+        const float *base = table + g0 * ncols + (row0 - g0);
+        for (uint32_t j = 0; j < ncols; j++) args[j + 1] = InferaSqlVector{INFERA_SQL_FLOAT, 0, base + uint64_t(j) * gr, nullptr, nullptr};
+        InferaSqlResult res;
+        if (infera_sql_call(fn.c_str(), args.data(), ncols + 1, nr, &res) != 0) {
+          std::lock_guard<std::mutex> lk(mu);
+          if (first_error.empty()) first_error = res.error ? res.error : "unknown error";
+          infera_sql_free_result(&res);
+          next.store(nchunks);
+          break;
+        }
+        // the consumer of the result vector (an aggregate above the scan) touches every element once
+        if (res.f32)
+          for (size_t i = 0; i < nr; i++) local += double(res.f32[i]);
+        else if (res.list_offsets)
+          for (uint64_t i = 0; i < res.list_offsets[nr]; i++) local += double(res.list_values[i]);
+        infera_sql_free_result(&res);
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      total += local;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker);
+    for (auto &x : th) x.join();
+    if (secs) secs[rep] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (checksum) *checksum = total;
+    if (!first_error.empty()) {
+      if (err && errlen) std::snprintf(err, size_t(errlen), "%s", first_error.c_str());
+      return -1;
+    }
+  }
+  return 0;
+}
+
+
 }  // extern "C"

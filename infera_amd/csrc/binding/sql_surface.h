@@ -27,6 +27,7 @@ extern "C" {
 
 #define INFERA_SQL_MAX_FEATURES 1024
 #define INFERA_SQL_VECTOR_SIZE 2048 /* DuckDB STANDARD_VECTOR_SIZE */
+#define INFERA_SQL_ROW_GROUP 122880 /* DuckDB's default row-group size = 60 vectors */
 
 typedef enum InferaSqlType {
   INFERA_SQL_VARCHAR = 0,
@@ -79,6 +80,19 @@ char *infera_sql_list_functions(void);
  * receives the f64 sum of every output element. */
 double infera_sql_bench_scan(const char *function, const char *model, uint64_t rows, uint32_t ncols, int32_t threads,
                              int32_t pool_chunks, uint64_t seed, double *checksum, char *err, uint64_t errlen);
+
+/* The same scan over a MATERIALISED columnar table held in host memory (what bench.py's `end_to_end` block times):
+ * row groups of INFERA_SQL_ROW_GROUP rows, one contiguous run per column inside a group -- DuckDB's storage shape, so
+ * every chunk column is an 8 KiB run somewhere in a multi-GB table rather than a cache-resident pool.
+ *   infera_sql_table_floats   number of floats such a table needs
+ *   infera_sql_synth_table    fills it with the generator of SURVEY.md 8d (value of (row, col) independent of layout)
+ *   infera_sql_bench_scan_table  runs `reps` complete scans with `threads` workers pulling 2048-row chunks from a
+ *                             shared counter; secs[rep] = wall time from the first chunk's gather to the last result
+ *                             element consumed.  Table generation is outside every timed region.  0 / -1 (+err). */
+uint64_t infera_sql_table_floats(uint64_t rows, uint32_t ncols);
+void infera_sql_synth_table(float *table, uint64_t seed, uint64_t rows, uint32_t ncols, int32_t threads);
+int32_t infera_sql_bench_scan_table(const char *function, const char *model, const float *table, uint64_t rows, uint32_t ncols,
+                                    int32_t threads, int32_t reps, double *secs, double *checksum, char *err, uint64_t errlen);
 
 #ifdef __cplusplus
 }

@@ -201,6 +201,10 @@ struct HostLease {
   HostLease &operator=(const HostLease &) = delete;
 };
 
+// Host-ABI work served per device slot (calls, rows): lets a scan report how DuckDB's worker threads were dealt over
+// the GPUs (infera_hip_get_devices), and lets the tests see that a second slot really took its share.
+std::atomic<uint64_t> g_slot_calls[64], g_slot_rows[64];
+
 int home_slot() {
   if (t_holder.home_slot < 0) t_holder.home_slot = int(g_next_home.fetch_add(1) % unsigned(devices().ids.size()));
   return t_holder.home_slot;
@@ -799,6 +803,11 @@ const DeviceModel &device_model(const LoadedModel &m, int slot) {
 
 // -------------------------------------------------------------------------------------------------
 
+void slot_counters(int slot, uint64_t *calls, uint64_t *rows) {
+  *calls = g_slot_calls[size_t(slot) % 64].load(std::memory_order_relaxed);
+  *rows = g_slot_rows[size_t(slot) % 64].load(std::memory_order_relaxed);
+}
+
 const DeviceSet &devices() {
   static const DeviceSet ds = [] {
     DeviceSet d;
@@ -910,6 +919,8 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   HostLease lease(slot);
   ThreadCtx &ctx = *lease.c;
   const DeviceModel &dm = device_model(m, slot);
+  g_slot_calls[size_t(slot) % 64].fetch_add(1, std::memory_order_relaxed);
+  g_slot_rows[size_t(slot) % 64].fetch_add(uint64_t(rows), std::memory_order_relaxed);
   const size_t in_row = size_t(m.plan.in_per_row()) * 4, out_row = size_t(m.plan.out_per_row()) * 4;
   const size_t widest = std::max(in_row, out_row);
   const bool use_graph = Config::get().use_hipgraph;

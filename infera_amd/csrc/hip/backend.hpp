@@ -28,6 +28,8 @@ struct DeviceSet {
   std::string why;
 };
 const DeviceSet &devices();
+// host-ABI calls / table rows served so far by device slot `slot` (index into DeviceSet::ids)
+void slot_counters(int slot, uint64_t *calls, uint64_t *rows);
 
 // Constants of one plan step resident in one GPU's HBM.
 struct DeviceStep {

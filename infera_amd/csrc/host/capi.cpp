@@ -291,10 +291,19 @@ char *infera_hip_get_devices(void) {
   std::string o = "{\"devices\":[";
   for (size_t i = 0; i < ds.ids.size(); i++) {
     if (i) o += ",";
-    o += "{\"arch\":" + json_str(ds.arch[i]) + ",\"cus\":" + std::to_string(ds.cus[i]) + ",\"ordinal\":" + std::to_string(ds.ids[i]) + "}";
+    uint64_t calls = 0, rows = 0;
+    slot_counters(int(i), &calls, &rows);
+    o += "{\"arch\":" + json_str(ds.arch[i]) + ",\"cus\":" + std::to_string(ds.cus[i]) + ",\"host_calls\":" + std::to_string(calls) +
+         ",\"host_rows\":" + std::to_string(rows) + ",\"ordinal\":" + std::to_string(ds.ids[i]) + ",\"slot\":" + std::to_string(i) + "}";
   }
   o += "],\"reason\":" + json_str(ds.why) + "}";
   return dup_cstr(o);
+}
+
+void infera_hip_shape_rows_cols(const uint64_t *shape, uintptr_t rank, uint64_t *rows, uint64_t *cols) {
+  const auto rc = shape_rows_cols(std::vector<uint64_t>(shape, shape + (shape ? rank : 0)));
+  if (rows) *rows = rc.first;
+  if (cols) *cols = rc.second;
 }
 
 char *infera_hip_get_plan(const char *model_name) {

@@ -58,6 +58,13 @@ def lib() -> C.CDLL:
         L.infera_sql_bench_scan.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64,
                                             C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
         L.infera_sql_bench_scan.restype = C.c_double
+        L.infera_sql_table_floats.argtypes = [C.c_uint64, C.c_uint32]
+        L.infera_sql_table_floats.restype = C.c_uint64
+        L.infera_sql_synth_table.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32]
+        L.infera_sql_synth_table.restype = None
+        L.infera_sql_bench_scan_table.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32,
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
+        L.infera_sql_bench_scan_table.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -203,3 +210,38 @@ def bench_scan(function: str, model: str, rows: int, ncols: int, threads: int, p
     if sec < 0:
         raise SqlError(err.value.decode())
     return sec, cs.value
+
+
+ROW_GROUP = 122880  # INFERA_SQL_ROW_GROUP
+
+
+def synth_table(rows: int, ncols: int, seed: int = 42, threads: int = 8) -> np.ndarray:
+    """A materialised columnar table in host memory (row groups of 122,880 rows, one contiguous run per column inside a
+    group), filled with the generator of SURVEY.md 8d.  Flat f32 array of rows*ncols elements."""
+    t = np.empty(int(lib().infera_sql_table_floats(rows, ncols)), np.float32)
+    lib().infera_sql_synth_table(t.ctypes.data, seed, rows, ncols, threads)
+    return t
+
+
+def table_rows(table: np.ndarray, rows: int, ncols: int, r0: int, n: int) -> np.ndarray:
+    """Rows [r0, r0+n) of such a table as a row-major [n, ncols] array (tests)."""
+    out = np.empty((n, ncols), np.float32)
+    for i in range(n):
+        r = r0 + i
+        g0 = r // ROW_GROUP * ROW_GROUP
+        gr = min(ROW_GROUP, rows - g0)
+        out[i] = table[g0 * ncols + (r - g0): g0 * ncols + ncols * gr: gr][:ncols]
+    return out
+
+
+def bench_scan_table(function: str, model: str, table: np.ndarray, rows: int, ncols: int, threads: int, reps: int = 1):
+    """`reps` complete scans of a materialised table through the SQL surface; returns ([seconds per scan], checksum)."""
+    assert table.dtype == np.float32 and table.flags.c_contiguous and table.size >= rows * ncols
+    secs = (C.c_double * reps)()
+    cs = C.c_double()
+    err = C.create_string_buffer(512)
+    rc = lib().infera_sql_bench_scan_table(function.encode(), model.encode(), table.ctypes.data, rows, ncols, threads, reps, secs,
+                                           C.byref(cs), err, len(err))
+    if rc != 0:
+        raise SqlError(err.value.decode())
+    return list(secs), cs.value

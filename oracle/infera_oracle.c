@@ -2129,3 +2129,99 @@ double orc_bench_scan(const OrcModel *m, uint64_t rows, uint64_t ncols, uint64_t
   if (failed) return -1.0;
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- the same scan over a MATERIALISED columnar table (bench.py's cpu_baseline leg) -----------
+ * The table is generated once by the caller, OUTSIDE every timed region (8d: "excludes ... data generation"),
+ * in DuckDB's storage shape: row groups of ORC_ROW_GROUP rows, one contiguous run per column inside a group.
+ * Each worker takes 2048-row chunks from a shared counter, gathers them the way ExtractFeatures does
+ * (infera_extension.cpp:199-227: row-outer, column-inner, one boxed value per cell) or with a plain strided
+ * copy (boxed = 0, the best a CPU gather can do), and runs the graph single-threaded on the chunk
+ * (engine.rs:139-154: one Tract run per call; the reference's parallelism is DuckDB's worker threads). */
+#define ORC_ROW_GROUP 122880
+
+typedef struct {
+  const OrcModel *m;
+  const float *table;
+  uint64_t rows, ncols;
+  int chunk_rows, boxed;
+  uint64_t *next_chunk;
+  double checksum;
+  int failed;
+} TableScanArg;
+
+static void *table_scan_worker(void *p) {
+  TableScanArg *a = (TableScanArg *)p;
+  size_t F = (size_t)a->ncols, CH = (size_t)a->chunk_rows;
+  float *feat = (float *)xmalloc(F * CH * 4);  /* row-major gather target */
+  float *resv = (float *)xmalloc(CH * 64 * 4); /* result vector */
+  uint64_t nchunks = (a->rows + CH - 1) / CH;
+  t_arena.cap = (size_t)256 << 20;
+  t_arena.base = (char *)xmalloc(t_arena.cap);
+  t_arena.active = 1;
+  for (;;) {
+    uint64_t c = __atomic_fetch_add(a->next_chunk, 1, __ATOMIC_RELAXED);
+    if (c >= nchunks) break;
+    uint64_t r0 = c * CH, g0 = r0 / ORC_ROW_GROUP * ORC_ROW_GROUP;
+    uint64_t gr = a->rows - g0 < ORC_ROW_GROUP ? a->rows - g0 : ORC_ROW_GROUP;
+    size_t nr = (size_t)((a->rows - r0) < CH ? (a->rows - r0) : CH);
+    const float *base = a->table + g0 * F + (r0 - g0); /* column j of this chunk: base + j*gr */
+    if (a->boxed) {
+      size_t k = 0;
+      for (size_t r = 0; r < nr; r++)
+        for (size_t j = 0; j < F; j++) {
+          BoxedValue b = box_get_value(base + j * gr, r);
+          if (b.is_null) { a->failed = 1; }
+          float v;
+          switch (b.type_id) {
+            case 1: v = b.v.f; break;
+            case 2: v = (float)b.v.d; break;
+            case 3: v = (float)b.v.i32; break;
+            default: v = (float)b.v.i64; break;
+          }
+          feat[k++] = v;
+        }
+    } else {
+      for (size_t r = 0; r < nr; r++)
+        for (size_t j = 0; j < F; j++) feat[r * F + j] = base[j * gr + r];
+    }
+    OrcResult res;
+    char err[256];
+    t_arena.off = 0;
+    if (orc_predict(a->m, feat, nr, F, &res, err, sizeof err)) { a->failed = 1; break; }
+    size_t take = res.len < CH * 64 ? res.len : CH * 64;
+    for (size_t i = 0; i < take; i++) { resv[i] = res.data[i]; a->checksum += (double)res.data[i]; }
+    orc_free_result(&res);
+  }
+  t_arena.active = 0;
+  free(t_arena.base);
+  free(feat);
+  free(resv);
+  return NULL;
+}
+
+double orc_bench_scan_table(const OrcModel *m, const float *table, uint64_t rows, uint64_t ncols, int threads, int chunk_rows,
+                            int boxed, double *checksum) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  if (chunk_rows < 1 || ORC_ROW_GROUP % chunk_rows) return -1.0;
+  uint64_t next = 0;
+  pthread_t th[256];
+  TableScanArg args[256];
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int i = 0; i < threads; i++) {
+    args[i] = (TableScanArg){m, table, rows, ncols, chunk_rows, boxed, &next, 0.0, 0};
+    pthread_create(&th[i], NULL, table_scan_worker, &args[i]);
+  }
+  double cs = 0.0;
+  int failed = 0;
+  for (int i = 0; i < threads; i++) {
+    pthread_join(th[i], NULL);
+    cs += args[i].checksum;
+    failed |= args[i].failed;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (checksum) *checksum = cs;
+  if (failed) return -1.0;
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -73,6 +73,13 @@ void orc_synth_fill_rowmajor(float *dst, uint64_t seed, uint64_t row0, uint64_t 
 double orc_bench_scan(const OrcModel *m, uint64_t rows, uint64_t ncols, uint64_t seed, int threads,
                       int chunk_rows, int boxed, double *checksum);
 
+/* The same scan over a table MATERIALISED by the caller in host memory (row groups of 122,880 rows, one
+ * contiguous run per column inside a group -- infera_amd/csrc/binding/sql_surface.h uses the same layout), so
+ * that table generation is outside the timed region and the CPU baseline and the GPU path read
+ * the very same bytes.  chunk_rows must divide 122,880. */
+double orc_bench_scan_table(const OrcModel *m, const float *table, uint64_t rows, uint64_t ncols,
+                            int threads, int chunk_rows, int boxed, double *checksum);
+
 #ifdef __cplusplus
 }
 #endif

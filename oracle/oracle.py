@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         L.orc_synth_fill_rowmajor.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_bench_scan.restype = C.c_double
         L.orc_bench_scan.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.orc_bench_scan_table.restype = C.c_double
+        L.orc_bench_scan_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -126,6 +128,17 @@ class Model:
         if sec < 0:
             raise OracleError("bench scan failed")
         return sec, cs.value
+
+
+def bench_scan_table(model: "Model", table: np.ndarray, rows: int, ncols: int, threads: int = 1, chunk_rows: int = 2048,
+                     boxed: bool = True) -> tuple[float, float]:
+    """Scan of a materialised columnar table (row groups of 122,880 rows, see infera_oracle.h); (seconds, checksum)."""
+    assert table.dtype == np.float32 and table.flags.c_contiguous and table.size >= rows * ncols
+    cs = C.c_double()
+    sec = lib().orc_bench_scan_table(model._h, table.ctypes.data, rows, ncols, threads, chunk_rows, int(boxed), C.byref(cs))
+    if sec < 0:
+        raise OracleError("bench scan failed")
+    return sec, cs.value
 
 
 def synth_table(seed: int, row0: int, rows: int, ncols: int) -> np.ndarray:

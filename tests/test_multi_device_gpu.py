@@ -1,0 +1,126 @@
+"""The multi-device code path on a ONE-GPU box.
+
+`INFERA_DEVICES=0,0` makes two device *slots* (both on HIP ordinal 0): weights are uploaded once per slot, caller
+threads are dealt round-robin over the slots, each slot has its own staging contexts and submission gate.  Results
+placed by row offset must equal the single-slot scan bit for bit and the device-resident scan of the same rows.
+Also: bench.py's N>1 control path (two ranks sharing device 0) and its single-process `--host-path` shape.
+The library reads INFERA_DEVICES once per process, so every case runs in a child process."""
+from __future__ import annotations
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCAN = r"""
+import os, sys, json, threading
+sys.path.insert(0, %(root)r)
+import numpy as np
+from infera_amd import capi, onnx_writer, synth
+rows, cols, CH, T = %(rows)d, 128, 2048, %(threads)d
+path = onnx_writer.write(os.path.join(%(tmp)r, "mlp.onnx"), onnx_writer.mlp((128, 256, 64, 1)))
+capi.load_model("m", path)
+x = synth.table(42, 0, rows, cols)
+colmajor = np.ascontiguousarray(x.T)            # one contiguous run per column, like a DuckDB vector
+out = np.empty((rows, 1), np.float32)
+nchunks = (rows + CH - 1) // CH
+lock, nxt, errs = threading.Lock(), [0], []
+def worker():
+    try:
+        while True:
+            with lock:
+                c = nxt[0]; nxt[0] += 1
+            if c >= nchunks: return
+            r0, r1 = c * CH, min(rows, (c + 1) * CH)
+            out[r0:r1] = capi.predict_columns("m", [colmajor[j, r0:r1] for j in range(cols)])
+    except Exception as e:  # noqa
+        errs.append(repr(e))
+ths = [threading.Thread(target=worker) for _ in range(T)]
+[t.start() for t in ths]; [t.join() for t in ths]
+assert not errs, errs
+# the same rows through the device-resident entry (slot of ordinal 0)
+dev = capi.device_ordinal(0)
+d_in = capi.DeviceBuffer(dev, rows * cols * 4); d_out = capi.DeviceBuffer(dev, rows * 4)
+capi.synth_fill(d_in, 42, 0, rows, cols)
+capi.predict_device("m", d_in, rows, cols, d_out)
+resident = d_out.download((rows, 1))
+np.save(os.path.join(%(tmp)r, "out_%(tag)s.npy"), out)
+print("RESULT " + json.dumps({"devices": capi.get_devices()["devices"], "resident_equal": bool(np.array_equal(resident, out)),
+                              "count": capi.device_count()}))
+"""
+
+
+def _child(code, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+@pytest.mark.gpu
+def test_two_device_slots_on_one_gpu_match_single_slot(gpu_api, tmp_path):
+    rows = 2048 * 37 + 311
+    args = {"root": ROOT, "rows": rows, "threads": 6, "tmp": str(tmp_path)}
+    two = _child(SCAN % dict(args, tag="two"), {"INFERA_DEVICES": "0,0"})
+    one = _child(SCAN % dict(args, tag="one"), {"INFERA_DEVICES": "0"})
+    assert two["count"] == 2 and one["count"] == 1
+    slots = two["devices"]
+    assert [d["slot"] for d in slots] == [0, 1] and all(d["ordinal"] == 0 for d in slots)
+    # both slots really took chunks (threads are dealt round-robin), and every row was served exactly once
+    assert all(d["host_rows"] > 0 and d["host_calls"] > 0 for d in slots), slots
+    assert sum(d["host_rows"] for d in slots) == rows and one["devices"][0]["host_rows"] == rows
+    a, b = np.load(tmp_path / "out_two.npy"), np.load(tmp_path / "out_one.npy")
+    assert np.array_equal(a, b)                      # placement by row offset == single-slot scan, bit for bit
+    assert two["resident_equal"] and one["resident_equal"]
+    from infera_amd import synth
+    from oracle import oracle
+
+    path = os.path.join(str(tmp_path), "mlp.onnx")
+    want = oracle.Model(path).predict(synth.table(42, 0, rows, 128))
+    assert np.all(np.abs(a - want) <= 1e-4 * np.abs(want) + 1e-6)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_one_gpu(gpu_api):
+    """bench.py's N>1 control path (gloo barrier, max over ranks, per-rank row ranges, concurrent host scans)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--rows", str(2048 * 300), "--share-device", "0", "--e2e-threads", "4", "--e2e-reps", "3"]
+    env = dict(os.environ)
+    env.pop("INFERA_DEVICES", None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["rows_per_gpu"] == 2048 * 300 and line["config"]["parallelism"] == "row-range x2"
+    e = line["end_to_end"]
+    assert e["ranks"] == 2 and e["threads_per_rank"] == 4 and len(e["scan_seconds"]) == 3 and e["rows_per_s"] > 0
+    assert "cpu_baseline" not in line  # rank 0 at N=1 only
+
+
+@pytest.mark.gpu
+def test_bench_host_path_single_process_two_slots(gpu_api):
+    """DuckDB's shape: one process, worker threads dealt over two device slots (both on GPU 0 here)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host-path", "--gpus", "2", "--share-device", "0", "--rows", str(2048 * 400),
+           "--e2e-threads", "8", "--e2e-reps", "3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["INFERA_DEVICES"] == "0,0"
+    slots = line["end_to_end"]["device_slots"]
+    assert len(slots) == 2 and all(s["rows_this_run"] > 0 for s in slots)
+    assert sum(s["rows_this_run"] for s in slots) == 3 * 2048 * 400
