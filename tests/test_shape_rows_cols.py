@@ -65,8 +65,10 @@ def test_gpu_results_report_rows_cols_by_the_rule(gpu_api, tmp_path, kind, cols,
     gpu_api.load_model("shp", p)
     try:
         got = gpu_api.predict_from_blob("shp", x.tobytes())
-        got2 = gpu_api.predict("shp", x)
+        # (infera_predict hands over a rank-2 tensor, which a rank-4 input rejects -- as in the reference, engine.rs:139-141)
+        with pytest.raises(gpu_api.InferaError, match="rank"):
+            gpu_api.predict("shp", x)
     finally:
         gpu_api.unload_model("shp")
-    assert got.shape == (rows, cols) == want.shape == got2.shape
-    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-6) and np.array_equal(got, got2)
+    assert got.shape == (rows, cols) == want.shape
+    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-6)

@@ -16,6 +16,8 @@ ap.add_argument("--threads", default="1,2,4,8,16,32,64")
 ap.add_argument("--workload", default="mlp")
 ap.add_argument("--dims", default="", help="custom MLP instead of a named workload, e.g. 30,100,2 (first = table columns)")
 ap.add_argument("--softmax", action="store_true")
+ap.add_argument("--pool", action="store_true", help="cache-resident per-thread chunk pool instead of the materialised table (round-1 behaviour)")
+ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
 tmp = tempfile.mkdtemp()
 if a.dims:
@@ -26,7 +28,15 @@ else:
     cols, fn = 128, "infera_predict" if a.workload == "mlp" else "infera_predict_array"
 capi.load_model("m", onnx_writer.write(os.path.join(tmp, "m.onnx"), blob))
 sqlmock.bench_scan(fn, "m", 2048 * 64, cols, 4)  # warm
-print(f"devices={capi.device_count()} workload={a.dims or a.workload} rows={a.rows} exec={capi.get_plan('m')['exec']}")
+print(f"devices={capi.get_devices()['devices']} workload={a.dims or a.workload} rows={a.rows} exec={capi.get_plan('m')['exec']} "
+      f"INFERA_HIPGRAPH={os.environ.get('INFERA_HIPGRAPH', '0')} source={'per-thread chunk pool' if a.pool else 'materialised columnar host table'}")
+table = None if a.pool else sqlmock.synth_table(a.rows, cols, 42, 16)
 for t in [int(x) for x in a.threads.split(",")]:
-    sec, cs = sqlmock.bench_scan(fn, "m", a.rows, cols, t)
-    print(f"threads={t:>3}  {a.rows / sec / 1e6:>9.2f} M rows/s  ({a.rows * cols * 4 / sec / 1e9:.2f} GB/s of features)  checksum={cs:.4f}")
+    if a.pool:
+        sec, cs = sqlmock.bench_scan(fn, "m", a.rows, cols, t)
+        secs = [sec]
+    else:
+        secs, cs = sqlmock.bench_scan_table(fn, "m", table, a.rows, cols, t, a.reps)
+    sec = sorted(secs)[len(secs) // 2]
+    print(f"threads={t:>3}  {a.rows / sec / 1e6:>9.2f} M rows/s  ({a.rows * cols * 4 / sec / 1e9:.2f} GB/s of features)  "
+          f"scans={[round(x, 4) for x in secs]}  checksum={cs:.4f}")
