@@ -137,7 +137,7 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
         cands = [max(4, min(24, budget["usable"] // world))]
     else:
         top = budget["usable"]
-        cands = sorted({t for t in (8, 16, 24, 32, 48, 64) if t <= max(8, top)})
+        cands = sorted({t for t in (8, 12, 16, 24, 32, 48, 64) if t <= max(8, 2 * top)})[:6]
     sqlmock.bench_scan_table(fn, model, table, min(rows, 60 * 2048 * 4), cols, cands[0], 1)  # contexts, pinned buffers, code objects
     sweep = {}
     if len(cands) > 1:
@@ -147,10 +147,13 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
         best_t = int(max(sweep, key=sweep.get))
     else:
         best_t = cands[0]
+    # what plain pinned H2D copies reach on this box: the practical ceiling of the link (best of two shapes)
+    dev0 = capi.device_ordinal(0)
+    h2d_measured = max(capi.h2d_probe(dev0, 8 << 20, 48, 2), capi.h2d_probe(dev0, 2 << 20, 128, 4))
     before = {d["slot"]: d["host_rows"] for d in capi.get_devices()["devices"]}
     barrier()
     t0 = time.perf_counter()
-    secs, checksum = sqlmock.bench_scan_table(fn, model, table, rows, cols, best_t, reps)
+    (secs, checksum), phases = sqlmock.phase_breakdown(sqlmock.bench_scan_table, fn, model, table, rows, cols, best_t, reps)
     barrier()
     wall = max_over_ranks(time.perf_counter() - t0)
     secs_sorted = sorted(secs)
@@ -169,6 +172,9 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
             "pcie_h2d_gbs_per_gpu": h2d, "pcie_d2h_gbs_per_gpu": d2h,
             "pcie_peak_gbs": PCIE_RAW_GBS, "pcie_achievable_gbs": PCIE_ACHIEVABLE_GBS,
             "frac_of_pcie": h2d / PCIE_RAW_GBS, "frac_of_pcie_achievable": h2d / PCIE_ACHIEVABLE_GBS,
+            "h2d_measured_gbs": h2d_measured, "frac_of_h2d_measured": h2d / h2d_measured if h2d_measured > 0 else None,
+            "h2d_measured_note": "plain pinned hipMemcpyAsync H2D on this box, no model (infera_hip_h2d_probe: 2 threads x 8 MiB and 4 x 2 MiB, best)",
+            "us_per_chunk_per_thread": phases,
             "pcie_bound_rows_per_s_per_gpu": {"raw": PCIE_RAW_GBS * 1e9 / (cols * 4), "achievable": PCIE_ACHIEVABLE_GBS * 1e9 / (cols * 4)},
             "device_slots": [{"slot": d["slot"], "ordinal": d["ordinal"], "rows_this_run": d["host_rows"] - before.get(d["slot"], 0)} for d in after]}
 

@@ -105,6 +105,11 @@ struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_na
  * (d0, max(prod(rest),1)).  infera_predict* report rows/cols of every result through exactly this function. */
 void infera_hip_shape_rows_cols(const uint64_t *shape, uintptr_t rank, uint64_t *rows, uint64_t *cols);
 
+/* Measurement helper: GB/s that plain pinned hipMemcpyAsync host->device transfers reach on this box (`threads` threads x
+ * `iters` transfers of `bytes`, each on its own stream).  The ceiling bench.py's end_to_end block quotes beside the
+ * 64 GB/s raw PCIe Gen5 x16 figure.  < 0 on failure. */
+double infera_hip_h2d_probe(int32_t device, uint64_t bytes, int32_t iters, int32_t threads);
+
 /* sha256(data) as 64 lower-case hex characters: the key under which infera_load_model("http://...") caches a
  * remote model (`<cache_dir>/<sha256(url)>.onnx`, reference http.rs:186-190).  Free with infera_free. */
 char *infera_hip_sha256_hex(const char *data, uintptr_t len);

@@ -28,7 +28,7 @@ EXTENSION_SYMBOLS = [
     "infera_hip_predict_device", "infera_hip_sync", "infera_hip_time_predict_device", "infera_hip_malloc",
     "infera_hip_free", "infera_hip_memcpy_h2d", "infera_hip_memcpy_d2h", "infera_hip_synth_fill",
     "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch", "infera_gather_columns",
-    "infera_hip_sha256_hex", "infera_hip_shape_rows_cols",
+    "infera_hip_sha256_hex", "infera_hip_shape_rows_cols", "infera_hip_h2d_probe",
 ]
 
 
@@ -119,6 +119,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.infera_predict_from_blob_batch.restype = InferaInferenceResult
     L.infera_hip_shape_rows_cols.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.infera_hip_shape_rows_cols.restype = None
+    L.infera_hip_h2d_probe.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_int32]
+    L.infera_hip_h2d_probe.restype = C.c_double
     _lib = L
     return L
 
@@ -214,6 +216,11 @@ def shape_rows_cols(shape: Sequence[int]) -> tuple[int, int]:
     r, c = C.c_uint64(), C.c_uint64()
     load_library().infera_hip_shape_rows_cols(arr, len(shape), C.byref(r), C.byref(c))
     return r.value, c.value
+
+
+def h2d_probe(device: int, nbytes: int = 8 << 20, iters: int = 64, threads: int = 4) -> float:
+    """GB/s of plain pinned hipMemcpyAsync H2D on this box (the host link's practical ceiling)."""
+    return float(load_library().infera_hip_h2d_probe(device, nbytes, iters, threads))
 
 
 def device_count() -> int:

@@ -91,6 +91,8 @@ double infera_sql_bench_scan(const char *function, const char *model, uint64_t r
  *                             element consumed.  Table generation is outside every timed region.  0 / -1 (+err). */
 uint64_t infera_sql_table_floats(uint64_t rows, uint32_t ncols);
 void infera_sql_synth_table(float *table, uint64_t seed, uint64_t rows, uint32_t ncols, int32_t threads);
+/* after infera_sql_bench_scan_table: ns spent inside infera_sql_call / inside the worker loops, summed over threads and reps */
+void infera_sql_bench_last_times(uint64_t *call_ns, uint64_t *thread_ns);
 int32_t infera_sql_bench_scan_table(const char *function, const char *model, const float *table, uint64_t rows, uint32_t ncols,
                                     int32_t threads, int32_t reps, double *secs, double *checksum, char *err, uint64_t errlen);
 

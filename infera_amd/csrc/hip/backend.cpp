@@ -2,12 +2,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <shared_mutex>
 #include <sstream>
+#include <thread>
 
 #include "../host/common.hpp"
 
@@ -61,6 +63,17 @@ struct ThreadCtx {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // completion of the pass that last used staging slot 0 / 1
+  hipEvent_t done_ev = nullptr;                // blocking-sync event: a host-ABI call sleeps on it instead of spinning
+  // waits for everything enqueued on `stream` so far
+  void wait_stream() {
+    if (Config::get().host_wait == 1) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      return;
+    }
+    if (!done_ev) HIP_TRY(hipEventCreateWithFlags(&done_ev, hipEventBlockingSync | hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(done_ev, stream));
+    HIP_TRY(hipEventSynchronize(done_ev));
+  }
   void drop_graphs() {
     for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
     graphs.clear();
@@ -73,7 +86,7 @@ struct ThreadCtx {
     if (p) HIP_TRY(hipHostFree(p));
     p = nullptr;
     cap = 0;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), bytes, hipHostMallocDefault));  // (host-coherent: kernels may store results into it)
     cap = bytes;
   }
   void ensure_dev(float *&p, size_t &cap, size_t bytes) {
@@ -204,6 +217,14 @@ struct HostLease {
 // Host-ABI work served per device slot (calls, rows): lets a scan report how DuckDB's worker threads were dealt over
 // the GPUs (infera_hip_get_devices), and lets the tests see that a second slot really took its share.
 std::atomic<uint64_t> g_slot_calls[64], g_slot_rows[64];
+
+// Where a host-ABI call's wall time goes (single-pass path = one DataChunk per call), summed over all calls, in ns:
+// lease (waiting for a staging context), gather (caller's buffer -> pinned), gate (waiting for admission), enqueue
+// (H2D + kernels [+ D2H] API calls), wait (until the device is done), copy_out (pinned -> result buffer).
+// Seven steady_clock reads per call (~0.2 us) -- always on, reported by infera_hip_get_devices.
+enum HostPhase { kPhLease, kPhGather, kPhGate, kPhEnqueue, kPhWait, kPhCopyOut, kPhCount };
+std::atomic<uint64_t> g_phase_ns[kPhCount], g_phase_calls;
+inline uint64_t now_ns() { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
 
 int home_slot() {
   if (t_holder.home_slot < 0) t_holder.home_slot = int(g_next_home.fetch_add(1) % unsigned(devices().ids.size()));
@@ -501,6 +522,24 @@ void schedule(LoadedModel &m) {
 
   // scratch slots by liveness: a slot is reused once its buffer has been read for the last time
   auto eff = effective_steps(m);
+  {  // the served output: one writer (a fused streaming kernel that only stores it), no reader
+    int writers = 0, readers = 0;
+    bool streaming = false;
+    for (const auto &e : eff) {
+      if (e.writes == m.plan.out_buf) {
+        writers++;
+        const ExecKind k = m.exec[size_t(e.idx)];
+        streaming = k == ExecKind::Mlp3Head || k == ExecKind::ChainHead || k == ExecKind::DenseSoftmax;
+      }
+      for (int b : e.reads) readers += b == m.plan.out_buf;
+    }
+    m.out_write_once = writers == 1 && readers == 0 && streaming && m.plan.out_buf != 0;
+    int in_readers = 0;
+    for (const auto &e : eff)
+      for (int b : e.reads) in_readers += b == 0;
+    m.in_colmajor_ok = !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::Mlp3Head && eff[0].reads[0] == 0 &&
+                       kern::mlp3_colmajor_supported(m.mlp3_shape);
+  }
   const size_t nb = m.plan.buf_per_row.size();
   std::vector<int> last_read(nb, -1);
   for (size_t e = 0; e < eff.size(); e++)
@@ -661,7 +700,9 @@ int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
   return rows_pass;
 }
 
-void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, const float *d_in, float *d_out, int64_t rows) {
+// in_colmajor: d_in is one column-major chunk [in_per_row][rows] (only with m.in_colmajor_ok, which implies a single pass)
+void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, const float *d_in, float *d_out, int64_t rows,
+               bool in_colmajor = false) {
   const Plan &p = m.plan;
   if (rows <= 0) return;
   hipStream_t s = ctx.stream;
@@ -694,7 +735,9 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case ExecKind::Mlp3Head:
         {
           std::string why;
-          if (!kern::mlp3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_packed, buf(st[i + 2].out), nr, dm.num_cus, &why))
+          const bool cm = in_colmajor && x.in0 == 0;
+          if (cm && nr != rows) throw InferaError::onnx("internal: column-major input needs a single pass");
+          if (!kern::mlp3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_packed, buf(st[i + 2].out), nr, dm.num_cus, &why, cm))
             throw InferaError::onnx("fused MLP kernel launch failed: " + why);
           continue;
         }
@@ -802,6 +845,47 @@ const DeviceModel &device_model(const LoadedModel &m, int slot) {
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
+
+// What the host link really delivers on this box: `threads` threads, each looping {hipMemcpyAsync(bytes) from its own
+// pinned buffer on its own stream; wait} -- the ceiling the host path's "fraction of PCIe" is honestly compared with
+// (measured 46-48 GB/s on the round-2 MI355X boxes against 64 GB/s raw Gen5 x16).
+double h2d_probe_gbs(int device_ordinal, size_t bytes, int iters, int threads) {
+  if (threads < 1) threads = 1;
+  if (iters < 1) iters = 1;
+  std::atomic<int> failed{0};
+  auto worker = [&] {
+    hipStream_t s = nullptr;
+    char *pin = nullptr, *dev = nullptr;
+    hipEvent_t ev = nullptr;
+    bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void **>(&pin), bytes, hipHostMallocDefault) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&dev), bytes) == hipSuccess &&
+              hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
+    if (ok) std::memset(pin, 1, bytes);
+    for (int i = 0; ok && i < iters; i++)
+      ok = hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, s) == hipSuccess && hipEventRecord(ev, s) == hipSuccess &&
+           hipEventSynchronize(ev) == hipSuccess;
+    if (!ok) failed = 1;
+    if (ev) (void)hipEventDestroy(ev);
+    if (dev) (void)hipFree(dev);
+    if (pin) (void)hipHostFree(pin);
+    if (s) (void)hipStreamDestroy(s);
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; t++) th.emplace_back(worker);
+  for (auto &x : th) x.join();
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  (void)hipGetLastError();
+  return failed ? -1.0 : double(bytes) * iters * threads / sec / 1e9;
+}
+
+std::string host_phase_json() {
+  static const char *names[kPhCount] = {"lease", "gather", "gate", "enqueue", "wait", "copy_out"};
+  std::string o = "{\"passes\":" + std::to_string(g_phase_calls.load(std::memory_order_relaxed));
+  for (int i = 0; i < kPhCount; i++) o += std::string(",\"") + names[i] + "_ns\":" + std::to_string(g_phase_ns[i].load(std::memory_order_relaxed));
+  return o + "}";
+}
 
 void slot_counters(int slot, uint64_t *calls, uint64_t *rows) {
   *calls = g_slot_calls[size_t(slot) % 64].load(std::memory_order_relaxed);
@@ -916,7 +1000,9 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
   if (rows <= 0) return;
   const int slot = home_slot();
+  const uint64_t t_entry = now_ns();
   HostLease lease(slot);
+  const uint64_t t_leased = now_ns();
   ThreadCtx &ctx = *lease.c;
   const DeviceModel &dm = device_model(m, slot);
   g_slot_calls[size_t(slot) % 64].fetch_add(1, std::memory_order_relaxed);
@@ -983,6 +1069,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   }
   int64_t rows_pass = std::max<int64_t>(1, int64_t(kHostPassBytes / widest));
   rows_pass = std::min(rows_pass, rows);
+  const bool direct_out = !use_graph && m.out_write_once && Config::get().host_direct_out && size_t(rows_pass) * out_row <= (1u << 20);
   ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows_pass) * out_row);
   ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, size_t(rows_pass) * in_row);
@@ -990,8 +1077,11 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
     const int64_t nr = std::min(rows_pass, rows - r0);
     // The caller's buffer is only borrowed for the call (SURVEY.md 8b "Ownership"): stage it.
+    const uint64_t t_f0 = now_ns();
     fill(ctx.pin_in, r0, nr);
+    const uint64_t t_f1 = now_ns();
     GateHold admitted(gate_for_slot(slot), Config::get().max_inflight);  // until this pass has been synchronised
+    const uint64_t t_g = now_ns();
     hipGraphExec_t exec = nullptr;
     if (use_graph) {
       (void)prepare_scratch(m, ctx, nr);  // may reallocate (and drop graphs) -- before the lookup
@@ -1040,12 +1130,31 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
         continue;  // this chunk's result is already in h_out
       }
     } else {
-      upload_pass(ctx.pin_in, ctx.dev_in, nr);
-      exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr);
-      HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+      // column-major chunk straight into the model's first kernel when it can read one (no transpose launch)
+      const bool cm_direct = col_major && m.in_colmajor_ok && Config::get().host_fused_transpose;
+      if (cm_direct) HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+      else upload_pass(ctx.pin_in, ctx.dev_in, nr);
+      if (direct_out) {
+        // the plan's only writer of the result stores it straight into the pinned (host-coherent) buffer: a few KB per
+        // chunk over PCIe from the kernel's epilogue instead of one more enqueue + blit kernel + dependency per chunk
+        exec_plan(m, dm, ctx, ctx.dev_in, ctx.pin_out, nr, cm_direct);
+      } else {
+        exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr, cm_direct);
+        HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+      }
     }
-    HIP_TRY(hipStreamSynchronize(ctx.stream));  // (spinning on hipStreamQuery instead measured slower: 41 vs 69 M rows/s at 16 threads)
+    const uint64_t t_e = now_ns();
+    ctx.wait_stream();  // (spinning on hipStreamQuery instead measured slower: 41 vs 69 M rows/s at 16 threads)
+    const uint64_t t_w = now_ns();
     std::memcpy(h_out + size_t(r0) * (out_row / 4), ctx.pin_out, size_t(nr) * out_row);
+    const uint64_t t_c = now_ns();
+    if (r0 == 0) g_phase_ns[kPhLease].fetch_add(t_leased - t_entry, std::memory_order_relaxed);
+    g_phase_ns[kPhGather].fetch_add(t_f1 - t_f0, std::memory_order_relaxed);
+    g_phase_ns[kPhGate].fetch_add(t_g - t_f1, std::memory_order_relaxed);
+    g_phase_ns[kPhEnqueue].fetch_add(t_e - t_g, std::memory_order_relaxed);
+    g_phase_ns[kPhWait].fetch_add(t_w - t_e, std::memory_order_relaxed);
+    g_phase_ns[kPhCopyOut].fetch_add(t_c - t_w, std::memory_order_relaxed);
+    g_phase_calls.fetch_add(1, std::memory_order_relaxed);
   }
 }
 

@@ -30,6 +30,11 @@ struct DeviceSet {
 const DeviceSet &devices();
 // host-ABI calls / table rows served so far by device slot `slot` (index into DeviceSet::ids)
 void slot_counters(int slot, uint64_t *calls, uint64_t *rows);
+// {"passes":n,"lease_ns":..,"gather_ns":..,"gate_ns":..,"enqueue_ns":..,"wait_ns":..,"copy_out_ns":..}: where the wall
+// time of the host-ABI calls went so far (single-pass path), summed over all caller threads
+std::string host_phase_json();
+// GB/s of plain pinned hipMemcpyAsync H2D on this box (threads x iters transfers of `bytes`); < 0 on failure
+double h2d_probe_gbs(int device_ordinal, size_t bytes, int iters, int threads);
 
 // Constants of one plan step resident in one GPU's HBM.
 struct DeviceStep {
@@ -71,6 +76,12 @@ class LoadedModel {
   // Convolutional plans keep every 4-D activation except the caller's input CHANNELS-LAST (NHWC) so
   // the implicit-GEMM gathers and stores are 16-byte vectors; decided per plan in schedule().
   bool cq_mode = false;
+  // the served output is stored exactly once, by the plan's last kernel, and never read back: that kernel may write
+  // straight into host-visible pinned memory (host path, small results)
+  bool out_write_once = false;
+  // the plan's first kernel is the only reader of the input table and has a variant that reads a column-major chunk
+  // [cols][rows] directly (host path: no transpose kernel between the H2D copy and the model)
+  bool in_colmajor_ok = false;
   // ... except the caller's input and what elementwise preprocessing makes of it (x/255, (x - mean) / std in the graph):
   // those few-channel tensors stay NCHW and the first convolution reads them with the patch kernel.
   std::vector<char> nchw_buf;

@@ -67,8 +67,11 @@ bool mlp3_supported(const Mlp3Shape &sh, std::string *why = nullptr);
 size_t mlp3_packed_floats(const Mlp3Shape &sh);
 void mlp3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                const float *b3, float *packed);
+// x_colmajor: X is a column-major chunk [d0][rows] (the host path's staging of flat DuckDB columns); only for the chains
+// mlp3_colmajor_supported() names.
 bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
-          std::string *why = nullptr);
+          std::string *why = nullptr, bool x_colmajor = false);
+bool mlp3_colmajor_supported(const Mlp3Shape &sh);
 std::string mlp3_kernel_name(const Mlp3Shape &sh);
 
 // ---- fused chain of small Dense layers over tables of any width (chain_device.inc, specialised with hipRTC) ----

@@ -47,13 +47,13 @@ namespace {
 
 using namespace mlpdev;
 
-template <class C, int SPLIT, int P2S, int NW = 8>
+template <class C, int SPLIT, int P2S, int NW = 8, bool XCM = false>
 void launch_split(hipStream_t s, const float *X, const float *packed, float *Y, int64_t rows, int num_cus) {
   static std::atomic<uint64_t> attr_done{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp3_split_kernel<C, SPLIT, P2S, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp3_split_kernel<C, SPLIT, P2S, NW, XCM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::N_LDS * 4);
     attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
   }
@@ -61,7 +61,7 @@ void launch_split(hipStream_t s, const float *X, const float *packed, float *Y, 
   int64_t blocks = (ntiles + NW - 1) / NW;
   if (blocks > num_cus) blocks = num_cus;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((mlp3_split_kernel<C, SPLIT, P2S, NW>), dim3((unsigned)blocks), dim3(NW * 64), C::N_LDS * 4, s, X, packed, Y, rows);
+  hipLaunchKernelGGL((mlp3_split_kernel<C, SPLIT, P2S, NW, XCM>), dim3((unsigned)blocks), dim3(NW * 64), C::N_LDS * 4, s, X, packed, Y, rows);
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -126,7 +126,7 @@ bool layout_matches_cfg() {
          L.N_LDS == C::N_LDS;
 }
 
-template <class C>
+template <class C, bool XCM = false>
 void launch_cfg(hipStream_t s, const float *X, const float *packed, float *Y, int64_t rows, int num_cus) {
   // > 64 KiB of dynamic LDS needs the attribute, once per device (not per launch: it is a runtime
   // API call behind a lock, and launches may be inside a stream capture).
@@ -134,7 +134,7 @@ void launch_cfg(hipStream_t s, const float *X, const float *packed, float *Y, in
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp3_kernel<C, XCM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::N_LDS * 4);
     attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
   }
@@ -142,7 +142,7 @@ void launch_cfg(hipStream_t s, const float *X, const float *packed, float *Y, in
   int64_t blocks = (ntiles + C::WAVES - 1) / C::WAVES;
   if (blocks > num_cus) blocks = num_cus;  // persistent: one workgroup per CU (the LDS image allows only one)
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((mlp3_kernel<C>), dim3((unsigned)blocks), dim3(C::WAVES * 64), C::N_LDS * 4, s, X, packed, Y, rows);
+  hipLaunchKernelGGL((mlp3_kernel<C, XCM>), dim3((unsigned)blocks), dim3(C::WAVES * 64), C::N_LDS * 4, s, X, packed, Y, rows);
 }
 
 // Ahead-of-time instantiations.  (act codes: 0 none, 1 relu)
@@ -201,9 +201,23 @@ void mlp3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const floa
   pack_layout(mlp3_layout(sh.d0, sh.d1, sh.d2, sh.d3), W1, b1, W2, b2, W3, b3, packed);
 }
 
+bool mlp3_colmajor_supported(const Mlp3Shape &sh) { return aot_match(sh); }
+
 bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
-          std::string *why) {
+          std::string *why, bool x_colmajor) {
   if (rows <= 0) return true;
+  if (x_colmajor) {  // the host path's column-major chunks (ahead-of-time configurations only)
+#define X_(C)                                                                        \
+  if (matches<C>(sh)) {                                                              \
+    if constexpr (C::L3V) launch_split<C, 4, 8, 8, true>(s, X, packed, Y, rows, num_cus); \
+    else launch_cfg<C, true>(s, X, packed, Y, rows, num_cus);                        \
+    return true;                                                                     \
+  }
+    INFERA_MLP3_CONFIGS(X_)
+#undef X_
+    if (why) *why = "no column-major instantiation for this chain";
+    return false;
+  }
 #ifdef INFERA_MLP3_PROBES
   if (matches<CfgC2>(sh)) {
     const char *v = std::getenv("INFERA_MLP3_VARIANT");

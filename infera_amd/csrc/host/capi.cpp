@@ -296,7 +296,7 @@ char *infera_hip_get_devices(void) {
     o += "{\"arch\":" + json_str(ds.arch[i]) + ",\"cus\":" + std::to_string(ds.cus[i]) + ",\"host_calls\":" + std::to_string(calls) +
          ",\"host_rows\":" + std::to_string(rows) + ",\"ordinal\":" + std::to_string(ds.ids[i]) + ",\"slot\":" + std::to_string(i) + "}";
   }
-  o += "],\"reason\":" + json_str(ds.why) + "}";
+  o += "],\"host_phases\":" + host_phase_json() + ",\"reason\":" + json_str(ds.why) + "}";
   return dup_cstr(o);
 }
 
@@ -304,6 +304,12 @@ void infera_hip_shape_rows_cols(const uint64_t *shape, uintptr_t rank, uint64_t 
   const auto rc = shape_rows_cols(std::vector<uint64_t>(shape, shape + (shape ? rank : 0)));
   if (rows) *rows = rc.first;
   if (cols) *cols = rc.second;
+}
+
+double infera_hip_h2d_probe(int32_t device, uint64_t bytes, int32_t iters, int32_t threads) {
+  double r = -1.0;
+  guarded([&] { r = h2d_probe_gbs(device, size_t(bytes), iters, threads); });
+  return r;
 }
 
 char *infera_hip_get_plan(const char *model_name) {

@@ -88,6 +88,9 @@ const Config &Config::get() {
     c.use_hipgraph = env_flag("INFERA_HIPGRAPH", false);
     c.max_inflight = int(env_u64("INFERA_MAX_INFLIGHT", 12));
     c.host_contexts = std::max(1, int(env_u64("INFERA_HOST_CONTEXTS", 24)));
+    c.host_wait = env_or("INFERA_HOST_WAIT", "block") == "spin" ? 1 : 0;
+    c.host_direct_out = env_flag("INFERA_HOST_DIRECT_OUT", true);
+    c.host_fused_transpose = env_flag("INFERA_HOST_FUSED_TRANSPOSE", true);
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);
     c.max_rows_per_pass = env_u64("INFERA_MAX_ROWS_PER_PASS", 1ull << 18);
     c.batch_split = env_flag("INFERA_BATCH_SPLIT", false);

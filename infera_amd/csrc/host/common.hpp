@@ -92,6 +92,12 @@ struct Config {
   bool use_hipgraph;                  // INFERA_HIPGRAPH=0|1      replay a per-(model,rows) hipGraph {H2D,kernels,D2H} per
                                       //   host-path chunk.  Default 0: measured SLOWER than three direct stream
                                       //   enqueues on MI355X/ROCm 7.2 (60 vs 82 M rows/s at 16 threads)
+  int host_wait;                      // INFERA_HOST_WAIT=block|spin  how a host-ABI call waits for its chunk: block = sleep on a
+                                      //   blocking-sync event (the caller's core is free for other workers' gathers: what a
+                                      //   CPU-quota'd container or a busy DuckDB pipeline needs), spin = hipStreamSynchronize
+  bool host_direct_out;               // INFERA_HOST_DIRECT_OUT=0|1  the last kernel of a write-once plan stores its results
+                                      //   straight into the pinned result buffer (no D2H copy enqueue per chunk)
+  bool host_fused_transpose;          // INFERA_HOST_FUSED_TRANSPOSE=0|1  the fused MLP reads column-major chunks itself (no transpose kernel)
   bool fused_mlp;                     // INFERA_FUSED_MLP=0|1     whole-chain fused kernel when the plan allows
   uint64_t max_rows_per_pass;         // INFERA_MAX_ROWS_PER_PASS scratch bound for unfused plans
   bool batch_split;                   // INFERA_BATCH_SPLIT=0|1   a model with a FIXED leading dim B accepts any multiple

@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         L.infera_sql_bench_scan_table.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32,
                                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
         L.infera_sql_bench_scan_table.restype = C.c_int32
+        L.infera_sql_bench_last_times.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.infera_sql_bench_last_times.restype = None
         _lib = L
     return _lib
 
@@ -245,3 +247,27 @@ def bench_scan_table(function: str, model: str, table: np.ndarray, rows: int, nc
     if rc != 0:
         raise SqlError(err.value.decode())
     return list(secs), cs.value
+
+
+def bench_last_times() -> tuple[int, int]:
+    """(ns inside infera_sql_call, ns inside the worker loops) of the last bench_scan_table, summed over threads and reps."""
+    a, b = C.c_uint64(), C.c_uint64()
+    lib().infera_sql_bench_last_times(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def phase_breakdown(fn, *args, **kw):
+    """Runs fn (a bench_scan_table call) and returns (its result, per-chunk microseconds by phase): the engine's host-path
+    phases (infera_hip_get_devices) plus what the binding layer and the scan loop add around them."""
+    from . import capi
+
+    before = capi.get_devices()["host_phases"]
+    out = fn(*args, **kw)
+    after = capi.get_devices()["host_phases"]
+    n = max(1, after["passes"] - before["passes"])
+    ph = {k[:-3]: (after[k] - before[k]) / n / 1e3 for k in after if k.endswith("_ns")}
+    call_ns, thread_ns = bench_last_times()
+    ph["binding_layer"] = call_ns / n / 1e3 - sum(ph.values())
+    ph["scan_loop"] = (thread_ns - call_ns) / n / 1e3
+    ph["chunks"] = n
+    return out, {k: round(v, 1) for k, v in ph.items()}

@@ -36,7 +36,7 @@ for t in [int(x) for x in a.threads.split(",")]:
         sec, cs = sqlmock.bench_scan(fn, "m", a.rows, cols, t)
         secs = [sec]
     else:
-        secs, cs = sqlmock.bench_scan_table(fn, "m", table, a.rows, cols, t, a.reps)
+        (secs, cs), phases = sqlmock.phase_breakdown(sqlmock.bench_scan_table, fn, "m", table, a.rows, cols, t, a.reps)
     sec = sorted(secs)[len(secs) // 2]
     print(f"threads={t:>3}  {a.rows / sec / 1e6:>9.2f} M rows/s  ({a.rows * cols * 4 / sec / 1e9:.2f} GB/s of features)  "
-          f"scans={[round(x, 4) for x in secs]}  checksum={cs:.4f}")
+          f"scans={[round(x, 4) for x in secs]}  checksum={cs:.4f}" + ("" if a.pool else f"\n             us/chunk/thread: {phases}"))
