@@ -20,11 +20,12 @@ from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinfera_sqlmock.so")
-
-VARCHAR, FLOAT, DOUBLE, INTEGER, BIGINT, BLOB, BOOLEAN, LIST_FLOAT = range(8)
-_NP = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE, np.dtype(np.int32): INTEGER, np.dtype(np.int64): BIGINT}
-
-
+# Two implementations of the same C ABI (csrc/binding/sql_surface.h):
+#   "mock"        libinfera_sqlmock.so -- the SQL layer written over a mock chunk (also holds the scan benchmarks)
+#   "duckdb_stub" tests/duckdb_stub/libinfera_duckdb_stub.so -- the REAL DuckDB extension source
+#                 (csrc/binding/infera_extension_hip.cpp) compiled against a test-only stand-in for duckdb.hpp
+BACKENDS = {"mock": LIB_PATH,
+            "duckdb_stub": os.path.join(os.path.dirname(_HERE), "tests", "duckdb_stub", "libinfera_duckdb_stub.so")}
 class SqlError(RuntimeError):
     """Carries the message exactly as DuckDB would print it ("Invalid Input Error: ...")."""
 
@@ -39,6 +40,39 @@ class _Result(C.Structure):
                 ("rows", C.c_uint64), ("f32", C.POINTER(C.c_float)), ("boolean", C.POINTER(C.c_uint8)),
                 ("strings", C.POINTER(C.c_char_p)), ("list_offsets", C.POINTER(C.c_uint64)),
                 ("list_values", C.POINTER(C.c_float)), ("validity", C.POINTER(C.c_uint64))]
+
+
+_backend = "mock"
+_libs: dict = {}
+
+
+def set_backend(name: str) -> None:
+    """Selects which library `sql()` / `list_functions()` talk to (the benchmarks always use the mock)."""
+    global _backend
+    if name not in BACKENDS:
+        raise ValueError(name)
+    _backend = name
+
+
+def _sql_lib() -> C.CDLL:
+    if _backend == "mock":
+        return lib()
+    if _backend not in _libs:
+        capi.load_library()
+        path = BACKENDS[_backend]
+        if not os.path.exists(path):
+            raise capi.InferaError(f"{path} is missing: run __graft_entry__.build()")
+        L = C.CDLL(path)
+        L.infera_sql_call.argtypes = [C.c_char_p, C.POINTER(_Vector), C.c_size_t, C.c_size_t, C.POINTER(_Result)]
+        L.infera_sql_call.restype = C.c_int32
+        L.infera_sql_free_result.argtypes = [C.POINTER(_Result)]
+        L.infera_sql_list_functions.restype = C.c_void_p
+        _libs[_backend] = L
+    return _libs[_backend]
+
+VARCHAR, FLOAT, DOUBLE, INTEGER, BIGINT, BLOB, BOOLEAN, LIST_FLOAT = range(8)
+_NP = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE, np.dtype(np.int32): INTEGER, np.dtype(np.int64): BIGINT}
+
 
 
 _lib = None
@@ -72,10 +106,18 @@ def lib() -> C.CDLL:
 
 
 def list_functions() -> list[dict]:
-    p = lib().infera_sql_list_functions()
+    p = _sql_lib().infera_sql_list_functions()
     s = C.string_at(p).decode()
     C.CDLL(None).free(C.c_void_p(p))
     return json.loads(s)
+
+
+class Decimal:
+    """A DECIMAL(18, scale) argument vector for the duckdb_stub backend (test-only): int64 values scaled by 10**scale."""
+
+    def __init__(self, values, scale: int = 3):
+        self.scale = scale
+        self.raw = np.ascontiguousarray(np.round(np.asarray(values, np.float64) * 10 ** scale).astype(np.int64))
 
 
 def _validity_words(mask_valid: np.ndarray) -> np.ndarray:
@@ -137,6 +179,11 @@ def _make_vector(arg: Any, keep: list) -> tuple[_Vector, int | None]:
             keep.append(words)
             v.validity = words.ctypes.data_as(C.POINTER(C.c_uint64))
         return v, n
+    if isinstance(arg, Decimal):
+        keep.append(arg.raw)
+        v.type = 8 | (arg.scale << 8)
+        v.data = arg.raw.ctypes.data
+        return v, len(arg.raw)
     a = arg
     mask = None
     if isinstance(a, np.ma.MaskedArray):
@@ -170,7 +217,7 @@ def sql(function: str, *args: Any, rows: int | None = None):
         rows = counts[0] if counts else 1
     assert all(c == rows for c in counts), "all flat vectors of a chunk must have the same row count"
     res = _Result()
-    rc = lib().infera_sql_call(function.encode(), vecs, len(args), rows, C.byref(res))
+    rc = _sql_lib().infera_sql_call(function.encode(), vecs, len(args), rows, C.byref(res))
     try:
         if rc != 0:
             raise SqlError(res.error.decode() if res.error else "unknown error")
@@ -200,7 +247,7 @@ def sql(function: str, *args: Any, rows: int | None = None):
                        np.ctypeslib.as_array(res.list_values, shape=(res.list_offsets[rows],))[a:b].copy())
         return out
     finally:
-        lib().infera_sql_free_result(C.byref(res))
+        _sql_lib().infera_sql_free_result(C.byref(res))
 
 
 def bench_scan(function: str, model: str, rows: int, ncols: int, threads: int, pool_chunks: int = 8, seed: int = 42):

@@ -12,12 +12,16 @@ LINEAR = os.path.join(ROOT, "tests", "golden", "linear.onnx")
 MULTI = os.path.join(ROOT, "tests", "golden", "multi_output.onnx")
 
 
-@pytest.fixture(scope="module")
-def S(built):
+# Every test below runs twice: against the SQL layer written over the mock chunk (csrc/binding/sql_surface.cpp) and against
+# the REAL DuckDB extension source (csrc/binding/infera_extension_hip.cpp) compiled against tests/duckdb_stub/.
+@pytest.fixture(scope="module", params=["mock", "duckdb_stub"])
+def S(built, request):
     from infera_amd import sqlmock
 
     sqlmock.lib()
-    return sqlmock
+    sqlmock.set_backend(request.param)
+    yield sqlmock
+    sqlmock.set_backend("mock")
 
 
 # ---------------------------------------------------------------- CPU: registration / management / errors
