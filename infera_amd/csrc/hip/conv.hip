@@ -23,6 +23,7 @@
 #include "device_common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -439,6 +440,181 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
     }
   }
 #endif
+}
+
+// ---- weight-stationary persistent kernel --------------------------------------------------------------------------
+// For convolutions whose packed weights (of one M-slice of 32*MT features) fit in LDS -- ResNet's 64-channel 3x3 layers
+// (9*64*64*4 = 144 KB), the 64-channel stride-2 entry of layer2 in two 64-feature slices, every 1x1 downsample -- the tiled
+// kernel's per-stage weight slab, its barrier per stage and its one-tile-per-workgroup prologue / epilogue are all
+// overhead.  Here the structure is the fused MLP's (mlp_device.inc): a PERSISTENT workgroup (one per CU, NW waves) loads
+// its weight slice into LDS once, then every wave walks 32-pixel tiles on its own -- no barrier after the prologue.  A
+// stage is S 32-channel chunks of one tap: its A fragments come from LDS through the same unit pipeline (ds_read_b128
+// ring + 4 MFMAs, sched_barrier-pinned), its B operands are gathered from the channel-quad planes one stage ahead.  The
+// stage stream is CONTINUOUS across tiles: while the last stage of a tile runs, the first stage of the wave's next tile
+// is already being gathered, and the epilogue's loads / stores drain under the next tile's MFMAs.
+// Same packed weights as the tiled kernel (chunk-major, conv2d_tiled_pack), same summation order -> bit-identical results.
+template <int MT, int S, int NW>
+__global__ __launch_bounds__(NW * 64) void conv2d_ws_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+                                                           const float *__restrict__ bias, const float *__restrict__ residual,
+                                                           float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
+  constexpr int NB = 4 * S;   // B fragments (16 B per lane) per stage
+  constexpr int U = NB * MT;  // units per stage
+  constexpr int P = 3;        // A-fragment ring depth
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int OHW = g.OH * g.OW;
+  const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
+  const int CS = g.C / (32 * S), ntaps = g.kh * g.kw, nstages = ntaps * CS, nchunks = nstages * S;
+  // ---- the slice's weights: chunk c of the packed blob holds MTtot KB-tiles; ours are [mt0, mt0 + MT) ----
+  for (int i = threadIdx.x; i < nchunks * MT * 256; i += NW * 64) {
+    const int chunk = i / (MT * 256), rem = i - chunk * (MT * 256);
+    reinterpret_cast<f32x4 *>(wlds)[i] = reinterpret_cast<const f32x4 *>(Wp + (int64_t(chunk) * MTtot + mt0) * 1024)[rem];
+  }
+  __syncthreads();
+
+  const int64_t ntiles = (total_pix + 31) >> 5;
+  const int64_t tstride = int64_t(gridDim.x) * NW;
+  int64_t tile = int64_t(blockIdx.x) * NW + wave;
+  if (tile >= ntiles) return;
+  const int HW4 = g.H * g.W * 4;  // floats per channel-quad plane
+  const float *zp = g_zero_page + 4 * h;
+
+  // ---- prefetch cursor: the (tile, stage) whose B operands are gathered next ----
+  const float *p_xc = zp;  // receptive-field corner of this lane's pixel in the cursor's tile
+  uint64_t p_ok = 0;       // taps of that pixel that lie inside the image
+  int p_tap = 0, p_kx = 0, p_off = 0, p_base = 0;
+  auto enter_tile = [&](int64_t t) {
+    const int64_t pix = (t << 5) + r;
+    const bool pvalid = t < ntiles && pix < total_pix;
+    const int64_t n = pvalid ? pix / OHW : 0;
+    const int prem = pvalid ? int(pix % OHW) : 0;
+    const int oh = prem / g.OW, ow = prem % g.OW;
+    const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
+    p_xc = X + n * int64_t(g.H) * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
+    p_ok = 0;
+    if (pvalid) {
+      int tap = 0;
+      for (int ky = 0; ky < g.kh; ky++)
+        for (int kx = 0; kx < g.kw; kx++, tap++) {
+          const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
+          if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) p_ok |= uint64_t(1) << tap;
+        }
+    }
+    p_tap = p_kx = p_off = p_base = 0;
+  };
+  int64_t p_tile = tile;
+  // gathers the cursor's stage into b, then advances the cursor (wrapping into the wave's next tile)
+  auto gather = [&](f32x4(&b)[NB]) {
+    const bool ok = (p_ok >> p_tap) & 1;
+    const float *p = ok ? p_xc + p_off : zp;
+    const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;  // group q+1 = two channel-quad planes further
+#pragma unroll
+    for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
+    p_tap++;
+    p_kx++;
+    p_off += g.dw * 4;
+    if (p_kx == g.kw) {
+      p_kx = 0;
+      p_off += (g.dh * g.W - g.kw * g.dw) * 4;
+    }
+    if (p_tap == ntaps) {
+      p_tap = 0;
+      p_base += 2 * NB * HW4;
+      p_off = p_base;
+      if (p_base == CS * 2 * NB * HW4) {  // all channel blocks done: on to this wave's next tile (or a tile of zeros)
+        p_tile += tstride;
+        enter_tile(p_tile);
+      }
+    }
+  };
+
+  f32x16 acc[MT];
+  auto zero_acc = [&] {
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+  };
+  auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage) {
+    const f32x4 *wl = reinterpret_cast<const f32x4 *>(wlds + int64_t(stage) * S * MT * 1024) + lane;
+    auto fidx = [](int u) { return (((u / MT) / 4 * MT + u % MT) * 4 + (u / MT) % 4) * 64; };
+    f32x4 ring[P];
+#pragma unroll
+    for (int u = 0; u < P && u < U; u++) ring[u] = wl[fidx(u)];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int q = u / MT, t = u % MT;
+      const f32x4 a = ring[u % P];
+      if (u + P < U) ring[u % P] = wl[fidx(u + P)];
+      if (u == 0) gather(bn);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bc[q][j], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
+  const int64_t OHW4 = int64_t(OHW) * 4;
+  auto epilogue = [&](int64_t t) {
+    const int64_t pix = (t << 5) + r;
+    if (pix >= total_pix) return;
+    const int64_t n = pix / OHW;
+    const int prem = int(pix - n * OHW);
+    const int64_t yoff = n * OHW * int64_t(g.M) + int64_t(8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+    float *yp = Y + yoff;
+    const float *rp = residual ? residual + yoff : nullptr;
+    auto fetch = [&](f32x4(&bv)[4], f32x4(&rv)[4], int t) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    dispatch_act(act.kind, [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
+      f32x4 bv[2][4], rv[2][4];
+      fetch(bv[0], rv[0], 0);
+#pragma unroll
+      for (int t = 0; t < MT; t++) {
+        if (t + 1 < MT) fetch(bv[(t + 1) & 1], rv[(t + 1) & 1], t + 1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[t][4 * q + j] + bv[t & 1][q][j]) + rv[t & 1][q][j], act.a, act.b);
+          *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
+        }
+      }
+    });
+  };
+
+  // One tile: its first stage is already in `ba`; on return the first stage of the wave's next tile is in `ba` when the
+  // stage count is even and in `bb` when it is odd (the caller alternates the roles).
+  auto run_tile = [&](f32x4(&ba)[NB], f32x4(&bb)[NB], int64_t t) {
+    zero_acc();
+    int stage = 0;
+    for (; stage + 2 <= nstages; stage += 2) {
+      step(ba, bb, stage);
+      step(bb, ba, stage + 1);
+    }
+    if (stage < nstages) step(ba, bb, stage);
+    epilogue(t);
+  };
+
+  f32x4 b0[NB], b1[NB];
+  enter_tile(tile);
+  gather(b0);
+  const bool odd = nstages & 1;
+  for (;;) {
+    run_tile(b0, b1, tile);
+    tile += tstride;
+    if (tile >= ntiles) break;
+    if (odd) {
+      run_tile(b1, b0, tile);
+      tile += tstride;
+      if (tile >= ntiles) break;
+    }
+  }
 }
 
 // ---- patch kernel: few input channels, NCHW input (the network's first convolution) -------------------------
@@ -1000,7 +1176,19 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
   };
   // feature tiles per workgroup: the largest of 4, 3, 2, 1 that divides M / 32 (ResNet: 2 or 4; MobileNet-style
   // widths such as 96, 160, 576, 960 take 3, 1, 3, 3)
-  const int m32 = g.M / 32, mt_pick = m32 % 4 == 0 ? 4 : m32 % 3 == 0 ? 3 : m32 % 2 == 0 ? 2 : 1;
+  const int m32 = g.M / 32;
+  int mt_pick = m32 % 4 == 0 ? 4 : m32 % 3 == 0 ? 3 : m32 % 2 == 0 ? 2 : 1;
+  // Few, long workgroups leave a tail: ResNet's 512-channel 3x3 layers are 1568 workgroups of 128 features x 72 stages
+  // on 512 slots -- three full rounds and a fourth that is 6 % full yet lasts a whole lone-workgroup time (13 % of the
+  // launch).  Below ~8 rounds 64-feature tiles (twice the workgroups, a quarter of the tail) win on stride-1 3x3 layers:
+  // 1.91 -> 1.79 ms (512 channels), 1.80 -> 1.76 (256); stride-2 and 1x1 layers lose (more slices re-gather more) and stay.
+  if (mt_pick == 4 && g.sh == 1 && g.sw == 1 && g.kh * g.kw > 1 && !g.padc && g.mvalid == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static int cus[64] = {};
+    if (!cus[dev & 63]) (void)hipDeviceGetAttribute(&cus[dev & 63], hipDeviceAttributeMultiprocessorCount, dev);
+    if (int64_t(bx) * (m32 / 4) < int64_t(8) * 2 * std::max(1, cus[dev & 63])) mt_pick = 2;
+  }
   const bool wide = mt_pick == 4, deep = g.C % 64 == 0;
 #ifdef INFERA_CONV_PROBES
   static const int probe = getenv("INFERA_CONV_PROBE") ? atoi(getenv("INFERA_CONV_PROBE")) : 0;
@@ -1036,6 +1224,36 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
     else if (mt_pick == 2) deep ? launch(conv2d_tiled_kernel<2, 2, 0, 1>, 2) : launch(conv2d_tiled_kernel<2, 1, 0, 1>, 2);
     else deep ? launch(conv2d_tiled_kernel<1, 2, 0, 1>, 1) : launch(conv2d_tiled_kernel<1, 1, 0, 1>, 1);
     return;
+  }
+  // Weight-stationary persistent kernel when one M-slice of the packed weights fits in LDS (64-channel 3x3 layers, 1x1
+  // downsamples): no per-stage weight slab, no barrier in the main loop, the stage stream runs through tile boundaries.
+  // INFERA_CONV_WS: 0 = never, 1 (default) = when the launch has enough tiles to fill the persistent grid, 2 = whenever
+  // the weights fit (tests).  Read per launch so one process can compare the two kernels.
+  const char *ws_env = getenv("INFERA_CONV_WS");
+  const int ws_mode = ws_env ? atoi(ws_env) : 1;
+  if (ws_mode == 2 || ((ws_mode == 1 || ws_mode == 3) && total_pix >= 32 * 2048)) {
+    constexpr size_t kWsLdsBytes = 160 * 1024 - 256;
+    const size_t slice32 = size_t(g.kh) * g.kw * g.C * 32 * sizeof(float);  // packed weights of 32 output features
+    auto launch_ws = [&](auto kernel, int mt, int nw) {
+      const size_t lds = slice32 * mt;
+      static std::atomic<uint64_t> attr_done{0};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      static int cus[64] = {};
+      if (!cus[dev & 63]) (void)hipDeviceGetAttribute(&cus[dev & 63], hipDeviceAttributeMultiprocessorCount, dev);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kWsLdsBytes));
+      (void)attr_done;
+      const unsigned slices = unsigned(g.M / (32 * mt));
+      const int64_t ntiles = (total_pix + 31) / 32;
+      unsigned gx = unsigned(std::max(1, cus[dev & 63] / int(slices)));
+      gx = unsigned(std::min<int64_t>(gx, (ntiles + nw - 1) / nw));
+      hipLaunchKernelGGL(kernel, dim3(gx, slices), dim3(unsigned(nw) * 64), lds, s, X, packed, bias, residual, Y, total_pix, g, act);
+    };
+    if (m32 % 4 == 0 && slice32 * 4 <= kWsLdsBytes) return deep ? launch_ws(conv2d_ws_kernel<4, 2, 8>, 4, 8) : launch_ws(conv2d_ws_kernel<4, 1, 8>, 4, 8);
+    if (m32 % 2 == 0 && slice32 * 2 <= kWsLdsBytes) return deep ? launch_ws(conv2d_ws_kernel<2, 2, 8>, 2, 8) : launch_ws(conv2d_ws_kernel<2, 1, 8>, 2, 8);
+    // 128-channel 3x3 layers: 32-feature slices still fit (144 KB); twice the gathers per MFMA of the 64-feature form, yet
+    // 1.76-1.78 ms against the tiled kernel's 1.79-1.81 per 236.8 GFLOP layer, and 0.94 against 0.98 ms on the stride-2 entry
+    if (deep && slice32 <= kWsLdsBytes && ws_mode != 3) return launch_ws(conv2d_ws_kernel<1, 2, 8>, 1, 8);
   }
   if (wide && deep) launch(conv2d_tiled_kernel<4, 2>, 4);
   else if (wide) launch(conv2d_tiled_kernel<4, 1>, 4);
