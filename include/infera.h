@@ -42,7 +42,10 @@ extern "C" {
  * weights to every selected GPU, registers under `name` (same name silently replaces,
  * engine.rs:74-80).  Paths starting with "http" are fetched into the on-disk model cache first, as in
  * the reference (lib.rs:47-58 -> http.rs:179-335: sha256(url) cache key, ETag revalidation, LRU eviction
- * under INFERA_CACHE_SIZE_LIMIT, retries); failures read "HTTP request failed: ...". 0 / -1. */
+ * under INFERA_CACHE_SIZE_LIMIT, retries); failures read "HTTP request failed: ...". 0 / -1.
+ * Additive: "<path>#<output>" registers the model with another graph output than the first as the one it serves
+ * (output name or decimal index; e.g. "clf.onnx#probabilities" beside "clf.onnx" = the label) -- the reference always
+ * serves output 0 (engine.rs:146-149).  A path that exists as written is taken as written. */
 int32_t infera_load_model(const char *name, const char *path);
 
 /* replaces rust.h:97 (lib.rs:81-102).  -1 + "Model not found: <name>" if absent. */

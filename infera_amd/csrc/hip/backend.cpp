@@ -933,13 +933,13 @@ DeviceModel::~DeviceModel() {
     if (p) (void)hipFree(p);
 }
 
-std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::string &path) {
+std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::string &path, const std::string &output_select) {
   static std::atomic<uint64_t> next_uid{1};
   auto m = std::make_shared<LoadedModel>();
   m->uid = next_uid.fetch_add(1);
   m->name = name;
   onnx::Model om = onnx::parse_file(path);
-  m->plan = lower_model(om);
+  m->plan = lower_model(om, output_select);
   schedule(*m);
   const DeviceSet &ds = devices();
   if (ds.ids.empty()) {

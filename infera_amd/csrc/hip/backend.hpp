@@ -101,7 +101,7 @@ class LoadedModel {
 };
 
 // Parse + lower + upload.  Throws InferaError.
-std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::string &path);
+std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::string &path, const std::string &output_select = "");
 
 // Host-memory inference (infera_predict / infera_predict_from_blob): `h_in` is rows x in_per_row
 // f32 in pageable host memory; result written to `h_out` (rows x out_per_row).  Blocks until done.

@@ -113,9 +113,17 @@ extern "C" {
 int32_t infera_load_model(const char *name, const char *path) {
   return guarded([&] {
            if (!name || !path) throw InferaError::null_pointer();
-           std::string n = checked_str(name), p = checked_str(path);
+           std::string n = checked_str(name), p = checked_str(path), select;
+           // "<path>#<output>" serves another graph output than the first (name or index) -- additive: a path that exists
+           // as written, '#' included, is taken as written; a URL's fragment never reaches the server anyway.
+           const size_t hash = p.rfind('#');
+           if (hash != std::string::npos && hash + 1 < p.size() && p.find('/', hash) == std::string::npos &&
+               (p.rfind("http", 0) == 0 || ::access(p.c_str(), F_OK) != 0)) {
+             select = p.substr(hash + 1);
+             p.resize(hash);
+           }
            if (p.rfind("http", 0) == 0) p = remote::handle_remote_model(p);  // lib.rs:47-51: fetch / revalidate into the cache
-           engine::load_model(n, p);
+           engine::load_model(n, p, select);
          })
              ? 0
              : -1;

@@ -32,10 +32,10 @@ std::string debug_i64(const std::vector<int64_t> &v, size_t from) {
 }
 }  // namespace
 
-void load_model(const std::string &name, const std::string &path) {
+void load_model(const std::string &name, const std::string &path, const std::string &output_select) {
   // Lowering and the HBM upload happen outside the registry lock; only the insert is exclusive
   // (the reference holds the write lock just for the insert too, engine.rs:80).
-  std::shared_ptr<const LoadedModel> m = build_model(name, path);
+  std::shared_ptr<const LoadedModel> m = build_model(name, path, output_select);
   std::unique_lock<std::shared_mutex> lk(g_mu);
   g_models[name] = std::move(m);  // same name silently replaces (engine.rs:74-80)
 }

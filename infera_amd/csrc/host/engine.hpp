@@ -27,7 +27,8 @@ std::pair<uint64_t, uint64_t> shape_rows_cols(const std::vector<uint64_t> &shape
 
 namespace engine {
 
-void load_model(const std::string &name, const std::string &path);  // replaces an existing name
+// replaces an existing name; output_select: "" = first graph output, else an output's name or decimal index
+void load_model(const std::string &name, const std::string &path, const std::string &output_select = "");
 bool unload_model(const std::string &name);
 std::shared_ptr<const LoadedModel> find(const std::string &name);  // throws ModelNotFound
 std::vector<std::string> loaded_names();

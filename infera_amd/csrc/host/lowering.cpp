@@ -73,7 +73,25 @@ struct Lowerer {
   std::map<int, int> alias_edges;  // nodes folded away whose input AND output denote the buffer
   std::set<int> int_bufs;  // buffers whose f32 values are whole numbers by construction (ArgMax, integer Cast, label arithmetic)
 
-  explicit Lowerer(const onnx::Model &model) : m(model) {}
+  Lowerer(const onnx::Model &model, const std::string &output_select) : m(model) {
+    // Which graph output is served.  Default: the first (engine.rs:146-149).  A selector names another one, by output
+    // name or by decimal index (infera_load_model(name, "model.onnx#probabilities"), SURVEY.md 8f-3 "named / multi outputs").
+    if (m.outputs.empty()) throw InferaError::onnx("model has no outputs");
+    if (!output_select.empty()) {
+      bool found = false;
+      for (size_t i = 0; i < m.outputs.size() && !found; i++)
+        if (m.outputs[i].name == output_select) out_index = i, found = true;
+      if (!found && output_select.find_first_not_of("0123456789") == std::string::npos && output_select.size() < 6 &&
+          size_t(std::atoi(output_select.c_str())) < m.outputs.size())
+        out_index = size_t(std::atoi(output_select.c_str())), found = true;
+      if (!found) {
+        std::string names;
+        for (const auto &o : m.outputs) names += (names.empty() ? "" : ", ") + o.name;
+        throw InferaError::onnx("model has no output '" + output_select + "' (outputs: " + names + ")");
+      }
+    }
+  }
+  size_t out_index = 0;
 
   int new_buf(const std::vector<int64_t> &shape) {
     // [N,C,L] tensors (1-D convolutional nets) are laid out and scheduled as [N,C,1,L]; values keep their 3-D shape
@@ -1457,7 +1475,7 @@ struct Lowerer {
       std::map<std::string, size_t> producer_of;
       for (size_t i = 0; i < m.nodes.size(); i++)
         for (const auto &o : m.nodes[i].outputs) producer_of[o] = i;
-      std::vector<std::string> work{m.outputs[0].name};
+      std::vector<std::string> work{m.outputs[out_index].name};
       while (!work.empty()) {
         const std::string v = work.back();
         work.pop_back();
@@ -1470,7 +1488,7 @@ struct Lowerer {
     for (size_t i = 0; i < m.nodes.size(); i++)
       if (live[i])
         for (const auto &in_name : m.nodes[i].inputs) uses[in_name]++;
-    uses[m.outputs[0].name]++;
+    uses[m.outputs[out_index].name]++;
 
     if (m.inputs.size() > 1) {
       int64_t off = 0;
@@ -1502,8 +1520,8 @@ struct Lowerer {
       else if (!n.domain.empty() && n.domain != "ai.onnx") unsupported(n, "operator domain '" + n.domain + "'");
       else lower_node(n);
     }
-    // first output only (engine.rs:146-149)
-    const onnx::ValueDef &out = m.outputs[0];
+    // one output is served: the first (engine.rs:146-149) unless the load call selected another
+    const onnx::ValueDef &out = m.outputs[out_index];
     auto it = vals.find(out.name);
     if (it == vals.end()) throw InferaError::onnx("output '" + out.name + "' is never produced");
     if (it->second.is_const) throw InferaError::onnx("output '" + out.name + "' is a constant; nothing to run");
@@ -1532,7 +1550,7 @@ struct Lowerer {
 
 }  // namespace
 
-Plan lower_model(const onnx::Model &m) { return Lowerer(m).run(); }
+Plan lower_model(const onnx::Model &m, const std::string &output_select) { return Lowerer(m, output_select).run(); }
 
 double Plan::flops_per_row() const {
   double f = 0;

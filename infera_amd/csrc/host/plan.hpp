@@ -92,6 +92,7 @@ struct Plan {
 };
 
 // Throws InferaError::onnx on unsupported graphs.
-Plan lower_model(const onnx::Model &m);
+// output_select: "" = the first graph output (the reference's behaviour), else an output's name or decimal index.
+Plan lower_model(const onnx::Model &m, const std::string &output_select = "");
 
 }  // namespace infera_hip
