@@ -298,11 +298,17 @@ def main():
 
     # ---- the metric as SURVEY 8(d) defines it: the host path, PCIe included (all ranks scan concurrently) ----
     e2e, table = None, None
+    e2e_error = None
     if sql_fn and not args.no_end_to_end:
         e2e_rows = min(rows, 10_000_000) if args.workload != "mlp" else rows
-        table = sqlmock.synth_table(e2e_rows, cols, 42 + rank, min(32, max(1, budget["usable"] // world)))
-        e2e = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, args.e2e_reps, budget, world, barrier,
-                         shard.max_over_ranks)
+        try:
+            table = sqlmock.synth_table(e2e_rows, cols, 42 + rank, min(32, max(1, budget["usable"] // world)))
+            e2e = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, args.e2e_reps, budget, world, barrier,
+                             shard.max_over_ranks)
+        except Exception as exc:  # the contract fields above must still be reported (single rank; N > 1 would have hung in a barrier)
+            if world > 1:
+                raise
+            e2e_error = f"{type(exc).__name__}: {exc}"
 
     if rank == 0:
         total_rows = rows * world * args.steps
@@ -328,6 +334,8 @@ def main():
         }
         if e2e:
             line["end_to_end"] = e2e
+        elif e2e_error:
+            line["end_to_end"] = {"error": e2e_error}
         if world == 1 and not args.no_cpu_baseline:
             if table is None:
                 table = sqlmock.synth_table(min(rows, 10_000_000), cols, 42, min(32, budget["usable"]))

@@ -364,6 +364,44 @@ def test_full_size_c2_properties(api, models):
     assert abs(total - parts) <= 1e-6 * abs(total) + 1e-6
 
 
+def test_full_size_c3_row_range_sharding_on_one_gpu(api, models):
+    """BASELINE config C3 -- the same MLP over 100M rows x 128, row-range sharded over 8 GPUs -- as far as ONE GPU allows:
+    the 51.2 GB table fits in HBM (288 GB), so the eight 12.5M-row shards a rank each would scan (shard.row_range) are
+    scanned one after the other from their own freshly generated row ranges, results placed by row offset, and compared
+    with ONE scan of the whole 100M-row table: bit-identical (row-range sharding does not change any row's arithmetic).
+    Oracle parity on chunks sampled from every shard, and the checksum of the shards' checksums equals the table's."""
+    from infera_amd import shard, synth
+    from oracle import oracle
+
+    world, per_rank, cols = 8, 12_500_000, 128
+    rows = world * per_rank
+    api.load_model("mlp", models["mlp"])
+    dev = api.device_ordinal(0)
+    d_in = api.DeviceBuffer(dev, rows * cols * 4)
+    d_out = api.DeviceBuffer(dev, rows * 4)
+    api.synth_fill(d_in, 42, 0, rows, cols)
+    assert api.predict_device("mlp", d_in, rows, cols, d_out) == (rows, 1)
+    whole = d_out.download((rows,))
+    assert np.isfinite(whole).all()
+    d_shard_in = api.DeviceBuffer(dev, per_rank * cols * 4)
+    d_shard_out = api.DeviceBuffer(dev, per_rank * 4)
+    om = oracle.Model(models["mlp"])
+    rng = np.random.default_rng(3)
+    shard_sums = []
+    for rank in range(world):
+        r0, r1 = shard.row_range(rank, world, per_rank)
+        api.synth_fill(d_shard_in, 42, r0, per_rank, cols)       # what rank `rank` generates for itself (bench.py)
+        assert api.predict_device("mlp", d_shard_in, per_rank, cols, d_shard_out) == (per_rank, 1)
+        part = d_shard_out.download((per_rank,))
+        assert np.array_equal(part, whole[r0:r1]), f"shard {rank} differs from its row range of the whole-table scan"
+        shard_sums.append(part.astype(np.float64).sum())
+        for s in [0, per_rank - 2048] + list(rng.integers(0, per_rank - 2048, 3)):
+            x = synth.table(42, r0 + int(s), 2048, cols)
+            assert_close(part[s:s + 2048].reshape(-1, 1), om.predict(x))
+    total = whole.astype(np.float64).sum()
+    assert abs(total - sum(shard_sums)) <= 1e-6 * abs(total) + 1e-6
+
+
 def test_full_size_c4_properties(api, models):
     """BASELINE config C4 at full size (50M rows x 128 -> softmax over 10 classes, device-resident):
       * every output row is a probability vector (sums to 1 within 4 ulp * 10, entries in [0, 1]);
