@@ -36,6 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (the headline figure with 2:1 sparsity is never used)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -48,6 +49,9 @@ def parse_args():
     ap.add_argument("--workload", default="mlp", choices=["mlp", "logreg", "resnet18"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="bf16x3 = the OPTIONAL fast mode of the fused MLP (three bf16 MFMAs per product; NOT the parity path, "
+                         "never the default, never the headline): the line is labelled accordingly")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-path (PCIe-inclusive) scan")
     ap.add_argument("--e2e-threads", default="", help="worker-thread counts to sweep for the host path (default: from the CPU budget)")
     ap.add_argument("--e2e-reps", type=int, default=5)
@@ -197,6 +201,8 @@ def main():
         # One process per GPU: this rank's library instance must only create a context / upload weights on
         # ITS device (read once at library load, so set before importing the binding).
         os.environ.setdefault("INFERA_DEVICES", str(dev))
+    if args.precision != "fp32":
+        os.environ["INFERA_PRECISION"] = args.precision  # read once at library load
     if world > 1:
         # control plane only (barrier + max-reduce of one float); the data path has no collective
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -275,7 +281,11 @@ def main():
     iters = max(3, min(args.steps, 10))
     ms = capi.time_predict_device("bench", d_in, rows, cols, d_out, iters)
     kernel_s = ms / 1e3 / iters
-    if bound == "mfma":
+    bf16x3 = "bf16x3" in str(plan.get("precision", ""))
+    if bound == "mfma" and bf16x3:
+        # three bf16 MFMAs per product: the algorithmic-flop ceiling is the dense bf16 peak / 3
+        achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 3.0, "TFLOP/s"
+    elif bound == "mfma":
         achieved, peak, unit = flops_row * rows / kernel_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
     else:
         achieved, peak, unit = bytes_row * rows / kernel_s / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -284,7 +294,7 @@ def main():
     # tools/profile_bench.sh (separate rocprofv3 --pmc passes of this same command) and committed as
     # profiles/traffic_<workload>.json.  Reported only when that file matches this workload and row count.
     traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}{'_bf16x3' if bf16x3 else ''}.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("rows") == rows:
@@ -323,9 +333,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x3 products, f32 accumulate -- OPTIONAL fast mode, NOT parity precision" if bf16x3 else "f32",
             "data": "synthetic (counter-based splitmix64 table, seed 42; random-init weights seed 1234)",
             "config": {"workload": wl_name, "rows_per_gpu": rows, "features": cols, "parallelism": f"row-range x{world}",
+                       "precision": plan.get("precision", "fp32"),
                        "entry": "infera_hip_predict_device (inputs resident in HBM)",
                        "kernel": plan.get("fused_kernel", ",".join(plan["exec"]))},
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,

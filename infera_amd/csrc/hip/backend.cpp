@@ -315,6 +315,7 @@ void schedule(LoadedModel &m) {
         m.exec[i] = ExecKind::Mlp3Head;
         m.exec[i + 1] = m.exec[i + 2] = ExecKind::Skipped;
         m.mlp3_shape = sh;
+        m.bf16x3 = Config::get().precision_bf16x3 && kern::mlp3_bf16x3_supported(sh);
         have_mlp3 = true;
         i += 2;
         continue;
@@ -538,7 +539,7 @@ void schedule(LoadedModel &m) {
     for (const auto &e : eff)
       for (int b : e.reads) in_readers += b == 0;
     m.in_colmajor_ok = !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::Mlp3Head && eff[0].reads[0] == 0 &&
-                       kern::mlp3_colmajor_supported(m.mlp3_shape);
+                       kern::mlp3_colmajor_supported(m.mlp3_shape) && !m.bf16x3;
   }
   const size_t nb = m.plan.buf_per_row.size();
   std::vector<int> last_read(nb, -1);
@@ -586,6 +587,15 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
                       s2.bias.empty() ? nullptr : s2.bias.data(), s3.W.data(), s3.bias.empty() ? nullptr : s3.bias.data(),
                       packed.data());
       dm.mlp3_packed = upload(packed, us);
+      if (m.bf16x3) {
+        std::vector<unsigned char> pb(kern::mlp3_bf16x3_packed_bytes(m.mlp3_shape));
+        kern::mlp3_bf16x3_pack(m.mlp3_shape, s1.W.data(), s1.bias.empty() ? nullptr : s1.bias.data(), s2.W.data(),
+                               s2.bias.empty() ? nullptr : s2.bias.data(), s3.W.data(), s3.bias.empty() ? nullptr : s3.bias.data(), pb.data());
+        HIP_TRY(hipMalloc(&dm.mlp3_bf16x3_packed, pb.size()));
+        hipError_t e = hipMemcpyAsync(dm.mlp3_bf16x3_packed, pb.data(), pb.size(), hipMemcpyHostToDevice, us);
+        if (e == hipSuccess) e = hipStreamSynchronize(us);
+        if (e != hipSuccess) hip_fail(e, "hipMemcpy(bf16x3 weights)");
+      }
       continue;
     }
     if (m.exec[i] == ExecKind::ChainHead) {
@@ -737,6 +747,11 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           std::string why;
           const bool cm = in_colmajor && x.in0 == 0;
           if (cm && nr != rows) throw InferaError::onnx("internal: column-major input needs a single pass");
+          if (dm.mlp3_bf16x3_packed && !cm) {
+            if (!kern::mlp3_bf16x3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_bf16x3_packed, buf(st[i + 2].out), nr, dm.num_cus))
+              throw InferaError::onnx("bf16x3 MLP kernel launch failed");
+            continue;
+          }
           if (!kern::mlp3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_packed, buf(st[i + 2].out), nr, dm.num_cus, &why, cm))
             throw InferaError::onnx("fused MLP kernel launch failed: " + why);
           continue;
@@ -929,6 +944,7 @@ DeviceModel::~DeviceModel() {
       if (p) (void)hipFree(p);
   }
   if (mlp3_packed) (void)hipFree(mlp3_packed);
+  if (mlp3_bf16x3_packed) (void)hipFree(mlp3_bf16x3_packed);
   for (float *p : chain_packed)
     if (p) (void)hipFree(p);
 }
@@ -1187,7 +1203,9 @@ std::string LoadedModel::describe_json() const {
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";
   for (size_t i = 0; i < exec.size(); i++)
-    if (exec[i] == ExecKind::Mlp3Head) o << ",\"fused_kernel\":" << json_str(kern::mlp3_kernel_name(mlp3_shape));
+    if (exec[i] == ExecKind::Mlp3Head)
+      o << ",\"fused_kernel\":" << json_str(bf16x3 ? kern::mlp3_bf16x3_kernel_name(mlp3_shape) : kern::mlp3_kernel_name(mlp3_shape))
+        << ",\"precision\":" << json_str(bf16x3 ? "bf16x3 (NOT parity precision)" : "fp32");
   if (!chains.empty()) {
     o << ",\"chain_kernels\":[";
     for (size_t i = 0; i < chains.size(); i++) o << (i ? "," : "") << json_str(kern::chain_kernel_name(chains[i].shape));

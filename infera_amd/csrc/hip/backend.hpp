@@ -49,6 +49,7 @@ struct DeviceModel {
   int num_cus = 0;
   std::vector<DeviceStep> steps;
   float *mlp3_packed = nullptr;
+  void *mlp3_bf16x3_packed = nullptr;  // INFERA_PRECISION=bf16x3 only: hi/lo bf16 fragments of the same chain
   std::vector<float *> chain_packed;  // parameter block per LoadedModel::chains entry
   ~DeviceModel();
 };
@@ -82,6 +83,8 @@ class LoadedModel {
   // the plan's first kernel is the only reader of the input table and has a variant that reads a column-major chunk
   // [cols][rows] directly (host path: no transpose kernel between the H2D copy and the model)
   bool in_colmajor_ok = false;
+  // INFERA_PRECISION=bf16x3 and the fused chain has a bf16x3 instantiation: NOT parity precision
+  bool bf16x3 = false;
   // ... except the caller's input and what elementwise preprocessing makes of it (x/255, (x - mean) / std in the graph):
   // those few-channel tensors stay NCHW and the first convolution reads them with the patch kernel.
   std::vector<char> nchw_buf;

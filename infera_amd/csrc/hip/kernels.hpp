@@ -74,6 +74,15 @@ bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packe
 bool mlp3_colmajor_supported(const Mlp3Shape &sh);
 std::string mlp3_kernel_name(const Mlp3Shape &sh);
 
+// OPTIONAL fast mode (INFERA_PRECISION=bf16x3, never the parity path): every fp32 product as hi*hi + hi*lo + lo*hi on the
+// bf16 matrix cores (mlp_bf16x3.hip).  Ahead-of-time configurations only (the BASELINE trunk, heads <= 4 wide).
+bool mlp3_bf16x3_supported(const Mlp3Shape &sh);
+size_t mlp3_bf16x3_packed_bytes(const Mlp3Shape &sh);
+void mlp3_bf16x3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                      const float *b3, void *packed);
+bool mlp3_bf16x3(hipStream_t s, const Mlp3Shape &sh, const float *X, const void *packed, float *Y, int64_t rows, int num_cus);
+std::string mlp3_bf16x3_kernel_name(const Mlp3Shape &sh);
+
 // ---- fused chain of small Dense layers over tables of any width (chain_device.inc, specialised with hipRTC) ----
 // k0 table columns; layer l maps dims[l-1] (dims[-1] = k0) -> dims[l] and applies acts[l] (plan.hpp Act 0..5) with
 // parameters pa/pb; sm: 0 plain, 1 softmax, 2 log-softmax, 3 argmax (label only) over the last layer's <= 16 outputs.

@@ -91,6 +91,7 @@ const Config &Config::get() {
     c.host_wait = env_or("INFERA_HOST_WAIT", "block") == "spin" ? 1 : 0;
     c.host_direct_out = env_flag("INFERA_HOST_DIRECT_OUT", true);
     c.host_fused_transpose = env_flag("INFERA_HOST_FUSED_TRANSPOSE", true);
+    c.precision_bf16x3 = env_or("INFERA_PRECISION", "fp32") == "bf16x3";
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);
     c.max_rows_per_pass = env_u64("INFERA_MAX_ROWS_PER_PASS", 1ull << 18);
     c.batch_split = env_flag("INFERA_BATCH_SPLIT", false);

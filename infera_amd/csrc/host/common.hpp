@@ -98,6 +98,8 @@ struct Config {
   bool host_direct_out;               // INFERA_HOST_DIRECT_OUT=0|1  the last kernel of a write-once plan stores its results
                                       //   straight into the pinned result buffer (no D2H copy enqueue per chunk)
   bool host_fused_transpose;          // INFERA_HOST_FUSED_TRANSPOSE=0|1  the fused MLP reads column-major chunks itself (no transpose kernel)
+  bool precision_bf16x3;              // INFERA_PRECISION=fp32|bf16x3  bf16x3 = OPTIONAL fast mode for the fused MLP (three bf16 MFMAs per
+                                      //   product, ~2^-16 relative error per product): NOT the parity path, never the default
   bool fused_mlp;                     // INFERA_FUSED_MLP=0|1     whole-chain fused kernel when the plan allows
   uint64_t max_rows_per_pass;         // INFERA_MAX_ROWS_PER_PASS scratch bound for unfused plans
   bool batch_split;                   // INFERA_BATCH_SPLIT=0|1   a model with a FIXED leading dim B accepts any multiple
