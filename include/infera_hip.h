@@ -110,6 +110,12 @@ void infera_hip_shape_rows_cols(const uint64_t *shape, uintptr_t rank, uint64_t 
  * 64 GB/s raw PCIe Gen5 x16 figure.  < 0 on failure. */
 double infera_hip_h2d_probe(int32_t device, uint64_t bytes, int32_t iters, int32_t threads);
 
+/* The policy that deals caller threads over device slots, exposed so it can be tested without 8 GPUs: slots on the
+ * thread's own NUMA node first (round-robin among them by `ticket_on_node`), else round-robin over all slots by
+ * `ticket_global`.  slot_numa[i] = NUMA node of slot i's GPU (-1 unknown); thread_node < 0 = unknown. */
+int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32_t thread_node, uint64_t ticket_on_node,
+                               uint64_t ticket_global);
+
 /* sha256(data) as 64 lower-case hex characters: the key under which infera_load_model("http://...") caches a
  * remote model (`<cache_dir>/<sha256(url)>.onnx`, reference http.rs:186-190).  Free with infera_free. */
 char *infera_hip_sha256_hex(const char *data, uintptr_t len);

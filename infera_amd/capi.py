@@ -28,7 +28,7 @@ EXTENSION_SYMBOLS = [
     "infera_hip_predict_device", "infera_hip_sync", "infera_hip_time_predict_device", "infera_hip_malloc",
     "infera_hip_free", "infera_hip_memcpy_h2d", "infera_hip_memcpy_d2h", "infera_hip_synth_fill",
     "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch", "infera_gather_columns",
-    "infera_hip_sha256_hex", "infera_hip_shape_rows_cols", "infera_hip_h2d_probe",
+    "infera_hip_sha256_hex", "infera_hip_shape_rows_cols", "infera_hip_h2d_probe", "infera_hip_choose_slot",
 ]
 
 
@@ -119,6 +119,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.infera_predict_from_blob_batch.restype = InferaInferenceResult
     L.infera_hip_shape_rows_cols.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.infera_hip_shape_rows_cols.restype = None
+    L.infera_hip_choose_slot.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.c_int32, C.c_uint64, C.c_uint64]
+    L.infera_hip_choose_slot.restype = C.c_int32
     L.infera_hip_h2d_probe.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_int32]
     L.infera_hip_h2d_probe.restype = C.c_double
     _lib = L
@@ -221,6 +223,12 @@ def shape_rows_cols(shape: Sequence[int]) -> tuple[int, int]:
 def h2d_probe(device: int, nbytes: int = 8 << 20, iters: int = 64, threads: int = 4) -> float:
     """GB/s of plain pinned hipMemcpyAsync H2D on this box (the host link's practical ceiling)."""
     return float(load_library().infera_hip_h2d_probe(device, nbytes, iters, threads))
+
+
+def choose_slot(slot_numa: Sequence[int], thread_node: int, ticket_on_node: int, ticket_global: int) -> int:
+    """The thread -> device-slot dealing policy (NUMA-local slots first), as the library applies it."""
+    arr = (C.c_int32 * max(len(slot_numa), 1))(*slot_numa)
+    return int(load_library().infera_hip_choose_slot(arr, len(slot_numa), thread_node, ticket_on_node, ticket_global))
 
 
 def device_count() -> int:

@@ -1,9 +1,13 @@
 #include "backend.hpp"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -226,8 +230,46 @@ enum HostPhase { kPhLease, kPhGather, kPhGate, kPhEnqueue, kPhWait, kPhCopyOut, 
 std::atomic<uint64_t> g_phase_ns[kPhCount], g_phase_calls;
 inline uint64_t now_ns() { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
 
+// NUMA node of the CPU the calling thread runs on right now (-1 = unknown), from /sys/devices/system/node/node*/cpulist
+int current_numa_node() {
+  static const std::vector<int> node_of_cpu = [] {
+    std::vector<int> map;
+    for (int node = 0; node < 64; node++) {
+      FILE *fp = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+      if (!fp) continue;
+      char buf[4096];
+      const size_t n = std::fread(buf, 1, sizeof buf - 1, fp);
+      std::fclose(fp);
+      buf[n] = 0;
+      for (char *p = buf; *p;) {  // "0-63,128-191"
+        char *end;
+        const long a = std::strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        if (*end == '-') b = std::strtol(end + 1, &end, 10);
+        for (long c = a; c <= b && c < 4096; c++) {
+          if (size_t(c) >= map.size()) map.resize(size_t(c) + 1, -1);
+          map[size_t(c)] = node;
+        }
+        p = *end == ',' ? end + 1 : end;
+        if (*end != ',') break;
+      }
+    }
+    return map;
+  }();
+  const int cpu = sched_getcpu();
+  return cpu >= 0 && size_t(cpu) < node_of_cpu.size() ? node_of_cpu[size_t(cpu)] : -1;
+}
+
+std::atomic<uint64_t> g_next_home_on_node[64];
+
 int home_slot() {
-  if (t_holder.home_slot < 0) t_holder.home_slot = int(g_next_home.fetch_add(1) % unsigned(devices().ids.size()));
+  if (t_holder.home_slot < 0) {
+    const auto &ds = devices();
+    const int node = ds.ids.size() > 1 ? current_numa_node() : -1;
+    const uint64_t on_node = node >= 0 ? g_next_home_on_node[size_t(node) % 64].fetch_add(1) : 0;
+    t_holder.home_slot = choose_slot(ds.numa, node, on_node, g_next_home.fetch_add(1));
+  }
   return t_holder.home_slot;
 }
 
@@ -902,6 +944,21 @@ std::string host_phase_json() {
   return o + "}";
 }
 
+int choose_slot(const std::vector<int> &slot_numa, int thread_node, uint64_t ticket_on_node, uint64_t ticket_global) {
+  const size_t n = slot_numa.size();
+  if (n <= 1) return 0;
+  if (thread_node >= 0) {
+    size_t local = 0;
+    for (int nd : slot_numa) local += nd == thread_node;
+    if (local > 0) {
+      size_t want = size_t(ticket_on_node % local);
+      for (size_t i = 0; i < n; i++)
+        if (slot_numa[i] == thread_node && want-- == 0) return int(i);
+    }
+  }
+  return int(ticket_global % n);
+}
+
 void slot_counters(int slot, uint64_t *calls, uint64_t *rows) {
   *calls = g_slot_calls[size_t(slot) % 64].load(std::memory_order_relaxed);
   *rows = g_slot_rows[size_t(slot) % 64].load(std::memory_order_relaxed);
@@ -927,6 +984,18 @@ const DeviceSet &devices() {
       d.ids.push_back(id);
       d.cus.push_back(prop.multiProcessorCount);
       d.arch.push_back(prop.gcnArchName);
+      int node = -1;
+      char bdf[64] = {0};
+      if (hipDeviceGetPCIBusId(bdf, int(sizeof bdf), id) == hipSuccess) {
+        std::string b = bdf;
+        for (auto &ch : b) ch = char(std::tolower(static_cast<unsigned char>(ch)));
+        if (FILE *fp = std::fopen(("/sys/bus/pci/devices/" + b + "/numa_node").c_str(), "r")) {
+          if (std::fscanf(fp, "%d", &node) != 1) node = -1;
+          std::fclose(fp);
+        }
+      }
+      (void)hipGetLastError();
+      d.numa.push_back(node);
     }
     if (d.ids.empty()) d.why = "INFERA_DEVICES selects no usable HIP device";
     return d;

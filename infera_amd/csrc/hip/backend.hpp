@@ -25,8 +25,14 @@ struct DeviceSet {
   std::vector<int> ids;  // HIP ordinals selected by INFERA_DEVICES (default: all)
   std::vector<int> cus;  // multiprocessor count per selected device
   std::vector<std::string> arch;
+  std::vector<int> numa;  // NUMA node of the device's PCIe function (/sys/bus/pci/devices/<bdf>/numa_node), -1 = unknown
   std::string why;
 };
+// Which device slot a new caller thread gets ("NUMA-pin threads / pinned buffers to the socket that hosts the
+// GPU"): round-robin over the slots on the thread's own NUMA node when there are any -- its gathers then write pinned
+// staging that is local to both the thread and the GPU's root complex -- else round-robin over all slots.  Pure function
+// of its arguments (per-node tickets are kept by the caller); thread_node < 0 or all-unknown topology = plain round-robin.
+int choose_slot(const std::vector<int> &slot_numa, int thread_node, uint64_t ticket_on_node, uint64_t ticket_global);
 const DeviceSet &devices();
 // host-ABI calls / table rows served so far by device slot `slot` (index into DeviceSet::ids)
 void slot_counters(int slot, uint64_t *calls, uint64_t *rows);

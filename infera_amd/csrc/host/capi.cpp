@@ -302,7 +302,8 @@ char *infera_hip_get_devices(void) {
     uint64_t calls = 0, rows = 0;
     slot_counters(int(i), &calls, &rows);
     o += "{\"arch\":" + json_str(ds.arch[i]) + ",\"cus\":" + std::to_string(ds.cus[i]) + ",\"host_calls\":" + std::to_string(calls) +
-         ",\"host_rows\":" + std::to_string(rows) + ",\"ordinal\":" + std::to_string(ds.ids[i]) + ",\"slot\":" + std::to_string(i) + "}";
+         ",\"host_rows\":" + std::to_string(rows) + ",\"numa_node\":" + std::to_string(i < ds.numa.size() ? ds.numa[i] : -1) +
+         ",\"ordinal\":" + std::to_string(ds.ids[i]) + ",\"slot\":" + std::to_string(i) + "}";
   }
   o += "],\"host_phases\":" + host_phase_json() + ",\"reason\":" + json_str(ds.why) + "}";
   return dup_cstr(o);
@@ -318,6 +319,11 @@ double infera_hip_h2d_probe(int32_t device, uint64_t bytes, int32_t iters, int32
   double r = -1.0;
   guarded([&] { r = h2d_probe_gbs(device, size_t(bytes), iters, threads); });
   return r;
+}
+
+int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32_t thread_node, uint64_t ticket_on_node,
+                               uint64_t ticket_global) {
+  return choose_slot(std::vector<int>(slot_numa, slot_numa + (slot_numa ? nslots : 0)), thread_node, ticket_on_node, ticket_global);
 }
 
 char *infera_hip_get_plan(const char *model_name) {

@@ -79,3 +79,25 @@ def test_shard_arithmetic():
         assert max(sizes) - min(sizes) <= 1
     assert [shard.chunk_owner(i, 8) for i in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
     assert shard.max_over_ranks(3.5) == 3.5  # no process group: identity
+
+
+def test_numa_aware_slot_dealing(built):
+    """caller threads are dealt to the GPUs of their own socket first.  An 8-GPU node with GPUs 0-3 on NUMA
+    node 0 and 4-7 on node 1: threads on node 0 round-robin over slots 0-3, threads on node 1 over 4-7; unknown topology or
+    a node without GPUs falls back to round-robin over all slots; one slot is always slot 0."""
+    from infera_amd import capi
+
+    topo = [0, 0, 0, 0, 1, 1, 1, 1]
+    assert [capi.choose_slot(topo, 0, k, 100 + k) for k in range(8)] == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert [capi.choose_slot(topo, 1, k, 100 + k) for k in range(8)] == [4, 5, 6, 7, 4, 5, 6, 7]
+    assert [capi.choose_slot(topo, 2, 0, k) for k in range(10)] == [k % 8 for k in range(10)]     # a socket without GPUs
+    assert [capi.choose_slot(topo, -1, 0, k) for k in range(10)] == [k % 8 for k in range(10)]    # thread's node unknown
+    assert [capi.choose_slot([-1] * 4, 0, k, k) for k in range(6)] == [0, 1, 2, 3, 0, 1]          # GPU topology unknown
+    assert [capi.choose_slot([1, 0, 1, 0], 0, k, 7) for k in range(4)] == [1, 3, 1, 3]             # interleaved topology
+    assert capi.choose_slot([0], 1, 5, 9) == 0 and capi.choose_slot([], 0, 0, 0) == 0
+    # every slot of a node gets the same share: 64 threads per node on the 8-GPU topology
+    counts = [0] * 8
+    for node in (0, 1):
+        for k in range(64):
+            counts[capi.choose_slot(topo, node, k, 0)] += 1
+    assert counts == [16] * 8
