@@ -553,7 +553,17 @@ __global__ __launch_bounds__(NW * 64) void conv2d_ws_kernel(const float *__restr
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // this lane's bias quads stay in registers for the workgroup's lifetime: a tile's epilogue has no load to wait for except
+  // the residual (MT <= 2: 32 registers; wider tiles keep loading them, they have the registers' worth of accumulators)
+  constexpr bool BRES = MT <= 2;
   const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
+  f32x4 bres[BRES ? MT : 1][4];
+  if constexpr (BRES) {
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) bres[t][q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int64_t OHW4 = int64_t(OHW) * 4;
   auto epilogue = [&](int64_t t) {
     const int64_t pix = (t << 5) + r;
@@ -566,7 +576,8 @@ __global__ __launch_bounds__(NW * 64) void conv2d_ws_kernel(const float *__restr
     auto fetch = [&](f32x4(&bv)[4], f32x4(&rv)[4], int t) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BRES) bv[q] = bres[t][q];
+        else bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
         rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     };
@@ -730,6 +741,13 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
   const int4 *ktab4 = reinterpret_cast<const int4 *>(ktab) + h;
   const int OHW = g.OH * g.OW;
 
+  // the lane's bias quads: constant for the (persistent) workgroup's lifetime -- resident in registers, so a tile's epilogue
+  // is add -> activation -> store with no load to wait for (the tiles are only 152 MFMAs long)
+  f32x4 bres[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) bres[t][q] = bias ? reinterpret_cast<const f32x4 *>(bias)[h + 8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
   float pv[kPatchMaxE];
   // XCD x (= blockIdx.x % 8) owns the contiguous tile range [x*chunk, (x+1)*chunk): neighbouring tiles overlap in
   // their receptive fields, and the overlap should be found in THAT XCD's L2 (with a plain grid stride the
@@ -821,19 +839,15 @@ __global__ __launch_bounds__(kBlock) void conv2d_patch_kernel(const float *__res
       // g.mvalid > 0: M was padded to whole 32-feature tiles (stems with 16 / 24 outputs); planes past mvalid/4 do not exist
       const int mreal = g.mvalid > 0 ? g.mvalid : g.M;
       float *yp = Y + img * OHW * mreal + (int64_t(h) * OHW + oy * g.OW + ox) * 4;
-      const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias) + h : nullptr;
       dispatch_act(act.kind, [&](auto kind_tag) {
         constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
         for (int t = 0; t < MT; t++) {
-          f32x4 bv[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>(acc[t][4 * q + j] + bv[q][j], act.a, act.b);
+            for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>(acc[t][4 * q + j] + bres[t][q][j], act.a, act.b);
             if (4 * (8 * t + 2 * q + h) < mreal) *reinterpret_cast<f32x4 *>(yp + int64_t(8 * t + 2 * q) * OHW * 4) = v;
           }
         }
