@@ -128,8 +128,55 @@ def cpu_baseline(model_path: str, table, rows: int, cols: int, target_s: float, 
                       "reference-shaped CPU restatement, not Tract"}
 
 
+def cpu_baseline_blobs(model_path: str, cols: int, budget: dict) -> dict:
+    """Config C5's CPU baseline: the oracle with the reference's BLOB execution shape -- one inference per ROW (the reference
+    makes one FFI call and one batch-1 Tract run per BLOB, infera_extension.cpp:303-326), T threads."""
+    from oracle import oracle
+
+    m = oracle.Model(model_path)
+    t = budget["usable"]
+    sec1, _ = m.bench_scan(t, cols, seed=42, threads=t, chunk_rows=1, boxed=False)  # one image per thread: sizes the sample
+    rows = int(max(t, min(4096, t * max(1.0, 10.0 / max(sec1, 1e-3)))))  # ~10 s of CPU work
+    sec, _ = m.bench_scan(rows, cols, seed=42, threads=t, chunk_rows=1, boxed=False)
+    return {"value": rows / sec, "unit": "rows/s (images/s)", "cores": t, "kind": "port",
+            "sample": f"{rows} images of {cols} f32, one inference per row (the reference's per-BLOB FFI shape), oracle/infera_oracle.c on {t} threads, "
+                      f"{sec:.2f} s wall (image generation included: < 0.1 % of a 3.6 GFLOP inference)",
+            "cpu_budget": budget,
+            "caveat": "Tract itself cannot be built or timed in this image: this is the reference-shaped CPU restatement, not Tract"}
+
+
 PCIE_RAW_GBS = 64.0         # PCIe Gen5 x16, one direction, raw
 PCIE_ACHIEVABLE_GBS = 55.0  # what large pinned hipMemcpyAsync transfers reach (SURVEY.md 8d)
+
+
+def end_to_end_blobs(model: str, images, blob_bytes: int, out_cols: int, threads_arg: str, reps: int, budget: dict) -> dict:
+    """The BLOB path end to end (config C5): T threads x 2048-row chunks of an image table in host memory through
+    infera_sql_call('infera_predict_from_blob') -- one batched engine call per chunk, pipelined pinned staging, H2D, the
+    conv net, D2H, LIST result.  Rows cycle over the images held in `images` (a 1M-row x 602 KB table does not fit)."""
+    from infera_amd import capi, sqlmock
+
+    nimg = images.nbytes // blob_bytes
+    cands = [int(x) for x in threads_arg.split(",")] if threads_arg else [4, 8, 16]
+    cands = [t for t in cands if t <= max(4, 2 * budget["usable"])] or [4]
+    sqlmock.bench_blob_scan(model, images, blob_bytes, 2048, 1, 1)  # contexts, pinned staging, scratch
+    sweep = {}
+    for t in cands:
+        rows = 2048 * max(t, 4)
+        secs, _ = sqlmock.bench_blob_scan(model, images, blob_bytes, rows, t, 1)
+        sweep[str(t)] = rows / secs[0]
+    best_t = int(max(sweep, key=sweep.get))
+    rows = 2048 * max(best_t, 4) * 2
+    secs, checksum = sqlmock.bench_blob_scan(model, images, blob_bytes, rows, best_t, reps)
+    med = sorted(secs)[len(secs) // 2]
+    rate = rows / med
+    h2d = rate * blob_bytes / 1e9
+    return {"rows_per_s": rate, "unit": "rows/s (images/s)", "rows_per_scan": rows, "threads": best_t, "scan_seconds": secs,
+            "median_scan_seconds": med, "checksum": checksum, "host_images": nimg,
+            "entry": "infera_sql_call('infera_predict_from_blob') per 2048-row chunk (one infera_predict_from_blob_batch per chunk: "
+                     "pipelined pinned staging -> hipMemcpyAsync H2D -> conv net -> D2H -> LIST result); rows cycle over the host images",
+            "thread_sweep_rows_per_s": sweep, "pcie_h2d_gbs_per_gpu": h2d, "pcie_peak_gbs": PCIE_RAW_GBS,
+            "frac_of_pcie": h2d / PCIE_RAW_GBS, "pcie_bound_rows_per_s_per_gpu": {"raw": PCIE_RAW_GBS * 1e9 / blob_bytes},
+            "device_slots": capi.get_devices()["devices"]}
 
 
 def bind_to_gpu_numa_node(numa_node: int) -> dict:
@@ -335,6 +382,15 @@ def main():
         node = capi.get_devices()["devices"][0].get("numa_node", -1)
         numa = bind_to_gpu_numa_node(node) if node >= 0 else {"bound": False, "why": "GPU's NUMA node unknown"}
         budget = cpu_budget()
+    if args.workload == "resnet18" and not args.no_end_to_end and world == 1:
+        try:
+            from infera_amd import synth
+
+            images = synth.table(7, 0, 512, cols)  # 512 images = 308 MB of host BLOBs
+            e2e = end_to_end_blobs("bench", images, cols * 4, out_cols, args.e2e_threads, max(1, min(args.e2e_reps, 3)), budget)
+            e2e["resident_rows_per_s"] = rows * args.steps / elapsed
+        except Exception as exc:
+            e2e_error = f"{type(exc).__name__}: {exc}"
     if sql_fn and not args.no_end_to_end:
         e2e_rows = min(rows, 10_000_000) if args.workload != "mlp" else rows
         try:
@@ -374,13 +430,18 @@ def main():
             line["end_to_end"] = e2e
         elif e2e_error:
             line["end_to_end"] = {"error": e2e_error}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "resnet18":
+            cb = cpu_baseline_blobs(path, cols, budget)
+            line["cpu_baseline"] = cb
+            if e2e:
+                e2e["vs_cpu_baseline"] = e2e["rows_per_s"] / cb["value"]
+        elif world == 1 and not args.no_cpu_baseline:
             if table is None:
                 table = sqlmock.synth_table(min(rows, 10_000_000), cols, 42, min(32, budget["usable"]))
             trows = table.size // cols
             cb = cpu_baseline(path, table, trows, cols, args.cpu_seconds, budget)
             line["cpu_baseline"] = cb
-            if e2e:
+            if e2e and sql_fn:
                 ratio = e2e["rows_per_s"] / cb["value"]
                 cap_raw = e2e["pcie_bound_rows_per_s_per_gpu"]["raw"] / cb["value"]
                 cap_ach = e2e["pcie_bound_rows_per_s_per_gpu"]["achievable"] / cb["value"]

@@ -660,4 +660,61 @@ int32_t infera_sql_bench_scan_table(const char *function, const char *model, con
 }
 
 
+// The BLOB path's scan (BASELINE config C5): `threads` workers pull 2048-row chunks of an image table whose BLOBs live in
+// host memory (`nblobs` blobs of `blob_bytes` each, row r uses blob r % nblobs: a 1M-row x 602 KB table is 602 GB, so the
+// rows cycle over a table that fits) and run `SELECT infera_predict_from_blob(model, img)` on each through infera_sql_call --
+// one batched engine call per chunk, pipelined pinned staging, H2D, the conv net, D2H, LIST result.  0 / -1.
+int32_t infera_sql_bench_blob_scan(const char *model, const uint8_t *blobs, uint64_t nblobs, uint64_t blob_bytes, uint64_t rows,
+                                   int32_t threads, int32_t reps, double *secs, double *checksum, char *err, uint64_t errlen) {
+  if (threads < 1) threads = 1;
+  const size_t CH = INFERA_SQL_VECTOR_SIZE;
+  const uint64_t nchunks = (rows + CH - 1) / CH;
+  std::string first_error;
+  std::mutex mu;
+  for (int rep = 0; rep < reps; rep++) {
+    std::atomic<uint64_t> next{0};
+    double total = 0.0;
+    auto worker = [&] {
+      InferaSqlVector args[2];
+      const uint8_t *name_ptr = reinterpret_cast<const uint8_t *>(model);
+      uint64_t name_len = std::strlen(model);
+      args[0] = InferaSqlVector{INFERA_SQL_VARCHAR, 1, &name_ptr, &name_len, nullptr};
+      std::vector<const uint8_t *> ptrs(CH);
+      std::vector<uint64_t> lens(CH, blob_bytes);
+      double local = 0.0;
+      for (;;) {
+        const uint64_t c = next.fetch_add(1, std::memory_order_relaxed);
+        if (c >= nchunks) break;
+        const size_t nr = size_t(std::min<uint64_t>(CH, rows - c * CH));
+        for (size_t i = 0; i < nr; i++) ptrs[i] = blobs + ((c * CH + i) % nblobs) * blob_bytes;
+        args[1] = InferaSqlVector{INFERA_SQL_BLOB, 0, ptrs.data(), lens.data(), nullptr};
+        InferaSqlResult res;
+        if (infera_sql_call("infera_predict_from_blob", args, 2, nr, &res) != 0) {
+          std::lock_guard<std::mutex> lk(mu);
+          if (first_error.empty()) first_error = res.error ? res.error : "unknown error";
+          infera_sql_free_result(&res);
+          next.store(nchunks);
+          break;
+        }
+        if (res.list_offsets) local += sum_block(res.list_values, size_t(res.list_offsets[nr]));
+        infera_sql_free_result(&res);
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      total += local;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker);
+    for (auto &x : th) x.join();
+    if (secs) secs[rep] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (checksum) *checksum = total;
+    if (!first_error.empty()) {
+      if (err && errlen) std::snprintf(err, size_t(errlen), "%s", first_error.c_str());
+      return -1;
+    }
+  }
+  return 0;
+}
+
+
 }  // extern "C"

@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
         L.infera_sql_bench_scan_table.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32,
                                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
         L.infera_sql_bench_scan_table.restype = C.c_int32
+        L.infera_sql_bench_blob_scan.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32,
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
+        L.infera_sql_bench_blob_scan.restype = C.c_int32
         L.infera_sql_bench_last_times.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.infera_sql_bench_last_times.restype = None
         _lib = L
@@ -318,3 +321,17 @@ def phase_breakdown(fn, *args, **kw):
     ph["scan_loop"] = (thread_ns - call_ns) / n / 1e3
     ph["chunks"] = n
     return out, {k: round(v, 1) for k, v in ph.items()}
+
+
+def bench_blob_scan(model: str, blobs: np.ndarray, blob_bytes: int, rows: int, threads: int, reps: int = 1):
+    """`reps` scans of `rows` BLOB rows (cycling over the blobs held in `blobs`, a contiguous byte/float array) through
+    infera_predict_from_blob in 2048-row chunks; returns ([seconds per scan], checksum)."""
+    assert blobs.flags.c_contiguous and blobs.nbytes % blob_bytes == 0
+    secs = (C.c_double * reps)()
+    cs = C.c_double()
+    err = C.create_string_buffer(512)
+    rc = lib().infera_sql_bench_blob_scan(model.encode(), blobs.ctypes.data, blobs.nbytes // blob_bytes, blob_bytes, rows, threads, reps,
+                                          secs, C.byref(cs), err, len(err))
+    if rc != 0:
+        raise SqlError(err.value.decode())
+    return list(secs), cs.value

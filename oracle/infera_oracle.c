@@ -2091,7 +2091,9 @@ static void *scan_worker(void *p) {
     OrcResult res;
     char err[256];
     t_arena.off = 0;
-    if (orc_predict(a->m, feat, nr, F, &res, err, sizeof err)) { a->failed = 1; break; }
+    /* models with an [N,C,H,W] input take the BLOB route, as in the reference (infera_predict_from_blob -> engine.rs:199-263) */
+    if (a->m->in_rank > 2 ? orc_predict_blob(a->m, (const uint8_t *)feat, nr * F * 4, &res, err, sizeof err)
+                          : orc_predict(a->m, feat, nr, F, &res, err, sizeof err)) { a->failed = 1; break; }
     size_t take = res.len < CH * 64 ? res.len : CH * 64;
     for (size_t i = 0; i < take; i++) { resv[i] = res.data[i]; a->checksum += (double)res.data[i]; }
     orc_free_result(&res);
@@ -2187,7 +2189,9 @@ static void *table_scan_worker(void *p) {
     OrcResult res;
     char err[256];
     t_arena.off = 0;
-    if (orc_predict(a->m, feat, nr, F, &res, err, sizeof err)) { a->failed = 1; break; }
+    /* models with an [N,C,H,W] input take the BLOB route, as in the reference (infera_predict_from_blob -> engine.rs:199-263) */
+    if (a->m->in_rank > 2 ? orc_predict_blob(a->m, (const uint8_t *)feat, nr * F * 4, &res, err, sizeof err)
+                          : orc_predict(a->m, feat, nr, F, &res, err, sizeof err)) { a->failed = 1; break; }
     size_t take = res.len < CH * 64 ? res.len : CH * 64;
     for (size_t i = 0; i < take; i++) { resv[i] = res.data[i]; a->checksum += (double)res.data[i]; }
     orc_free_result(&res);
