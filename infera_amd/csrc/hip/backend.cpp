@@ -60,7 +60,7 @@ struct ThreadCtx {
   // instead of one per node).  Any reallocation of the buffers the graph points at drops the cache.
   struct GraphEntry {
     uint64_t uid;
-    int64_t rows;
+    int64_t rows;  // (bit 62 set: the graph was captured for a column-major chunk)
     hipGraphExec_t exec;
     uint64_t last_use;
   };
@@ -1095,7 +1095,9 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   const size_t in_row = size_t(m.plan.in_per_row()) * 4, out_row = size_t(m.plan.out_per_row()) * 4;
   const size_t widest = std::max(in_row, out_row);
   const bool use_graph = Config::get().use_hipgraph;
-  if (col_major && use_graph) throw InferaError::onnx("internal: column-major staging is not captured in hipGraph mode");
+  // hipGraph mode captures {H2D, kernels[, D2H]}: a column-major chunk only when the model's first kernel reads it itself (the
+  // transposing path allocates per pass, which a capture cannot contain)
+  if (col_major && use_graph && !m.in_colmajor_ok) throw InferaError::onnx("internal: column-major staging is not captured in hipGraph mode for this plan");
   // H2D of one pass; a column-major pass lands in dev_cm first and is transposed into the row-major table on the GPU
   auto upload_pass = [&](const float *pin, float *din, int64_t nr) {
     if (col_major) {
@@ -1154,7 +1156,8 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   }
   int64_t rows_pass = std::max<int64_t>(1, int64_t(kHostPassBytes / widest));
   rows_pass = std::min(rows_pass, rows);
-  const bool direct_out = !use_graph && m.out_write_once && Config::get().host_direct_out && size_t(rows_pass) * out_row <= (1u << 20);
+  const bool direct_out = m.out_write_once && Config::get().host_direct_out && size_t(rows_pass) * out_row <= (1u << 20);
+  const bool cm_graph = use_graph && col_major;  // (implies m.in_colmajor_ok)
   ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows_pass) * out_row);
   ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, size_t(rows_pass) * in_row);
@@ -1171,7 +1174,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
     if (use_graph) {
       (void)prepare_scratch(m, ctx, nr);  // may reallocate (and drop graphs) -- before the lookup
       for (auto &g : ctx.graphs)
-        if (g.uid == m.uid && g.rows == nr) {
+        if (g.uid == m.uid && g.rows == (nr | (cm_graph ? int64_t(1) << 62 : 0))) {
           g.last_use = ++ctx.graph_clock;
           exec = g.exec;
         }
@@ -1182,8 +1185,8 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
         // hipFuncSetAttribute / code-object loading must not happen inside a capture -- and then record
         // the graph (capturing does not execute anything) for the chunks that follow.
         HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
-        exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr);
-        HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+        exec_plan(m, dm, ctx, ctx.dev_in, direct_out ? ctx.pin_out : ctx.dev_out, nr, cm_graph);
+        if (!direct_out) HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
         HIP_TRY(hipStreamSynchronize(ctx.stream));
         std::memcpy(h_out + size_t(r0) * (out_row / 4), ctx.pin_out, size_t(nr) * out_row);
         hipGraph_t graph = nullptr;
@@ -1191,13 +1194,13 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
         HIP_TRY(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
         hipError_t e = hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream);
         try {
-          if (e == hipSuccess) exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr);
+          if (e == hipSuccess) exec_plan(m, dm, ctx, ctx.dev_in, direct_out ? ctx.pin_out : ctx.dev_out, nr, cm_graph);
         } catch (...) {
           (void)hipStreamEndCapture(ctx.stream, &graph);
           if (graph) (void)hipGraphDestroy(graph);
           throw;
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream);
+        if (e == hipSuccess && !direct_out) e = hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream);
         hipError_t e2 = hipStreamEndCapture(ctx.stream, &graph);
         if (e != hipSuccess) hip_fail(e, "stream capture");
         if (e2 != hipSuccess) hip_fail(e2, "hipStreamEndCapture");
@@ -1211,7 +1214,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
           (void)hipGraphExecDestroy(ctx.graphs[victim].exec);
           ctx.graphs.erase(ctx.graphs.begin() + long(victim));
         }
-        ctx.graphs.push_back({m.uid, nr, exec, ++ctx.graph_clock});
+        ctx.graphs.push_back({m.uid, nr | (cm_graph ? int64_t(1) << 62 : 0), exec, ++ctx.graph_clock});
         continue;  // this chunk's result is already in h_out
       }
     } else {

@@ -477,7 +477,7 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
       // 128 memcpys per chunk instead of a 2048 x 128 transpose (SURVEY.md 7 "hard parts": the host gather is what
       // limits an 8-GPU host).  Anything else (DOUBLE/INTEGER/BIGINT, constant vectors) converts on the host while
       // gathering straight into the row-major staging buffer.
-      bool flat_f32 = !Config::get().use_hipgraph && ncols > 0;
+      bool flat_f32 = ncols > 0 && (!Config::get().use_hipgraph || m->in_colmajor_ok);  // (hipGraph mode: only what it can capture)
       for (uintptr_t c = 0; c < ncols && flat_f32; c++) flat_f32 = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
       if (flat_f32) {
         run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) {
