@@ -571,8 +571,13 @@ void schedule(LoadedModel &m) {
     for (const auto &e : eff) {
       if (e.writes == m.plan.out_buf) {
         writers++;
+        // every tabular head qualifies: fused chains, Dense with or without a fused Softmax / ArgMax epilogue, a row Softmax or
+        // ArgMax kernel -- each stores every result element exactly once (convolutional plans keep the D2H copy: their
+        // outputs leave in strided channel-quad order)
         const ExecKind k = m.exec[size_t(e.idx)];
-        streaming = k == ExecKind::Mlp3Head || k == ExecKind::ChainHead || k == ExecKind::DenseSoftmax;
+        const StepKind sk = st[size_t(e.idx)].kind;
+        streaming = k == ExecKind::Mlp3Head || k == ExecKind::ChainHead || k == ExecKind::DenseSoftmax || k == ExecKind::DenseArgMax ||
+                    k == ExecKind::DenseTiled || (k == ExecKind::Normal && (sk == StepKind::Dense || sk == StepKind::Softmax || sk == StepKind::ArgMax));
       }
       for (int b : e.reads) readers += b == m.plan.out_buf;
     }
