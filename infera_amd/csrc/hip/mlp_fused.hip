@@ -203,14 +203,32 @@ void mlp3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const floa
 
 bool mlp3_colmajor_supported(const Mlp3Shape &sh) { return aot_match(sh); }
 
+namespace {
+// Short launches (a DataChunk through the host ABI): one workgroup per 32-row tile, bit-identical to the split kernel
+// (mlp_device.inc, mlp3_tile_kernel).  Up to this many rows the persistent kernels leave most of the chip idle behind their
+// 160 KB LDS image: 2048 rows 50 us there, ~12 us here.
+constexpr int64_t kTileKernelMaxRows = 32768;
+template <class C, bool XCM>
+void launch_tile(hipStream_t s, const float *X, const float *packed, float *Y, int64_t rows) {
+  const int64_t ntiles = (rows + 31) / 32;
+  hipLaunchKernelGGL((mlp3_tile_kernel<C, XCM>), dim3(unsigned(ntiles)), dim3(256), 0, s, X, packed, Y, rows);
+}
+bool tile_kernel_enabled() {
+  static const bool on = !(std::getenv("INFERA_MLP3_TILE") && std::atoi(std::getenv("INFERA_MLP3_TILE")) == 0);
+  return on;
+}
+}  // namespace
+
 bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
           std::string *why, bool x_colmajor) {
   if (rows <= 0) return true;
   if (x_colmajor) {  // the host path's column-major chunks (ahead-of-time configurations only)
 #define X_(C)                                                                        \
   if (matches<C>(sh)) {                                                              \
-    if constexpr (C::L3V) launch_split<C, 4, 8, 8, true>(s, X, packed, Y, rows, num_cus); \
-    else launch_cfg<C, true>(s, X, packed, Y, rows, num_cus);                        \
+    if constexpr (C::L3V) {                                                          \
+      if (rows <= kTileKernelMaxRows && tile_kernel_enabled()) launch_tile<C, true>(s, X, packed, Y, rows); \
+      else launch_split<C, 4, 8, 8, true>(s, X, packed, Y, rows, num_cus);           \
+    } else launch_cfg<C, true>(s, X, packed, Y, rows, num_cus);                      \
     return true;                                                                     \
   }
     INFERA_MLP3_CONFIGS(X_)
@@ -243,8 +261,10 @@ bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packe
   // vs one wave per SIMD 7.11 ms; 3 waves per SIMD 6.9 ms.  Heads wider than 4 keep the 1-wave kernel.
 #define X_(C)                                                                  \
   if (matches<C>(sh)) {                                                        \
-    if constexpr (C::L3V) launch_split<C, 4, 8, 8>(s, X, packed, Y, rows, num_cus); \
-    else launch_cfg<C>(s, X, packed, Y, rows, num_cus);                        \
+    if constexpr (C::L3V) {                                                    \
+      if (rows <= kTileKernelMaxRows && tile_kernel_enabled()) launch_tile<C, false>(s, X, packed, Y, rows); \
+      else launch_split<C, 4, 8, 8>(s, X, packed, Y, rows, num_cus);           \
+    } else launch_cfg<C>(s, X, packed, Y, rows, num_cus);                      \
     return true;                                                               \
   }
   INFERA_MLP3_CONFIGS(X_)
