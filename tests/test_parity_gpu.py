@@ -364,6 +364,32 @@ def test_full_size_c2_properties(api, models):
     assert abs(total - parts) <= 1e-6 * abs(total) + 1e-6
 
 
+def test_full_size_c2_host_scan_equals_device_scan(api, models):
+    """BASELINE config C2 at full size through the WHOLE host path: a 10M-row x 128-col columnar table materialised in host
+    memory (DuckDB's storage shape), scanned by 16 worker threads in 2048-row chunks through the SQL surface
+    (gather -> pinned staging -> H2D -> kernel -> result vector), must produce the same outputs as one device-resident
+    scan of the same table: every chunk is bit-identical to its slice (asserted on samples elsewhere), so the f64 sum of all
+    10M outputs -- a checksum over every chunk, thread and staging context -- agrees to summation-order rounding; the
+    per-slot row counter accounts for every row exactly once."""
+    from infera_amd import sqlmock
+
+    rows, cols = 10_000_000, 128
+    api.load_model("mlp", models["mlp"])
+    dev = api.device_ordinal(0)
+    d_in = api.DeviceBuffer(dev, rows * cols * 4)
+    d_out = api.DeviceBuffer(dev, rows * 4)
+    api.synth_fill(d_in, 42, 0, rows, cols)
+    api.predict_device("mlp", d_in, rows, cols, d_out)
+    want = d_out.download((rows,)).astype(np.float64).sum()
+    del d_in, d_out
+    table = sqlmock.synth_table(rows, cols, 42, 16)
+    before = sum(d["host_rows"] for d in api.get_devices()["devices"])
+    for threads in (16, 3):
+        secs, checksum = sqlmock.bench_scan_table("infera_predict", "mlp", table, rows, cols, threads, 1)
+        assert abs(checksum - want) <= 1e-9 * abs(want) + 1e-6, (threads, checksum, want)
+    assert sum(d["host_rows"] for d in api.get_devices()["devices"]) - before == 2 * rows
+
+
 def test_full_size_c3_row_range_sharding_on_one_gpu(api, models):
     """BASELINE config C3 -- the same MLP over 100M rows x 128, row-range sharded over 8 GPUs -- as far as ONE GPU allows:
     the 51.2 GB table fits in HBM (288 GB), so the eight 12.5M-row shards a rank each would scan (shard.row_range) are
