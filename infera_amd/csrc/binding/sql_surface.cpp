@@ -594,6 +594,39 @@ void infera_sql_bench_last_times(uint64_t *call_ns, uint64_t *thread_ns) {
 
 int32_t infera_sql_bench_scan_table(const char *function, const char *model, const float *table, uint64_t rows, uint32_t ncols,
                                     int32_t threads, int32_t reps, double *secs, double *checksum, char *err, uint64_t errlen) {
+  return infera_sql_bench_scan_table_typed(function, model, table, INFERA_SQL_FLOAT, rows, ncols, threads, reps, secs, checksum, err, errlen);
+}
+
+void infera_sql_synth_table_f64(double *table, uint64_t seed, uint64_t rows, uint32_t ncols, int32_t threads) {
+  if (threads < 1) threads = 1;
+  const uint64_t RG = INFERA_SQL_ROW_GROUP, ngroups = (rows + RG - 1) / RG;
+  std::atomic<uint64_t> next{0};
+  auto worker = [&] {
+    for (;;) {
+      const uint64_t task = next.fetch_add(1, std::memory_order_relaxed);
+      if (task >= ngroups * ncols) break;
+      const uint64_t g = task / ncols, c = task % ncols, r0 = g * RG, gr = std::min<uint64_t>(RG, rows - r0);
+      double *dst = table + r0 * ncols + c * gr;
+      for (uint64_t r = 0; r < gr; r++) {
+        const uint64_t u = splitmix64(seed ^ ((r0 + r) * ncols + c));
+        dst[r] = double(float(u >> 40) * (1.0f / 16777216.0f) * 2.0f - 1.0f);  // the same values as the FLOAT table, widened
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; t++) th.emplace_back(worker);
+  for (auto &x : th) x.join();
+}
+
+int32_t infera_sql_bench_scan_table_typed(const char *function, const char *model, const void *table_v, int32_t elem_type, uint64_t rows,
+                                          uint32_t ncols, int32_t threads, int32_t reps, double *secs, double *checksum, char *err,
+                                          uint64_t errlen) {
+  if (elem_type != INFERA_SQL_FLOAT && elem_type != INFERA_SQL_DOUBLE) {
+    if (err && errlen) std::snprintf(err, size_t(errlen), "table element type must be FLOAT or DOUBLE");
+    return -1;
+  }
+  const size_t esz = elem_type == INFERA_SQL_DOUBLE ? 8 : 4;
+  const uint8_t *table = static_cast<const uint8_t *>(table_v);
   if (threads < 1) threads = 1;
   const size_t CH = INFERA_SQL_VECTOR_SIZE;
   const uint64_t RG = INFERA_SQL_ROW_GROUP;
@@ -618,8 +651,8 @@ int32_t infera_sql_bench_scan_table(const char *function, const char *model, con
         if (c >= nchunks) break;
         const uint64_t row0 = c * CH, g = row0 / RG, g0 = g * RG, gr = std::min<uint64_t>(RG, rows - g0);
         const size_t nr = size_t(std::min<uint64_t>(CH, rows - row0));
-        const float *base = table + g0 * ncols + (row0 - g0);
-        for (uint32_t j = 0; j < ncols; j++) args[j + 1] = InferaSqlVector{INFERA_SQL_FLOAT, 0, base + uint64_t(j) * gr, nullptr, nullptr};
+        const uint8_t *base = table + (g0 * ncols + (row0 - g0)) * esz;
+        for (uint32_t j = 0; j < ncols; j++) args[j + 1] = InferaSqlVector{elem_type, 0, base + uint64_t(j) * gr * esz, nullptr, nullptr};
         InferaSqlResult res;
         const uint64_t t_c0 = bench_now_ns();
         const int32_t rc = infera_sql_call(fn.c_str(), args.data(), ncols + 1, nr, &res);

@@ -91,6 +91,11 @@ double infera_sql_bench_scan(const char *function, const char *model, uint64_t r
  *                             element consumed.  Table generation is outside every timed region.  0 / -1 (+err). */
 uint64_t infera_sql_table_floats(uint64_t rows, uint32_t ncols);
 void infera_sql_synth_table(float *table, uint64_t seed, uint64_t rows, uint32_t ncols, int32_t threads);
+/* The same with a table of DOUBLE columns (DuckDB's default floating type; the values are the FLOAT table's, widened) */
+void infera_sql_synth_table_f64(double *table, uint64_t seed, uint64_t rows, uint32_t ncols, int32_t threads);
+int32_t infera_sql_bench_scan_table_typed(const char *function, const char *model, const void *table, int32_t elem_type, uint64_t rows,
+                                          uint32_t ncols, int32_t threads, int32_t reps, double *secs, double *checksum, char *err,
+                                          uint64_t errlen);
 /* The BLOB path's scan (config C5): rows cycle over `nblobs` host-resident blobs of `blob_bytes` each, 2048-row chunks through
  * infera_sql_call("infera_predict_from_blob"); secs[rep] = wall time of scan `rep`.  0 / -1 (+err). */
 int32_t infera_sql_bench_blob_scan(const char *model, const uint8_t *blobs, uint64_t nblobs, uint64_t blob_bytes, uint64_t rows,

@@ -472,18 +472,18 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
     OutShape o = engine::validate_predict(*m, rows, ncols);
     float *out = alloc_out(o.len);
     try {
-      // All-FLOAT flat columns (the FLOAT overloads, infera_extension.cpp:554-557): each column is copied into pinned
-      // staging as the contiguous run it already is and the transpose to [rows][F] runs on the GPU -- the host does
-      // 128 memcpys per chunk instead of a 2048 x 128 transpose (SURVEY.md 7 "hard parts": the host gather is what
-      // limits an 8-GPU host).  Anything else (DOUBLE/INTEGER/BIGINT, constant vectors) converts on the host while
-      // gathering straight into the row-major staging buffer.
-      bool flat_f32 = ncols > 0 && (!Config::get().use_hipgraph || m->in_colmajor_ok);  // (hipGraph mode: only what it can capture)
-      for (uintptr_t c = 0; c < ncols && flat_f32; c++) flat_f32 = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
-      if (flat_f32) {
-        run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) {
-          for (uintptr_t c = 0; c < ncols; c++)
-            std::memcpy(dst + size_t(c) * size_t(nr), static_cast<const float *>(columns[c].data) + r0, size_t(nr) * sizeof(float));
-        }, out, int64_t(rows), /*col_major=*/true);
+      // Column-major staging: every column is converted / copied into pinned staging as the contiguous run it already is
+      // (FLOAT: memcpy; DOUBLE / INTEGER: vectorised conversion of the run; constant vectors filled) and the GPU reads the
+      // chunk column-major -- the host does 128 streaming passes per chunk instead of a 2048 x 128 transposing gather
+      // (SURVEY.md 7 "hard parts": the host gather is what limits an 8-GPU host).  Plans whose first kernel cannot read a
+      // column-major chunk get a GPU transpose in front; only hipGraph mode on such a plan (the transpose path allocates per
+      // pass, which a capture cannot contain) falls back to the AVX2 transposing gather into row-major staging.
+      bool col_major = ncols > 0 && (m->in_colmajor_ok || !Config::get().use_hipgraph);
+      if (col_major && !Config::get().host_colmajor_typed)  // A/B knob: only all-FLOAT chunks are staged column-major (round-1 rule)
+        for (uintptr_t c = 0; c < ncols && col_major; c++) col_major = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
+      if (col_major) {
+        run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) { gather_column_major(columns, 0, ncols, size_t(r0), size_t(nr), dst); },
+                      out, int64_t(rows), /*col_major=*/true);
       } else {
         run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) { gather_columns(columns, ncols, size_t(r0), size_t(nr), dst); }, out,
                       int64_t(rows));

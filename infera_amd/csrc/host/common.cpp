@@ -90,6 +90,7 @@ const Config &Config::get() {
     c.host_contexts = std::max(1, int(env_u64("INFERA_HOST_CONTEXTS", 24)));
     c.host_wait = env_or("INFERA_HOST_WAIT", "block") == "spin" ? 1 : 0;
     c.host_direct_out = env_flag("INFERA_HOST_DIRECT_OUT", true);
+    c.host_colmajor_typed = env_flag("INFERA_HOST_COLMAJOR_TYPED", true);
     c.host_fused_transpose = env_flag("INFERA_HOST_FUSED_TRANSPOSE", true);
     c.precision_bf16x3 = env_or("INFERA_PRECISION", "fp32") == "bf16x3";
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);

@@ -97,6 +97,8 @@ struct Config {
                                       //   CPU-quota'd container or a busy DuckDB pipeline needs), spin = hipStreamSynchronize
   bool host_direct_out;               // INFERA_HOST_DIRECT_OUT=0|1  the last kernel of a write-once plan stores its results
                                       //   straight into the pinned result buffer (no D2H copy enqueue per chunk)
+  bool host_colmajor_typed;           // INFERA_HOST_COLMAJOR_TYPED=0|1  DOUBLE / INTEGER / BIGINT / constant columns are staged column-major too
+                                      //   (converted run by run) instead of through the AVX2 transposing gather.  Default 1
   bool host_fused_transpose;          // INFERA_HOST_FUSED_TRANSPOSE=0|1  the fused MLP reads column-major chunks itself (no transpose kernel)
   bool precision_bf16x3;              // INFERA_PRECISION=fp32|bf16x3  bf16x3 = OPTIONAL fast mode for the fused MLP (three bf16 MFMAs per
                                       //   product, ~2^-16 relative error per product): NOT the parity path, never the default

@@ -2,6 +2,7 @@
 
 #include <immintrin.h>
 
+#include <cstring>
 #include <vector>
 
 namespace infera_hip {
@@ -127,6 +128,52 @@ __attribute__((target("avx2"))) void gather_blocks_avx2(const infera::InferaColu
 }
 
 }  // namespace
+
+namespace {
+__attribute__((target("avx2"))) void convert_f64_avx2(const double *src, float *dst, size_t n) {
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    _mm_storeu_ps(dst + i, _mm256_cvtpd_ps(_mm256_loadu_pd(src + i)));
+    _mm_storeu_ps(dst + i + 4, _mm256_cvtpd_ps(_mm256_loadu_pd(src + i + 4)));
+  }
+  for (; i < n; i++) dst[i] = static_cast<float>(src[i]);
+}
+__attribute__((target("avx2"))) void convert_i32_avx2(const int32_t *src, float *dst, size_t n) {
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) _mm256_storeu_ps(dst + i, _mm256_cvtepi32_ps(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i))));
+  for (; i < n; i++) dst[i] = static_cast<float>(src[i]);
+}
+}  // namespace
+
+// Column-major staging: rows [row0, row0 + nrows) of column c -> dst[c * nrows ...] as f32, the column's own run converted in
+// place of the plain memcpy a FLOAT column gets (static_cast<float> per the reference, infera_extension.cpp:211-222: RNE for
+// DOUBLE -- what vcvtpd2ps does).  DuckDB's default floating type is DOUBLE, so this is the common case of a real table: no
+// transposing gather on the CPU, the GPU kernel reads the chunk column-major.
+void gather_column_major(const infera::InferaColumn *cols, size_t c0, size_t c1, size_t row0, size_t nrows, float *dst) {
+  static const bool have_avx2 = __builtin_cpu_supports("avx2");
+  for (size_t c = c0; c < c1; c++) {
+    const infera::InferaColumn &col = cols[c];
+    float *d = dst + c * nrows;
+    if (col.is_constant) {
+      const float v = cell(col, 0);
+      for (size_t r = 0; r < nrows; r++) d[r] = v;
+      continue;
+    }
+    switch (col.type) {
+      case infera::INFERA_COL_FLOAT: std::memcpy(d, static_cast<const float *>(col.data) + row0, nrows * sizeof(float)); break;
+      case infera::INFERA_COL_DOUBLE:
+        if (have_avx2) convert_f64_avx2(static_cast<const double *>(col.data) + row0, d, nrows);
+        else for (size_t r = 0; r < nrows; r++) d[r] = static_cast<float>(static_cast<const double *>(col.data)[row0 + r]);
+        break;
+      case infera::INFERA_COL_INTEGER:
+        if (have_avx2) convert_i32_avx2(static_cast<const int32_t *>(col.data) + row0, d, nrows);
+        else for (size_t r = 0; r < nrows; r++) d[r] = static_cast<float>(static_cast<const int32_t *>(col.data)[row0 + r]);
+        break;
+      default:
+        for (size_t r = 0; r < nrows; r++) d[r] = static_cast<float>(static_cast<const int64_t *>(col.data)[row0 + r]);
+    }
+  }
+}
 
 void gather_columns(const infera::InferaColumn *cols, size_t ncols, size_t row0, size_t nrows, float *dst) {
   static const bool have_avx2 = __builtin_cpu_supports("avx2");

@@ -99,6 +99,11 @@ def lib() -> C.CDLL:
         L.infera_sql_bench_scan_table.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32,
                                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
         L.infera_sql_bench_scan_table.restype = C.c_int32
+        L.infera_sql_synth_table_f64.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32]
+        L.infera_sql_synth_table_f64.restype = None
+        L.infera_sql_bench_scan_table_typed.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32,
+                                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
+        L.infera_sql_bench_scan_table_typed.restype = C.c_int32
         L.infera_sql_bench_blob_scan.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32,
                                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
         L.infera_sql_bench_blob_scan.restype = C.c_int32
@@ -267,11 +272,15 @@ def bench_scan(function: str, model: str, rows: int, ncols: int, threads: int, p
 ROW_GROUP = 122880  # INFERA_SQL_ROW_GROUP
 
 
-def synth_table(rows: int, ncols: int, seed: int = 42, threads: int = 8) -> np.ndarray:
+def synth_table(rows: int, ncols: int, seed: int = 42, threads: int = 8, dtype=np.float32) -> np.ndarray:
     """A materialised columnar table in host memory (row groups of 122,880 rows, one contiguous run per column inside a
-    group), filled with the generator of SURVEY.md 8d.  Flat f32 array of rows*ncols elements."""
-    t = np.empty(int(lib().infera_sql_table_floats(rows, ncols)), np.float32)
-    lib().infera_sql_synth_table(t.ctypes.data, seed, rows, ncols, threads)
+    group), filled with the generator of SURVEY.md 8d.  Flat array of rows*ncols elements, float32 (FLOAT columns) or
+    float64 (DOUBLE columns, the same values widened)."""
+    t = np.empty(int(lib().infera_sql_table_floats(rows, ncols)), dtype)
+    if t.dtype == np.float64:
+        lib().infera_sql_synth_table_f64(t.ctypes.data, seed, rows, ncols, threads)
+    else:
+        lib().infera_sql_synth_table(t.ctypes.data, seed, rows, ncols, threads)
     return t
 
 
@@ -288,12 +297,12 @@ def table_rows(table: np.ndarray, rows: int, ncols: int, r0: int, n: int) -> np.
 
 def bench_scan_table(function: str, model: str, table: np.ndarray, rows: int, ncols: int, threads: int, reps: int = 1):
     """`reps` complete scans of a materialised table through the SQL surface; returns ([seconds per scan], checksum)."""
-    assert table.dtype == np.float32 and table.flags.c_contiguous and table.size >= rows * ncols
+    assert table.dtype in (np.float32, np.float64) and table.flags.c_contiguous and table.size >= rows * ncols
     secs = (C.c_double * reps)()
     cs = C.c_double()
     err = C.create_string_buffer(512)
-    rc = lib().infera_sql_bench_scan_table(function.encode(), model.encode(), table.ctypes.data, rows, ncols, threads, reps, secs,
-                                           C.byref(cs), err, len(err))
+    rc = lib().infera_sql_bench_scan_table_typed(function.encode(), model.encode(), table.ctypes.data, DOUBLE if table.dtype == np.float64 else FLOAT,
+                                                 rows, ncols, threads, reps, secs, C.byref(cs), err, len(err))
     if rc != 0:
         raise SqlError(err.value.decode())
     return list(secs), cs.value

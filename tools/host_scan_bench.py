@@ -18,6 +18,7 @@ ap.add_argument("--dims", default="", help="custom MLP instead of a named worklo
 ap.add_argument("--softmax", action="store_true")
 ap.add_argument("--pool", action="store_true", help="cache-resident per-thread chunk pool instead of the materialised table (round-1 behaviour)")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--double", action="store_true", help="DOUBLE columns (DuckDB's default floating type) instead of FLOAT")
 a = ap.parse_args()
 tmp = tempfile.mkdtemp()
 if a.dims:
@@ -30,7 +31,9 @@ capi.load_model("m", onnx_writer.write(os.path.join(tmp, "m.onnx"), blob))
 sqlmock.bench_scan(fn, "m", 2048 * 64, cols, 4)  # warm
 print(f"devices={capi.get_devices()['devices']} workload={a.dims or a.workload} rows={a.rows} exec={capi.get_plan('m')['exec']} "
       f"INFERA_HIPGRAPH={os.environ.get('INFERA_HIPGRAPH', '0')} source={'per-thread chunk pool' if a.pool else 'materialised columnar host table'}")
-table = None if a.pool else sqlmock.synth_table(a.rows, cols, 42, 16)
+import numpy as np  # noqa: E402
+table = None if a.pool else sqlmock.synth_table(a.rows, cols, 42, 16, np.float64 if a.double else np.float32)
+print("column type:", "DOUBLE" if a.double else "FLOAT")
 for t in [int(x) for x in a.threads.split(",")]:
     if a.pool:
         sec, cs = sqlmock.bench_scan(fn, "m", a.rows, cols, t)
