@@ -34,6 +34,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -104,7 +105,7 @@ void SetConstantBool(Vector &result, bool v) {
 // column cast to DOUBLE, a dictionary vector compacted through its selection vector).
 struct FeatureColumns {
   std::vector<infera::InferaColumn> cols;
-  std::vector<UnifiedVectorFormat> fmt;
+  std::unique_ptr<UnifiedVectorFormat[]> fmt;  // (not a std::vector: UnifiedVectorFormat is not copyable)
   std::vector<unique_ptr<Vector>> casts;
   std::vector<std::vector<uint8_t>> compacted;
 
@@ -126,7 +127,7 @@ struct FeatureColumns {
   FeatureColumns(DataChunk &args, idx_t count) {
     const idx_t F = args.ColumnCount() - 1;
     cols.resize(F);
-    fmt.resize(F);
+    fmt.reset(new UnifiedVectorFormat[F]);
     for (idx_t c = 0; c < F; c++) {
       Vector *v = &args.data[c + 1];
       int32_t type;

@@ -164,6 +164,9 @@ private:
 enum class VectorType : uint8_t { FLAT_VECTOR, CONSTANT_VECTOR, DICTIONARY_VECTOR };
 
 struct UnifiedVectorFormat {
+  UnifiedVectorFormat() = default;
+  UnifiedVectorFormat(const UnifiedVectorFormat &) = delete;  // as in DuckDB: neither copyable nor (portably) movable
+  UnifiedVectorFormat &operator=(const UnifiedVectorFormat &) = delete;
   const SelectionVector *sel = nullptr;
   data_ptr_t data = nullptr;
   ValidityMask validity;
