@@ -1257,8 +1257,10 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
       (void)hipGetDevice(&dev);
       static int cus[64] = {};
       if (!cus[dev & 63]) (void)hipDeviceGetAttribute(&cus[dev & 63], hipDeviceAttributeMultiprocessorCount, dev);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kWsLdsBytes));
-      (void)attr_done;
+      if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {  // once per kernel instantiation and device
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kWsLdsBytes));
+        attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+      }
       const unsigned slices = unsigned(g.M / (32 * mt));
       const int64_t ntiles = (total_pix + 31) / 32;
       unsigned gx = unsigned(std::max(1, cus[dev & 63] / int(slices)));
