@@ -314,6 +314,9 @@ std::vector<EffStep> effective_steps(const LoadedModel &m) {
       case ExecKind::Mlp3Head: out.push_back({int(i), {st[i].in0}, st[i + 2].out}); break;
       case ExecKind::DenseSoftmax: out.push_back({int(i), {st[i].in0}, st[i + 1].out}); break;
       case ExecKind::ChainHead: out.push_back({int(i), {st[i].in0}, st[i + size_t(m.chain_at(i)->nsteps) - 1].out}); break;
+      case ExecKind::ConvPatch:
+        out.push_back({int(i), {st[i].in0}, i < m.conv_fused_pool.size() && m.conv_fused_pool[i] >= 0 ? st[size_t(m.conv_fused_pool[i])].out : st[i].out});
+        break;
       case ExecKind::ConvTiled:
         if (i < m.conv_fused_add.size() && m.conv_fused_add[i] >= 0)
           out.push_back({int(i), {st[i].in0, m.conv_residual_buf[i]}, st[size_t(m.conv_fused_add[i])].out});
@@ -525,6 +528,7 @@ void schedule(LoadedModel &m) {
         for (int64_t p = 0; p < HW; p++) c2[size_t((((c >> 2) * HW + p) << 2) + (c & 3))] = b.cst[size_t(c * HW + p)];
       b.cst = std::move(c2);
     }
+  m.conv_fused_pool.assign(n, -1);
   if (m.cq_mode)
     for (size_t i = 0; i < n; i++) {
       const Step &s = st[i];
@@ -532,7 +536,23 @@ void schedule(LoadedModel &m) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
                        int(s.sh), int(s.sw), int(s.pt), int(s.pl), int(s.dh), int(s.dw), int(s.groups)};
       if (m.nchw_buf[size_t(s.in0)]) {  // the caller's NCHW blob (or its normalised copy): few channels -> LDS patch kernel
-        if (kern::conv2d_patch_supported(kern::conv2d_patch_geom(g))) m.exec[i] = ExecKind::ConvPatch;
+        if (!kern::conv2d_patch_supported(kern::conv2d_patch_geom(g))) continue;
+        m.exec[i] = ExecKind::ConvPatch;
+        // stem -> MaxPool 3x3 / 2 (ResNet, DenseNet, SqueezeNet): pooled in the stem's kernel, the stem's own output is never stored
+        // (INFERA_STEM_POOL=0, read at load time: the two kernels)
+        const char *sp = getenv("INFERA_STEM_POOL");
+        if (!(sp && sp[0] == '0') && uses[size_t(s.out)] == 1 && s.out != m.plan.out_buf)
+          for (size_t j = i + 1; j < n; j++) {
+            const Step &q = st[j];
+            if (q.in0 != s.out && q.in1 != s.out) continue;
+            const kern::PoolTail tail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)};
+            if (q.kind == StepKind::Pool2d && m.exec[j] == ExecKind::Normal && q.is_max && q.kh == 3 && q.kw == 3 && q.sh == 2 && q.sw == 2 &&
+                q.dh == 1 && q.dw == 1 && kern::conv2d_patch_pool_supported(kern::conv2d_patch_geom(g), tail)) {
+              m.conv_fused_pool[i] = int(j);
+              m.exec[j] = ExecKind::Skipped;
+            }
+            break;
+          }
         continue;
       }
       if (kern::conv2d_tiled_supported(g)) m.exec[i] = ExecKind::ConvTiled;
@@ -719,7 +739,13 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
         }
         continue;
       }
-      kern::conv2d_patch_pack(g, s.W.data(), packed.data());
+      if (const int fj = m.conv_fused_pool[i]; fj >= 0) {
+        const Step &q = st[size_t(fj)];
+        const kern::PoolTail tail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)};
+        kern::conv2d_patch_pack(g, s.W.data(), packed.data(), &tail);
+      } else {
+        kern::conv2d_patch_pack(g, s.W.data(), packed.data());
+      }
       d.W = upload(packed, us);
     } else if (s.kind == StepKind::Conv2d) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
@@ -843,6 +869,12 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         case ExecKind::ConvPatch: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
+          if (const int fj = m.conv_fused_pool[i]; fj >= 0) {
+            const Step &q = st[size_t(fj)];
+            kern::conv2d_patch_pool(s, buf(x.in0), d.W, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
+                                    kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus);
+            continue;
+          }
           kern::conv2d_patch(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, kern::conv2d_patch_geom(g), act_of(x), dm.num_cus);
           continue;
         }
@@ -1275,7 +1307,8 @@ std::string LoadedModel::describe_json() const {
   static const char *ek[] = {"normal", "skipped", "mlp3_fused", "dense_softmax", "conv_tiled_cq", "conv_patch", "conv_depthwise", "dense_tiled", "dense_argmax", "chain_fused"};
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
-  for (size_t i = 0; i < exec.size(); i++) o << (i ? "," : "") << "\"" << ek[int(exec[i])] << "\"";
+  for (size_t i = 0; i < exec.size(); i++)
+    o << (i ? "," : "") << "\"" << (i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : ek[int(exec[i])]) << "\"";
   o << "],\"activation_layout\":\"" << (cq_mode ? "NC/4HW4" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";

@@ -96,6 +96,7 @@ class LoadedModel {
   std::vector<char> nchw_buf;
   // A ConvTiled step that absorbed the residual Add (+ activation) following it: per conv step, the
   // index of the fused BinaryAct step (-1: none) and which of its operands is the skip tensor.
+  std::vector<int> conv_fused_pool;  // per step: the MaxPool 3x3/2 step a ConvPatch stem computes in its own kernel, or -1
   std::vector<int> conv_fused_add;
   std::vector<int> conv_residual_buf;
   std::vector<int> slot_of_buf;        // scratch slot per activation buffer (-1: external in/out)

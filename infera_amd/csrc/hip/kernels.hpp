@@ -125,7 +125,15 @@ void conv2d(hipStream_t s, const float *X, const float *Wk, const float *bias, f
 // M in {32, 64, 96, 128}, groups == 1; the receptive field of a pixel tile is staged in LDS.
 bool conv2d_patch_supported(const ConvGeom &g);
 size_t conv2d_patch_packed_floats(const ConvGeom &g);
-void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed);
+// ... with the MaxPool 3x3 / stride 2 that follows it in the same kernel (ResNet / DenseNet / SqueezeNet stems): the convolution's
+// own output never reaches memory.  pool = pooled extent and the pooling's pads (0 or 1).  Pack with the same PoolTail.
+struct PoolTail {
+  int OH = 0, OW = 0, pt = 0, pl = 0;
+};
+bool conv2d_patch_pool_supported(const ConvGeom &g, const PoolTail &pool);
+void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
+                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus);
+void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail *pool = nullptr);
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                   const ConvGeom &g, ActParam act, int num_cus);
 // Depthwise convolution (groups == C == M, C % 4 == 0) in channel-quad planes; packed = [C/4][tap][4].

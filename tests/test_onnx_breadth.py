@@ -204,7 +204,7 @@ def np_pool(x, k, stride, pad, o, is_max):
 
 
 POOL_CASES = [("MaxPool", 7, 3, 2, 0, True), ("MaxPool", 8, 3, 2, 1, True), ("AveragePool", 7, 2, 2, 0, True), ("MaxPool", 9, 2, 2, 0, True),
-              ("AveragePool", 8, 3, 2, 1, False)]
+              ("AveragePool", 8, 3, 2, 1, False), ("MaxPool", 6, 3, 1, 1, False), ("MaxPool", 5, 2, 1, 0, False), ("MaxPool", 10, 3, 3, 1, True)]
 
 
 @pytest.mark.parametrize("op,hw,k,stride,pad,ceil", POOL_CASES)

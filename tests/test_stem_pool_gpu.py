@@ -1,0 +1,72 @@
+"""Stem convolution + MaxPool 3x3/2 in one kernel (conv2d_patch_kernel<.., POOL>, csrc/hip/conv.hip): the pooled tensor must
+be bit-for-bit what the stem kernel followed by the pooling kernel produce (INFERA_STEM_POOL=0 at load time) -- the same
+MFMA chains per convolution pixel, and a maximum is exact in any order -- and match the oracle.  Geometries: the ResNet stem
+(7x7/2 pad 3 -> pool pad 1) on image sizes whose pooled extent is and is not a multiple of the 8 x 7 pooled tile, a 3x3/2
+stem with pool pad 0 and ceil_mode (SqueezeNet), 32 and 64 stem features, 1- / 3- / 4-channel images, a 5x5 stem with stride 1,
+more tiles than workgroups, and a stem whose pooled output is the only thing between it and the head."""
+import os
+
+import numpy as np
+import pytest
+
+from infera_amd import onnx_writer as W
+from infera_amd import synth
+
+
+def _net(cin, hw, m, k, stride, pad, pool_pad, ceil, relu=True, hw2=None):
+    rng = np.random.default_rng(23)
+    w = (rng.standard_normal((m, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = (rng.standard_normal(m) * 0.2).astype(np.float32)
+    w2 = (rng.standard_normal((m, m, 1, 1)) / np.sqrt(m)).astype(np.float32)
+    nodes = [W.node("Conv", ["X", "w", "b"], ["c"], [W.attr_ints("kernel_shape", [k, k]), W.attr_ints("strides", [stride] * 2), W.attr_ints("pads", [pad] * 4)])]
+    src = "c"
+    if relu:
+        nodes.append(W.node("Relu", ["c"], ["r"]))
+        src = "r"
+    nodes += [W.node("MaxPool", [src], ["p"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("strides", [2, 2]), W.attr_ints("pads", [pool_pad] * 4),
+                                              W.attr_i("ceil_mode", 1 if ceil else 0)]),
+              W.node("Conv", ["p", "w2"], ["c2"], [W.attr_ints("kernel_shape", [1, 1])]),
+              W.node("GlobalAveragePool", ["c2"], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
+    return W.model("stem", nodes, [W.tensor("w", w), W.tensor("b", b), W.tensor("w2", w2)],
+                   [W.value_info("X", ["N", cin, hw, hw2 or hw])], [W.value_info("Y", ["N", m])])
+
+
+CASES = {
+    "resnet_stem_64": dict(cin=3, hw=64, m=64, k=7, stride=2, pad=3, pool_pad=1, ceil=False, rows=3),       # conv 32x32 -> pooled 16x16: 2 x 3 tiles, ragged columns
+    "resnet_stem_224": dict(cin=3, hw=224, m=64, k=7, stride=2, pad=3, pool_pad=1, ceil=False, rows=2),     # the real thing: 56 x 56 = 7 x 8 whole tiles
+    "odd_extent": dict(cin=3, hw=50, m=64, k=7, stride=2, pad=3, pool_pad=1, ceil=False, rows=4),           # conv 25x25 -> pooled 13x13
+    "squeezenet_like": dict(cin=3, hw=59, m=64, k=3, stride=2, pad=0, pool_pad=0, ceil=True, rows=3),       # conv 29x29 -> pooled 14x14 (ceil), windows past the edge
+    "m32_gray": dict(cin=1, hw=40, m=32, k=5, stride=1, pad=2, pool_pad=1, ceil=False, rows=5),             # stride-1 stem, one channel, 32 features
+    "four_channels_no_relu": dict(cin=4, hw=36, m=64, k=3, stride=1, pad=1, pool_pad=1, ceil=False, rows=2, relu=False),  # negative values reach the pool
+    "many_tiles": dict(cin=3, hw=96, m=64, k=7, stride=2, pad=3, pool_pad=1, ceil=False, rows=40),          # 40 x 3 x 4 = 480 tiles > 256 workgroups
+    "rectangular": dict(cin=3, hw=44, hw2=70, m=64, k=7, stride=2, pad=3, pool_pad=1, ceil=False, rows=3),  # H != W
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_gpu_stem_with_fused_maxpool_matches_two_kernels_and_oracle(gpu_api, tmp_path, case):
+    from oracle import oracle
+
+    c = dict(CASES[case])
+    rows = c.pop("rows")
+    path = W.write(str(tmp_path / "stem.onnx"), _net(**c))
+    x = synth.table(37, 0, rows, c["cin"] * c["hw"] * (c.get("hw2") or c["hw"]))
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["INFERA_STEM_POOL"] = mode  # read when the model is scheduled
+            gpu_api.load_model("stem", path)
+            plan = gpu_api.get_plan("stem")
+            assert plan["activation_layout"] == "NC/4HW4"
+            assert ("conv_patch_pool" in plan["exec"]) == (mode == "1"), plan["exec"]
+            assert ("conv_patch" in plan["exec"]) == (mode == "0"), plan["exec"]
+            out[mode] = gpu_api.predict_from_blob("stem", x.tobytes())
+            assert np.array_equal(out[mode], gpu_api.predict_from_blob("stem", x.tobytes()))
+            gpu_api.unload_model("stem")
+    finally:
+        os.environ.pop("INFERA_STEM_POOL", None)
+    assert np.array_equal(out["0"], out["1"]), np.abs(out["0"] - out["1"]).max()
+    want = oracle.Model(path).predict_blob(x.tobytes())
+    assert out["1"].shape == want.shape
+    assert np.all(np.abs(out["1"] - want) <= 1e-4 * np.abs(want) + 1e-6), np.abs(out["1"] - want).max()
