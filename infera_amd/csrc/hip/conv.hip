@@ -651,6 +651,7 @@ constexpr int kPatchMaxE = 16;
 
 // The stem + max-pool kernel (POOL): a 512-thread workgroup owns an 8 x 7 tile of POOLED pixels, i.e. the 17 x 15 convolution
 // pixels its 3x3/2 windows cover (255 = eight 32-pixel MFMA tiles, one per wave, pixel p -> row p/15, column p%15).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kPoolBlock = 512, kPoolCR = 17, kPoolCC = 15, kPoolTR = 8, kPoolTC = 7;
 static PatchGeom patch_pool_geom(const ConvGeom &g, const PoolTail &pool) {
   PatchGeom p{};
@@ -675,7 +676,7 @@ static PatchGeom patch_pool_geom(const ConvGeom &g, const PoolTail &pool) {
 }
 
 static size_t patch_pool_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
-  return (size_t(p.K8) * (g.M / 32) * 256 + size_t(p.K8) * 8 + 2 * size_t(g.C) * p.PLANE + 256 * size_t(g.M + 4)) * sizeof(float);
+  return (size_t(p.K8) * (g.M / 32) * 256 + size_t(p.K8) * 8 + 2 * size_t(g.C) * p.PLANE + 8 + 256 * size_t(g.M + 4)) * sizeof(float);
 }
 
 static PatchGeom patch_geom(const ConvGeom &g) {
@@ -702,7 +703,7 @@ static PatchGeom patch_geom(const ConvGeom &g) {
 }
 
 static size_t patch_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
-  return (size_t(p.K8) * (g.M / 32) * 256 + size_t(p.K8) * 8 + 2 * size_t(g.C) * p.PLANE) * sizeof(float);
+  return (size_t(p.K8) * (g.M / 32) * 256 + size_t(p.K8) * 8 + 2 * size_t(g.C) * p.PLANE + 4) * sizeof(float);
 }
 
 // K8C > 0: the number of k groups is a compile-time constant and the group loop is fully unrolled (register
@@ -746,37 +747,50 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
     const bool live = i < pg.NE && c < g.C;
     e_rel[i] = (c * g.H + row) * g.W + col;
     e_rc[i] = live ? (row << 16) | col : -1;
-    e_lds[i] = c * pg.PLANE + row * pg.ROWS + (col % g.sw) * pg.HALF + col / g.sw;
+    e_lds[i] = live ? c * pg.PLANE + row * pg.ROWS + (col % g.sw) * pg.HALF + col / g.sw : -1;
   }
+  // The staging code carries no branch: a word outside the image (or past this thread's share) loads the image's first
+  // pixel and is zeroed by a select, a dead slot stores into four spare floats behind the two patch buffers.  (Guarded
+  // element by element, each of the 16 slots was its own exec-masked block: ~400 scalar-heavy instructions per tile.)
+  // Slots 8.. and 12.. are skipped by one uniform branch each when the share is that short.
+  const bool ne8 = pg.NE <= 8, ne12 = pg.NE <= 12;
   const int tiles_per_img = pg.tiles_x * pg.tiles_y;
-  auto tile_origin = [&](int64_t t, int64_t &img, int &oy0, int &ox0) {
-    img = t / tiles_per_img;
-    const int rem = int(t - img * tiles_per_img), ty = rem / pg.tiles_x, tx = rem - ty * pg.tiles_x;
+  // (32-bit: the launcher keeps ntiles below 2^31.  As 64-bit divisions, executed by every lane for every tile, the two
+  // calls per tile were ~300 instructions: a tenth of a tile's time, outside the MFMA loop)
+  auto tile_origin = [&](int64_t t, int &img, int &oy0, int &ox0) {
+    const unsigned u = unsigned(t), im = u / unsigned(tiles_per_img), rem = u - im * unsigned(tiles_per_img);
+    const unsigned ty = rem / unsigned(pg.tiles_x), tx = rem - ty * unsigned(pg.tiles_x);
+    img = int(im);
     if constexpr (POOL) {  // first convolution pixel under the tile's first pooled pixel
-      oy0 = ty * kPoolTR * 2 - pool.pt;
-      ox0 = tx * kPoolTC * 2 - pool.pl;
+      oy0 = int(ty) * kPoolTR * 2 - pool.pt;
+      ox0 = int(tx) * kPoolTC * 2 - pool.pl;
     } else {
-      oy0 = ty * 4 * pg.TR;
-      ox0 = tx * pg.TC;
+      oy0 = int(ty) * 4 * pg.TR;
+      ox0 = int(tx) * pg.TC;
     }
   };
-  auto load_patch = [&](float(&v)[kPatchMaxE], int64_t t) {
-    int64_t img;
-    int oy0, ox0;
-    tile_origin(t, img, oy0, ox0);
+  // one slot of the patch of the tile at (img, oy0, ox0): a dead slot has row -1 / column 65535 -- never inside
+  auto load_slot = [&](int i, const float *image, int iy0, int ix0) -> float {
+    const int iy = iy0 + (e_rc[i] >> 16), ix = ix0 + (e_rc[i] & 0xffff);
+    const bool ok = unsigned(iy) < unsigned(g.H) && unsigned(ix) < unsigned(g.W);
+    const float x = image[ok ? iy0 * g.W + ix0 + e_rel[i] : 0];
+    return ok ? x : 0.f;
+  };
+  auto load_patch = [&](float(&v)[kPatchMaxE], int img, int oy0, int ox0) {
     const int iy0 = oy0 * g.sh - g.pt, ix0 = ox0 * g.sw - g.pl;
-    const float *corner = X + img * g.C * g.H * g.W + int64_t(iy0) * g.W + ix0;
+    const float *image = X + int64_t(img) * g.C * g.H * g.W;
 #pragma unroll
     for (int i = 0; i < kPatchMaxE; i++) {
-      const int iy = iy0 + (e_rc[i] >> 16), ix = ix0 + (e_rc[i] & 0xffff);
-      const bool ok = e_rc[i] >= 0 && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-      v[i] = ok ? corner[e_rel[i]] : 0.f;
+      if ((i == 8 && ne8) || (i == 12 && ne12)) break;
+      v[i] = load_slot(i, image, iy0, ix0);
     }
   };
-  auto store_patch = [&](const float(&v)[kPatchMaxE], int buf) {
+  auto store_patch = [&](const float(&v)[kPatchMaxE], int buf, bool all) {  // all: every slot was fetched (dead ones too)
 #pragma unroll
-    for (int i = 0; i < kPatchMaxE; i++)
-      if (e_rc[i] >= 0) patch[buf * psz + e_lds[i]] = v[i];
+    for (int i = 0; i < kPatchMaxE; i++) {
+      if (!all && ((i == 8 && ne8) || (i == 12 && ne12))) break;
+      patch[e_lds[i] >= 0 ? buf * psz + e_lds[i] : 2 * psz + (i & 3)] = v[i];
+    }
   };
 
   // lane's pixel inside the workgroup tile, and its word offset inside a patch channel
@@ -802,15 +816,98 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
   const int64_t chunk = (ntiles + 7) >> 3, t_end = min(ntiles, (int64_t(blockIdx.x & 7) + 1) * chunk);
   const int64_t tstep = (gridDim.x + 7 - (blockIdx.x & 7)) >> 3;  // workgroups on this XCD
   int64_t tile = int64_t(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  int img_n = 0, oy0_n = 0, ox0_n = 0;  // origin of the tile whose patch is being fetched (the next one; first: this one)
   if (tile < t_end) {
-    load_patch(pv, tile);
-    store_patch(pv, 0);
+    tile_origin(tile, img_n, oy0_n, ox0_n);
+    load_patch(pv, img_n, oy0_n, ox0_n);
+    store_patch(pv, 0, false);
   }
   __syncthreads();
+  // the first two offset quads and the first A fragments are the same for every tile: read once (a tile then starts with
+  // its B words, not with an offset read -> B read -> MFMA chain of two LDS latencies)
+  const int4 ko_first = ktab4[0], ko_second = ktab4[K8C > 1 ? 2 : 0];
+  f32x4 a_first[MT];
+#pragma unroll
+  for (int t = 0; t < MT; t++) a_first[t] = wfrag[t * 64];
+  // ---- POOL: the exchange tile and this thread's (at most two) pooled (pixel, channel quad) items ----
+  constexpr int XQ = 8 * MT + 1, NQ = 8 * MT, PT = kPoolTR * kPoolTC;  // quads per pixel in the exchange tile; quads; pooled pixels
+  // SHADOW: the pooling of tile k-1 runs inside tile k's MFMA loop (compile-time k loops of at least 22 units), one LDS read or
+  // one quad of max per unit in the shadow of the unit's first MFMA, results stored through a buffer descriptor (lanes whose
+  // pooled pixel lies outside the tensor carry offset -1 and are dropped by the bounds check: no branch in the loop; the first
+  // tile's "previous tile" has a descriptor of zero bytes).  The exchange tile stays valid until the barrier in front of the
+  // next exchange write.  Otherwise (short or run-time k loops) every thread pools right after the exchange, in lock step.
+  constexpr bool SHADOW = POOL && K8C >= 6;
+  f32x4 *exch = reinterpret_cast<f32x4 *>(patch + ((2 * psz + 4 + 3) & ~3));  // behind the patch buffers and their four spare floats
+  int pwin[2] = {0, 0}, poff[2] = {-1, -1}, ppr[2] = {0, 0}, ppc[2] = {0, 0};
+  if constexpr (POOL) {
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const int it = threadIdx.x + n * BS;
+      const bool ok = it < NQ * PT;
+      const int cq = ok ? it / PT : 0, pp = ok ? it % PT : 0, pr = pp / kPoolTC, pc = pp % kPoolTC;
+      pwin[n] = ((2 * pr) * kPoolCC + 2 * pc) * XQ + cq;
+      ppr[n] = pr;
+      ppc[n] = pc;
+      poff[n] = ok ? ((cq * pool.OH + pr) * pool.OW + pc) * 16 : -1;  // bytes from the image's pooled pixel (0, 0) of quad 0
+    }
+  }
+  const unsigned pooled_img_bytes = unsigned(NQ) * unsigned(pool.OH) * unsigned(pool.OW) * 16u;
+  auto pooled_rsrc = [&](int img, bool live) {
+    const char *base = reinterpret_cast<const char *>(Y) + int64_t(__builtin_amdgcn_readfirstlane(img)) * pooled_img_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, live ? int(pooled_img_bytes) : 0, 0x00020000);
+  };
+  auto pooled_voff = [&](int n, int pr0, int pc0) {
+    return (poff[n] >= 0 && pr0 + ppr[n] < pool.OH && pc0 + ppc[n] < pool.OW) ? poff[n] + (pr0 * pool.OW + pc0) * 16 : -1;
+  };
+  auto pooled_store = [&](const f32x4 &m, __amdgpu_buffer_rsrc_t rs, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), rs, voff, 0, 0);
+  };
+  auto pool_tile = [&](int img, int pr0, int pc0) {  // lock step: this thread's items of the tile in the exchange tile
+    const __amdgpu_buffer_rsrc_t rs = pooled_rsrc(img, true);
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      if (n * BS >= NQ * PT) break;
+      const f32x4 *win = exch + pwin[n];
+      f32x4 m = win[0];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const f32x4 v = win[(i * kPoolCC + j) * XQ];
+#pragma unroll
+          for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
+        }
+      pooled_store(m, rs, pooled_voff(n, pr0, pc0));
+    }
+  };
+  int img_p = 0, pr0_p = 0, pc0_p = 0;  // the tile whose exchange tile is waiting to be pooled
+  bool have_p = false;
   int buf = 0;
   for (; tile < t_end; tile += tstep, buf ^= 1) {
     const int64_t next = tile + tstep;
-    if (next < t_end) load_patch(pv, next);  // lands under this tile's MFMAs
+    const int img = img_n, oy0 = oy0_n, ox0 = ox0_n;
+    // (SHADOW) descriptor and offsets of the previous tile's pooled outputs, and the in-loop pooling state
+    const __amdgpu_buffer_rsrc_t rs_p = pooled_rsrc(img_p, have_p);
+    const int voff_p[2] = {pooled_voff(0, pr0_p, pc0_p), pooled_voff(1, pr0_p, pc0_p)};
+    f32x4 ptmp[2], pm;
+    auto shadow_pool = [&](int uu) {  // item 0: units 0..10, item 1: units 11..21 (nine reads, nine maxima one unit later, the store)
+      const int n = uu / 11, st = uu - 11 * n;
+      if (n > 1) return;
+      if (st < 9) ptmp[st & 1] = exch[pwin[n] + ((st / 3) * kPoolCC + st % 3) * XQ];
+      if (st == 1) pm = ptmp[0];
+      if (st >= 2 && st <= 9) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) pm[e] = fmaxf(pm[e], ptmp[(st - 1) & 1][e]);
+      }
+      if (st == 10) pooled_store(pm, rs_p, voff_p[n]);
+    };
+    // The next tile's patch is fetched under this tile's MFMAs.  Compile-time k loop: slot by slot INSIDE the loop, each slot's
+    // bounds test, address and load in the shadow of one MFMA (ahead of the loop the ~200 instructions were exposed: every wave of
+    // the workgroup is in the same phase).  The last tile re-fetches itself (no branch in the loop; nothing is stored).
+    tile_origin(next < t_end ? next : tile, img_n, oy0_n, ox0_n);
+    const int iy0_n = oy0_n * g.sh - g.pt, ix0_n = ox0_n * g.sw - g.pl;
+    const float *image_n = X + int64_t(img_n) * g.C * g.H * g.W;
+    if constexpr (K8C == 0) load_patch(pv, img_n, oy0_n, ox0_n);
 
     f32x16 acc[MT];
 #pragma unroll
@@ -823,27 +920,43 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
       int4 ko[3];
       float b[2][4];
       f32x4 a[2][MT];
-      ko[0] = ktab4[0];
-      if (K8C > 1) ko[1] = ktab4[2];
+      ko[0] = ko_first;
+      ko[1] = ko_second;
 #pragma unroll
       for (int j = 0; j < 4; j++) b[0][j] = pb[(&ko[0].x)[j]];
 #pragma unroll
-      for (int t = 0; t < MT; t++) a[0][t] = wfrag[t * 64];
+      for (int t = 0; t < MT; t++) a[0][t] = a_first[t];
 #pragma unroll
       for (int grp = 0; grp < K8C; grp++) {
-        if (grp + 2 < K8C) ko[(grp + 2) % 3] = ktab4[(grp + 2) * 2];
-        if (grp + 1 < K8C) {
+        // A group = four units of (one B word x MT MFMAs).  Each unit also ISSUES a quarter of the next group's LDS reads -- its
+        // B word j, A fragment j, the offsets of the group after that -- in the shadow of the unit's first MFMA: a whole group
+        // (8 MFMAs at MT = 2) before they are used, and with the matrix pipe already busy.  (Left to the scheduler the reads sank
+        // behind the group's last MFMA and every group opened with s_waitcnt lgkmcnt(0); pinned in front of the group's first MFMA
+        // the pipe idled while a dozen reads and address adds issued.)
+        const int cur = grp & 1, nxt = cur ^ 1;
 #pragma unroll
-          for (int j = 0; j < 4; j++) b[(grp + 1) & 1][j] = pb[(&ko[(grp + 1) % 3].x)[j]];
+        for (int j = 0; j < 4; j++) {
+          if (grp + 1 < K8C) {
+            b[nxt][j] = pb[(&ko[(grp + 1) % 3].x)[j]];
+            if (j < MT) a[nxt][j] = wfrag[((grp + 1) * MT + j) * 64];
+          }
+          if (j == 0 && grp + 2 < K8C) ko[(grp + 2) % 3] = ktab4[(grp + 2) * 2];  // (used from the next group's first unit on)
+          // patch slots of the next tile, spread evenly over the 4 * K8C units
 #pragma unroll
-          for (int t = 0; t < MT; t++) a[(grp + 1) & 1][t] = wfrag[((grp + 1) * MT + t) * 64];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
+          for (int sl = 0; sl < kPatchMaxE; sl++)
+            if (sl * (4 * K8C) / kPatchMaxE == grp * 4 + j) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
+          if constexpr (SHADOW) shadow_pool(grp * 4 + j);
 #pragma unroll
           for (int t = 0; t < MT; t++)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][t][j], b[grp & 1][j], acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t][j], b[cur][j], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // the unit's first MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // address arithmetic of ...
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // ... the next group's reads (and one of the pooling's)
+          __builtin_amdgcn_sched_group_barrier(0x020, K8C < 4 ? 4 : (K8C < 8 ? 2 : 1), 0);  // ... and of this unit's patch slot(s), if any
+          __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // (a pooled store)
+          if (MT > 1) __builtin_amdgcn_sched_group_barrier(0x008, MT - 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     } else {
     int4 ko_n = ktab4[0];
@@ -878,15 +991,10 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
     }
 
     // epilogue: lane (r,h) holds pixel (oy, ox), channels 32t + 8q + 4h + j -> channel quad 8t + 2q + h
-    int64_t img;
-    int oy0, ox0;
-    tile_origin(tile, img, oy0, ox0);
     const int oy = oy0 + py, ox = ox0 + px;
     if constexpr (POOL) {
-      constexpr int XQ = 8 * MT + 1;  // quads per pixel in the exchange tile
-      f32x4 *exch = reinterpret_cast<f32x4 *>(patch + 2 * psz);
       const bool inside = oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
-      __syncthreads();  // the previous tile's pooling has read the exchange tile (everybody has been through a whole k loop since)
+      __syncthreads();  // the previous tile's pooling has read the exchange tile (SHADOW: inside the k loop everybody has just left)
       dispatch_act(act.kind, [&](auto kind_tag) {
         constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
@@ -900,32 +1008,21 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
           }
         }
       });
-      if (next < t_end) store_patch(pv, buf ^ 1);
+      // (unconditional -- the last tile parks its own re-fetched patch: a fetch that is consumed on one path only leaves the loop
+      // head with an s_waitcnt vmcnt that also drains the pooled stores issued just before it, every tile)
+      store_patch(pv, buf ^ 1, K8C > 0);
       __syncthreads();
-      const int pr0 = (oy0 + pool.pt) >> 1, pc0 = (ox0 + pool.pl) >> 1;
-      constexpr int NQ = 8 * MT, PT = kPoolTR * kPoolTC;
-      float *yimg = Y + img * int64_t(NQ) * pool.OH * pool.OW * 4;
-      for (int it = threadIdx.x; it < NQ * PT; it += BS) {
-        const int cq = it / PT, pp = it - cq * PT, pr = pp / kPoolTC, pc = pp - pr * kPoolTC;
-        const f32x4 *win = exch + ((2 * pr) * kPoolCC + 2 * pc) * XQ + cq;
-        f32x4 m = win[0];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            const f32x4 v = win[(i * kPoolCC + j) * XQ];
-#pragma unroll
-            for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
-          }
-        if (pr0 + pr < pool.OH && pc0 + pc < pool.OW)
-          *reinterpret_cast<f32x4 *>(yimg + ((int64_t(cq) * pool.OH + pr0 + pr) * pool.OW + pc0 + pc) * 4) = m;
-      }
+      img_p = img;
+      pr0_p = (oy0 + pool.pt) >> 1;
+      pc0_p = (ox0 + pool.pl) >> 1;
+      have_p = true;
+      if constexpr (!SHADOW) pool_tile(img_p, pr0_p, pc0_p);
       continue;  // (both barriers of this tile are behind us; the patch for the next tile is in place)
     }
     if (oy < g.OH && ox < g.OW) {
       // g.mvalid > 0: M was padded to whole 32-feature tiles (stems with 16 / 24 outputs); planes past mvalid/4 do not exist
       const int mreal = g.mvalid > 0 ? g.mvalid : g.M;
-      float *yp = Y + img * OHW * mreal + (int64_t(h) * OHW + oy * g.OW + ox) * 4;
+      float *yp = Y + int64_t(img) * OHW * mreal + (int64_t(h) * OHW + oy * g.OW + ox) * 4;
       dispatch_act(act.kind, [&](auto kind_tag) {
         constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
@@ -940,9 +1037,11 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
         }
       });
     }
-    if (next < t_end) store_patch(pv, buf ^ 1);
+    store_patch(pv, buf ^ 1, K8C > 0);  // (unconditional: see the pooled epilogue)
     __syncthreads();
   }
+  if constexpr (SHADOW)
+    if (have_p) pool_tile(img_p, pr0_p, pc0_p);  // the workgroup's last tile has no k loop behind it to hide under
 }
 
 // Depthwise convolution (groups == C == M) in channel-quad planes: HBM-bound, no matrix cores.  One thread per
@@ -1175,6 +1274,7 @@ bool conv2d_patch_pool_supported(const ConvGeom &g, const PoolTail &pool) {
   if (!conv2d_patch_supported(g) || g.mvalid > 0 || g.M > 64 || pool.OH < 1 || pool.OW < 1 || pool.pt < 0 || pool.pt > 1 || pool.pl < 0 || pool.pl > 1)
     return false;
   if ((pool.OH - 1) * 2 - pool.pt >= g.OH || (pool.OW - 1) * 2 - pool.pl >= g.OW) return false;  // a window with no pixel at all
+  if (int64_t(g.M) * pool.OH * pool.OW * 4 >= (int64_t(1) << 31)) return false;                  // (one image's pooled planes = one buffer descriptor)
   const PatchGeom p = patch_pool_geom(g, pool);
   return p.NE <= kPatchMaxE && p.PR < 32768 && p.PC < 65536 && patch_pool_lds_bytes(g, p) <= 160 * 1024;
 }
@@ -1211,6 +1311,11 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
                        const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus) {
   if (rows <= 0) return;
   const PatchGeom p = patch_pool_geom(g, pool);
+  if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {  // (the kernel counts tiles in 32 bits)
+    for (int64_t r0 = 0; r0 < rows; r0 += cap)
+      conv2d_patch_pool(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus);
+    return;
+  }
   const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
   const size_t lds = patch_pool_lds_bytes(g, p);
   const unsigned grid = unsigned(std::min<int64_t>(ntiles, int64_t(num_cus > 0 ? num_cus : 256)));
@@ -1235,6 +1340,12 @@ void conv2d_patch(hipStream_t s, const float *X, const float *packed, const floa
                   const ConvGeom &g, ActParam act, int num_cus) {
   if (rows <= 0) return;
   const PatchGeom p = patch_geom(g);
+  if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {  // (the kernel counts tiles in 32 bits)
+    const int64_t out_row = int64_t(g.mvalid > 0 ? g.mvalid : g.M) * g.OH * g.OW;
+    for (int64_t r0 = 0; r0 < rows; r0 += cap)
+      conv2d_patch(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * out_row, std::min(cap, rows - r0), g, act, num_cus);
+    return;
+  }
   const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
   const size_t lds = patch_lds_bytes(g, p);
   const int per_cu = int(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds)));
