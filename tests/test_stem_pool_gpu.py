@@ -39,6 +39,9 @@ CASES = {
     "m32_gray": dict(cin=1, hw=40, m=32, k=5, stride=1, pad=2, pool_pad=1, ceil=False, rows=5),             # stride-1 stem, one channel, 32 features
     "four_channels_no_relu": dict(cin=4, hw=36, m=64, k=3, stride=1, pad=1, pool_pad=1, ceil=False, rows=2, relu=False),  # negative values reach the pool
     "many_tiles": dict(cin=3, hw=96, m=64, k=7, stride=2, pad=3, pool_pad=1, ceil=False, rows=40),          # 40 x 3 x 4 = 480 tiles > 256 workgroups
+    "k5_rgb": dict(cin=3, hw=48, m=64, k=5, stride=2, pad=2, pool_pad=1, ceil=False, rows=6),                # 75 taps -> 10 k groups: in-loop pooling over 40 units
+    "m32_rgb7": dict(cin=3, hw=40, m=32, k=7, stride=2, pad=3, pool_pad=1, ceil=False, rows=5),             # one feature tile per wave, in-loop pooling, 448 items
+    "cin2_k3": dict(cin=2, hw=30, m=64, k=3, stride=1, pad=1, pool_pad=0, ceil=False, rows=3),              # 18 taps -> run-time k loop, lock-step pooling
     "rectangular": dict(cin=3, hw=44, hw2=70, m=64, k=7, stride=2, pad=3, pool_pad=1, ceil=False, rows=3),  # H != W
 }
 
