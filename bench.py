@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="bf16x3 = the OPTIONAL fast mode of the fused MLP (three bf16 MFMAs per product; NOT the parity path, "
                          "never the default, never the headline): the line is labelled accordingly")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default run only: skip the short device-resident C4 / C5 measurements reported under other_workloads")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-path (PCIe-inclusive) scan")
     ap.add_argument("--e2e-threads", default="", help="worker-thread counts to sweep for the host path (default: from the CPU budget)")
     ap.add_argument("--e2e-reps", type=int, default=5)
@@ -251,6 +253,57 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
             "device_slots": [{"slot": d["slot"], "ordinal": d["ordinal"], "rows_this_run": d["host_rows"] - before.get(d["slot"], 0)} for d in after]}
 
 
+def traffic_for(workload: str, rows: int, bf16x3: bool = False):
+    """HBM bytes per launch from the committed PMC passes (tools/profile_bench.sh), when they match this workload and row count."""
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}{'_bf16x3' if bf16x3 else ''}.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("rows") == rows:
+            return tj["traffic_bytes_per_launch"], f"profiles/{os.path.basename(tpath)} (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, {tj.get('round', '')})"
+    return None, None
+
+
+def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str) -> dict:
+    """BASELINE configs C4 / C5 beside the headline, device-resident and short (2 warm + 5 timed passes, HIP events on the
+    launching stream): the same definitions as `value` / `roofline`, so that the driver's own run records them too.  Their
+    full lines (end_to_end, cpu_baseline) are `bench.py --workload logreg|resnet18`."""
+    if which == "logreg":
+        path = onnx_writer.write(os.path.join(tmp, "c4.onnx"), onnx_writer.logreg_softmax(128, 10))
+        rows, cols, out_cols, bound, flops_row, bytes_row = 50_000_000, 128, 10, "hbm", 2560.0, 552.0
+        name = "C4: logistic regression Gemm(128->10)+Softmax(axis=1), 50M-row x 128-col FLOAT table resident in HBM"
+    else:
+        path = onnx_writer.write(os.path.join(tmp, "c5.onnx"), onnx_writer.resnet18(in_hw=224))
+        rows, cols, out_cols, bound, flops_row, bytes_row = 1024, 3 * 224 * 224, 1000, "mfma", 3628146688.0, 606112.0
+        name = "C5: ResNet-18 topology (random weights), 1024 BLOB[3x224x224] f32 images resident in HBM"
+    model = "bench_" + which
+    capi.load_model(model, path)
+    try:
+        d_in = capi.DeviceBuffer(dev, rows * cols * 4)
+        d_out = capi.DeviceBuffer(dev, rows * out_cols * 4)
+        capi.synth_fill(d_in, 42, 0, rows, cols)
+        for _ in range(2):
+            capi.predict_device(model, d_in, rows, cols, d_out, sync=False)
+        capi.sync(dev)
+        iters = 5
+        kernel_s = capi.time_predict_device(model, d_in, rows, cols, d_out, iters) / 1e3 / iters
+        y = d_out.download((2, out_cols))
+        assert all(v == v for v in y.ravel().tolist()), "NaN in output"
+        plan = capi.get_plan(model)
+        del d_in, d_out
+    finally:
+        capi.unload_model(model)
+    if bound == "mfma":
+        achieved, peak, unit = flops_row * rows / kernel_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        achieved, peak, unit = bytes_row * rows / kernel_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    traffic, traffic_source = traffic_for(which, rows)
+    return {"workload": name, "rows": rows, "rows_per_s": rows / kernel_s, "ms_per_pass": kernel_s * 1e3, "passes_timed": iters, "dtype": "f32",
+            "kernel": plan.get("fused_kernel", ",".join(sorted(set(plan["exec"]) - {"skipped"}))),
+            "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": traffic_source, "algorithmic_bytes": bytes_row * rows,
+                         "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}}}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -361,18 +414,21 @@ def main():
     # HBM traffic per launch: PMC counters cannot be read from inside this process; they are collected by
     # tools/profile_bench.sh (separate rocprofv3 --pmc passes of this same command) and committed as
     # profiles/traffic_<workload>.json.  Reported only when that file matches this workload and row count.
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}{'_bf16x3' if bf16x3 else ''}.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("rows") == rows:
-            traffic = tj["traffic_bytes_per_launch"]  # HBM bytes per launch, a plain number as the contract asks
-            traffic_source = f"profiles/{os.path.basename(tpath)} (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, {tj.get('round', '')})"
+    traffic, traffic_source = traffic_for(args.workload, rows, bf16x3)  # HBM bytes per launch, a plain number as the contract asks
 
     # a cheap end-of-run sanity check so a silently wrong kernel cannot post a number
     y = d_out.download((4, out_cols))
     assert os.environ.get("INFERA_CONV_PROBE") or all(map(lambda v: v == v, y.ravel().tolist())), "NaN in output"
     del d_in, d_out
+
+    # ---- the other two GPU configs of BASELINE.json, short and device-resident (default single-GPU run only) ----
+    others = {}
+    if args.workload == "mlp" and world == 1 and not bf16x3 and not args.no_other_workloads and args.rows is None:
+        for key, which in (("C4", "logreg"), ("C5", "resnet18")):
+            try:
+                others[key] = other_workload(capi, onnx_writer, tmp, dev, which)
+            except Exception as exc:  # never at the expense of the headline line
+                others[key] = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- the metric as SURVEY 8(d) defines it: the host path, PCIe included (all ranks scan concurrently) ----
     e2e, table = None, None
@@ -425,6 +481,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": bytes_row * rows,
                          "kernel_ms": kernel_s * 1e3, "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}},
         }
+        if others:
+            line["other_workloads"] = others
         if e2e:
             e2e["numa_binding"] = numa
             line["end_to_end"] = e2e

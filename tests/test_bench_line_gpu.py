@@ -1,0 +1,39 @@
+"""bench.py's default invocation (what the driver runs: no flags beyond --steps / --warmup) on one GPU: the contract fields, the
+roofline / cpu_baseline / end_to_end blocks, and the short device-resident C4 / C5 measurements under `other_workloads` (same
+definitions as `value` / `roofline`) -- so that the driver-recorded line carries all three GPU configs of BASELINE.json."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_default_bench_line_has_contract_fields_and_other_workloads():
+    env = dict(os.environ)
+    env.pop("INFERA_DEVICES", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-seconds", "3", "--e2e-reps", "2"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["unit"] == "rows/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("C2:") and d["config"]["rows_per_gpu"] == 10_000_000
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.5 < r["frac"] < 1.0
+    assert abs(d["value"] - 10_000_000 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    e = d["end_to_end"]
+    assert e["rows_per_s"] > 0 and 0 < e["frac_of_pcie"] < 1.2 and "vs_cpu_baseline" in e
+    o = d["other_workloads"]
+    c4, c5 = o["C4"], o["C5"]
+    assert c4["roofline"]["bound"] == "hbm" and c4["rows"] == 50_000_000 and 0.3 < c4["roofline"]["frac"] < 1.0, c4
+    assert c5["roofline"]["bound"] == "mfma" and c5["rows"] == 1024 and 0.3 < c5["roofline"]["frac"] < 1.0, c5
+    assert abs(c4["rows_per_s"] - c4["rows"] / (c4["ms_per_pass"] / 1e3)) / c4["rows_per_s"] < 1e-9

@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-prof}
 shift || true
-BENCH_ARGS=${*:---steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end}
+BENCH_ARGS=${*:---steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
