@@ -456,7 +456,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
 // is already being gathered, and the epilogue's loads / stores drain under the next tile's MFMAs.
 // Same packed weights as the tiled kernel (chunk-major, conv2d_tiled_pack), same summation order -> bit-identical results.
 // (Measured and dropped: 12 waves per workgroup = 3 per SIMD for the 64-feature form -- needs 168 registers, spills 114,
-// 1.96-2.11 ms against 1.73-1.78; 32-feature slices for 256-channel layers do not fit.)
+// 1.96-2.11 ms against 1.73-1.78; 32-feature slices for 256-channel layers do not fit.  An A-fragment ring that runs on through
+// stage and tile boundaries -- no P reads + wait at the head of a stage -- measured the same: the SIMD's other wave covers it.)
 template <int MT, int S, int NW>
 __global__ __launch_bounds__(NW * 64) void conv2d_ws_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                            const float *__restrict__ bias, const float *__restrict__ residual,
