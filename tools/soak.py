@@ -17,6 +17,8 @@ blob_path = W.write(f"{d}/zoo.onnx", W.zoo_ops_net()[0])
 for k, p in paths.items():
     capi.load_model(k, p)
 capi.load_model("zoo", blob_path)
+capi.load_model("r18s", W.write(f"{d}/r18s.onnx", W.resnet18(in_hw=64)))  # fused stem + pool, weight-stationary and tiled convolutions
+imgs64 = synth.table(9, 0, 6, 3 * 64 * 64)
 tables = {k: synth.table(7, 0, 4096, c) for k, c in cols.items()}
 imgs = synth.table(8, 0, 24, 3 * 16 * 16)
 ref, ref_mu = {}, threading.Lock()
@@ -41,9 +43,12 @@ def worker(t):
                 lo = rng.randrange(0, 2048, 256)
                 n = rng.choice([1, 33, 500, 2048])
                 check((k, lo, n), capi.predict(k, tables[k][lo:lo + n]))
-            elif r < 0.92:
+            elif r < 0.88:
                 n = rng.choice([1, 5, 24])
                 check(("zoo", n), capi.predict_from_blob("zoo", imgs[:n].tobytes()))
+            elif r < 0.92:
+                n = rng.choice([1, 3, 6])
+                check(("r18s", n), capi.predict_from_blob("r18s", imgs64[:n].tobytes()))
             else:
                 name = f"tmp{t}"
                 capi.load_model(name, paths[rng.choice(["skl", "tiny", "wide"])])
