@@ -607,6 +607,10 @@ void schedule(LoadedModel &m) {
       for (int b : e.reads) in_readers += b == 0;
     m.in_colmajor_ok = !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::Mlp3Head && eff[0].reads[0] == 0 &&
                        kern::mlp3_colmajor_supported(m.mlp3_shape) && !m.bf16x3;
+    // the fused small-MLP chain reads a column-major chunk too (a run-time flag of the same kernel); INFERA_CHAIN_XCM=0: transpose first
+    const char *cx = getenv("INFERA_CHAIN_XCM");
+    if (!(cx && cx[0] == '0') && !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::ChainHead && eff[0].reads[0] == 0)
+      m.in_colmajor_ok = true;
   }
   const size_t nb = m.plan.buf_per_row.size();
   std::vector<int> last_read(nb, -1);
@@ -833,7 +837,7 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           const LoadedModel::ChainRun &run = *m.chain_at(i);
           std::string why;
           if (!kern::chain(s, run.shape, buf(x.in0), dm.chain_packed[size_t(&run - m.chains.data())],
-                           buf(st[i + size_t(run.nsteps) - 1].out), nr, dm.num_cus, &why))
+                           buf(st[i + size_t(run.nsteps) - 1].out), nr, dm.num_cus, &why, in_colmajor && x.in0 == 0))
             throw InferaError::onnx("fused chain kernel launch failed: " + why);
           continue;
         }

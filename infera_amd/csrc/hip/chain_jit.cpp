@@ -172,7 +172,7 @@ bool chain_supported(const ChainShape &s, std::string *why) {
 }
 
 bool chain(hipStream_t st, const ChainShape &s, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
-           std::string *why) {
+           std::string *why, bool x_colmajor) {
   hipFunction_t fn = nullptr;
   const int lds = int(lds_bytes(s));
   {
@@ -205,7 +205,7 @@ bool chain(hipStream_t st, const ChainShape &s, const float *X, const float *pac
   const int per_cu = int(std::min<size_t>(8, std::max<size_t>(1, kLdsBudget / size_t(lds))));
   const int waves = waves_of(s);
   int64_t blocks = std::min<int64_t>((ntiles + waves - 1) / waves, int64_t(num_cus) * per_cu);
-  int aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0 ? 1 : 0;
+  int aligned = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 ? 1 : 0) | (x_colmajor ? 2 : 0);  // (chain_device.inc: x_aligned16 bits)
   void *args[] = {(void *)&X, (void *)&packed, (void *)&Y, (void *)&rows, (void *)&aligned};
   hipError_t e = hipModuleLaunchKernel(fn, unsigned(blocks), 1, 1, unsigned(waves) * 64, 1, 1, unsigned(lds), st, args, nullptr);
   if (e != hipSuccess) {

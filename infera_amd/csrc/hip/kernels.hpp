@@ -97,8 +97,9 @@ bool chain_supported(const ChainShape &s, std::string *why = nullptr);
 size_t chain_packed_floats(const ChainShape &s);
 // W[l] is [K_l, M_l] row-major, bias[l] has M_l floats or is null
 void chain_pack(const ChainShape &s, const std::vector<const float *> &W, const std::vector<const float *> &bias, float *out);
+// x_colmajor: X is one column-major chunk [k0][rows] (the host path's staging layout) instead of the row-major table
 bool chain(hipStream_t st, const ChainShape &s, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
-           std::string *why);
+           std::string *why, bool x_colmajor = false);
 std::string chain_kernel_name(const ChainShape &s);
 
 // ---- convolution / pooling (conv.hip) ----------------------------------------------------------

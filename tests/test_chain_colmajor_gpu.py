@@ -1,0 +1,57 @@
+"""The fused small-MLP chain kernel reading a COLUMN-MAJOR chunk (chain_device.inc, x_aligned16 bit 1): the host path stages a
+DataChunk's flat columns as they lie and the kernel reads them itself -- no transpose launch in front.  Results through the
+columnar entry (`infera_predict_columns`) must be bit-for-bit those of the row-major host entry (`infera_predict`: same kernel,
+same sums, only the operand fetch differs) and match the oracle: table widths that are and are not multiples of 4, row counts
+that are not multiples of 4 (unaligned column starts -> element-wise fetch), one row, several 32-row tiles, DOUBLE / INTEGER
+columns, a chain behind PadCols, softmax / argmax epilogues.  INFERA_CHAIN_XCM=0 at load time = transpose launch first."""
+import os
+
+import numpy as np
+import pytest
+
+from infera_amd import onnx_writer as W
+from infera_amd import synth
+
+SHAPES = {
+    "sklearn_default": dict(dims=(30, 100, 2), softmax=True),
+    "regressor": dict(dims=(13, 64, 32, 1), softmax=False),
+    "iris": dict(dims=(4, 10, 3), softmax=True),
+    "wide_first": dict(dims=(100, 64, 4), softmax=False),
+    "odd_columns": dict(dims=(77, 20, 5), softmax=True),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+@pytest.mark.parametrize("rows", [1, 33, 1234, 2048, 4099])
+def test_gpu_chain_kernel_reads_column_major_chunks(gpu_api, tmp_path, shape, rows):
+    from oracle import oracle
+
+    sp = SHAPES[shape]
+    k = sp["dims"][0]
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp(sp["dims"], final_softmax=sp["softmax"]))
+    x = synth.table(11, 0, rows, k)
+    cols = [np.ascontiguousarray(x[:, c]) for c in range(k)]
+    cols[0] = cols[0].astype(np.float64)  # DuckDB's default floating type: converted while staged
+    if k > 2:
+        cols[2] = np.round(cols[2] * 100).astype(np.int32)
+        x = x.copy()
+        x[:, 2] = cols[2].astype(np.float32)
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["INFERA_CHAIN_XCM"] = mode  # read when the model is scheduled
+            gpu_api.load_model("m", path)
+            assert "chain_fused" in gpu_api.get_plan("m")["exec"]
+            out[mode] = gpu_api.predict_columns("m", cols)
+            assert np.array_equal(out[mode], gpu_api.predict_columns("m", cols))
+            if mode == "1":
+                row_major = gpu_api.predict("m", x)
+            gpu_api.unload_model("m")
+    finally:
+        os.environ.pop("INFERA_CHAIN_XCM", None)
+    assert np.array_equal(out["1"], out["0"]), np.abs(out["1"] - out["0"]).max()
+    assert np.array_equal(out["1"], row_major), np.abs(out["1"] - row_major).max()
+    want = oracle.Model(path).predict(x)
+    assert out["1"].shape == want.shape
+    assert np.all(np.abs(out["1"] - want) <= 1e-4 * np.abs(want) + 1e-6), np.abs(out["1"] - want).max()
