@@ -611,6 +611,16 @@ void schedule(LoadedModel &m) {
     const char *cx = getenv("INFERA_CHAIN_XCM");
     if (!(cx && cx[0] == '0') && !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::ChainHead && eff[0].reads[0] == 0)
       m.in_colmajor_ok = true;
+    // ... and so do the two as-it-lies streaming kernels of single narrow layers (linear / logistic regression, with or without the
+    // softmax / label epilogue); INFERA_DENSE_XCM=0: transpose first
+    const char *dx = getenv("INFERA_DENSE_XCM");
+    if (!(dx && dx[0] == '0') && !eff.empty() && in_readers == 1 && eff[0].reads[0] == 0) {
+      const size_t i0 = size_t(eff[0].idx);
+      const ExecKind k0 = m.exec[i0];
+      if (st[i0].kind == StepKind::Dense && (k0 == ExecKind::Normal || k0 == ExecKind::DenseSoftmax || k0 == ExecKind::DenseArgMax) &&
+          kern::dense_colmajor_supported(int(st[i0].K), int(st[i0].M)))
+        m.in_colmajor_ok = true;
+    }
   }
   const size_t nb = m.plan.buf_per_row.size();
   std::vector<int> last_read(nb, -1);
@@ -842,15 +852,15 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           continue;
         }
         case ExecKind::DenseArgMax:
-          if (kern::dense_can_fuse_argmax(buf(x.in0), int(x.K), int(x.M))) {
-            kern::dense(s, buf(x.in0), d.W, d.bias, buf(st[i + 1].out), nr, int(x.K), int(x.M), act_of(x), 3);
+          if ((in_colmajor && x.in0 == 0) || kern::dense_can_fuse_argmax(buf(x.in0), int(x.K), int(x.M))) {  // (both column-major kernels have the epilogue)
+            kern::dense(s, buf(x.in0), d.W, d.bias, buf(st[i + 1].out), nr, int(x.K), int(x.M), act_of(x), 3, in_colmajor && x.in0 == 0);
             i += 1;  // the ArgMax step is done
             continue;
           }
           break;  // as two kernels
         case ExecKind::DenseSoftmax:
           kern::dense(s, buf(x.in0), d.W, d.bias, buf(st[i + 1].out), nr, int(x.K), int(x.M), act_of(x),
-                      st[i + 1].log_softmax ? 2 : 1);
+                      st[i + 1].log_softmax ? 2 : 1, in_colmajor && x.in0 == 0);
           continue;
         case ExecKind::ConvTiled: {
           kern::ConvGeom g{int(x.C), int(x.H), int(x.Wd), int(x.Mo), int(x.OH), int(x.OW), int(x.kh), int(x.kw),
@@ -885,7 +895,7 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         default: break;
       }
       switch (x.kind) {
-        case StepKind::Dense: kern::dense(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, int(x.K), int(x.M), act_of(x), 0); break;
+        case StepKind::Dense: kern::dense(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, int(x.K), int(x.M), act_of(x), 0, in_colmajor && x.in0 == 0); break;
         case StepKind::Unary: kern::unary(s, buf(x.in0), buf(x.out), nr * p.buf_per_row[size_t(x.out)], act_of(x)); break;
         case StepKind::AffineChannel:
           kern::affine_channel(s, buf(x.in0), d.scale, d.shift, buf(x.out), nr, x.C, x.S, act_of(x), m.cq_mode && !m.nchw_buf[size_t(x.in0)]);

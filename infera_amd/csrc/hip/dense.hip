@@ -544,8 +544,12 @@ static void launch_narrow16s(hipStream_t s, const float *X, const float *W, cons
 template <int SM, int NL>
 __global__ __launch_bounds__(WAVES * 64) void dense_narrow16g_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                     const float *__restrict__ bias, float *__restrict__ Y,
-                                                                    int64_t rows, int K, int M, ActParam act, bool x_aligned16) {
+                                                                    int64_t rows, int K, int M, ActParam act, int xflags) {
+  // xflags: bit 0 = X is 16-byte aligned; bit 1 = X is ONE COLUMN-MAJOR chunk [K][rows] (the host path's staging layout: a DataChunk's
+  // flat columns as they were copied) -- column k of a tile is 32 consecutive floats at X + k*rows + row0: quad p -> column p/8, rows
+  // 4*(p%8)..+3, scattered down a column of the LDS tile; everything after the tile is the row-major kernel.
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [G][64][4] weights, then WAVES x [32 rows][KP] tiles
+  const bool x_aligned16 = xflags & 1, xcm = xflags & 2;
   const int G = (K + 15) >> 4, KP = 16 * G + 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = lane & 15, q = lane >> 4;
@@ -577,9 +581,24 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16g_kernel(const float
     slot[i] = p < nq ? r * KP + col[i] : 31 * KP + 16 * G;
   }
   const int64_t ntiles = (rows + 31) >> 5, total = rows * K;
-  const int64_t full_tiles = x_aligned16 ? rows >> 5 : 0;  // tiles that lie inside the table and start 16-byte aligned
+  const int64_t full_tiles = x_aligned16 && (!xcm || (rows & 3) == 0) ? rows >> 5 : 0;  // tiles inside the table whose quads are 16-byte aligned
   const int64_t tstride = int64_t(gridDim.x) * WAVES;
   auto fetch = [&](f32x4(&v)[NL], int64_t tile) {
+    if (xcm) {
+      const int64_t row0 = tile << 5;
+      if (tile < full_tiles) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) v[i] = *reinterpret_cast<const f32x4 *>(X + int64_t(pq[i] >> 3) * rows + row0 + 4 * (pq[i] & 7));
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < NL; i++) {  // ragged last tile / a row count that is no multiple of 4: element by element
+        const int64_t r = row0 + 4 * (pq[i] & 7);
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[i][u] = r + u < rows ? X[int64_t(pq[i] >> 3) * rows + r + u] : 0.f;
+      }
+      return;
+    }
     if (tile < full_tiles) {  // wave-uniform: straight-line loads, all in flight together
       const f32x4 *src = reinterpret_cast<const f32x4 *>(X + tile * 32 * K);
 #pragma unroll
@@ -599,10 +618,19 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16g_kernel(const float
   if (tile < ntiles) fetch(stage, tile);
   const float *x0p = xs + n * KP + 4 * q, *x1p = xs + (16 + n) * KP + 4 * q;
   for (; tile < ntiles; tile += tstride) {
+    if (xcm) {
 #pragma unroll
-    for (int i = 0; i < NL; i++)
+      for (int i = 0; i < NL; i++) {
+        const int p = i * 64 + lane;
 #pragma unroll
-      for (int u = 0; u < 4; u++) xs[slot[i] + u + (col[i] + u >= K ? KP - K : 0)] = stage[i][u];  // K >= 4: one wrap at most
+        for (int u = 0; u < 4; u++) xs[p < nq ? (4 * (p & 7) + u) * KP + (p >> 3) : 31 * KP + 16 * G + u] = stage[i][u];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) xs[slot[i] + u + (col[i] + u >= K ? KP - K : 0)] = stage[i][u];  // K >= 4: one wrap at most
+    }
     if (tile + tstride < ntiles) fetch(stage, tile + tstride);
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // operands of group g+1 are read while the eight MFMAs of group g run
@@ -678,13 +706,13 @@ static bool narrow16g_ok(int K, int M) {
 }
 
 static void launch_narrow16g(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
-                             ActParam act, int softmax_mode) {
+                             ActParam act, int softmax_mode, bool x_colmajor = false) {
   const int G = (K + 15) / 16, KP = 16 * G + 4;
   const int64_t ntiles = (rows + 31) / 32;
   const size_t lds = (size_t(G) * 256 + size_t(WAVES) * 32 * KP) * sizeof(float);
   const int per_cu = int(std::clamp<size_t>((160 * 1024) / lds, 1, 8));
   const int64_t blocks = std::min<int64_t>((ntiles + WAVES - 1) / WAVES, 256 * per_cu);
-  const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  const int aligned = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 ? 1 : 0) | (x_colmajor ? 2 : 0);
   dim3 grid((unsigned)blocks), block(WAVES * 64);
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -931,7 +959,10 @@ static void launch_narrow16w(hipStream_t s, const float *X, const float *W, cons
 template <int MMAX, int SM, int R>
 __global__ __launch_bounds__(R) void dense_skinny_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                          const float *__restrict__ bias, float *__restrict__ Y, int64_t rows, int K,
-                                                         int M, ActParam act, bool x_aligned16) {
+                                                         int M, ActParam act, int xflags) {
+  // xflags: bit 0 = X is 16-byte aligned; bit 1 = X is one column-major chunk [K][rows] (host path): a lane then reads its own row
+  // straight from memory -- element k of 256 consecutive rows is one contiguous 1 KB run -- and nothing is staged in LDS.
+  const bool x_aligned16 = xflags & 1, xcm = xflags & 2;
   extern __shared__ __attribute__((aligned(16))) float sk[];  // [K][MMAX] weights (zero-padded), [MMAX] bias, [R][KS] rows, 4 spare
   const int KS = K | 1;
   float *wl = sk, *bl = sk + K * MMAX, *xs = bl + MMAX;
@@ -956,10 +987,12 @@ __global__ __launch_bounds__(R) void dense_skinny_kernel(const float *__restrict
     c0[j] = 4 * q - r0[j] * K;
     if (q >= nq) r0[j] = c0[j] = -8;  // parked: stays negative through the four column steps below
   }
+  if (xcm) __syncthreads();  // weights visible (the row-major path has its own barriers per tile)
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * R * K;
     f32x4 v[NQ];
-    if (tile < full_tiles) {
+    if (xcm) {
+    } else if (tile < full_tiles) {
       const f32x4 *src = reinterpret_cast<const f32x4 *>(X + base);
 #pragma unroll
       for (int j = 0; j < NQ; j++)
@@ -973,30 +1006,52 @@ __global__ __launch_bounds__(R) void dense_skinny_kernel(const float *__restrict
         for (int u = 0; u < 4; u++) v[j][u] = e + u < total ? X[e + u] : 0.f;
       }
     }
-    __syncthreads();  // weights visible (first trip) / previous tile's rows consumed
+    if (!xcm) {
+      __syncthreads();  // weights visible (first trip) / previous tile's rows consumed
 #pragma unroll
-    for (int j = 0; j < NQ; j++) {
-      if (j >= nj) break;
-      int r = r0[j], c = c0[j];
+      for (int j = 0; j < NQ; j++) {
+        if (j >= nj) break;
+        int r = r0[j], c = c0[j];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        xs[c < 0 ? R * KS + u : r * KS + c] = v[j][u];
-        if (++c == K) {
-          c = 0;
-          r++;
+        for (int u = 0; u < 4; u++) {
+          xs[c < 0 ? R * KS + u : r * KS + c] = v[j][u];
+          if (++c == K) {
+            c = 0;
+            r++;
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
     float acc[MMAX];
 #pragma unroll
     for (int m = 0; m < MMAX; m++) acc[m] = 0.f;
     const int lrow = int(threadIdx.x);
-    const float *xr = xs + lrow * KS;
-    for (int k = 0; k < K; k++) {
-      const float x = xr[k];
+    if (xcm) {  // the same k-ordered fmaf chain, the row's elements eight at a time straight from the column-major chunk
+      const int64_t grow = min(tile * R + lrow, rows - 1);  // (lanes past the table re-read its last row; nothing is stored for them)
+      const float *xc = X + grow;
+      auto chain = [&](auto n_tag) {  // ALL of the row's elements requested before the first is used: one memory round trip per tile
+        constexpr int NK = decltype(n_tag)::value;
+        float xv[NK];
 #pragma unroll
-      for (int m = 0; m < MMAX; m++) acc[m] = fmaf(x, wl[k * MMAX + m], acc[m]);
+        for (int u = 0; u < NK; u++) xv[u] = xc[int64_t(min(u, K - 1)) * rows];
+#pragma unroll
+        for (int u = 0; u < NK; u++) {
+          if (u >= K) break;
+#pragma unroll
+          for (int m = 0; m < MMAX; m++) acc[m] = fmaf(xv[u], wl[u * MMAX + m], acc[m]);
+        }
+      };
+      if (K <= 8) chain(std::integral_constant<int, 8>{});
+      else if (K <= 16) chain(std::integral_constant<int, 16>{});
+      else chain(std::integral_constant<int, 32>{});
+    } else {
+      const float *xr = xs + lrow * KS;
+      for (int k = 0; k < K; k++) {
+        const float x = xr[k];
+#pragma unroll
+        for (int m = 0; m < MMAX; m++) acc[m] = fmaf(x, wl[k * MMAX + m], acc[m]);
+      }
     }
     dispatch_act(act.kind, [&](auto kind_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
@@ -1051,13 +1106,13 @@ __global__ __launch_bounds__(R) void dense_skinny_kernel(const float *__restrict
 static bool skinny_ok(int K, int M) { return M >= 1 && M <= 16 && K >= 1 && K <= 32; }
 
 static void launch_skinny(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
-                          ActParam act, int softmax_mode) {
+                          ActParam act, int softmax_mode, bool x_colmajor = false) {
   const int mmax = M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : 16;
   constexpr int R = 256;  // rows per workgroup, one thread each
   const size_t lds = (size_t(K) * mmax + mmax + size_t(R) * size_t(K | 1) + 4) * sizeof(float);
   const int64_t ntiles = (rows + R - 1) / R;
   const unsigned grid = unsigned(std::min<int64_t>(ntiles, 256 * 8));
-  const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  const int aligned = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 ? 1 : 0) | (x_colmajor ? 2 : 0);
   auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(R), lds, s, X, W, bias, Y, rows, K, M, act, aligned); };
   auto by_sm = [&](auto mm) {
     constexpr int MM = decltype(mm)::value;
@@ -1082,9 +1137,19 @@ bool dense_can_fuse_argmax(const float *X, int K, int M) {
          (M <= 16 && K % 16 == 0 && K <= 1024 && (reinterpret_cast<uintptr_t>(X) & 15) == 0);
 }
 
+// Layers whose kernels can read a column-major chunk (the host path's staging layout) themselves: the two as-it-lies streaming
+// kernels, up to 63 columns and 16 outputs -- the linear / logistic regressions and small classifiers of the tabular world.
+// (64 columns and more: the chunk is 0.5 MB+, one more tiny launch no longer shows, and the transposed chunk feeds the faster
+// aligned kernels -- measured equal or a few percent behind on 128 -> 10)
+bool dense_colmajor_supported(int K, int M) { return M >= 1 && M <= 16 && K >= 1 && K < 64; }
+
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
-           ActParam act, int softmax_mode) {
+           ActParam act, int softmax_mode, bool x_colmajor) {
   if (rows <= 0) return;
+  if (x_colmajor) {  // (callers checked dense_colmajor_supported; 64 / 128 columns too: their row-major kernels need 16-byte rows)
+    if (K >= 8 && (K > 32 || M >= 3)) return launch_narrow16g(s, X, W, bias, Y, rows, K, M, act, softmax_mode, true);
+    return launch_skinny(s, X, W, bias, Y, rows, K, M, act, softmax_mode, true);
+  }
   static const int wide16 = getenv("INFERA_DENSE16W") ? atoi(getenv("INFERA_DENSE16W")) : 1;  // 0 off, 2 = also where aligned kernels exist (A/B)
   if (wide16 == 2 && M <= 16 && K >= 64) return launch_narrow16w(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
   if (narrow16g_ok(K, M)) return launch_narrow16g(s, X, W, bias, Y, rows, K, M, act, softmax_mode);

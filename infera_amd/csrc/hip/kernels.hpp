@@ -45,8 +45,10 @@ void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_
 // ---- dense layer, fp32 MFMA (dense.hip) -------------------------------------------------------
 // Y[rows, M] = act(X[rows, K] . W[K, M] + bias[M]); W row-major, bias may be null.
 // softmax_fused: apply a row softmax over the M outputs in the epilogue (requires M <= 256).
+// x_colmajor: X is ONE column-major chunk [K][rows] (host path staging; only where dense_colmajor_supported(K, M)).
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
-           ActParam act, int softmax_mode /*0 none,1 softmax,2 log-softmax,3 argmax (label only)*/);
+           ActParam act, int softmax_mode /*0 none,1 softmax,2 log-softmax,3 argmax (label only)*/, bool x_colmajor = false);
+bool dense_colmajor_supported(int K, int M);
 // where a streaming kernel carries the softmax epilogue (wider heads: tiled Dense + the row softmax kernel is faster)
 bool dense_can_fuse_softmax(int K, int M);
 // softmax_mode 3: Y[rows] = float(index of the first maximum of the M scores) -- only where this returns true

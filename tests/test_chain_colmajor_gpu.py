@@ -55,3 +55,65 @@ def test_gpu_chain_kernel_reads_column_major_chunks(gpu_api, tmp_path, shape, ro
     want = oracle.Model(path).predict(x)
     assert out["1"].shape == want.shape
     assert np.all(np.abs(out["1"] - want) <= 1e-4 * np.abs(want) + 1e-6), np.abs(out["1"] - want).max()
+
+
+DENSE_SHAPES = {
+    "linreg_13": dict(dims=(13, 1), softmax=False),          # one lane per row, fmaf chains (skinny kernel)
+    "linreg_3": dict(dims=(3, 1), softmax=False),
+    "logreg_30x2": dict(dims=(30, 2), softmax=True),
+    "softmax_30x3": dict(dims=(30, 3), softmax=True),        # 16x16x4 streaming kernel from here on
+    "softmax_100x10": dict(dims=(100, 10), softmax=True),
+    "c4_128x10": dict(dims=(128, 10), softmax=True),         # BASELINE C4: 64+ columns keep the transposed path (still checked here)
+    "dense_64x5": dict(dims=(64, 5), softmax=False),
+    "dense_8x16": dict(dims=(8, 16), softmax=False),
+    "dense_77x1": dict(dims=(77, 1), softmax=False),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", sorted(DENSE_SHAPES))
+@pytest.mark.parametrize("rows", [1, 33, 1234, 2048, 4099])
+def test_gpu_single_layer_kernels_read_column_major_chunks(gpu_api, tmp_path, shape, rows):
+    from oracle import oracle
+
+    sp = DENSE_SHAPES[shape]
+    k = sp["dims"][0]
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp(sp["dims"], final_softmax=sp["softmax"]))
+    x = synth.table(13, 0, rows, k)
+    cols = [np.ascontiguousarray(x[:, c]) for c in range(k)]
+    cols[0] = cols[0].astype(np.float64)
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["INFERA_DENSE_XCM"] = mode  # read when the model is scheduled
+            gpu_api.load_model("m", path)
+            assert gpu_api.get_plan("m")["exec"][0] in ("normal", "dense_softmax"), gpu_api.get_plan("m")["exec"]
+            out[mode] = gpu_api.predict_columns("m", cols)
+            assert np.array_equal(out[mode], gpu_api.predict_columns("m", cols))
+            if mode == "1":
+                row_major = gpu_api.predict("m", x)
+            gpu_api.unload_model("m")
+    finally:
+        os.environ.pop("INFERA_DENSE_XCM", None)
+    assert np.array_equal(out["1"], out["0"]), np.abs(out["1"] - out["0"]).max()
+    assert np.array_equal(out["1"], row_major), np.abs(out["1"] - row_major).max()
+    want = oracle.Model(path).predict(x)
+    assert out["1"].shape == want.shape
+    assert np.all(np.abs(out["1"] - want) <= 1e-4 * np.abs(want) + 1e-6), np.abs(out["1"] - want).max()
+
+
+@pytest.mark.gpu
+def test_gpu_label_epilogue_reads_column_major_chunks(gpu_api, tmp_path):
+    """Dense -> ArgMax (a classifier serving its label) through the columnar entry: the label kernel reads the chunk column-major."""
+    from oracle import oracle
+
+    path = W.write(str(tmp_path / "lab.onnx"), W.sklearn_pipeline(30, 3))
+    x = synth.table(17, 0, 1500, 30)
+    cols = [np.ascontiguousarray(x[:, c]) for c in range(30)]
+    gpu_api.load_model("lab", path)
+    try:
+        got = gpu_api.predict_columns("lab", cols)
+        assert np.array_equal(got, gpu_api.predict("lab", x))
+    finally:
+        gpu_api.unload_model("lab")
+    assert np.array_equal(got, oracle.Model(path).predict(x))
