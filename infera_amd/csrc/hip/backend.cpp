@@ -605,6 +605,16 @@ void schedule(LoadedModel &m) {
     int in_readers = 0;
     for (const auto &e : eff)
       for (int b : e.reads) in_readers += b == 0;
+    m.in_single_reader = false;
+    if (in_readers == 1)
+      for (const auto &e : eff) {
+        if (std::find(e.reads.begin(), e.reads.end(), 0) == e.reads.end()) continue;
+        // ... and that kernel streams it about once (a windowed kernel would fetch a small image over PCIe once per tap)
+        const StepKind sk = st[size_t(e.idx)].kind;
+        const bool windowed = (sk == StepKind::Conv2d && m.exec[size_t(e.idx)] != ExecKind::ConvPatch) || sk == StepKind::Pool2d || sk == StepKind::LRN;
+        m.in_single_reader = !windowed;
+        break;
+      }
     m.in_colmajor_ok = !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::Mlp3Head && eff[0].reads[0] == 0 &&
                        kern::mlp3_colmajor_supported(m.mlp3_shape) && !m.bf16x3;
     // the fused small-MLP chain reads a column-major chunk too (a run-time flag of the same kernel); INFERA_CHAIN_XCM=0: transpose first
@@ -1271,14 +1281,29 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
     } else {
       // column-major chunk straight into the model's first kernel when it can read one (no transpose launch)
       const bool cm_direct = col_major && m.in_colmajor_ok && Config::get().host_fused_transpose;
-      if (cm_direct) HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
-      else upload_pass(ctx.pin_in, ctx.dev_in, nr);
+      // Small inputs (a narrow table's chunk, a point query; INFERA_HOST_DIRECT_IN bytes, default 128 KB) are not copied to HBM first:
+      // the kernel that reads them -- the plan's first kernel, or the transpose in front of it -- loads them from the pinned
+      // (host-coherent) buffer over PCIe itself.  One submission less per call, and a DMA engine's start-up latency is as long as
+      // such a transfer: 13-column table +6..17 % at 2..64 threads.  (1 MB chunks read this way reach 34 GB/s against the copy
+      // engines' 50: C2 and every larger chunk keep the H2D copy.)
+      const bool small_in = int64_t(nr) * int64_t(in_row) <= int64_t(Config::get().host_direct_in_bytes);
+      const float *kin = ctx.dev_in;
+      if (cm_direct) {
+        if (small_in) kin = ctx.pin_in;
+        else HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+      } else if (col_major && small_in) {
+        kern::transpose_cm(ctx.stream, ctx.pin_in, ctx.dev_in, nr, int64_t(in_row / 4));
+      } else if (!col_major && small_in && m.in_single_reader) {
+        kin = ctx.pin_in;
+      } else {
+        upload_pass(ctx.pin_in, ctx.dev_in, nr);
+      }
       if (direct_out) {
         // the plan's only writer of the result stores it straight into the pinned (host-coherent) buffer: a few KB per
         // chunk over PCIe from the kernel's epilogue instead of one more enqueue + blit kernel + dependency per chunk
-        exec_plan(m, dm, ctx, ctx.dev_in, ctx.pin_out, nr, cm_direct);
+        exec_plan(m, dm, ctx, kin, ctx.pin_out, nr, cm_direct);
       } else {
-        exec_plan(m, dm, ctx, ctx.dev_in, ctx.dev_out, nr, cm_direct);
+        exec_plan(m, dm, ctx, kin, ctx.dev_out, nr, cm_direct);
         HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
       }
     }

@@ -89,6 +89,7 @@ class LoadedModel {
   // the plan's first kernel is the only reader of the input table and has a variant that reads a column-major chunk
   // [cols][rows] directly (host path: no transpose kernel between the H2D copy and the model)
   bool in_colmajor_ok = false;
+  bool in_single_reader = false;  // the input buffer is read by exactly one kernel of the plan (small host inputs: straight from pinned memory)
   // INFERA_PRECISION=bf16x3 and the fused chain has a bf16x3 instantiation: NOT parity precision
   bool bf16x3 = false;
   // ... except the caller's input and what elementwise preprocessing makes of it (x/255, (x - mean) / std in the graph):

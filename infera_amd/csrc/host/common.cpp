@@ -92,6 +92,7 @@ const Config &Config::get() {
     c.host_direct_out = env_flag("INFERA_HOST_DIRECT_OUT", true);
     c.host_colmajor_typed = env_flag("INFERA_HOST_COLMAJOR_TYPED", true);
     c.host_fused_transpose = env_flag("INFERA_HOST_FUSED_TRANSPOSE", true);
+    c.host_direct_in_bytes = (long long)env_u64("INFERA_HOST_DIRECT_IN", 128 * 1024);
     c.precision_bf16x3 = env_or("INFERA_PRECISION", "fp32") == "bf16x3";
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);
     c.max_rows_per_pass = env_u64("INFERA_MAX_ROWS_PER_PASS", 1ull << 18);

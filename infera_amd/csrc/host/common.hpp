@@ -99,6 +99,7 @@ struct Config {
                                       //   straight into the pinned result buffer (no D2H copy enqueue per chunk)
   bool host_colmajor_typed;           // INFERA_HOST_COLMAJOR_TYPED=0|1  DOUBLE / INTEGER / BIGINT / constant columns are staged column-major too
                                       //   (converted run by run) instead of through the AVX2 transposing gather.  Default 1
+  long long host_direct_in_bytes;     // INFERA_HOST_DIRECT_IN=<bytes>  chunks up to this size are read from pinned memory by the first kernel itself (default 131072; 0 = always H2D)
   bool host_fused_transpose;          // INFERA_HOST_FUSED_TRANSPOSE=0|1  the fused MLP reads column-major chunks itself (no transpose kernel)
   bool precision_bf16x3;              // INFERA_PRECISION=fp32|bf16x3  bf16x3 = OPTIONAL fast mode for the fused MLP (three bf16 MFMAs per
                                       //   product, ~2^-16 relative error per product): NOT the parity path, never the default
