@@ -191,8 +191,10 @@ def build(kind, seed, tmp_path):
     return W.write(str(tmp_path / f"{kind}{seed}.onnx"), blob), in_shape, out_w
 
 
-DENSE_SEEDS = list(range(120))
-CONV_SEEDS = list(range(1000, 1120))
+# INFERA_FUZZ_SEEDS=<n>: a longer one-off sweep (n seeds per kind, past the committed ones) -- e.g. 2000 on a GPU box after a kernel change
+_EXTRA = int(os.environ.get("INFERA_FUZZ_SEEDS", "0"))
+DENSE_SEEDS = list(range(120)) + list(range(100000, 100000 + _EXTRA))
+CONV_SEEDS = list(range(1000, 1120)) + list(range(200000, 200000 + _EXTRA))
 
 
 @pytest.mark.parametrize("kind,seeds", [("dense", DENSE_SEEDS), ("conv", CONV_SEEDS)])
