@@ -73,3 +73,37 @@ def test_gpu_stem_with_fused_maxpool_matches_two_kernels_and_oracle(gpu_api, tmp
     want = oracle.Model(path).predict_blob(x.tobytes())
     assert out["1"].shape == want.shape
     assert np.all(np.abs(out["1"] - want) <= 1e-4 * np.abs(want) + 1e-6), np.abs(out["1"] - want).max()
+
+
+@pytest.mark.gpu
+def test_gpu_random_stem_geometries_fused_equals_two_kernels(gpu_api, tmp_path):
+    """40 seeded random stems (1-4 input channels, 3x3 / 5x5 / 7x7, stride 1-2, any padding up to k//2, 32 or 64 features, H != W, pool
+    pad 0 / 1, ceil_mode on / off, with and without ReLU): fused kernel == stem kernel + pooling kernel, bit for bit, and both match
+    the oracle."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(2024)
+    n_fused = 0
+    for case in range(40):
+        k = int(rng.choice([3, 5, 7]))
+        c = dict(cin=int(rng.integers(1, 5)), hw=int(rng.integers(k + 6, 72)), hw2=int(rng.integers(k + 6, 72)), m=int(rng.choice([32, 64])), k=k,
+                 stride=int(rng.choice([1, 2])), pad=int(rng.integers(0, k // 2 + 1)), pool_pad=int(rng.choice([0, 1])), ceil=bool(rng.random() < 0.5),
+                 relu=bool(rng.random() < 0.7))
+        rows = int(rng.choice([1, 2, 5]))
+        path = W.write(str(tmp_path / f"s{case}.onnx"), _net(**c))
+        x = synth.table(100 + case, 0, rows, c["cin"] * c["hw"] * c["hw2"])
+        out = {}
+        try:
+            for mode in ("1", "0"):
+                os.environ["INFERA_STEM_POOL"] = mode
+                gpu_api.load_model("s", path)
+                if mode == "1":
+                    n_fused += "conv_patch_pool" in gpu_api.get_plan("s")["exec"]
+                out[mode] = gpu_api.predict_from_blob("s", x.tobytes())
+                gpu_api.unload_model("s")
+        finally:
+            os.environ.pop("INFERA_STEM_POOL", None)
+        assert np.array_equal(out["0"], out["1"]), (case, c, float(np.abs(out["0"] - out["1"]).max()))
+        want = oracle.Model(path).predict_blob(x.tobytes())
+        assert np.all(np.abs(out["1"] - want) <= 1e-4 * np.abs(want) + 1e-6), (case, c, float(np.abs(out["1"] - want).max()))
+    assert n_fused >= 30  # (a few geometries have no pooled pixel with a whole window inside the image or exceed the LDS budget)
