@@ -726,6 +726,10 @@ static size_t patch_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
 // and every thread then takes the maximum of nine quads per pooled (pixel, channel quad) and stores it.  The row / column
 // between neighbouring tiles is computed by both (256 / 224 = 1.14x the MFMA work) -- against a 3.3 GB tensor written, read back
 // and a separate launch.  Two barriers per tile; the second one (exchange tile free again) is reached long after the last reader.
+// (Tried on top of this: the exchange write of tile k-1 -- from a saved copy of its accumulators -- and the patch store of tile k+1
+// moved into tile k's k loop as well, one quad / one word per unit, a barrier in the middle of the loop; nothing left between two
+// loops but 32 register moves and one barrier.  2.75 ms against 2.60: the extra LDS traffic in the loop's in-order lgkmcnt stream
+// and the second rendezvous cost more than the lock-step phases they replaced.)
 template <int MT, int K8C, bool POOL = false>
 __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                              const float *__restrict__ bias, float *__restrict__ Y,
