@@ -615,8 +615,10 @@ void schedule(LoadedModel &m) {
         m.in_single_reader = !windowed;
         break;
       }
+    m.in_colmajor_max_rows = INT64_MAX;
     m.in_colmajor_ok = !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::Mlp3Head && eff[0].reads[0] == 0 &&
                        kern::mlp3_colmajor_supported(m.mlp3_shape) && !m.bf16x3;
+    if (m.in_colmajor_ok) m.in_colmajor_max_rows = kern::mlp3_colmajor_max_rows(m.mlp3_shape);
     // the fused small-MLP chain reads a column-major chunk too (a run-time flag of the same kernel); INFERA_CHAIN_XCM=0: transpose first
     const char *cx = getenv("INFERA_CHAIN_XCM");
     if (!(cx && cx[0] == '0') && !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::ChainHead && eff[0].reads[0] == 0)
@@ -1280,7 +1282,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
       }
     } else {
       // column-major chunk straight into the model's first kernel when it can read one (no transpose launch)
-      const bool cm_direct = col_major && m.in_colmajor_ok && Config::get().host_fused_transpose;
+      const bool cm_direct = col_major && m.in_colmajor_ok && nr <= m.in_colmajor_max_rows && Config::get().host_fused_transpose;
       // Small inputs (a narrow table's chunk, a point query; INFERA_HOST_DIRECT_IN bytes, default 128 KB) are not copied to HBM first:
       // the kernel that reads them -- the plan's first kernel, or the transpose in front of it -- loads them from the pinned
       // (host-coherent) buffer over PCIe itself.  One submission less per call, and a DMA engine's start-up latency is as long as

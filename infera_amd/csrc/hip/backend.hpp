@@ -89,6 +89,7 @@ class LoadedModel {
   // the plan's first kernel is the only reader of the input table and has a variant that reads a column-major chunk
   // [cols][rows] directly (host path: no transpose kernel between the H2D copy and the model)
   bool in_colmajor_ok = false;
+  int64_t in_colmajor_max_rows = 0;  // longest column-major chunk the first kernel reads itself (load-time specialised MLP chains: their tile kernel's range)
   bool in_single_reader = false;  // the input buffer is read by exactly one kernel of the plan (small host inputs: straight from pinned memory)
   // INFERA_PRECISION=bf16x3 and the fused chain has a bf16x3 instantiation: NOT parity precision
   bool bf16x3 = false;

@@ -74,6 +74,7 @@ void mlp3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const floa
 bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
           std::string *why = nullptr, bool x_colmajor = false);
 bool mlp3_colmajor_supported(const Mlp3Shape &sh);
+int64_t mlp3_colmajor_max_rows(const Mlp3Shape &sh);  // longest column-major chunk the chain's kernels read themselves (0: none)
 std::string mlp3_kernel_name(const Mlp3Shape &sh);
 
 // OPTIONAL fast mode (INFERA_PRECISION=bf16x3, never the parity path): every fp32 product as hi*hi + hi*lo + lo*hi on the

@@ -34,6 +34,7 @@
 //     next tile's rows are requested right after this tile's last layer-2 L2 load, so nothing in
 //     this tile ever queues behind HBM latency on the in-order vmcnt counter.
 #include <atomic>
+#include <cstdint>
 #include <cstdlib>
 
 #include "device_common.hpp"
@@ -201,7 +202,9 @@ void mlp3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const floa
   pack_layout(mlp3_layout(sh.d0, sh.d1, sh.d2, sh.d3), W1, b1, W2, b2, W3, b3, packed);
 }
 
-bool mlp3_colmajor_supported(const Mlp3Shape &sh) { return aot_match(sh); }
+bool mlp3_colmajor_supported(const Mlp3Shape &sh) { return mlp3_colmajor_max_rows(sh) > 0; }
+// ahead-of-time configurations read column-major chunks of any length; load-time specialised chains on their tile kernel only
+int64_t mlp3_colmajor_max_rows(const Mlp3Shape &sh) { return aot_match(sh) ? INT64_MAX : mlp3_jit_colmajor_max_rows(sh); }
 
 namespace {
 // Short launches (a DataChunk through the host ABI): one workgroup per 32-row tile, bit-identical to the split kernel
@@ -233,8 +236,7 @@ bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packe
   }
     INFERA_MLP3_CONFIGS(X_)
 #undef X_
-    if (why) *why = "no column-major instantiation for this chain";
-    return false;
+    return mlp3_jit_launch(s, sh, X, packed, Y, rows, num_cus, why, true);
   }
 #ifdef INFERA_MLP3_PROBES
   if (matches<CfgC2>(sh)) {

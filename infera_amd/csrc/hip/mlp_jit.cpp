@@ -14,6 +14,7 @@
 #include <tuple>
 #include <vector>
 
+#include "../host/common.hpp"
 #include "../host/remote.hpp"
 #include "mlp_layout.hpp"
 
@@ -179,20 +180,30 @@ namespace {
 using Key = std::tuple<int, int, int, int, int, int, int>;
 Key key_of(const Mlp3Shape &s) { return {s.d0, s.d1, s.d2, s.d3, s.act1, s.act2, s.act3}; }
 
+// The latency-shaped kernel for short launches (mlp3_tile_kernel, mlp_device.inc: one workgroup per 32-row tile, bit-identical to the
+// persistent kernels) in its row-major and column-major (XCM) forms: what the host path's 2048-row chunks run on.
+struct Variant {
+  bool ok = false;
+  std::string expr, lowered, why;
+  std::vector<char> code;
+  std::map<int, hipFunction_t> fn_by_device;
+};
+
 struct Compiled {
   std::mutex mu;  // compile + per-device module load of THIS shape
   bool ok = false;
-  std::string why, expr, lowered;
+  std::string why, expr, lowered, cfg;
   std::vector<char> code;
   int threads = 256, lds_bytes = 0;
   std::map<int, hipFunction_t> fn_by_device;
+  Variant tile, tile_xcm;
 };
 
 std::mutex g_mu;  // the map only
 std::map<Key, std::shared_ptr<Compiled>> g_cache;
 
 // Picks the kernel template and its tuning parameters for a shape; returns the name expression.
-bool plan_kernel(const Mlp3Shape &s, const Mlp3Layout &L, std::string &expr, int &threads, std::string &why) {
+bool plan_kernel(const Mlp3Shape &s, const Mlp3Layout &L, std::string &expr, std::string &cfg, int &threads, std::string &why) {
   if (s.d0 % 8 || s.d1 % 32 || s.d2 % 32 || s.d0 < 8 || s.d1 < 32 || s.d2 < 32 || s.d3 < 1 || s.d3 > 32) {
     why = "chain dims must satisfy d0%8==0, d1%32==0, d2%32==0, 1<=d3<=32";
     return false;
@@ -217,8 +228,8 @@ bool plan_kernel(const Mlp3Shape &s, const Mlp3Layout &L, std::string &expr, int
     const int regs = L.G0 * 4 + mth * 16 + L.MT2 * 16 + 12 + p2s * 4 + 40;
     const int p1 = L.G0 * mth < 3 ? L.G0 * mth : 3;
     if (regs <= 250 && u2h >= p2s && L.G1 % split == 0) {
-      expr = "infera_hip::kern::mlpdev::mlp3_split_kernel<" + cfg_head + std::to_string(p1) + ",16>," + std::to_string(split) + "," +
-             std::to_string(p2s) + ",8>";
+      cfg = cfg_head + std::to_string(p1) + ",16>";
+      expr = "infera_hip::kern::mlpdev::mlp3_split_kernel<" + cfg + "," + std::to_string(split) + "," + std::to_string(p2s) + ",8>";
       threads = 512;
       return true;
     }
@@ -230,7 +241,8 @@ bool plan_kernel(const Mlp3Shape &s, const Mlp3Layout &L, std::string &expr, int
   const int nq = L.MT2 * 4;
   const int u1 = L.G0 * L.MT1, p1 = u1 < 3 ? u1 : 3;
   if (regs <= 480 && p2 >= 1 && (!L.l3v || u1 > nq) && (L.l3v || L.G2 >= 2)) {
-    expr = "infera_hip::kern::mlpdev::mlp3_kernel<" + cfg_head + std::to_string(p1) + "," + std::to_string(p2) + ">>";
+    cfg = cfg_head + std::to_string(p1) + "," + std::to_string(p2) + ">";
+    expr = "infera_hip::kern::mlpdev::mlp3_kernel<" + cfg + ">";
     threads = 256;
     return true;
   }
@@ -251,10 +263,41 @@ Compiled &compile_locked(const Mlp3Shape &s, std::unique_lock<std::mutex> &held)
   held = std::unique_lock<std::mutex>(c.mu);
   if (c.ok || !c.why.empty()) return c;
   const Mlp3Layout L = mlp3_layout(s.d0, s.d1, s.d2, s.d3);
-  if (!plan_kernel(s, L, c.expr, c.threads, c.why)) return c;
+  if (!plan_kernel(s, L, c.expr, c.cfg, c.threads, c.why)) return c;
   c.lds_bytes = L.N_LDS * 4;
   c.ok = jit_compile(kMlpDeviceSrc, "infera_mlp_jit.hip", c.expr, c.code, c.lowered, c.why);
+  // the tile kernel's preconditions (mlp_device.inc: VALU head, layer 1 in four slices, at most four layer-2 tiles, its 32 x (D1+4)
+  // activation tile in static LDS); a failed compile of a variant only means short launches keep the persistent kernel
+  static const bool tile_on = !(std::getenv("INFERA_MLP3_TILE") && std::atoi(std::getenv("INFERA_MLP3_TILE")) == 0);
+  if (c.ok && tile_on && L.l3v && L.MT1 % 4 == 0 && L.MT2 <= 4 && 32 * (s.d1 + 4) * 4 <= 60 * 1024) {
+    for (Variant *v : {&c.tile, &c.tile_xcm}) {
+      v->expr = "infera_hip::kern::mlpdev::mlp3_tile_kernel<" + c.cfg + "," + (v == &c.tile_xcm ? "true" : "false") + ">";
+      v->ok = jit_compile(kMlpDeviceSrc, "infera_mlp_jit.hip", v->expr, v->code, v->lowered, v->why);
+      if (!v->ok) log_msg(1, "fused MLP " + c.expr + ": no tile kernel (" + v->why.substr(0, 300) + ")");
+    }
+  }
   return c;
+}
+
+// the function of a compiled code object on the current device (loaded on first use); the caller holds the shape's mutex
+hipFunction_t function_on_device(std::vector<char> &code, const std::string &lowered, std::map<int, hipFunction_t> &cache, int lds_bytes,
+                                 std::string *why) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto it = cache.find(dev);
+  if (it != cache.end()) return it->second;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  hipError_t e = hipModuleLoadData(&mod, code.data());
+  if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, lowered.c_str());
+  if (e == hipSuccess && lds_bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    if (why) *why = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
+    return nullptr;
+  }
+  cache[dev] = fn;
+  return fn;
 }
 
 }  // namespace
@@ -266,10 +309,19 @@ bool mlp3_jit_prepare(const Mlp3Shape &sh, std::string *why) {
   return c.ok;
 }
 
+constexpr int64_t kTileKernelMaxRows = 32768;  // (as for the ahead-of-time configurations, mlp_fused.hip)
+
+int64_t mlp3_jit_colmajor_max_rows(const Mlp3Shape &sh) {
+  std::unique_lock<std::mutex> lk;
+  Compiled &c = compile_locked(sh, lk);
+  return c.ok && c.tile_xcm.ok ? kTileKernelMaxRows : 0;
+}
+
 bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows,
-                     int num_cus, std::string *why) {
+                     int num_cus, std::string *why, bool x_colmajor) {
   hipFunction_t fn = nullptr;
   int threads = 256, lds = 0;
+  bool tile = false;
   {
     std::unique_lock<std::mutex> lk;
     Compiled &c = compile_locked(sh, lk);
@@ -277,31 +329,28 @@ bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const f
       if (why) *why = c.why;
       return false;
     }
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    auto it = c.fn_by_device.find(dev);
-    if (it == c.fn_by_device.end()) {
-      hipModule_t mod = nullptr;
-      hipError_t e = hipModuleLoadData(&mod, c.code.data());
-      if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, c.lowered.c_str());
-      if (e == hipSuccess && c.lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds_bytes);
-      if (e != hipSuccess) {
-        if (why) *why = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
-        return false;
-      }
-      c.fn_by_device[dev] = fn;
+    Variant &v = x_colmajor ? c.tile_xcm : c.tile;
+    if (rows <= kTileKernelMaxRows && v.ok) {
+      tile = true;
+      fn = function_on_device(v.code, v.lowered, v.fn_by_device, 0, why);
+    } else if (x_colmajor) {
+      if (why) *why = "no column-major kernel of this chain for " + std::to_string(rows) + " rows";
+      return false;
     } else {
-      fn = it->second;
+      fn = function_on_device(c.code, c.lowered, c.fn_by_device, c.lds_bytes, why);
+      threads = c.threads;
+      lds = c.lds_bytes;
     }
-    threads = c.threads;
-    lds = c.lds_bytes;
+    if (!fn) return false;
   }
-  const int waves = threads / 64;
   const int64_t ntiles = (rows + 31) / 32;
-  int64_t blocks = (ntiles + waves - 1) / waves;
-  if (blocks > num_cus) blocks = num_cus;
-  if (blocks < 1) blocks = 1;
+  int64_t blocks = ntiles;  // tile kernel: one workgroup per 32-row tile
+  if (!tile) {
+    const int waves = threads / 64;
+    blocks = (ntiles + waves - 1) / waves;
+    if (blocks > num_cus) blocks = num_cus;
+    if (blocks < 1) blocks = 1;
+  }
   void *args[] = {(void *)&X, (void *)&packed, (void *)&Y, (void *)&rows};
   hipError_t e = hipModuleLaunchKernel(fn, unsigned(blocks), 1, 1, unsigned(threads), 1, 1, unsigned(lds), s, args, nullptr);
   if (e != hipSuccess) {

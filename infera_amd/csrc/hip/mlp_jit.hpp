@@ -20,8 +20,10 @@ bool jit_compile(const char *src, const char *file, const std::string &expr, std
 // True if a kernel for `sh` is (or was just) compiled; on failure `why` says what went wrong (shape
 // constraints, hipRTC missing, compile error) and the caller falls back to layer-by-layer kernels.
 bool mlp3_jit_prepare(const Mlp3Shape &sh, std::string *why);
+// rows <= 32768 run on the shape's tile kernel when it has one (column-major X only there)
 bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows,
-                     int num_cus, std::string *why);
+                     int num_cus, std::string *why, bool x_colmajor = false);
+int64_t mlp3_jit_colmajor_max_rows(const Mlp3Shape &sh);  // 0: no column-major kernel
 std::string mlp3_jit_kernel_name(const Mlp3Shape &sh);
 
 }  // namespace infera_hip::kern
