@@ -180,8 +180,10 @@ def predict(name: str, x: np.ndarray) -> np.ndarray:
 
 
 def predict_from_blob(name: str, blob: bytes) -> np.ndarray:
-    buf = C.create_string_buffer(blob, max(len(blob), 1))
-    res = load_library().infera_predict_from_blob(_enc(name), C.addressof(buf), len(blob))
+    # (no copy: a pointer into the bytes object, which outlives the call -- a 38 MB batch used to spend 9 of its 13 ms in
+    # create_string_buffer)
+    ptr = C.cast(C.c_char_p(blob if len(blob) else b"\0"), C.c_void_p)
+    res = load_library().infera_predict_from_blob(_enc(name), ptr, len(blob))
     return _take_result(res, "infera_predict_from_blob")
 
 
@@ -366,8 +368,8 @@ def gather_columns(columns: Sequence[np.ndarray], rows: int | None = None, row0:
 
 def predict_from_blob_batch(name: str, blobs: Sequence[bytes]) -> np.ndarray:
     n = len(blobs)
-    bufs = [C.create_string_buffer(b, max(len(b), 1)) for b in blobs]
-    ptrs = (C.c_void_p * max(n, 1))(*[C.addressof(b) for b in bufs])
+    keep = [b if len(b) else b"\0" for b in blobs]  # (pointers into the bytes objects: no copies)
+    ptrs = (C.c_void_p * max(n, 1))(*[C.cast(C.c_char_p(b), C.c_void_p).value for b in keep])
     lens = (C.c_size_t * max(n, 1))(*[len(b) for b in blobs])
     res = load_library().infera_predict_from_blob_batch(_enc(name), ptrs, lens, n)
     return _take_result(res, "infera_predict_from_blob_batch")

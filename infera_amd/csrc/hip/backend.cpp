@@ -1191,8 +1191,12 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
     auto slot_ptr = [&](float *base, int k, size_t row_bytes) { return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + size_t(k) * size_t(P) * row_bytes); };
     auto drain = [&](int k) {
       if (!pend_nr[k]) return;
+      const uint64_t t0 = now_ns();
       HIP_TRY(hipEventSynchronize(ctx.pipe_ev[k]));
+      const uint64_t t1 = now_ns();
       std::memcpy(h_out + size_t(pend_r0[k]) * (out_row / 4), slot_ptr(ctx.pin_out, k, out_row), size_t(pend_nr[k]) * out_row);
+      g_phase_ns[kPhWait].fetch_add(t1 - t0, std::memory_order_relaxed);
+      g_phase_ns[kPhCopyOut].fetch_add(now_ns() - t1, std::memory_order_relaxed);
       pend_nr[k] = 0;
     };
     int k = 0;
@@ -1201,11 +1205,16 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
         const int64_t nr = std::min(P, rows - r0);
         drain(k);
         float *pin = slot_ptr(ctx.pin_in, k, in_row), *din = slot_ptr(ctx.dev_in, k, in_row), *dout = slot_ptr(ctx.dev_out, k, out_row);
+        const uint64_t t_f0 = now_ns();
         fill(pin, r0, nr);
+        const uint64_t t_f1 = now_ns();
         upload_pass(pin, din, nr);
         exec_plan(m, dm, ctx, din, dout, nr);
         HIP_TRY(hipMemcpyAsync(slot_ptr(ctx.pin_out, k, out_row), dout, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
         HIP_TRY(hipEventRecord(ctx.pipe_ev[k], ctx.stream));
+        g_phase_ns[kPhGather].fetch_add(t_f1 - t_f0, std::memory_order_relaxed);  // (the per-phase counters of infera_hip_get_devices)
+        g_phase_ns[kPhEnqueue].fetch_add(now_ns() - t_f1, std::memory_order_relaxed);
+        g_phase_calls.fetch_add(1, std::memory_order_relaxed);
         pend_r0[k] = r0;
         pend_nr[k] = nr;
       }
