@@ -58,9 +58,25 @@ def worker(t):
         errors.append((t, repr(e)))
 
 
+def rss_mb():
+    for line in open("/proc/self/status"):
+        if line.startswith("VmRSS"):
+            return int(line.split()[1]) / 1024
+    return -1.0
+
+
+def sampler():  # host RSS every few seconds: load / unload cycles and leased contexts must not grow it without bound
+    while time.time() < stop:
+        samples.append((round(time.time() - t_start, 1), round(rss_mb())))
+        time.sleep(max(2.0, secs / 12))
+
+
+samples, t_start = [], time.time()
+threading.Thread(target=sampler, daemon=True).start()
 th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
 [x.start() for x in th]
 [x.join(timeout=secs + 120) for x in th]
 stuck = sum(x.is_alive() for x in th)
 print(f"calls={sum(counts)} threads={nthreads} stuck={stuck} errors={errors[:3]}")
+print("host RSS (s, MB):", samples)
 sys.exit(1 if (errors or stuck) else 0)
