@@ -1,5 +1,5 @@
 """Load-time specialised fused MLP chains (hipRTC, mlp_jit.cpp) on the latency-shaped tile kernel: a chain without an
-ahead-of-time instantiation whose shape allows it (VALU head, D1 a multiple of 128, D2 <= 128) gets mlp3_tile_kernel<Cfg, XCM> compiled
+ahead-of-time instantiation whose shape allows it (VALU head, D2 <= 128) gets mlp3_tile_kernel<Cfg, XCM> compiled
 beside its persistent kernel, so that short launches -- the host path's 2048-row chunks -- neither sit behind a 160 KB LDS image nor need
 a transpose launch.  Every row must come out bit-for-bit as the persistent kernel computes it (a chunk == its slice of a long scan),
 through the row-major entry and through the columnar entry, and match the oracle.  Shapes that do not qualify keep one kernel."""
@@ -10,7 +10,8 @@ from infera_amd import onnx_writer as W
 from infera_amd import synth
 
 SHAPES = [((128, 256, 128, 1), True), ((64, 128, 64, 1), True), ((32, 384, 96, 2), True), ((128, 128, 32, 3), True),
-          ((64, 64, 64, 1), False),    # D1 = 64: two layer-1 tiles, not four slices -> persistent kernel only
+          ((64, 64, 64, 1), True),     # D1 = 64: two layer-1 slices
+          ((64, 96, 32, 1), True),     # D1 = 96: one slice of three tiles
           ((128, 256, 64, 8), False)]  # 8 outputs: MFMA head -> persistent kernel only
 
 
