@@ -881,7 +881,7 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
     for (int n = 0; n < 2; n++) {
       if (n * BS >= NQ * PT) break;
       const f32x4 *win = exch + pwin[n];
-      f32x4 m = win[0];
+      f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -907,8 +907,8 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
       const int n = uu / 11, st = uu - 11 * n;
       if (n > 1) return;
       if (st < 9) ptmp[st & 1] = exch[pwin[n] + ((st / 3) * kPoolCC + st % 3) * XQ];
-      if (st == 1) pm = ptmp[0];
-      if (st >= 2 && st <= 9) {
+      if (st == 0) pm = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // (as the pooling kernels: a window of NaNs only pools to -inf)
+      if (st >= 1 && st <= 9) {
 #pragma unroll
         for (int e = 0; e < 4; e++) pm[e] = fmaxf(pm[e], ptmp[(st - 1) & 1][e]);
       }

@@ -107,3 +107,27 @@ def test_gpu_random_stem_geometries_fused_equals_two_kernels(gpu_api, tmp_path):
         want = oracle.Model(path).predict_blob(x.tobytes())
         assert np.all(np.abs(out["1"] - want) <= 1e-4 * np.abs(want) + 1e-6), (case, c, float(np.abs(out["1"] - want).max()))
     assert n_fused >= 30  # (a few geometries have no pooled pixel with a whole window inside the image or exceed the LDS budget)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_stem_pool_treats_nan_and_inf_like_the_two_kernels(gpu_api, tmp_path):
+    """Images with NaN, +inf and -inf pixels (no ReLU, so they reach the pooling): the fused kernel must give the same bit patterns
+    as the stem kernel followed by the pooling kernel -- a window holding only NaNs pools to -inf in both, a NaN beside finite
+    values is ignored by both."""
+    c = dict(cin=3, hw=40, m=64, k=7, stride=2, pad=3, pool_pad=1, ceil=False, relu=False)
+    path = W.write(str(tmp_path / "nan.onnx"), _net(**c))
+    x = synth.table(5, 0, 3, 3 * 40 * 40).reshape(3, 3, 40, 40).copy()
+    x[0, :, 10:14, 10:14] = np.nan   # a patch of NaNs: a whole neighbourhood of convolution outputs is NaN
+    x[1, 1, 20, 20] = np.inf
+    x[1, 2, 5, 30] = -np.inf
+    x[2, 0, 0, 0] = np.nan           # a corner: windows that also hold padding
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["INFERA_STEM_POOL"] = mode
+            gpu_api.load_model("nan", path)
+            out[mode] = gpu_api.predict_from_blob("nan", x.astype(np.float32).tobytes())
+            gpu_api.unload_model("nan")
+    finally:
+        os.environ.pop("INFERA_STEM_POOL", None)
+    assert np.array_equal(out["0"].view(np.uint32), out["1"].view(np.uint32))
