@@ -1113,11 +1113,11 @@ std::shared_ptr<LoadedModel> build_model(const std::string &name, const std::str
 // H2D and their sync; the others finish gathering their chunk into pinned memory and wait their turn.
 class SubmitGate {
  public:
-  void acquire(int limit) {
-    if (limit <= 0) return;
+  int acquire(int limit) {  // returns the number of calls in flight on this GPU, this one included
+    if (limit <= 0) return 1;
     std::unique_lock<std::mutex> lk(mu_);
     cv_.wait(lk, [&] { return in_flight_ < limit; });
-    in_flight_++;
+    return ++in_flight_;
   }
   void release(int limit) {
     if (limit <= 0) return;
@@ -1140,7 +1140,8 @@ SubmitGate &gate_for_slot(int slot) {
 struct GateHold {
   SubmitGate &g;
   int limit;
-  GateHold(SubmitGate &gate, int lim) : g(gate), limit(lim) { g.acquire(limit); }
+  int in_flight = 1;
+  GateHold(SubmitGate &gate, int lim) : g(gate), limit(lim) { in_flight = g.acquire(limit); }
   ~GateHold() { g.release(limit); }
 };
 
@@ -1297,7 +1298,13 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
       // (host-coherent) buffer over PCIe itself.  One submission less per call, and a DMA engine's start-up latency is as long as
       // such a transfer: 13-column table +6..17 % at 2..64 threads.  (1 MB chunks read this way reach 34 GB/s against the copy
       // engines' 50: C2 and every larger chunk keep the H2D copy.)
-      const bool small_in = int64_t(nr) * int64_t(in_row) <= int64_t(Config::get().host_direct_in_bytes);
+      // (a quiet GPU reads larger chunks this way -- twice that size with at most four calls in flight, four times with at most two: a
+      // few kernels pulling over PCIe do not yet compete with each other, and the copy engine's latency is the larger part of such a
+      // call.  30 -> 100 -> 2, 245 KB chunks: +17 / +8 / +6 / +4 % at 1 / 2 / 4 / 8 threads; 64 -> 128 -> 64 -> 1, 512 KB: +13 / +6 % at 1 / 2)
+      static const bool quiet_on = [] { const char *e = getenv("INFERA_HOST_DIRECT_IN_QUIET"); return !(e && e[0] == '0'); }();  // (0: A/B)
+      const int quiet_mult = !quiet_on ? 1 : admitted.in_flight <= 2 ? 4 : admitted.in_flight <= 4 ? 2 : 1;
+      const int64_t din_limit = int64_t(Config::get().host_direct_in_bytes) * quiet_mult;
+      const bool small_in = int64_t(nr) * int64_t(in_row) <= din_limit;
       const float *kin = ctx.dev_in;
       if (cm_direct) {
         if (small_in) kin = ctx.pin_in;
