@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <sys/resource.h>
 #include <cstdio>
 #include <mutex>
 #include <thread>
@@ -568,6 +569,15 @@ void infera_sql_synth_table(float *table, uint64_t seed, uint64_t rows, uint32_t
 }
 
 namespace {
+// process CPU time (user + system, all threads) -- what a cgroup CPU quota meters
+double process_cpu_seconds(double *sys_out = nullptr) {
+  rusage ru;
+  getrusage(RUSAGE_SELF, &ru);
+  const double sys = double(ru.ru_stime.tv_sec) + double(ru.ru_stime.tv_usec) * 1e-6;
+  if (sys_out) *sys_out = sys;
+  return double(ru.ru_utime.tv_sec) + double(ru.ru_utime.tv_usec) * 1e-6 + sys;
+}
+double g_bench_cpu_s = 0.0, g_bench_sys_s = 0.0, g_bench_wall_s = 0.0;
 std::atomic<uint64_t> g_bench_call_ns{0}, g_bench_thread_ns{0};
 inline uint64_t bench_now_ns() {
   return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count());
@@ -586,6 +596,12 @@ double sum_block(const float *v, size_t n) {
   return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
 }
 }  // namespace
+
+void infera_sql_bench_last_cpu(double *cpu_seconds, double *sys_seconds, double *wall_seconds) {
+  if (cpu_seconds) *cpu_seconds = g_bench_cpu_s;
+  if (sys_seconds) *sys_seconds = g_bench_sys_s;
+  if (wall_seconds) *wall_seconds = g_bench_wall_s;
+}
 
 void infera_sql_bench_last_times(uint64_t *call_ns, uint64_t *thread_ns) {
   if (call_ns) *call_ns = g_bench_call_ns.load();
@@ -677,12 +693,19 @@ int32_t infera_sql_bench_scan_table_typed(const char *function, const char *mode
     if (rep == 0) {
       g_bench_call_ns = 0;
       g_bench_thread_ns = 0;
+      g_bench_cpu_s = g_bench_sys_s = g_bench_wall_s = 0.0;
     }
+    double sys0 = 0.0, sys1 = 0.0;
+    const double cpu0 = process_cpu_seconds(&sys0);
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int t = 0; t < threads; t++) th.emplace_back(worker);
     for (auto &x : th) x.join();
-    if (secs) secs[rep] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_bench_cpu_s += process_cpu_seconds(&sys1) - cpu0;  // every thread of the process: workers, HIP runtime helpers, interrupts' bottom halves charged to us
+    g_bench_sys_s += sys1 - sys0;
+    g_bench_wall_s += wall;
+    if (secs) secs[rep] = wall;
     if (checksum) *checksum = total;
     if (!first_error.empty()) {
       if (err && errlen) std::snprintf(err, size_t(errlen), "%s", first_error.c_str());

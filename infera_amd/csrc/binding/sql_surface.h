@@ -102,6 +102,9 @@ int32_t infera_sql_bench_blob_scan(const char *model, const uint8_t *blobs, uint
                                    int32_t threads, int32_t reps, double *secs, double *checksum, char *err, uint64_t errlen);
 /* after infera_sql_bench_scan_table: ns spent inside infera_sql_call / inside the worker loops, summed over threads and reps */
 void infera_sql_bench_last_times(uint64_t *call_ns, uint64_t *thread_ns);
+/* process CPU seconds (user + system over every thread), the system share, and wall seconds of the last bench_scan_table call,
+ * summed over its reps: CPU time per chunk is what a cgroup CPU quota meters when 16 CPUs feed 8 GPUs */
+void infera_sql_bench_last_cpu(double *cpu_seconds, double *sys_seconds, double *wall_seconds);
 int32_t infera_sql_bench_scan_table(const char *function, const char *model, const float *table, uint64_t rows, uint32_t ncols,
                                     int32_t threads, int32_t reps, double *secs, double *checksum, char *err, uint64_t errlen);
 

@@ -1,6 +1,8 @@
 #include "backend.hpp"
 
 #include <sched.h>
+#include <sys/prctl.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -68,10 +70,43 @@ struct ThreadCtx {
   uint64_t graph_clock = 0;
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // completion of the pass that last used staging slot 0 / 1
   hipEvent_t done_ev = nullptr;                // blocking-sync event: a host-ABI call sleeps on it instead of spinning
+  hipEvent_t poll_ev = nullptr;                // INFERA_HOST_WAIT=poll: queried between naps
+  double wait_ema_ns = 40000.0;                // recent wait of this context's calls (poll mode: length of the first nap)
   // waits for everything enqueued on `stream` so far
   void wait_stream() {
-    if (Config::get().host_wait == 1) {
+    const int mode = Config::get().host_wait;
+    if (mode == 1) {
       HIP_TRY(hipStreamSynchronize(stream));
+      return;
+    }
+    if (mode == 2) {
+      // Sleep-poll: ROCm's blocking event wait spins before it blocks and pays an interrupt + wake-up per chunk; under a CPU quota
+      // (16 CPUs feeding 8 GPUs) CPU time per chunk is what bounds the scan.  Nap for most of what this context's recent calls
+      // waited, then query between short naps: one or two clock_nanosleep calls and a few event queries per chunk.
+      static thread_local bool slack_set = false;
+      if (!slack_set) {
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // default slack is 50 us: a 20 us nap would last 70
+        slack_set = true;
+      }
+      if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(poll_ev, stream));
+      const auto t0 = std::chrono::steady_clock::now();
+      auto nap = [](double ns) {
+        if (ns < 1500.0) return;
+        timespec ts{0, long(ns)};
+        if (ts.tv_nsec >= 1000000000L) ts = timespec{ts.tv_nsec / 1000000000L, ts.tv_nsec % 1000000000L};
+        (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
+      };
+      nap(std::min(wait_ema_ns * 0.75, 2.0e6));
+      for (;;) {
+        const hipError_t e = hipEventQuery(poll_ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery");
+        nap(std::max(3000.0, std::min(wait_ema_ns * 0.1, 50000.0)));
+      }
+      (void)hipGetLastError();  // hipErrorNotReady from the queries must not surface at the next launch check
+      const double waited = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+      wait_ema_ns = 0.75 * wait_ema_ns + 0.25 * waited;
       return;
     }
     if (!done_ev) HIP_TRY(hipEventCreateWithFlags(&done_ev, hipEventBlockingSync | hipEventDisableTiming));
@@ -105,6 +140,7 @@ struct ThreadCtx {
     cap = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), bytes));
     cap = bytes;
+    if (Config::get().probe_elide_h2d) HIP_TRY(hipMemset(p, 0, bytes));  // (measurement mode: the kernels read this buffer without it ever being filled)
   }
 };
 
@@ -791,9 +827,8 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
   }
 }
 
-// Rows per device pass for plans that need activation scratch; also grows the scratch (never inside a
-// stream capture: callers that capture call this first).
-int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
+// Rows per device pass for plans that need activation scratch (pure: no allocation).
+int64_t rows_per_pass(const LoadedModel &m, int64_t rows) {
   if (m.scratch_per_row <= 0 || m.plan.out_buf == 0) return rows;
   int64_t by_budget = int64_t(kScratchBudgetBytes / (size_t(m.scratch_per_row) * 4));
   // INFERA_MAX_ROWS_PER_PASS (2^18) bounds the scratch of plans with wide intermediates; plans whose intermediates are a
@@ -804,8 +839,13 @@ int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
   int64_t rows_pass = std::min<int64_t>(rows, std::max<int64_t>(1, std::min<int64_t>(by_budget, cap)));
   // equal passes (2000 images at 1783 per pass run as 1000 + 1000, not 1783 + 217: the short tail would leave the chip half empty)
   const int64_t npass = (rows + rows_pass - 1) / rows_pass;
-  rows_pass = (rows + npass - 1) / npass;
-  ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass) * size_t(m.scratch_per_row) * 4);
+  return (rows + npass - 1) / npass;
+}
+
+// ... and grows the scratch for it (never inside a stream capture: callers that capture call this first).
+int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
+  const int64_t rows_pass = rows_per_pass(m, rows);
+  if (m.scratch_per_row > 0 && m.plan.out_buf != 0) ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass) * size_t(m.scratch_per_row) * 4);
   return rows_pass;
 }
 
@@ -820,6 +860,9 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
     return;
   }
   const int64_t rows_pass = prepare_scratch(m, ctx, rows);
+  // a column-major chunk [K][rows] cannot be cut into row passes (pass r0 would start at a row-major offset with stride nr):
+  // callers check single_pass() first and stage such calls row-major instead; this guards every kernel family at once
+  if (in_colmajor && rows_pass != rows) throw InferaError::onnx("internal: column-major input needs a single pass");
   std::vector<int64_t> slot_base(m.slot_per_row.size(), 0);
   {
     int64_t off = 0;
@@ -845,7 +888,6 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         {
           std::string why;
           const bool cm = in_colmajor && x.in0 == 0;
-          if (cm && nr != rows) throw InferaError::onnx("internal: column-major input needs a single pass");
           if (dm.mlp3_bf16x3_packed && !cm) {
             if (!kern::mlp3_bf16x3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_bf16x3_packed, buf(st[i + 2].out), nr, dm.num_cus))
               throw InferaError::onnx("bf16x3 MLP kernel launch failed");
@@ -1133,17 +1175,41 @@ class SubmitGate {
   std::condition_variable cv_;
   int in_flight_ = 0;
 };
+// One gate per PHYSICAL GPU, not per device slot: two slots on one GPU (INFERA_DEVICES=0,0) used to admit 2 x 12 calls onto the
+// same submission path -- the 2-slot scan fell from 101 to 66 M rows/s between 16 and 32 caller threads where the 1-slot scan
+// held 94-110.  INFERA_MAX_INFLIGHT_TOTAL adds a process-wide cap on top (all GPUs share one HIP runtime).
 SubmitGate &gate_for_slot(int slot) {
   static SubmitGate gates[64];
-  return gates[size_t(slot) % 64];
+  return gates[size_t(devices().ids[size_t(slot)]) % 64];
+}
+SubmitGate &total_gate() {
+  static SubmitGate g;
+  return g;
 }
 struct GateHold {
   SubmitGate &g;
-  int limit;
+  int limit, total_limit;
   int in_flight = 1;
-  GateHold(SubmitGate &gate, int lim) : g(gate), limit(lim) { in_flight = g.acquire(limit); }
-  ~GateHold() { g.release(limit); }
+  GateHold(SubmitGate &gate, int lim, int total_lim) : g(gate), limit(lim), total_limit(total_lim) {
+    if (total_limit > 0) total_gate().acquire(total_limit);  // (order: process-wide first, then the GPU's -- released in reverse)
+    in_flight = g.acquire(limit);
+  }
+  ~GateHold() {
+    g.release(limit);
+    if (total_limit > 0) total_gate().release(total_limit);
+  }
 };
+
+// Can the model's first kernel take a host call of `rows` rows as column-major chunks as they lie?  It must be able to read one
+// (in_colmajor_ok, up to in_colmajor_max_rows) AND every host pass must be ONE device pass: a plan with activation scratch cuts long
+// calls into row passes, which a [K][rows] chunk cannot be cut into (300k rows x 16 columns through a narrow Dense +
+// unfused tail read the chunk with the wrong stride).
+bool colmajor_direct_ok(const LoadedModel &m, int64_t rows) {
+  if (!m.in_colmajor_ok || rows <= 0) return false;
+  const size_t widest = std::max(size_t(m.plan.in_per_row()), size_t(m.plan.out_per_row())) * 4;
+  const int64_t nr = std::min<int64_t>(rows, std::max<int64_t>(1, int64_t(kHostPassBytes / widest)));
+  return nr <= m.in_colmajor_max_rows && rows_per_pass(m, nr) == nr;
+}
 
 void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major) {
   if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
@@ -1163,13 +1229,16 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   // transposing path allocates per pass, which a capture cannot contain)
   if (col_major && use_graph && !m.in_colmajor_ok) throw InferaError::onnx("internal: column-major staging is not captured in hipGraph mode for this plan");
   // H2D of one pass; a column-major pass lands in dev_cm first and is transposed into the row-major table on the GPU
+  // (INFERA_HOST_PROBE_ELIDE_H2D, measurement only: a 4 KiB token crosses the link instead of the chunk)
+  const bool elide = Config::get().probe_elide_h2d;
+  auto h2d_bytes = [&](int64_t nr) { return elide ? std::min<size_t>(size_t(nr) * in_row, 4096) : size_t(nr) * in_row; };
   auto upload_pass = [&](const float *pin, float *din, int64_t nr) {
     if (col_major) {
       ctx.ensure_dev(ctx.dev_cm, ctx.dev_cm_cap, size_t(nr) * in_row);
-      HIP_TRY(hipMemcpyAsync(ctx.dev_cm, pin, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+      HIP_TRY(hipMemcpyAsync(ctx.dev_cm, pin, h2d_bytes(nr), hipMemcpyHostToDevice, ctx.stream));
       kern::transpose_cm(ctx.stream, ctx.dev_cm, din, nr, int64_t(in_row / 4));
     } else {
-      HIP_TRY(hipMemcpyAsync(din, pin, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+      HIP_TRY(hipMemcpyAsync(din, pin, h2d_bytes(nr), hipMemcpyHostToDevice, ctx.stream));
     }
   };
   if (!use_graph && size_t(rows) * widest > kPipePassBytes + kPipePassBytes / 2 && size_t(rows) > 1) {
@@ -1241,11 +1310,14 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
     const uint64_t t_f0 = now_ns();
     fill(ctx.pin_in, r0, nr);
     const uint64_t t_f1 = now_ns();
-    GateHold admitted(gate_for_slot(slot), Config::get().max_inflight);  // until this pass has been synchronised
+    GateHold admitted(gate_for_slot(slot), Config::get().max_inflight, Config::get().max_inflight_total);  // until this pass has been synchronised
     const uint64_t t_g = now_ns();
     hipGraphExec_t exec = nullptr;
+    // one device pass for the whole chunk?  (plans with activation scratch split long calls; may reallocate -- and drop graphs --
+    // so before the lookup).  A column-major chunk is only handed to the first kernel as it lies when it is.
+    const bool single_pass = prepare_scratch(m, ctx, nr) == nr;
+    if (cm_graph && !single_pass) throw InferaError::onnx("internal: column-major chunk of " + std::to_string(nr) + " rows needs several device passes; not captured in hipGraph mode");
     if (use_graph) {
-      (void)prepare_scratch(m, ctx, nr);  // may reallocate (and drop graphs) -- before the lookup
       for (auto &g : ctx.graphs)
         if (g.uid == m.uid && g.rows == (nr | (cm_graph ? int64_t(1) << 62 : 0))) {
           g.last_use = ++ctx.graph_clock;
@@ -1292,7 +1364,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
       }
     } else {
       // column-major chunk straight into the model's first kernel when it can read one (no transpose launch)
-      const bool cm_direct = col_major && m.in_colmajor_ok && nr <= m.in_colmajor_max_rows && Config::get().host_fused_transpose;
+      const bool cm_direct = col_major && m.in_colmajor_ok && nr <= m.in_colmajor_max_rows && single_pass && Config::get().host_fused_transpose;
       // Small inputs (a narrow table's chunk, a point query; INFERA_HOST_DIRECT_IN bytes, default 128 KB) are not copied to HBM first:
       // the kernel that reads them -- the plan's first kernel, or the transpose in front of it -- loads them from the pinned
       // (host-coherent) buffer over PCIe itself.  One submission less per call, and a DMA engine's start-up latency is as long as
@@ -1307,8 +1379,8 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
       const bool small_in = int64_t(nr) * int64_t(in_row) <= din_limit;
       const float *kin = ctx.dev_in;
       if (cm_direct) {
-        if (small_in) kin = ctx.pin_in;
-        else HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, size_t(nr) * in_row, hipMemcpyHostToDevice, ctx.stream));
+        if (small_in && !elide) kin = ctx.pin_in;
+        else HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, h2d_bytes(nr), hipMemcpyHostToDevice, ctx.stream));
       } else if (col_major && small_in) {
         kern::transpose_cm(ctx.stream, ctx.pin_in, ctx.dev_in, nr, int64_t(in_row / 4));
       } else if (!col_major && small_in && m.in_single_reader) {

@@ -124,6 +124,8 @@ using FillFn = std::function<void(float *dst, int64_t row0, int64_t nrows)>;
 // col_major: `fill` writes the pass as [in_per_row][nrows] (column-major -- flat columns are copied as they are) and
 // the transpose to the row-major table happens on the GPU.
 void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major = false);
+// whether a host call of `rows` rows can be handed to the plan's first kernel as column-major chunks (one device pass per host pass)
+bool colmajor_direct_ok(const LoadedModel &m, int64_t rows);
 
 // Device-resident inference: d_in / d_out live on HIP device `device_ordinal`.  Enqueues on the
 // calling thread's stream for that device and returns without synchronising.

@@ -478,7 +478,7 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
       // (SURVEY.md 7 "hard parts": the host gather is what limits an 8-GPU host).  Plans whose first kernel cannot read a
       // column-major chunk get a GPU transpose in front; only hipGraph mode on such a plan (the transpose path allocates per
       // pass, which a capture cannot contain) falls back to the AVX2 transposing gather into row-major staging.
-      bool col_major = ncols > 0 && ((m->in_colmajor_ok && int64_t(rows) <= m->in_colmajor_max_rows) || !Config::get().use_hipgraph);
+      bool col_major = ncols > 0 && (colmajor_direct_ok(*m, int64_t(rows)) || !Config::get().use_hipgraph);
       if (col_major && !Config::get().host_colmajor_typed)  // A/B knob: only all-FLOAT chunks are staged column-major (round-1 rule)
         for (uintptr_t c = 0; c < ncols && col_major; c++) col_major = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
       if (col_major) {

@@ -1,5 +1,7 @@
 #include "gather.hpp"
 
+#include "common.hpp"
+
 #include <immintrin.h>
 
 #include <cstring>
@@ -145,15 +147,55 @@ __attribute__((target("avx2"))) void convert_i32_avx2(const int32_t *src, float 
 }
 }  // namespace
 
+namespace {
+// One FLOAT column run into pinned staging with non-temporal 64-byte stores (INFERA_HOST_GATHER=nt|ntpf): the staging lines are
+// not read for ownership and do not displace the caller's working set; the DMA engine reads them from DRAM.  Measured on the
+// round-3 boxes (tools/ubench/gather_probe, 2x EPYC 9575F): 29-30 us per 1 MiB chunk against memcpy's 41 with 1-2 gathering
+// threads, but SLOWER than memcpy from 8 threads on (137 vs 210 GB/s at 16: the reused staging buffer stays cache-resident under
+// regular stores) -- so the default stays memcpy and this is the A/B knob.
+__attribute__((target("avx512f"))) void stream_copy_f32_avx512(float *d, const float *s, size_t n) {
+  size_t i = 0;
+  while (i < n && (reinterpret_cast<uintptr_t>(d + i) & 63)) d[i] = s[i], i++;
+  for (; i + 64 <= n; i += 64) {
+    const __m512i a = _mm512_loadu_si512(s + i), b = _mm512_loadu_si512(s + i + 16), c = _mm512_loadu_si512(s + i + 32), e = _mm512_loadu_si512(s + i + 48);
+    _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i), a);
+    _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i + 16), b);
+    _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i + 32), c);
+    _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i + 48), e);
+  }
+  for (; i + 16 <= n; i += 16) _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i), _mm512_loadu_si512(s + i));
+  for (; i < n; i++) d[i] = s[i];
+}
+__attribute__((target("avx2"))) void stream_copy_f32_avx2(float *d, const float *s, size_t n) {
+  size_t i = 0;
+  while (i < n && (reinterpret_cast<uintptr_t>(d + i) & 31)) d[i] = s[i], i++;
+  for (; i + 8 <= n; i += 8) _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i)));
+  for (; i < n; i++) d[i] = s[i];
+}
+}  // namespace
+
 // Column-major staging: rows [row0, row0 + nrows) of column c -> dst[c * nrows ...] as f32, the column's own run converted in
 // place of the plain memcpy a FLOAT column gets (static_cast<float> per the reference, infera_extension.cpp:211-222: RNE for
 // DOUBLE -- what vcvtpd2ps does).  DuckDB's default floating type is DOUBLE, so this is the common case of a real table: no
 // transposing gather on the CPU, the GPU kernel reads the chunk column-major.
 void gather_column_major(const infera::InferaColumn *cols, size_t c0, size_t c1, size_t row0, size_t nrows, float *dst) {
   static const bool have_avx2 = __builtin_cpu_supports("avx2");
+  static const bool have_avx512 = __builtin_cpu_supports("avx512f");
+  const int mode = have_avx2 ? Config::get().host_gather : 0;
+  bool streamed = false;
   for (size_t c = c0; c < c1; c++) {
     const infera::InferaColumn &col = cols[c];
     float *d = dst + c * nrows;
+    if (mode == 2 && c + 1 < c1 && !cols[c + 1].is_constant) {  // the next run's first lines: its page walk and DRAM row open overlap this run's copy
+      const size_t esz = cols[c + 1].type == infera::INFERA_COL_FLOAT || cols[c + 1].type == infera::INFERA_COL_INTEGER ? 4 : 8;
+      const char *nx = static_cast<const char *>(cols[c + 1].data) + row0 * esz;
+      for (int l = 0; l < 4; l++) _mm_prefetch(nx + 64 * l, _MM_HINT_T0);
+    }
+    if (mode && !col.is_constant && col.type == infera::INFERA_COL_FLOAT) {
+      (have_avx512 ? stream_copy_f32_avx512 : stream_copy_f32_avx2)(d, static_cast<const float *>(col.data) + row0, nrows);
+      streamed = true;
+      continue;
+    }
     if (col.is_constant) {
       const float v = cell(col, 0);
       for (size_t r = 0; r < nrows; r++) d[r] = v;
@@ -173,6 +215,7 @@ void gather_column_major(const infera::InferaColumn *cols, size_t c0, size_t c1,
         for (size_t r = 0; r < nrows; r++) d[r] = static_cast<float>(static_cast<const int64_t *>(col.data)[row0 + r]);
     }
   }
+  if (streamed) _mm_sfence();  // non-temporal stores are weakly ordered: globally visible before the copy engine is rung
 }
 
 void gather_columns(const infera::InferaColumn *cols, size_t ncols, size_t row0, size_t nrows, float *dst) {

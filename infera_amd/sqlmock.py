@@ -109,6 +109,8 @@ def lib() -> C.CDLL:
         L.infera_sql_bench_blob_scan.restype = C.c_int32
         L.infera_sql_bench_last_times.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.infera_sql_bench_last_times.restype = None
+        L.infera_sql_bench_last_cpu.argtypes = [C.POINTER(C.c_double)] * 3
+        L.infera_sql_bench_last_cpu.restype = None
         _lib = L
     return _lib
 
@@ -315,6 +317,13 @@ def bench_last_times() -> tuple[int, int]:
     return a.value, b.value
 
 
+def bench_last_cpu() -> tuple[float, float, float]:
+    """(process CPU seconds, of which system, wall seconds) of the last bench_scan_table call, summed over its reps."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    lib().infera_sql_bench_last_cpu(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
 def phase_breakdown(fn, *args, **kw):
     """Runs fn (a bench_scan_table call) and returns (its result, per-chunk microseconds by phase): the engine's host-path
     phases (infera_hip_get_devices) plus what the binding layer and the scan loop add around them."""
@@ -329,6 +338,10 @@ def phase_breakdown(fn, *args, **kw):
     ph["binding_layer"] = call_ns / n / 1e3 - sum(ph.values())
     ph["scan_loop"] = (thread_ns - call_ns) / n / 1e3
     ph["chunks"] = n
+    cpu_s, sys_s, wall_s = bench_last_cpu()
+    ph["cpu_us_per_chunk"] = cpu_s / n * 1e6          # process CPU time (user + sys, every thread) per chunk
+    ph["sys_us_per_chunk"] = sys_s / n * 1e6
+    ph["cpus_busy"] = cpu_s / wall_s if wall_s > 0 else 0.0
     return out, {k: round(v, 1) for k, v in ph.items()}
 
 

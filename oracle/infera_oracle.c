@@ -20,6 +20,7 @@
 #define _GNU_SOURCE
 #include "infera_oracle.h"
 
+#include <immintrin.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdarg.h>
@@ -591,8 +592,123 @@ static const Tensor *get_in(Exec *x, const Node *nd, size_t k) {
     return -1;                                     \
   } while (0)
 
+/* ---- "best CPU" GEMM for bench.py's cpu_baseline.best_cpu leg ------------------------
+ * A register-blocked micro-kernel: 6 rows x 32 columns (AVX-512: 12 zmm accumulators, 2 B loads and one broadcast per k) or
+ * 6 x 16 (AVX2), the B panel of one column block walked top to bottom for every row block (K x 32 floats: L1-resident).  Every
+ * C element is still ONE k-ordered fmaf chain from 0, so the results are bit-identical to gemm_nn below (tests/test_oracle_
+ * blocked_gemm.py) -- only the instruction schedule is what a packed SIMD matmul such as Tract's runs.  Selected per thread
+ * (t_gemm_blocked) by the bench scan only; every parity test runs the plain loop. */
+static __thread int t_gemm_blocked;
+
+__attribute__((target("avx512f"))) static void gemm_block_avx512(const float *A, const float *B, float *C, size_t N, size_t K, size_t M) {
+  size_t j = 0;
+  for (; j + 32 <= M; j += 32) {
+    size_t n = 0;
+    for (; n + 6 <= N; n += 6) {
+      __m512 c00 = _mm512_setzero_ps(), c01 = c00, c10 = c00, c11 = c00, c20 = c00, c21 = c00, c30 = c00, c31 = c00, c40 = c00, c41 = c00, c50 = c00, c51 = c00;
+      const float *a0 = A + n * K, *b = B + j;
+      for (size_t k = 0; k < K; k++, b += M) {
+        const __m512 b0 = _mm512_loadu_ps(b), b1 = _mm512_loadu_ps(b + 16);
+        __m512 a;
+        a = _mm512_set1_ps(a0[k]);         c00 = _mm512_fmadd_ps(a, b0, c00); c01 = _mm512_fmadd_ps(a, b1, c01);
+        a = _mm512_set1_ps(a0[K + k]);     c10 = _mm512_fmadd_ps(a, b0, c10); c11 = _mm512_fmadd_ps(a, b1, c11);
+        a = _mm512_set1_ps(a0[2 * K + k]); c20 = _mm512_fmadd_ps(a, b0, c20); c21 = _mm512_fmadd_ps(a, b1, c21);
+        a = _mm512_set1_ps(a0[3 * K + k]); c30 = _mm512_fmadd_ps(a, b0, c30); c31 = _mm512_fmadd_ps(a, b1, c31);
+        a = _mm512_set1_ps(a0[4 * K + k]); c40 = _mm512_fmadd_ps(a, b0, c40); c41 = _mm512_fmadd_ps(a, b1, c41);
+        a = _mm512_set1_ps(a0[5 * K + k]); c50 = _mm512_fmadd_ps(a, b0, c50); c51 = _mm512_fmadd_ps(a, b1, c51);
+      }
+      float *c = C + n * M + j;
+      _mm512_storeu_ps(c, c00);         _mm512_storeu_ps(c + 16, c01);
+      _mm512_storeu_ps(c + M, c10);     _mm512_storeu_ps(c + M + 16, c11);
+      _mm512_storeu_ps(c + 2 * M, c20); _mm512_storeu_ps(c + 2 * M + 16, c21);
+      _mm512_storeu_ps(c + 3 * M, c30); _mm512_storeu_ps(c + 3 * M + 16, c31);
+      _mm512_storeu_ps(c + 4 * M, c40); _mm512_storeu_ps(c + 4 * M + 16, c41);
+      _mm512_storeu_ps(c + 5 * M, c50); _mm512_storeu_ps(c + 5 * M + 16, c51);
+    }
+    for (; n < N; n++) {  /* row tail: one row x 32 columns */
+      __m512 c0 = _mm512_setzero_ps(), c1 = c0;
+      const float *a0 = A + n * K, *b = B + j;
+      for (size_t k = 0; k < K; k++, b += M) {
+        const __m512 a = _mm512_set1_ps(a0[k]);
+        c0 = _mm512_fmadd_ps(a, _mm512_loadu_ps(b), c0);
+        c1 = _mm512_fmadd_ps(a, _mm512_loadu_ps(b + 16), c1);
+      }
+      _mm512_storeu_ps(C + n * M + j, c0);
+      _mm512_storeu_ps(C + n * M + j + 16, c1);
+    }
+  }
+  if (j < M) { /* column tail (< 32 columns, e.g. the MLP's 64 -> 1 head): eight independent row chains in flight */
+    size_t n = 0;
+    for (; n + 8 <= N; n += 8)
+      for (size_t jj = j; jj < M; jj++) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float *a0 = A + n * K;
+        for (size_t k = 0; k < K; k++) {
+          const float bk = B[k * M + jj];
+          for (int r = 0; r < 8; r++) acc[r] = fmaf(a0[(size_t)r * K + k], bk, acc[r]);
+        }
+        for (int r = 0; r < 8; r++) C[(n + (size_t)r) * M + jj] = acc[r];
+      }
+    for (; n < N; n++)
+      for (size_t jj = j; jj < M; jj++) {
+        float acc = 0.0f;
+        for (size_t k = 0; k < K; k++) acc = fmaf(A[n * K + k], B[k * M + jj], acc);
+        C[n * M + jj] = acc;
+      }
+  }
+}
+
+__attribute__((target("avx2,fma"))) static void gemm_block_avx2(const float *A, const float *B, float *C, size_t N, size_t K, size_t M) {
+  size_t j = 0;
+  for (; j + 16 <= M; j += 16) {
+    size_t n = 0;
+    for (; n + 6 <= N; n += 6) {
+      __m256 c00 = _mm256_setzero_ps(), c01 = c00, c10 = c00, c11 = c00, c20 = c00, c21 = c00, c30 = c00, c31 = c00, c40 = c00, c41 = c00, c50 = c00, c51 = c00;
+      const float *a0 = A + n * K, *b = B + j;
+      for (size_t k = 0; k < K; k++, b += M) {
+        const __m256 b0 = _mm256_loadu_ps(b), b1 = _mm256_loadu_ps(b + 8);
+        __m256 a;
+        a = _mm256_broadcast_ss(a0 + k);         c00 = _mm256_fmadd_ps(a, b0, c00); c01 = _mm256_fmadd_ps(a, b1, c01);
+        a = _mm256_broadcast_ss(a0 + K + k);     c10 = _mm256_fmadd_ps(a, b0, c10); c11 = _mm256_fmadd_ps(a, b1, c11);
+        a = _mm256_broadcast_ss(a0 + 2 * K + k); c20 = _mm256_fmadd_ps(a, b0, c20); c21 = _mm256_fmadd_ps(a, b1, c21);
+        a = _mm256_broadcast_ss(a0 + 3 * K + k); c30 = _mm256_fmadd_ps(a, b0, c30); c31 = _mm256_fmadd_ps(a, b1, c31);
+        a = _mm256_broadcast_ss(a0 + 4 * K + k); c40 = _mm256_fmadd_ps(a, b0, c40); c41 = _mm256_fmadd_ps(a, b1, c41);
+        a = _mm256_broadcast_ss(a0 + 5 * K + k); c50 = _mm256_fmadd_ps(a, b0, c50); c51 = _mm256_fmadd_ps(a, b1, c51);
+      }
+      float *c = C + n * M + j;
+      _mm256_storeu_ps(c, c00);         _mm256_storeu_ps(c + 8, c01);
+      _mm256_storeu_ps(c + M, c10);     _mm256_storeu_ps(c + M + 8, c11);
+      _mm256_storeu_ps(c + 2 * M, c20); _mm256_storeu_ps(c + 2 * M + 8, c21);
+      _mm256_storeu_ps(c + 3 * M, c30); _mm256_storeu_ps(c + 3 * M + 8, c31);
+      _mm256_storeu_ps(c + 4 * M, c40); _mm256_storeu_ps(c + 4 * M + 8, c41);
+      _mm256_storeu_ps(c + 5 * M, c50); _mm256_storeu_ps(c + 5 * M + 8, c51);
+    }
+    for (; n < N; n++) {
+      __m256 c0 = _mm256_setzero_ps(), c1 = c0;
+      const float *a0 = A + n * K, *b = B + j;
+      for (size_t k = 0; k < K; k++, b += M) {
+        const __m256 a = _mm256_broadcast_ss(a0 + k);
+        c0 = _mm256_fmadd_ps(a, _mm256_loadu_ps(b), c0);
+        c1 = _mm256_fmadd_ps(a, _mm256_loadu_ps(b + 8), c1);
+      }
+      _mm256_storeu_ps(C + n * M + j, c0);
+      _mm256_storeu_ps(C + n * M + j + 8, c1);
+    }
+  }
+  for (size_t n = 0; j < M && n < N; n++)
+    for (size_t jj = j; jj < M; jj++) {
+      float acc = 0.0f;
+      for (size_t k = 0; k < K; k++) acc = fmaf(A[n * K + k], B[k * M + jj], acc);
+      C[n * M + jj] = acc;
+    }
+}
+
 /* C[n][m] = sum_k A[n][k] * B[k][m], k-ordered fmaf chain from 0, vectorisable over m. */
 static void gemm_nn(const float *A, const float *B, float *C, size_t N, size_t K, size_t M) {
+  if (t_gemm_blocked) {
+    if (__builtin_cpu_supports("avx512f")) { gemm_block_avx512(A, B, C, N, K, M); return; }
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) { gemm_block_avx2(A, B, C, N, K, M); return; }
+  }
   for (size_t n = 0; n < N; n++) {
     float *c = C + n * M;
     for (size_t j = 0; j < M; j++) c[j] = 0.0f;
@@ -604,6 +720,9 @@ static void gemm_nn(const float *A, const float *B, float *C, size_t N, size_t K
     }
   }
 }
+
+/* test hook: the calling thread's later orc_predict calls use the blocked GEMM (1) or the plain loop (0) */
+void orc_set_blocked_gemm(int on) { t_gemm_blocked = on; }
 
 /* numpy-style broadcast of two shapes; returns rank or -1 */
 static int bcast_shape(const Tensor *a, const Tensor *b, int64_t *out) {
@@ -2182,6 +2301,22 @@ static void *table_scan_worker(void *p) {
           }
           feat[k++] = v;
         }
+    } else if (a->boxed == 2) {
+      /* best CPU: 8-row x 8-column tiles, so the column runs are read as 32-byte pieces and the row-major target is written as
+       * 32-byte pieces (the plain strided copy below touches one float per 512-byte stride) */
+      size_t r = 0;
+      for (; r + 8 <= nr; r += 8) {
+        size_t j = 0;
+        for (; j + 8 <= F; j += 8)
+          for (size_t jj = 0; jj < 8; jj++) {
+            const float *src = base + (j + jj) * gr + r;
+            for (size_t rr = 0; rr < 8; rr++) feat[(r + rr) * F + j + jj] = src[rr];
+          }
+        for (; j < F; j++)
+          for (size_t rr = 0; rr < 8; rr++) feat[(r + rr) * F + j] = base[j * gr + r + rr];
+      }
+      for (; r < nr; r++)
+        for (size_t j = 0; j < F; j++) feat[r * F + j] = base[j * gr + r];
     } else {
       for (size_t r = 0; r < nr; r++)
         for (size_t j = 0; j < F; j++) feat[r * F + j] = base[j * gr + r];
@@ -2189,6 +2324,7 @@ static void *table_scan_worker(void *p) {
     OrcResult res;
     char err[256];
     t_arena.off = 0;
+    t_gemm_blocked = a->boxed == 2;
     /* models with an [N,C,H,W] input take the BLOB route, as in the reference (infera_predict_from_blob -> engine.rs:199-263) */
     if (a->m->in_rank > 2 ? orc_predict_blob(a->m, (const uint8_t *)feat, nr * F * 4, &res, err, sizeof err)
                           : orc_predict(a->m, feat, nr, F, &res, err, sizeof err)) { a->failed = 1; break; }

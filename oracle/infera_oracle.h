@@ -76,9 +76,14 @@ double orc_bench_scan(const OrcModel *m, uint64_t rows, uint64_t ncols, uint64_t
 /* The same scan over a table MATERIALISED by the caller in host memory (row groups of 122,880 rows, one
  * contiguous run per column inside a group -- infera_amd/csrc/binding/sql_surface.h uses the same layout), so
  * that table generation is outside the timed region and the CPU baseline and the GPU path read
- * the very same bytes.  chunk_rows must divide 122,880. */
+ * the very same bytes.  chunk_rows must divide 122,880.
+ * boxed: 1 = the reference's per-cell boxed gather + plain GEMM loop ("reference-shaped"); 0 = plain strided gather, same GEMM;
+ * 2 = "best CPU" (BASELINE.md 3b): tiled transposing gather + register-blocked AVX-512 / AVX2 micro-kernel GEMM -- bit-identical
+ * results (every element stays one k-ordered fmaf chain), the instruction schedule of a packed SIMD matmul such as Tract's. */
 double orc_bench_scan_table(const OrcModel *m, const float *table, uint64_t rows, uint64_t ncols,
                             int threads, int chunk_rows, int boxed, double *checksum);
+/* test hook: later orc_predict calls ON THE CALLING THREAD use the blocked GEMM (1) or the plain loop (0, default) */
+void orc_set_blocked_gemm(int on);
 
 #ifdef __cplusplus
 }

@@ -117,3 +117,40 @@ def test_gpu_label_epilogue_reads_column_major_chunks(gpu_api, tmp_path):
     finally:
         gpu_api.unload_model("lab")
     assert np.array_equal(got, oracle.Model(path).predict(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hipgraph", ["0", "1"])
+def test_gpu_column_major_chunk_longer_than_one_device_pass(tmp_path, hipgraph):
+    """a plan whose FIRST kernel reads column-major chunks (narrow Dense 16 -> 8) followed by unfused wide
+    intermediates (8 -> 520 -> 1: scratch of > 256 floats per row) cuts a 300k-row call into two device passes -- a [K][rows]
+    chunk cannot be cut into row passes, so such a call must be staged the transposing way.  Through the columnar entry the
+    results must equal the row-major entry bit for bit, and the oracle.  Child process: INFERA_HIPGRAPH is read once."""
+    import subprocess
+    import sys
+
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp((16, 8, 520, 1)))
+    code = f"""
+import numpy as np
+from infera_amd import capi, synth
+from oracle import oracle
+rows, k = 300_000, 16
+capi.load_model("m", {path!r})
+plan = capi.get_plan("m")
+assert plan["scratch_floats_per_row"] > 256, plan
+x = synth.table(23, 0, rows, k)
+cols = [np.ascontiguousarray(x[:, c]) for c in range(k)]
+got = capi.predict_columns("m", cols)
+assert np.array_equal(got, capi.predict("m", x)), float(np.abs(got - capi.predict("m", x)).max())
+short = capi.predict_columns("m", [c[:2048] for c in cols])
+assert np.array_equal(short, got[:2048])
+want = oracle.Model({path!r}).predict(x[:4096])
+assert np.all(np.abs(got[:4096] - want) <= 1e-4 * np.abs(want) + 1e-6), float(np.abs(got[:4096] - want).max())
+tail = oracle.Model({path!r}).predict(x[-4096:])
+assert np.all(np.abs(got[-4096:] - tail) <= 1e-4 * np.abs(tail) + 1e-6), float(np.abs(got[-4096:] - tail).max())
+print("ok", plan["exec"])
+"""
+    env = dict(os.environ, INFERA_HIPGRAPH=hipgraph)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout + r.stderr

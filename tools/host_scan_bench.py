@@ -19,7 +19,17 @@ ap.add_argument("--softmax", action="store_true")
 ap.add_argument("--pool", action="store_true", help="cache-resident per-thread chunk pool instead of the materialised table (round-1 behaviour)")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--double", action="store_true", help="DOUBLE columns (DuckDB's default floating type) instead of FLOAT")
+ap.add_argument("--numa", default="off", choices=["auto", "off"], help="auto: bind the process to the CPUs of the (first) GPU's NUMA node before any thread exists")
 a = ap.parse_args()
+if a.numa == "auto":
+    node = capi.get_devices()["devices"][0].get("numa_node", -1)
+    if node >= 0:
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus & os.sched_getaffinity(0))
+        print(f"bound to NUMA node {node}: {len(os.sched_getaffinity(0))} CPUs")
 tmp = tempfile.mkdtemp()
 if a.dims:
     dims = tuple(int(x) for x in a.dims.split(","))
@@ -30,7 +40,7 @@ else:
 capi.load_model("m", onnx_writer.write(os.path.join(tmp, "m.onnx"), blob))
 sqlmock.bench_scan(fn, "m", 2048 * 64, cols, 4)  # warm
 print(f"devices={capi.get_devices()['devices']} workload={a.dims or a.workload} rows={a.rows} exec={capi.get_plan('m')['exec']} "
-      f"INFERA_HIPGRAPH={os.environ.get('INFERA_HIPGRAPH', '0')} source={'per-thread chunk pool' if a.pool else 'materialised columnar host table'}")
+      f"env={ {k: v for k, v in os.environ.items() if k.startswith('INFERA_')} } source={'per-thread chunk pool' if a.pool else 'materialised columnar host table'}")
 import numpy as np  # noqa: E402
 table = None if a.pool else sqlmock.synth_table(a.rows, cols, 42, 16, np.float64 if a.double else np.float32)
 print("column type:", "DOUBLE" if a.double else "FLOAT")
