@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <sstream>
@@ -79,7 +80,7 @@ struct ThreadCtx {
       HIP_TRY(hipStreamSynchronize(stream));
       return;
     }
-    if (mode == 2) {
+    if (mode >= 2) {
       // Sleep-poll: ROCm's blocking event wait spins before it blocks and pays an interrupt + wake-up per chunk; under a CPU quota
       // (16 CPUs feeding 8 GPUs) CPU time per chunk is what bounds the scan.  Nap for most of what this context's recent calls
       // waited, then query between short naps: one or two clock_nanosleep calls and a few event queries per chunk.
@@ -88,8 +89,11 @@ struct ThreadCtx {
         (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // default slack is 50 us: a 20 us nap would last 70
         slack_set = true;
       }
-      if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(poll_ev, stream));
+      // (mode 3, "pollq": hipStreamQuery instead of a recorded event -- no marker packet on the queue, one API call less per chunk)
+      if (mode == 2) {
+        if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(poll_ev, stream));
+      }
       const auto t0 = std::chrono::steady_clock::now();
       auto nap = [](double ns) {
         if (ns < 1500.0) return;
@@ -99,9 +103,9 @@ struct ThreadCtx {
       };
       nap(std::min(wait_ema_ns * 0.75, 2.0e6));
       for (;;) {
-        const hipError_t e = hipEventQuery(poll_ev);
+        const hipError_t e = mode == 2 ? hipEventQuery(poll_ev) : hipStreamQuery(stream);
         if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery");
+        if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery / hipStreamQuery");
         nap(std::max(3000.0, std::min(wait_ema_ns * 0.1, 50000.0)));
       }
       (void)hipGetLastError();  // hipErrorNotReady from the queries must not surface at the next launch check
@@ -140,7 +144,7 @@ struct ThreadCtx {
     cap = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), bytes));
     cap = bytes;
-    if (Config::get().probe_elide_h2d) HIP_TRY(hipMemset(p, 0, bytes));  // (measurement mode: the kernels read this buffer without it ever being filled)
+    if (Config::get().probe_elide_h2d > 0) HIP_TRY(hipMemset(p, 0, bytes));  // (measurement mode: the kernels read this buffer without it ever being filled)
   }
 };
 
@@ -263,7 +267,7 @@ std::atomic<uint64_t> g_slot_calls[64], g_slot_rows[64];
 // (H2D + kernels [+ D2H] API calls), wait (until the device is done), copy_out (pinned -> result buffer).
 // Seven steady_clock reads per call (~0.2 us) -- always on, reported by infera_hip_get_devices.
 enum HostPhase { kPhLease, kPhGather, kPhGate, kPhEnqueue, kPhWait, kPhCopyOut, kPhCount };
-std::atomic<uint64_t> g_phase_ns[kPhCount], g_phase_calls;
+std::atomic<uint64_t> g_phase_ns[kPhCount], g_phase_calls, g_split_calls;
 inline uint64_t now_ns() { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
 
 // NUMA node of the CPU the calling thread runs on right now (-1 = unknown), from /sys/devices/system/node/node*/cpulist
@@ -1044,7 +1048,8 @@ double h2d_probe_gbs(int device_ordinal, size_t bytes, int iters, int threads) {
 
 std::string host_phase_json() {
   static const char *names[kPhCount] = {"lease", "gather", "gate", "enqueue", "wait", "copy_out"};
-  std::string o = "{\"passes\":" + std::to_string(g_phase_calls.load(std::memory_order_relaxed));
+  std::string o = "{\"passes\":" + std::to_string(g_phase_calls.load(std::memory_order_relaxed)) +
+                  ",\"split_calls\":" + std::to_string(g_split_calls.load(std::memory_order_relaxed));
   for (int i = 0; i < kPhCount; i++) o += std::string(",\"") + names[i] + "_ns\":" + std::to_string(g_phase_ns[i].load(std::memory_order_relaxed));
   return o + "}";
 }
@@ -1159,6 +1164,7 @@ class SubmitGate {
     if (limit <= 0) return 1;
     std::unique_lock<std::mutex> lk(mu_);
     cv_.wait(lk, [&] { return in_flight_ < limit; });
+    approx_.store(in_flight_ + 1, std::memory_order_relaxed);
     return ++in_flight_;
   }
   void release(int limit) {
@@ -1166,14 +1172,17 @@ class SubmitGate {
     {
       std::lock_guard<std::mutex> lk(mu_);
       in_flight_--;
+      approx_.store(in_flight_, std::memory_order_relaxed);
     }
     cv_.notify_one();
   }
+  int peek() const { return approx_.load(std::memory_order_relaxed); }  // calls in flight right now (unlocked read: a hint)
 
  private:
   std::mutex mu_;
   std::condition_variable cv_;
   int in_flight_ = 0;
+  std::atomic<int> approx_{0};
 };
 // One gate per PHYSICAL GPU, not per device slot: two slots on one GPU (INFERA_DEVICES=0,0) used to admit 2 x 12 calls onto the
 // same submission path -- the 2-slot scan fell from 101 to 66 M rows/s between 16 and 32 caller threads where the 1-slot scan
@@ -1230,7 +1239,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   if (col_major && use_graph && !m.in_colmajor_ok) throw InferaError::onnx("internal: column-major staging is not captured in hipGraph mode for this plan");
   // H2D of one pass; a column-major pass lands in dev_cm first and is transposed into the row-major table on the GPU
   // (INFERA_HOST_PROBE_ELIDE_H2D, measurement only: a 4 KiB token crosses the link instead of the chunk)
-  const bool elide = Config::get().probe_elide_h2d;
+  const bool elide = Config::get().probe_elide_h2d > 0, elide_kernel = Config::get().probe_elide_h2d > 1;
   auto h2d_bytes = [&](int64_t nr) { return elide ? std::min<size_t>(size_t(nr) * in_row, 4096) : size_t(nr) * in_row; };
   auto upload_pass = [&](const float *pin, float *din, int64_t nr) {
     if (col_major) {
@@ -1304,6 +1313,89 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
   ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows_pass) * out_row);
   ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_dev(ctx.dev_out, ctx.dev_out_cap, size_t(rows_pass) * out_row);
+  // H2D (or not: small inputs are read from pinned memory by the kernel itself) + the plan's kernels [+ D2H] of ONE pass whose staged
+  // input is at `pin`, on ctx.stream; results land at `pout` (a position in the pinned result buffer).  Non-graph mode.
+  auto enqueue_pass = [&](const float *pin, float *din, float *dout, float *pout, int64_t nr, bool single_pass, int in_flight, bool allow_small) {
+    // column-major chunk straight into the model's first kernel when it can read one (no transpose launch)
+    const bool cm_direct = col_major && m.in_colmajor_ok && nr <= m.in_colmajor_max_rows && single_pass && Config::get().host_fused_transpose;
+    // Small inputs (a narrow table's chunk, a point query; INFERA_HOST_DIRECT_IN bytes, default 128 KB) are not copied to HBM first:
+    // the kernel that reads them -- the plan's first kernel, or the transpose in front of it -- loads them from the pinned
+    // (host-coherent) buffer over PCIe itself.  One submission less per call, and a DMA engine's start-up latency is as long as
+    // such a transfer: 13-column table +6..17 % at 2..64 threads.  (1 MB chunks read this way reach 34 GB/s against the copy
+    // engines' 50: C2 and every larger chunk keep the H2D copy.)
+    // (a quiet GPU reads larger chunks this way -- twice that size with at most four calls in flight, four times with at most two: a
+    // few kernels pulling over PCIe do not yet compete with each other, and the copy engine's latency is the larger part of such a
+    // call.  30 -> 100 -> 2, 245 KB chunks: +17 / +8 / +6 / +4 % at 1 / 2 / 4 / 8 threads; 64 -> 128 -> 64 -> 1, 512 KB: +13 / +6 % at 1 / 2)
+    static const bool quiet_on = [] { const char *e = getenv("INFERA_HOST_DIRECT_IN_QUIET"); return !(e && e[0] == '0'); }();  // (0: A/B)
+    const int quiet_mult = !quiet_on ? 1 : in_flight <= 2 ? 4 : in_flight <= 4 ? 2 : 1;
+    const int64_t din_limit = int64_t(Config::get().host_direct_in_bytes) * quiet_mult;
+    const bool small_in = allow_small && !elide && int64_t(nr) * int64_t(in_row) <= din_limit;
+    const float *kin = din;
+    if (cm_direct) {
+      if (small_in) kin = pin;
+      else HIP_TRY(hipMemcpyAsync(din, pin, h2d_bytes(nr), hipMemcpyHostToDevice, ctx.stream));
+    } else if (col_major && small_in) {
+      kern::transpose_cm(ctx.stream, pin, din, nr, int64_t(in_row / 4));
+    } else if (!col_major && small_in && m.in_single_reader) {
+      kin = pin;
+    } else {
+      upload_pass(pin, din, nr);
+    }
+    const int64_t kr = elide_kernel ? std::min<int64_t>(nr, 32) : nr;  // (probe level 2: a one-tile launch instead of the chunk's)
+    if (direct_out) {
+      // the plan's only writer of the result stores it straight into the pinned (host-coherent) buffer: a few KB per
+      // chunk over PCIe from the kernel's epilogue instead of one more enqueue + blit kernel + dependency per chunk
+      exec_plan(m, dm, ctx, kin, pout, kr, cm_direct);
+    } else {
+      exec_plan(m, dm, ctx, kin, dout, kr, cm_direct);
+      HIP_TRY(hipMemcpyAsync(pout, dout, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
+    }
+  };
+  // One call = one DataChunk (the usual case): a quiet GPU -- few callers, what each of 8 GPUs sees when 16 CPUs feed them --
+  // is not kept busy by calls that gather, THEN transfer, THEN compute: the chunk goes through as `split` sub-passes on the
+  // call's stream, the gather of sub-pass i+1 overlapping the H2D + kernels of sub-pass i, one wait at the end.  Row-independent
+  // plans give the same bits whatever the split (sub-passes are multiples of 32 rows: whole MFMA tiles).
+  {
+    const int split_mode = Config::get().host_split;  // 0 never (default: measured a loss, see common.hpp), 1 auto, n >= 2 always n sub-passes
+    const int quiet = gate_for_slot(slot).peek();
+    int split = split_mode >= 2 ? split_mode : (split_mode == 1 && quiet <= Config::get().host_split_quiet ? 2 : 1);
+    const int64_t sub = split > 1 ? ((rows + split - 1) / split + 31) / 32 * 32 : rows;
+    if (!use_graph && split > 1 && rows <= rows_pass && sub < rows && size_t(sub) * in_row >= (256u << 10) && rows_per_pass(m, sub) == sub) {
+      const uint64_t t_f0 = now_ns();
+      uint64_t gather_ns = 0, enq_ns = 0, gate_ns = 0;
+      (void)prepare_scratch(m, ctx, sub);
+      std::unique_ptr<GateHold> admitted;
+      for (int64_t r0 = 0; r0 < rows; r0 += sub) {
+        const int64_t nr = std::min(sub, rows - r0);
+        const uint64_t a = now_ns();
+        float *pin = ctx.pin_in + size_t(r0) * (in_row / 4);
+        fill(pin, r0, nr);
+        const uint64_t b = now_ns();
+        if (!admitted) admitted = std::make_unique<GateHold>(gate_for_slot(slot), Config::get().max_inflight, Config::get().max_inflight_total);
+        const uint64_t c = now_ns();
+        enqueue_pass(pin, ctx.dev_in + size_t(r0) * (in_row / 4), ctx.dev_out + size_t(r0) * (out_row / 4), ctx.pin_out + size_t(r0) * (out_row / 4), nr,
+                     true, admitted->in_flight, false);
+        gather_ns += b - a;
+        gate_ns += c - b;
+        enq_ns += now_ns() - c;
+      }
+      const uint64_t t_e = now_ns();
+      ctx.wait_stream();
+      const uint64_t t_w = now_ns();
+      std::memcpy(h_out, ctx.pin_out, size_t(rows) * out_row);
+      const uint64_t t_c = now_ns();
+      (void)t_f0;
+      g_phase_ns[kPhLease].fetch_add(t_leased - t_entry, std::memory_order_relaxed);
+      g_phase_ns[kPhGather].fetch_add(gather_ns, std::memory_order_relaxed);
+      g_phase_ns[kPhGate].fetch_add(gate_ns, std::memory_order_relaxed);
+      g_phase_ns[kPhEnqueue].fetch_add(enq_ns, std::memory_order_relaxed);
+      g_phase_ns[kPhWait].fetch_add(t_w - t_e, std::memory_order_relaxed);
+      g_phase_ns[kPhCopyOut].fetch_add(t_c - t_w, std::memory_order_relaxed);
+      g_phase_calls.fetch_add(1, std::memory_order_relaxed);
+      g_split_calls.fetch_add(1, std::memory_order_relaxed);
+      return;
+    }
+  }
   for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
     const int64_t nr = std::min(rows_pass, rows - r0);
     // The caller's buffer is only borrowed for the call (SURVEY.md 8b "Ownership"): stage it.
@@ -1363,39 +1455,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
         continue;  // this chunk's result is already in h_out
       }
     } else {
-      // column-major chunk straight into the model's first kernel when it can read one (no transpose launch)
-      const bool cm_direct = col_major && m.in_colmajor_ok && nr <= m.in_colmajor_max_rows && single_pass && Config::get().host_fused_transpose;
-      // Small inputs (a narrow table's chunk, a point query; INFERA_HOST_DIRECT_IN bytes, default 128 KB) are not copied to HBM first:
-      // the kernel that reads them -- the plan's first kernel, or the transpose in front of it -- loads them from the pinned
-      // (host-coherent) buffer over PCIe itself.  One submission less per call, and a DMA engine's start-up latency is as long as
-      // such a transfer: 13-column table +6..17 % at 2..64 threads.  (1 MB chunks read this way reach 34 GB/s against the copy
-      // engines' 50: C2 and every larger chunk keep the H2D copy.)
-      // (a quiet GPU reads larger chunks this way -- twice that size with at most four calls in flight, four times with at most two: a
-      // few kernels pulling over PCIe do not yet compete with each other, and the copy engine's latency is the larger part of such a
-      // call.  30 -> 100 -> 2, 245 KB chunks: +17 / +8 / +6 / +4 % at 1 / 2 / 4 / 8 threads; 64 -> 128 -> 64 -> 1, 512 KB: +13 / +6 % at 1 / 2)
-      static const bool quiet_on = [] { const char *e = getenv("INFERA_HOST_DIRECT_IN_QUIET"); return !(e && e[0] == '0'); }();  // (0: A/B)
-      const int quiet_mult = !quiet_on ? 1 : admitted.in_flight <= 2 ? 4 : admitted.in_flight <= 4 ? 2 : 1;
-      const int64_t din_limit = int64_t(Config::get().host_direct_in_bytes) * quiet_mult;
-      const bool small_in = int64_t(nr) * int64_t(in_row) <= din_limit;
-      const float *kin = ctx.dev_in;
-      if (cm_direct) {
-        if (small_in && !elide) kin = ctx.pin_in;
-        else HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, h2d_bytes(nr), hipMemcpyHostToDevice, ctx.stream));
-      } else if (col_major && small_in) {
-        kern::transpose_cm(ctx.stream, ctx.pin_in, ctx.dev_in, nr, int64_t(in_row / 4));
-      } else if (!col_major && small_in && m.in_single_reader) {
-        kin = ctx.pin_in;
-      } else {
-        upload_pass(ctx.pin_in, ctx.dev_in, nr);
-      }
-      if (direct_out) {
-        // the plan's only writer of the result stores it straight into the pinned (host-coherent) buffer: a few KB per
-        // chunk over PCIe from the kernel's epilogue instead of one more enqueue + blit kernel + dependency per chunk
-        exec_plan(m, dm, ctx, kin, ctx.pin_out, nr, cm_direct);
-      } else {
-        exec_plan(m, dm, ctx, kin, ctx.dev_out, nr, cm_direct);
-        HIP_TRY(hipMemcpyAsync(ctx.pin_out, ctx.dev_out, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
-      }
+      enqueue_pass(ctx.pin_in, ctx.dev_in, ctx.dev_out, ctx.pin_out, nr, single_pass, admitted.in_flight, true);
     }
     const uint64_t t_e = now_ns();
     ctx.wait_stream();  // (spinning on hipStreamQuery instead measured slower: 41 vs 69 M rows/s at 16 threads)
@@ -1445,6 +1505,20 @@ std::string LoadedModel::describe_json() const {
     if (exec[i] == ExecKind::Mlp3Head)
       o << ",\"fused_kernel\":" << json_str(bf16x3 ? kern::mlp3_bf16x3_kernel_name(mlp3_shape) : kern::mlp3_kernel_name(mlp3_shape))
         << ",\"precision\":" << json_str(bf16x3 ? "bf16x3 (NOT parity precision)" : "fp32");
+  {  // kernel family of every Dense layer that runs on the streaming / generic Dense kernels, for a large aligned device-resident scan
+    std::string dk;
+    for (size_t i = 0; i < exec.size(); i++) {
+      const Step &x = plan.steps[i];
+      if (x.kind != StepKind::Dense) continue;
+      int sm = -1;
+      if (exec[i] == ExecKind::DenseSoftmax) sm = plan.steps[i + 1].log_softmax ? 2 : 1;
+      else if (exec[i] == ExecKind::DenseArgMax) sm = 3;
+      else if (exec[i] == ExecKind::Normal) sm = 0;
+      if (sm < 0) continue;
+      dk += std::string(dk.empty() ? "" : ",") + json_str(kern::dense_kernel_family(int64_t(1) << 20, int(x.K), int(x.M), sm, false, true));
+    }
+    if (!dk.empty()) o << ",\"dense_kernels\":[" << dk << "]";
+  }
   if (!chains.empty()) {
     o << ",\"chain_kernels\":[";
     for (size_t i = 0; i < chains.size(); i++) o << (i ? "," : "") << json_str(kern::chain_kernel_name(chains[i].shape));

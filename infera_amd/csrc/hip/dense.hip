@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <string_view>
 
 namespace infera_hip::kern {
 
@@ -1143,25 +1144,38 @@ bool dense_can_fuse_argmax(const float *X, int K, int M) {
 // aligned kernels -- measured equal or a few percent behind on 128 -> 10)
 bool dense_colmajor_supported(int K, int M) { return M >= 1 && M <= 16 && K >= 1 && K < 64; }
 
+// Which kernel family serves a Dense layer: ONE decision function, used by the launcher below and by the plan description
+// (infera_hip_get_plan "dense_kernels": what profiles/traffic_*.json and the rocprofv3 summaries must name).
+const char *dense_kernel_family(int64_t rows, int K, int M, int softmax_mode, bool x_colmajor, bool aligned16) {
+  if (x_colmajor) return K >= 8 && (K > 32 || M >= 3) ? "dense_narrow16g_kernel" : "dense_skinny_kernel";
+  static const int wide16 = getenv("INFERA_DENSE16W") ? atoi(getenv("INFERA_DENSE16W")) : 1;  // 0 off, 2 = also where aligned kernels exist (A/B)
+  if (wide16 == 2 && M <= 16 && K >= 64) return "dense_narrow16w_kernel";
+  if (narrow16g_ok(K, M)) return "dense_narrow16g_kernel";
+  if (skinny_ok(K, M)) return "dense_skinny_kernel";
+  static const bool staged16 = !(getenv("INFERA_DENSE16_STAGED") && atoi(getenv("INFERA_DENSE16_STAGED")) == 0);
+  if (staged16 && M <= 16 && (K == 64 || K == 128 || K == 256) && rows >= 4096 && aligned16) return "dense_narrow16s_kernel";
+  if (M <= 16 && K % 16 == 0 && K <= 1024 && aligned16) return "dense_narrow16_kernel";
+  if (wide16 && narrow16w_ok(K, M)) return "dense_narrow16w_kernel";
+  if (softmax_mode == 3) return "";  // callers check dense_can_fuse_argmax first; nothing below has that epilogue
+  if (M <= 32 && K % 8 == 0 && K <= 512 && aligned16) return "dense_narrow_kernel";
+  return "dense_kernel";
+}
+
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
            ActParam act, int softmax_mode, bool x_colmajor) {
   if (rows <= 0) return;
-  if (x_colmajor) {  // (callers checked dense_colmajor_supported; 64 / 128 columns too: their row-major kernels need 16-byte rows)
-    if (K >= 8 && (K > 32 || M >= 3)) return launch_narrow16g(s, X, W, bias, Y, rows, K, M, act, softmax_mode, true);
-    return launch_skinny(s, X, W, bias, Y, rows, K, M, act, softmax_mode, true);
-  }
-  static const int wide16 = getenv("INFERA_DENSE16W") ? atoi(getenv("INFERA_DENSE16W")) : 1;  // 0 off, 2 = also where aligned kernels exist (A/B)
-  if (wide16 == 2 && M <= 16 && K >= 64) return launch_narrow16w(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
-  if (narrow16g_ok(K, M)) return launch_narrow16g(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
-  if (skinny_ok(K, M)) return launch_skinny(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
-  static const bool staged16 = !(getenv("INFERA_DENSE16_STAGED") && atoi(getenv("INFERA_DENSE16_STAGED")) == 0);
-  if (staged16 && M <= 16 && (K == 64 || K == 128 || K == 256) && rows >= 4096 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+  const std::string_view fam = dense_kernel_family(rows, K, M, softmax_mode, x_colmajor, (reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (fam.empty()) return;
+  if (fam == "dense_narrow16g_kernel") return launch_narrow16g(s, X, W, bias, Y, rows, K, M, act, softmax_mode, x_colmajor);
+  if (fam == "dense_skinny_kernel") return launch_skinny(s, X, W, bias, Y, rows, K, M, act, softmax_mode, x_colmajor);
+  if (fam == "dense_narrow16w_kernel") return launch_narrow16w(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
+  if (fam == "dense_narrow16s_kernel") {
     if (K == 64) launch_narrow16s<64>(s, X, W, bias, Y, rows, M, act, softmax_mode);
     else if (K == 128) launch_narrow16s<128>(s, X, W, bias, Y, rows, M, act, softmax_mode);
     else launch_narrow16s<256>(s, X, W, bias, Y, rows, M, act, softmax_mode);
     return;
   }
-  if (M <= 16 && K % 16 == 0 && K <= 1024 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+  if (fam == "dense_narrow16_kernel") {
     const int64_t ntiles = (rows + 31) / 32;
     int64_t blocks = (ntiles + WAVES - 1) / WAVES;
     if (blocks > 256 * 8) blocks = 256 * 8;
@@ -1173,9 +1187,7 @@ void dense(hipStream_t s, const float *X, const float *W, const float *bias, flo
     else hipLaunchKernelGGL((dense_narrow16_kernel<3>), grid, block, lds, s, X, W, bias, Y, rows, K, M, act);
     return;
   }
-  if (wide16 && narrow16w_ok(K, M)) return launch_narrow16w(s, X, W, bias, Y, rows, K, M, act, softmax_mode);
-  if (softmax_mode == 3) return;  // callers check dense_can_fuse_argmax first; nothing below has that epilogue
-  if (M <= 32 && K % 8 == 0 && K <= 512 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+  if (fam == "dense_narrow_kernel") {
     const int64_t ntiles = (rows + 31) / 32;
     int64_t blocks = (ntiles + WAVES - 1) / WAVES;
     if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 blocks per CU

@@ -46,6 +46,8 @@ void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_
 // Y[rows, M] = act(X[rows, K] . W[K, M] + bias[M]); W row-major, bias may be null.
 // softmax_fused: apply a row softmax over the M outputs in the epilogue (requires M <= 256).
 // x_colmajor: X is ONE column-major chunk [K][rows] (host path staging; only where dense_colmajor_supported(K, M)).
+// kernel family that serves a Dense layer (the launcher's own decision function; "" = none carries that epilogue)
+const char *dense_kernel_family(int64_t rows, int K, int M, int softmax_mode, bool x_colmajor, bool aligned16);
 void dense(hipStream_t s, const float *X, const float *W, const float *bias, float *Y, int64_t rows, int K, int M,
            ActParam act, int softmax_mode /*0 none,1 softmax,2 log-softmax,3 argmax (label only)*/, bool x_colmajor = false);
 bool dense_colmajor_supported(int K, int M);

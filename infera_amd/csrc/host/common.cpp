@@ -88,12 +88,14 @@ const Config &Config::get() {
     c.use_hipgraph = env_flag("INFERA_HIPGRAPH", false);
     c.max_inflight = int(env_u64("INFERA_MAX_INFLIGHT", 12));
     c.host_contexts = std::max(1, int(env_u64("INFERA_HOST_CONTEXTS", 24)));
-    const std::string hw = env_or("INFERA_HOST_WAIT", "block");
-    c.host_wait = hw == "spin" ? 1 : hw == "poll" ? 2 : 0;
+    const std::string hw = env_or("INFERA_HOST_WAIT", "poll");
+    c.host_wait = hw == "spin" ? 1 : hw == "poll" ? 2 : hw == "pollq" ? 3 : hw == "block" ? 0 : 2;
     const std::string hg = env_or("INFERA_HOST_GATHER", "memcpy");
     c.host_gather = hg == "nt" ? 1 : hg == "ntpf" ? 2 : 0;
     c.max_inflight_total = int(env_u64("INFERA_MAX_INFLIGHT_TOTAL", 0));
-    c.probe_elide_h2d = env_flag("INFERA_HOST_PROBE_ELIDE_H2D", false);
+    c.probe_elide_h2d = int(env_u64("INFERA_HOST_PROBE_ELIDE_H2D", 0));
+    c.host_split = int(env_u64("INFERA_HOST_SPLIT", 0));
+    c.host_split_quiet = int(env_u64("INFERA_HOST_SPLIT_QUIET", 4));
     c.host_direct_out = env_flag("INFERA_HOST_DIRECT_OUT", true);
     c.host_colmajor_typed = env_flag("INFERA_HOST_COLMAJOR_TYPED", true);
     c.host_fused_transpose = env_flag("INFERA_HOST_FUSED_TRANSPOSE", true);

@@ -92,18 +92,29 @@ struct Config {
   bool use_hipgraph;                  // INFERA_HIPGRAPH=0|1      replay a per-(model,rows) hipGraph {H2D,kernels,D2H} per
                                       //   host-path chunk.  Default 0: measured SLOWER than three direct stream
                                       //   enqueues on MI355X/ROCm 7.2 (60 vs 82 M rows/s at 16 threads)
-  int host_wait;                      // INFERA_HOST_WAIT=block|spin|poll  how a host-ABI call waits for its chunk: block (0) = sleep on a
-                                      //   blocking-sync event (the caller's core is free for other workers' gathers: what a
-                                      //   CPU-quota'd container or a busy DuckDB pipeline needs), spin (1) = hipStreamSynchronize,
-                                      //   poll (2) = nap for most of the expected wait (clock_nanosleep), then hipEventQuery between short naps
+  int host_wait;                      // INFERA_HOST_WAIT=poll|pollq|block|spin  how a host-ABI call waits for its chunk.  poll (2, default) = nap
+                                      //   for most of the expected wait (clock_nanosleep), then hipEventQuery between short naps: the caller's
+                                      //   core is free for other workers' gathers -- what a CPU-quota'd container or a busy DuckDB pipeline
+                                      //   needs; pollq (3) = the same on hipStreamQuery (no event record); block (0) = hipEventSynchronize on a
+                                      //   blocking-sync event, which on ROCm 7.2 BURNS the core for the whole wait (measured: 277 us of CPU per
+                                      //   chunk at 16 threads against 85 with poll, same rows/s; profiles/r03_host_cpu_ab_wait_gather.txt);
+                                      //   spin (1) = hipStreamSynchronize
   int host_gather;                    // INFERA_HOST_GATHER=memcpy|nt|ntpf  how FLOAT column runs are copied into pinned staging: memcpy (0),
                                       //   non-temporal 64-byte stores (1: no read-for-ownership of the staging lines, which the DMA engine
                                       //   reads from DRAM anyway), the same + software prefetch of the next column run's first lines (2)
   int max_inflight_total;             // INFERA_MAX_INFLIGHT_TOTAL=n  host-ABI calls the PROCESS admits between first H2D and sync over all
                                       //   GPUs (0 = no process-wide limit; the per-GPU limit is INFERA_MAX_INFLIGHT)
-  bool probe_elide_h2d;               // INFERA_HOST_PROBE_ELIDE_H2D=1  MEASUREMENT ONLY (bench.py --elide-h2d): host-path H2D copies move a
+  int probe_elide_h2d;                // INFERA_HOST_PROBE_ELIDE_H2D=1|2  MEASUREMENT ONLY (bench.py --elide-h2d): host-path H2D copies move a
                                       //   4 KiB token instead of the chunk, so the gather / lease / gate / submit machinery can be timed with
-                                      //   the link taken out.  Results are meaningless in this mode
+                                      //   the link taken out; 2 = the kernels also run on one 32-row tile only (8 slots sharing ONE
+                                      //   GPU are otherwise bound by that GPU's kernel dispatch rate).  Results are meaningless in this mode
+  int host_split;                     // INFERA_HOST_SPLIT=0|1|n  one-DataChunk calls go through as sub-passes on the call's stream, the gather
+                                      //   of sub-pass i+1 overlapping H2D + kernels of sub-pass i: 0 never (default), 1 two halves when the GPU
+                                      //   is quiet (at most INFERA_HOST_SPLIT_QUIET calls in flight), n >= 2 always n sub-passes.  Measured a LOSS
+                                      //   at every thread count (C2, 1 / 4 / 8 callers: 20.3 / 61.2 / 92.9 M rows/s whole, 18.5 / 51.4 / 81.2 in
+                                      //   halves; profiles/r03_host_cpu_ab_split_pollq.txt): a chunk's 45-50 us in flight are fixed latencies
+                                      //   (copy-engine start, dispatch, completion), not its 20 us of transfer -- halves pay them twice
+  int host_split_quiet;               // INFERA_HOST_SPLIT_QUIET=n (default 4)
   bool host_direct_out;               // INFERA_HOST_DIRECT_OUT=0|1  the last kernel of a write-once plan stores its results
                                       //   straight into the pinned result buffer (no D2H copy enqueue per chunk)
   bool host_colmajor_typed;           // INFERA_HOST_COLMAJOR_TYPED=0|1  DOUBLE / INTEGER / BIGINT / constant columns are staged column-major too

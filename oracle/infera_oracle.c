@@ -2187,8 +2187,9 @@ static void *scan_worker(void *p) {
     /* table generation (outside what the reference would time, but identical for every backend) */
     for (size_t j = 0; j < F; j++)
       for (size_t r = 0; r < nr; r++) cols[j * CH + r] = orc_synth_value(a->seed, r0 + r, j, F);
-    /* ExtractFeatures, infera_extension.cpp:199-227: row-outer, col-inner */
-    if (a->boxed) {
+    /* ExtractFeatures, infera_extension.cpp:199-227: row-outer, col-inner  (boxed == 2: plain gather + the blocked GEMM, "best CPU") */
+    t_gemm_blocked = a->boxed == 2;
+    if (a->boxed == 1) {
       size_t k = 0;
       for (size_t r = 0; r < nr; r++)
         for (size_t j = 0; j < F; j++) {
@@ -2286,7 +2287,7 @@ static void *table_scan_worker(void *p) {
     uint64_t gr = a->rows - g0 < ORC_ROW_GROUP ? a->rows - g0 : ORC_ROW_GROUP;
     size_t nr = (size_t)((a->rows - r0) < CH ? (a->rows - r0) : CH);
     const float *base = a->table + g0 * F + (r0 - g0); /* column j of this chunk: base + j*gr */
-    if (a->boxed) {
+    if (a->boxed == 1) {
       size_t k = 0;
       for (size_t r = 0; r < nr; r++)
         for (size_t j = 0; j < F; j++) {

@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         L.orc_synth_fill_rowmajor.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_bench_scan.restype = C.c_double
         L.orc_bench_scan.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.orc_set_blocked_gemm.restype = None
+        L.orc_set_blocked_gemm.argtypes = [C.c_int]
         L.orc_bench_scan_table.restype = C.c_double
         L.orc_bench_scan_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
@@ -122,7 +124,7 @@ class Model:
         return self._take(res)
 
     def bench_scan(self, rows: int, ncols: int, seed: int = 42, threads: int = 1, chunk_rows: int = 2048,
-                   boxed: bool = True) -> tuple[float, float]:
+                   boxed: bool | int = True) -> tuple[float, float]:
         cs = C.c_double()
         sec = lib().orc_bench_scan(self._h, rows, ncols, seed, threads, chunk_rows, int(boxed), C.byref(cs))
         if sec < 0:
@@ -130,9 +132,16 @@ class Model:
         return sec, cs.value
 
 
+def set_blocked_gemm(on: bool) -> None:
+    """Test hook: later predict() calls on THIS thread use the register-blocked GEMM of the bench's best-CPU leg (bit-identical)."""
+    lib().orc_set_blocked_gemm(int(on))
+
+
 def bench_scan_table(model: "Model", table: np.ndarray, rows: int, ncols: int, threads: int = 1, chunk_rows: int = 2048,
-                     boxed: bool = True) -> tuple[float, float]:
-    """Scan of a materialised columnar table (row groups of 122,880 rows, see infera_oracle.h); (seconds, checksum)."""
+                     boxed: bool | int = True) -> tuple[float, float]:
+    """Scan of a materialised columnar table (row groups of 122,880 rows, see infera_oracle.h); (seconds, checksum).
+    boxed: True / 1 = reference-shaped (per-cell boxed gather, plain GEMM loop), False / 0 = plain strided gather,
+    2 = best CPU (tiled gather + register-blocked AVX-512 / AVX2 GEMM, bit-identical results)."""
     assert table.dtype == np.float32 and table.flags.c_contiguous and table.size >= rows * ncols
     cs = C.c_double()
     sec = lib().orc_bench_scan_table(model._h, table.ctypes.data, rows, ncols, threads, chunk_rows, int(boxed), C.byref(cs))

@@ -37,3 +37,23 @@ def test_default_bench_line_has_contract_fields_and_other_workloads():
     assert c4["roofline"]["bound"] == "hbm" and c4["rows"] == 50_000_000 and 0.3 < c4["roofline"]["frac"] < 1.0, c4
     assert c5["roofline"]["bound"] == "mfma" and c5["rows"] == 1024 and 0.3 < c5["roofline"]["frac"] < 1.0, c5
     assert abs(c4["rows_per_s"] - c4["rows"] / (c4["ms_per_pass"] / 1e3)) / c4["rows_per_s"] < 1e-9
+    assert c4["passes_timed"] >= 20
+    # round 3: `value` says what it is; the CPU baseline carries a best-CPU leg and ratios are taken against the faster one
+    assert d["value_is"].startswith("device_resident")
+    b = c["best_cpu"]
+    assert b["value"] > 0 and b["gflops_per_cpu"] > c["gflops_per_cpu"] > 0 and c["host_cpu"]["fma_peak_gflops_per_cpu"] > 0
+    assert abs(e["vs_cpu_baseline"] - e["rows_per_s"] / max(c["value"], b["value"])) / e["vs_cpu_baseline"] < 1e-9
+    assert e["vs_cpu_reference_shaped"] >= e["vs_cpu_baseline"]
+    # ... the host CPU cost per chunk, the 8-GPU prediction it implies and the CPU count that 6x would need
+    h = e["host_cpu_cost"]
+    assert 5 < h["cpu_us_per_chunk"] < 2000 and abs(h["rows_per_cpu_second"] - 2048e6 / h["cpu_us_per_chunk"]) / h["rows_per_cpu_second"] < 1e-6
+    assert h["predicted_rows_per_s_at_8_gpus"] <= 8 * e["rows_per_s"] * (1 + 1e-9) and h["cpus_needed_for_6x"] > 0
+    # ... the link-elided 8-slot probe of the host side (child process)
+    pr = e["host_ceiling_probe"]
+    assert "error" not in pr, pr
+    assert pr["device_slots"] == 8 and pr["rows_per_s"] > 0 and pr["host_cpu_cost"]["cpu_us_per_chunk"] > 0
+    # ... and C4 / C5 end to end beside their CPU baselines in the same line
+    for w in (c4, c5):
+        assert w["end_to_end"]["rows_per_s"] > 0 and w["cpu_baseline"]["value"] > 0 and w["cpu_baseline"]["best_cpu"]["value"] > 0, w.keys()
+        assert w["end_to_end"]["vs_cpu_baseline"] > 0
+    assert c5["end_to_end"]["rows_per_s"] > 0.5 * c5["rows_per_s"]  # C5 stays kernel-bound end to end

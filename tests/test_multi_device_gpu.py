@@ -124,3 +124,39 @@ def test_bench_host_path_single_process_two_slots(gpu_api):
     slots = line["end_to_end"]["device_slots"]
     assert len(slots) == 2 and all(s["rows_this_run"] > 0 for s in slots)
     assert sum(s["rows_this_run"] for s in slots) == 3 * 2048 * 400
+
+
+@pytest.mark.gpu
+def test_two_slots_on_one_gpu_hold_the_single_slot_rate_at_32_threads(gpu_api):
+    """admission is per PHYSICAL GPU, so two device slots on one GPU admit as many calls onto its submission
+    path as one slot does -- the 2-slot scan at 32 caller threads used to fall to 66 M rows/s where the 1-slot scan held 94-110.
+    Asserted: within 10 % of the 1-slot scan (same process shape, same table size, medians of 5 scans)."""
+    rates = {}
+    for slots in (1, 2):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host-path", "--gpus", str(slots), "--share-device", "0", "--rows", "6000000",
+               "--e2e-threads", "32", "--e2e-reps", "5"]
+        env = dict(os.environ)
+        env.pop("INFERA_DEVICES", None)
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["value_is"] == "end_to_end" and len(line["end_to_end"]["device_slots"]) == slots
+        rates[slots] = line["end_to_end"]["rows_per_s"]
+    assert rates[2] >= 0.9 * rates[1], rates
+
+
+@pytest.mark.gpu
+def test_bench_host_ceiling_probe_mode(gpu_api):
+    """`bench.py --host-path --gpus 8 --share-device 0 --elide-h2d 2`: the link- and kernel-elided 8-slot probe runs, labels itself as a
+    probe, and serves rows on all 8 slots."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host-path", "--gpus", "8", "--share-device", "0", "--elide-h2d", "2", "--rows", "2000000",
+           "--e2e-threads", "16", "--e2e-reps", "2", "--e2e-numa", "off"]
+    env = dict(os.environ)
+    env.pop("INFERA_DEVICES", None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert "PROBE" in line["metric"] and line["value_is"].startswith("host_ceiling_probe") and line["config"]["elide_h2d"] == 2
+    slots = line["end_to_end"]["device_slots"]
+    assert len(slots) == 8 and all(s["rows_this_run"] > 0 for s in slots)
+    assert line["end_to_end"]["host_cpu_cost"]["cpu_us_per_chunk"] > 0

@@ -8,6 +8,7 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -97,14 +98,28 @@ int main(int argc, char **argv) {
                               {"st512", copy_st512, 0, false},        {"movsb", copy_movsb, 0, false},      {"nt512+pf4", copy_nt512, 4, true},
                               {"nt512+pf16", copy_nt512, 16, true},   {"memcpy+pf8", copy_memcpy, 8, false}, {"st512+pf8", copy_st512, 8, false}};
   const int nbuf = getenv("PROBE_NBUF") ? atoi(getenv("PROBE_NBUF")) : 1;  // staging buffers a thread cycles through
-  std::printf("rows=%zu chunks=%zu huge=%d nbuf=%d affinity_cpus=%d\n", rows, nchunks, int(huge), nbuf, [] { cpu_set_t s; sched_getaffinity(0, sizeof s, &s); return CPU_COUNT(&s); }());
+  const int passes = getenv("PROBE_PASSES") ? atoi(getenv("PROBE_PASSES")) : 1;  // scans of the table per measurement
+  // PROBE_PIN: none | spread (thread t on its own CCD: physical core 8t, alternating sockets) | pack (thread t on core t)
+  const std::string pin_mode = getenv("PROBE_PIN") ? getenv("PROBE_PIN") : "none";
+  const int ncpu = int(sysconf(_SC_NPROCESSORS_ONLN)), nphys = ncpu / 2;
+  std::printf("rows=%zu chunks=%zu huge=%d nbuf=%d passes=%d pin=%s affinity_cpus=%d\n", rows, nchunks, int(huge), nbuf, passes, pin_mode.c_str(), [] { cpu_set_t s; sched_getaffinity(0, sizeof s, &s); return CPU_COUNT(&s); }());
   for (const Variant &v : variants) {
     if (only[0] && !std::strstr(only, v.name)) continue;
     for (int T : {1, 2, 4, 8, 12, 16, 24, 32}) {
       std::atomic<size_t> next{0};
       std::atomic<int> ready{0};
       std::atomic<bool> go{false};
+      std::atomic<int> tid{0};
       auto worker = [&] {
+        const int me = tid.fetch_add(1);
+        if (pin_mode != "none") {
+          // EPYC 9575F: 2 sockets x 8 CCDs x 8 cores; logical CPU c < 128 is a physical core, c + 128 its SMT sibling; socket = c / 64
+          int cpu = pin_mode == "pack" ? me % nphys : ((me % 2) * (nphys / 2) + (me / 2) * 8 % (nphys / 2) + (me / 2) * 8 / (nphys / 2)) % nphys;
+          cpu_set_t set;
+          CPU_ZERO(&set);
+          CPU_SET(cpu, &set);
+          sched_setaffinity(0, sizeof set, &set);
+        }
         std::vector<float *> pins(nbuf);
         for (auto &p : pins) {
           CK(hipHostMalloc((void **)&p, size_t(CH) * ncols * 4, hipHostMallocDefault));
@@ -114,8 +129,9 @@ int main(int argc, char **argv) {
         while (!go.load()) std::this_thread::yield();
         size_t k = 0;
         for (;;) {
-          const size_t c = next.fetch_add(1);
-          if (c >= nchunks) break;
+          size_t c = next.fetch_add(1);
+          if (c >= nchunks * size_t(passes)) break;
+          c %= nchunks;
           const size_t row0 = c * CH, g0 = row0 / RG * RG, gr = std::min(RG, rows - g0);
           const float *base = table + g0 * ncols + (row0 - g0);
           float *pin = pins[k++ % size_t(nbuf)];
@@ -137,8 +153,9 @@ int main(int argc, char **argv) {
       for (auto &x : th) x.join();
       const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       const double cpu = cpu_seconds() - c0;
+      const double nch = double(nchunks) * passes;
       std::printf("%-12s threads=%2d  %6.1f GB/s  %7.1f M rows/s  wall/chunk/thread %6.1f us  cpu/chunk %6.1f us  (cpu %.2f s / wall %.2f s = %.1f cpus)\n", v.name, T,
-                  double(nchunks) * CH * ncols * 4 / sec / 1e9, double(nchunks) * CH / sec / 1e6, sec * T / nchunks * 1e6, cpu / nchunks * 1e6, cpu, sec, cpu / sec);
+                  nch * CH * ncols * 4 / sec / 1e9, nch * CH / sec / 1e6, sec * T / nch * 1e6, cpu / nch * 1e6, cpu, sec, cpu / sec);
       std::fflush(stdout);
     }
   }
