@@ -115,6 +115,10 @@ double infera_hip_h2d_probe(int32_t device, uint64_t bytes, int32_t iters, int32
  * `ticket_global`.  slot_numa[i] = NUMA node of slot i's GPU (-1 unknown); thread_node < 0 = unknown. */
 int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32_t thread_node, uint64_t ticket_on_node,
                                uint64_t ticket_global);
+/* The load-aware form the library applies to a caller thread's first call (INFERA_NUMA_SLOTS=1, default): the least-loaded slot
+ * on the thread's NUMA node unless it already carries more than one thread above the least-loaded slot overall -- then that one.
+ * slot_threads[i] = caller threads currently homed on slot i.  Pure function, exposed for tests. */
+int32_t infera_hip_choose_slot_balanced(const int32_t *slot_numa, const int32_t *slot_threads, uintptr_t nslots, int32_t thread_node);
 
 /* sha256(data) as 64 lower-case hex characters: the key under which infera_load_model("http://...") caches a
  * remote model (`<cache_dir>/<sha256(url)>.onnx`, reference http.rs:186-190).  Free with infera_free. */

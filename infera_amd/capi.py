@@ -29,6 +29,7 @@ EXTENSION_SYMBOLS = [
     "infera_hip_free", "infera_hip_memcpy_h2d", "infera_hip_memcpy_d2h", "infera_hip_synth_fill",
     "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch", "infera_gather_columns",
     "infera_hip_sha256_hex", "infera_hip_shape_rows_cols", "infera_hip_h2d_probe", "infera_hip_choose_slot",
+    "infera_hip_choose_slot_balanced",
 ]
 
 
@@ -121,6 +122,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.infera_hip_shape_rows_cols.restype = None
     L.infera_hip_choose_slot.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.c_int32, C.c_uint64, C.c_uint64]
     L.infera_hip_choose_slot.restype = C.c_int32
+    L.infera_hip_choose_slot_balanced.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, C.c_int32]
+    L.infera_hip_choose_slot_balanced.restype = C.c_int32
     L.infera_hip_h2d_probe.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_int32]
     L.infera_hip_h2d_probe.restype = C.c_double
     _lib = L
@@ -231,6 +234,14 @@ def choose_slot(slot_numa: Sequence[int], thread_node: int, ticket_on_node: int,
     """The thread -> device-slot dealing policy (NUMA-local slots first), as the library applies it."""
     arr = (C.c_int32 * max(len(slot_numa), 1))(*slot_numa)
     return int(load_library().infera_hip_choose_slot(arr, len(slot_numa), thread_node, ticket_on_node, ticket_global))
+
+
+def choose_slot_balanced(slot_numa: Sequence[int], slot_threads: Sequence[int], thread_node: int) -> int:
+    """The load-aware dealing the library applies to a caller thread's first call (NUMA-local first, bounded by load)."""
+    n = len(slot_numa)
+    a = (C.c_int32 * max(n, 1))(*slot_numa)
+    b = (C.c_int32 * max(n, 1))(*slot_threads)
+    return int(load_library().infera_hip_choose_slot_balanced(a, b, n, thread_node))
 
 
 def device_count() -> int:

@@ -110,6 +110,7 @@ struct FeatureColumns {
   std::vector<std::vector<uint8_t>> compacted;
 
   static bool AnyNull(const UnifiedVectorFormat &f, idx_t count, bool flat) {
+    static_assert(sizeof(validity_t) == 8, "the word-at-a-time NULL scan assumes DuckDB's 64-bit validity words");
     if (f.validity.AllValid()) return false;
     if (flat) {  // whole validity words (DuckDB: bit set = valid, 64 rows per word -- the engine's format too)
       const auto *w = f.validity.GetData();

@@ -154,10 +154,12 @@ struct ThreadCtx {
 std::mutex g_pool_mu;
 std::vector<std::vector<ThreadCtx *>> g_pool;  // [device slot] -> free contexts
 
+extern std::atomic<int> g_slot_threads[64];
 struct ThreadHolder {
   std::vector<ThreadCtx *> by_slot;
   int home_slot = -1;
   ~ThreadHolder() {
+    if (home_slot >= 0) g_slot_threads[size_t(home_slot) % 64].fetch_sub(1, std::memory_order_relaxed);
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (size_t s = 0; s < by_slot.size(); s++)
       if (by_slot[s]) g_pool[s].push_back(by_slot[s]);
@@ -301,14 +303,21 @@ int current_numa_node() {
   return cpu >= 0 && size_t(cpu) < node_of_cpu.size() ? node_of_cpu[size_t(cpu)] : -1;
 }
 
-std::atomic<uint64_t> g_next_home_on_node[64];
+// caller threads whose home is slot i right now (a thread leaves when it exits)
+std::atomic<int> g_slot_threads[64];
 
 int home_slot() {
   if (t_holder.home_slot < 0) {
     const auto &ds = devices();
-    const int node = ds.ids.size() > 1 ? current_numa_node() : -1;
-    const uint64_t on_node = node >= 0 ? g_next_home_on_node[size_t(node) % 64].fetch_add(1) : 0;
-    t_holder.home_slot = choose_slot(ds.numa, node, on_node, g_next_home.fetch_add(1));
+    const size_t n = ds.ids.size();
+    // INFERA_NUMA_SLOTS=0: no NUMA preference at all (unpinned workers that all START on one socket, or a
+    // taskset'ed process, must not leave the other socket's GPUs idle -- the balanced policy below already bounds that
+    // imbalance to one thread per slot; the knob switches the preference off altogether)
+    const int node = n > 1 && Config::get().numa_slots ? current_numa_node() : -1;
+    std::vector<int> load(n);
+    for (size_t i = 0; i < n; i++) load[i] = g_slot_threads[i % 64].load(std::memory_order_relaxed);
+    t_holder.home_slot = choose_slot_balanced(ds.numa, load, node);
+    g_slot_threads[size_t(t_holder.home_slot) % 64].fetch_add(1, std::memory_order_relaxed);
   }
   return t_holder.home_slot;
 }
@@ -580,8 +589,7 @@ void schedule(LoadedModel &m) {
         m.exec[i] = ExecKind::ConvPatch;
         // stem -> MaxPool 3x3 / 2 (ResNet, DenseNet, SqueezeNet): pooled in the stem's kernel, the stem's own output is never stored
         // (INFERA_STEM_POOL=0, read at load time: the two kernels)
-        const char *sp = getenv("INFERA_STEM_POOL");
-        if (!(sp && sp[0] == '0') && uses[size_t(s.out)] == 1 && s.out != m.plan.out_buf)
+        if (ScheduleKnobs::read().stem_pool && uses[size_t(s.out)] == 1 && s.out != m.plan.out_buf)
           for (size_t j = i + 1; j < n; j++) {
             const Step &q = st[j];
             if (q.in0 != s.out && q.in1 != s.out) continue;
@@ -660,13 +668,12 @@ void schedule(LoadedModel &m) {
                        kern::mlp3_colmajor_supported(m.mlp3_shape) && !m.bf16x3;
     if (m.in_colmajor_ok) m.in_colmajor_max_rows = kern::mlp3_colmajor_max_rows(m.mlp3_shape);
     // the fused small-MLP chain reads a column-major chunk too (a run-time flag of the same kernel); INFERA_CHAIN_XCM=0: transpose first
-    const char *cx = getenv("INFERA_CHAIN_XCM");
-    if (!(cx && cx[0] == '0') && !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::ChainHead && eff[0].reads[0] == 0)
+    const ScheduleKnobs knobs = ScheduleKnobs::read();
+    if (knobs.chain_xcm && !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::ChainHead && eff[0].reads[0] == 0)
       m.in_colmajor_ok = true;
     // ... and so do the two as-it-lies streaming kernels of single narrow layers (linear / logistic regression, with or without the
     // softmax / label epilogue); INFERA_DENSE_XCM=0: transpose first
-    const char *dx = getenv("INFERA_DENSE_XCM");
-    if (!(dx && dx[0] == '0') && !eff.empty() && in_readers == 1 && eff[0].reads[0] == 0) {
+    if (knobs.dense_xcm && !eff.empty() && in_readers == 1 && eff[0].reads[0] == 0) {
       const size_t i0 = size_t(eff[0].idx);
       const ExecKind k0 = m.exec[i0];
       if (st[i0].kind == StepKind::Dense && (k0 == ExecKind::Normal || k0 == ExecKind::DenseSoftmax || k0 == ExecKind::DenseArgMax) &&
@@ -1069,6 +1076,22 @@ int choose_slot(const std::vector<int> &slot_numa, int thread_node, uint64_t tic
   return int(ticket_global % n);
 }
 
+// Load-aware dealing (what home_slot() uses): the least-loaded slot on the thread's own NUMA node, unless it already carries more
+// than ONE thread above the least-loaded slot of the whole set -- then that one.  A node whose workers all start on one socket thus
+// fills its local GPUs first and spills to the other socket's GPUs one round later; nobody stays idle.  Ties: lowest index.
+int choose_slot_balanced(const std::vector<int> &slot_numa, const std::vector<int> &slot_threads, int thread_node) {
+  const size_t n = std::min(slot_numa.size(), slot_threads.size());
+  if (n <= 1) return 0;
+  size_t g = 0;
+  long l = -1;
+  for (size_t i = 0; i < n; i++) {
+    if (slot_threads[i] < slot_threads[g]) g = i;
+    if (thread_node >= 0 && slot_numa[i] == thread_node && (l < 0 || slot_threads[i] < slot_threads[size_t(l)])) l = long(i);
+  }
+  if (l >= 0 && slot_threads[size_t(l)] <= slot_threads[g] + 1) return int(l);
+  return int(g);
+}
+
 void slot_counters(int slot, uint64_t *calls, uint64_t *rows) {
   *calls = g_slot_calls[size_t(slot) % 64].load(std::memory_order_relaxed);
   *rows = g_slot_rows[size_t(slot) % 64].load(std::memory_order_relaxed);
@@ -1326,7 +1349,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
     // (a quiet GPU reads larger chunks this way -- twice that size with at most four calls in flight, four times with at most two: a
     // few kernels pulling over PCIe do not yet compete with each other, and the copy engine's latency is the larger part of such a
     // call.  30 -> 100 -> 2, 245 KB chunks: +17 / +8 / +6 / +4 % at 1 / 2 / 4 / 8 threads; 64 -> 128 -> 64 -> 1, 512 KB: +13 / +6 % at 1 / 2)
-    static const bool quiet_on = [] { const char *e = getenv("INFERA_HOST_DIRECT_IN_QUIET"); return !(e && e[0] == '0'); }();  // (0: A/B)
+    const bool quiet_on = Config::get().host_direct_in_quiet;  // (0: A/B)
     const int quiet_mult = !quiet_on ? 1 : in_flight <= 2 ? 4 : in_flight <= 4 ? 2 : 1;
     const int64_t din_limit = int64_t(Config::get().host_direct_in_bytes) * quiet_mult;
     const bool small_in = allow_small && !elide && int64_t(nr) * int64_t(in_row) <= din_limit;

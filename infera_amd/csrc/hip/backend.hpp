@@ -33,6 +33,8 @@ struct DeviceSet {
 // staging that is local to both the thread and the GPU's root complex -- else round-robin over all slots.  Pure function
 // of its arguments (per-node tickets are kept by the caller); thread_node < 0 or all-unknown topology = plain round-robin.
 int choose_slot(const std::vector<int> &slot_numa, int thread_node, uint64_t ticket_on_node, uint64_t ticket_global);
+// the policy home_slot() applies: NUMA-local first, bounded by load (slot_threads[i] = caller threads homed on slot i)
+int choose_slot_balanced(const std::vector<int> &slot_numa, const std::vector<int> &slot_threads, int thread_node);
 const DeviceSet &devices();
 // host-ABI calls / table rows served so far by device slot `slot` (index into DeviceSet::ids)
 void slot_counters(int slot, uint64_t *calls, uint64_t *rows);

@@ -34,6 +34,8 @@
 //     next tile's rows are requested right after this tile's last layer-2 L2 load, so nothing in
 //     this tile ever queues behind HBM latency on the in-order vmcnt counter.
 #include <atomic>
+
+#include "../host/common.hpp"
 #include <cstdint>
 #include <cstdlib>
 
@@ -217,7 +219,7 @@ void launch_tile(hipStream_t s, const float *X, const float *packed, float *Y, i
   hipLaunchKernelGGL((mlp3_tile_kernel<C, XCM>), dim3(unsigned(ntiles)), dim3(256), 0, s, X, packed, Y, rows);
 }
 bool tile_kernel_enabled() {
-  static const bool on = !(std::getenv("INFERA_MLP3_TILE") && std::atoi(std::getenv("INFERA_MLP3_TILE")) == 0);
+  const bool on = infera_hip::Config::get().mlp3_tile;
   return on;
 }
 }  // namespace

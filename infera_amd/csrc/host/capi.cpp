@@ -114,15 +114,23 @@ int32_t infera_load_model(const char *name, const char *path) {
   return guarded([&] {
            if (!name || !path) throw InferaError::null_pointer();
            std::string n = checked_str(name), p = checked_str(path), select;
-           // "<path>#<output>" serves another graph output than the first (name or index) -- additive: a path that exists
-           // as written, '#' included, is taken as written; a URL's fragment never reaches the server anyway.
+           // "<path>#<output>" serves another graph output than the first (name or index) -- additive, and never at the expense of
+           // what the reference does with the same string:
+           //  * a local path that exists as written, '#' included, is taken as written; the selector is split off only when the
+           //    path before '#' exists (so a mistyped path is reported exactly as it was typed);
+           //  * a URL is fetched and cached under the string AS WRITTEN (the reference's cache key is sha256 of that string,
+           //    http.rs:187-190; the fragment never reaches the server -- the clients cut it from the request line), and its
+           //    fragment selects an output only if the parsed model HAS an output of that name or index ("?" = optional:
+           //    "http://h/m.onnx#v2" keeps loading output 0 like the reference).
            const size_t hash = p.rfind('#');
-           if (hash != std::string::npos && hash + 1 < p.size() && p.find('/', hash) == std::string::npos &&
-               (p.rfind("http", 0) == 0 || ::access(p.c_str(), F_OK) != 0)) {
+           const bool has_fragment = hash != std::string::npos && hash + 1 < p.size() && p.find('/', hash) == std::string::npos;
+           if (p.rfind("http", 0) == 0) {
+             if (has_fragment) select = "?" + p.substr(hash + 1);
+             p = remote::handle_remote_model(p);  // lib.rs:47-51: fetch / revalidate into the cache
+           } else if (has_fragment && ::access(p.c_str(), F_OK) != 0 && ::access(p.substr(0, hash).c_str(), F_OK) == 0) {
              select = p.substr(hash + 1);
              p.resize(hash);
            }
-           if (p.rfind("http", 0) == 0) p = remote::handle_remote_model(p);  // lib.rs:47-51: fetch / revalidate into the cache
            engine::load_model(n, p, select);
          })
              ? 0
@@ -324,6 +332,11 @@ double infera_hip_h2d_probe(int32_t device, uint64_t bytes, int32_t iters, int32
 int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32_t thread_node, uint64_t ticket_on_node,
                                uint64_t ticket_global) {
   return choose_slot(std::vector<int>(slot_numa, slot_numa + (slot_numa ? nslots : 0)), thread_node, ticket_on_node, ticket_global);
+}
+
+int32_t infera_hip_choose_slot_balanced(const int32_t *slot_numa, const int32_t *slot_threads, uintptr_t nslots, int32_t thread_node) {
+  if (!slot_numa || !slot_threads) return 0;
+  return choose_slot_balanced(std::vector<int>(slot_numa, slot_numa + nslots), std::vector<int>(slot_threads, slot_threads + nslots), thread_node);
 }
 
 char *infera_hip_get_plan(const char *model_name) {

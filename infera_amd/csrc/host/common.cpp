@@ -94,12 +94,15 @@ const Config &Config::get() {
     c.host_gather = hg == "nt" ? 1 : hg == "ntpf" ? 2 : 0;
     c.max_inflight_total = int(env_u64("INFERA_MAX_INFLIGHT_TOTAL", 0));
     c.probe_elide_h2d = int(env_u64("INFERA_HOST_PROBE_ELIDE_H2D", 0));
+    c.numa_slots = env_flag("INFERA_NUMA_SLOTS", true);
     c.host_split = int(env_u64("INFERA_HOST_SPLIT", 0));
     c.host_split_quiet = int(env_u64("INFERA_HOST_SPLIT_QUIET", 4));
     c.host_direct_out = env_flag("INFERA_HOST_DIRECT_OUT", true);
     c.host_colmajor_typed = env_flag("INFERA_HOST_COLMAJOR_TYPED", true);
     c.host_fused_transpose = env_flag("INFERA_HOST_FUSED_TRANSPOSE", true);
     c.host_direct_in_bytes = (long long)env_u64("INFERA_HOST_DIRECT_IN", 128 * 1024);
+    c.host_direct_in_quiet = env_flag("INFERA_HOST_DIRECT_IN_QUIET", true);
+    c.mlp3_tile = env_flag("INFERA_MLP3_TILE", true);
     c.precision_bf16x3 = env_or("INFERA_PRECISION", "fp32") == "bf16x3";
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);
     c.max_rows_per_pass = env_u64("INFERA_MAX_ROWS_PER_PASS", 1ull << 18);
@@ -107,6 +110,10 @@ const Config &Config::get() {
     return c;
   }();
   return cfg;
+}
+
+ScheduleKnobs ScheduleKnobs::read() {
+  return ScheduleKnobs{env_flag("INFERA_STEM_POOL", true), env_flag("INFERA_CHAIN_XCM", true), env_flag("INFERA_DENSE_XCM", true)};
 }
 
 void log_msg(int level, const std::string &msg) {

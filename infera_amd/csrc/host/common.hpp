@@ -108,6 +108,7 @@ struct Config {
                                       //   4 KiB token instead of the chunk, so the gather / lease / gate / submit machinery can be timed with
                                       //   the link taken out; 2 = the kernels also run on one 32-row tile only (8 slots sharing ONE
                                       //   GPU are otherwise bound by that GPU's kernel dispatch rate).  Results are meaningless in this mode
+  bool numa_slots;                    // INFERA_NUMA_SLOTS=0|1 (default 1)  caller threads prefer the device slots on their own NUMA node (bounded by load)
   int host_split;                     // INFERA_HOST_SPLIT=0|1|n  one-DataChunk calls go through as sub-passes on the call's stream, the gather
                                       //   of sub-pass i+1 overlapping H2D + kernels of sub-pass i: 0 never (default), 1 two halves when the GPU
                                       //   is quiet (at most INFERA_HOST_SPLIT_QUIET calls in flight), n >= 2 always n sub-passes.  Measured a LOSS
@@ -119,7 +120,12 @@ struct Config {
                                       //   straight into the pinned result buffer (no D2H copy enqueue per chunk)
   bool host_colmajor_typed;           // INFERA_HOST_COLMAJOR_TYPED=0|1  DOUBLE / INTEGER / BIGINT / constant columns are staged column-major too
                                       //   (converted run by run) instead of through the AVX2 transposing gather.  Default 1
-  long long host_direct_in_bytes;     // INFERA_HOST_DIRECT_IN=<bytes>  chunks up to this size are read from pinned memory by the first kernel itself (default 131072; 0 = always H2D)
+  long long host_direct_in_bytes;     // INFERA_HOST_DIRECT_IN=<bytes>  chunks up to this size are read from pinned memory by the first kernel itself
+                                      //   (default 131072; 0 = always H2D).  On a quiet GPU the effective limit is higher: x2 with at most four
+                                      //   host-ABI calls in flight, x4 (512 KB) with at most two -- INFERA_HOST_DIRECT_IN_QUIET=0 switches that off
+  bool host_direct_in_quiet;          // INFERA_HOST_DIRECT_IN_QUIET=0|1 (default 1)  the x2 / x4 multiplier above
+  bool mlp3_tile;                     // INFERA_MLP3_TILE=0|1 (default 1)  launches of up to 32,768 rows of a fused MLP take the one-workgroup-per-tile
+                                      //   kernel (ahead-of-time and load-time specialised chains alike; read by mlp_fused.hip and mlp_jit.cpp)
   bool host_fused_transpose;          // INFERA_HOST_FUSED_TRANSPOSE=0|1  the fused MLP reads column-major chunks itself (no transpose kernel)
   bool precision_bf16x3;              // INFERA_PRECISION=fp32|bf16x3  bf16x3 = OPTIONAL fast mode for the fused MLP (three bf16 MFMAs per
                                       //   product, ~2^-16 relative error per product): NOT the parity path, never the default
@@ -130,6 +136,18 @@ struct Config {
                                       //   the reference's behaviour: rows != B is an error (test/models/README.md:5)
   static const Config &get();
 };
+
+// Knobs that are read EVERY TIME a model is scheduled (infera_load_model), not once per process, so that one process can load the
+// same graph both ways (the bit-identity tests do): each defaults to on.
+struct ScheduleKnobs {
+  bool stem_pool;   // INFERA_STEM_POOL=0|1   stem convolution + MaxPool 3x3/2 in one kernel
+  bool chain_xcm;   // INFERA_CHAIN_XCM=0|1   the fused small-MLP chain kernel reads column-major host chunks itself (0: transpose launch first)
+  bool dense_xcm;   // INFERA_DENSE_XCM=0|1   the same for the as-it-lies streaming kernels of single narrow layers
+  static ScheduleKnobs read();
+};
+// Read at first use inside the kernel launchers, A/B experiments only (no effect on results; defaults are the shipped paths):
+//   INFERA_CONV_WS (0 tiled kernel only | 1 default | 2 force the weight-stationary kernel), INFERA_DENSE16W, INFERA_DENSE16_STAGED,
+//   INFERA_DENSE16G_MIN_M, INFERA_SOFTMAX_ROWS, INFERA_POOL_FAST, INFERA_CHAIN_WAVES, INFERA_MLP3_VARIANT (PROBES builds), INFERA_CONV_PROBE.
 
 void log_msg(int level, const std::string &msg);  // config.rs:200-207 `log!`
 

@@ -73,10 +73,13 @@ struct Lowerer {
   std::map<int, int> alias_edges;  // nodes folded away whose input AND output denote the buffer
   std::set<int> int_bufs;  // buffers whose f32 values are whole numbers by construction (ArgMax, integer Cast, label arithmetic)
 
-  Lowerer(const onnx::Model &model, const std::string &output_select) : m(model) {
+  Lowerer(const onnx::Model &model, const std::string &output_select_in) : m(model) {
     // Which graph output is served.  Default: the first (engine.rs:146-149).  A selector names another one, by output
     // name or by decimal index (infera_load_model(name, "model.onnx#probabilities"), SURVEY.md 8f-3 "named / multi outputs").
     if (m.outputs.empty()) throw InferaError::onnx("model has no outputs");
+    // (a leading '?' makes the selector optional -- a URL fragment that names no output leaves the default, capi.cpp)
+    const bool optional = !output_select_in.empty() && output_select_in[0] == '?';
+    const std::string output_select = optional ? output_select_in.substr(1) : output_select_in;
     if (!output_select.empty()) {
       bool found = false;
       for (size_t i = 0; i < m.outputs.size() && !found; i++)
@@ -84,7 +87,7 @@ struct Lowerer {
       if (!found && output_select.find_first_not_of("0123456789") == std::string::npos && output_select.size() < 6 &&
           size_t(std::atoi(output_select.c_str())) < m.outputs.size())
         out_index = size_t(std::atoi(output_select.c_str())), found = true;
-      if (!found) {
+      if (!found && !optional) {
         std::string names;
         for (const auto &o : m.outputs) names += (names.empty() ? "" : ", ") + o.name;
         throw InferaError::onnx("model has no output '" + output_select + "' (outputs: " + names + ")");

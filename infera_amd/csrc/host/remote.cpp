@@ -138,7 +138,10 @@ Url parse_url(const std::string &url) {
   Url u;
   const size_t hs = 7, slash = url.find('/', hs);
   std::string hostport = url.substr(hs, slash == std::string::npos ? std::string::npos : slash - hs);
+  if (const size_t frag = hostport.find('#'); frag != std::string::npos) hostport.resize(frag);
   u.path = slash == std::string::npos ? "/" : url.substr(slash);
+  if (const size_t frag = u.path.find('#'); frag != std::string::npos) u.path.resize(frag);  // a fragment is never sent (RFC 9110 7.1)
+  if (u.path.empty()) u.path = "/";
   const size_t at = hostport.rfind('@');
   if (at != std::string::npos) hostport = hostport.substr(at + 1);
   const size_t colon = hostport.rfind(':');

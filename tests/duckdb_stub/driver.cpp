@@ -10,6 +10,7 @@
 // INFERA_STUB_DICTIONARY=1 wraps every flat numeric argument in a dictionary vector (permuted buffer + selection
 // vector), the form a filter or a join hands to a function.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -266,6 +267,26 @@ char *infera_sql_list_functions(void) {
          (kv.second.is_volatile ? "true" : "false") + ",\"fallible\":" + (kv.second.fallible ? "true" : "false") + "}";
   }
   return strdup((o + "]").c_str());
+}
+
+// Cost of the extension's registration (256 x {FLOAT, DOUBLE} x 4 predict families = 2,048 overloads): builds a
+// fresh catalog `reps` times and reports the seconds per load, the overloads registered and the LogicalType objects they hold
+// (what a real DuckDB would copy into its catalog).  The stub's catalog is a vector, so this times the extension's side only.
+double infera_stub_registration_seconds(int32_t reps, uint64_t *overloads, uint64_t *argument_types) {
+  if (reps < 1) reps = 1;
+  uint64_t n = 0, types = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < reps; i++) {
+    DatabaseInstance fresh;
+    ExtensionLoader loader(fresh, "infera");
+    infera_duckdb_cpp_init(loader);
+    n = fresh.catalog.size();
+    types = 0;
+    for (const auto &f : fresh.catalog) types += f.arguments.size();
+  }
+  if (overloads) *overloads = n;
+  if (argument_types) *argument_types = types;
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 
 }  // extern "C"

@@ -101,3 +101,29 @@ def test_numa_aware_slot_dealing(built):
         for k in range(64):
             counts[capi.choose_slot(topo, node, k, 0)] += 1
     assert counts == [16] * 8
+
+
+def test_balanced_slot_dealing_never_starves_the_other_socket():
+    """the load-aware policy home_slot() applies.  Workers that all START on one socket fill its GPUs first and spill
+    to the other socket's one round later -- no slot may carry more than one thread above the least-loaded slot, and no slot
+    stays idle; threads spread over both sockets get their own node's GPUs."""
+    from infera_amd import capi
+
+    topo = [0, 0, 0, 0, 1, 1, 1, 1]
+    load = [0] * 8
+    order = []
+    for _ in range(24):  # every thread on node 0
+        s = capi.choose_slot_balanced(topo, load, 0)
+        load[s] += 1
+        order.append(s)
+    assert order[:8] == [0, 1, 2, 3, 0, 1, 2, 3] and sorted(order[8:12]) == [4, 5, 6, 7]
+    assert max(load) - min(load) <= 2 and min(load) >= 2, load
+    load = [0] * 8
+    for k in range(32):  # alternating nodes: everyone stays local
+        node = k % 2
+        s = capi.choose_slot_balanced(topo, load, node)
+        assert topo[s] == node
+        load[s] += 1
+    assert load == [4] * 8
+    assert capi.choose_slot_balanced(topo, [3, 3, 3, 3, 0, 0, 0, 0], -1) == 4      # node unknown: least loaded
+    assert capi.choose_slot_balanced([0], [5], 1) == 0 and capi.choose_slot_balanced([-1, -1], [1, 0], 0) == 1

@@ -161,3 +161,22 @@ def test_gpu_blob_chunk_is_one_batched_call_and_keeps_null_rows(gpu_api, X, tmp_
         assert got[1].shape == (4,)
     finally:
         X.sql("infera_unload_model", "bm")
+
+
+def test_registration_cost_of_2048_overloads(built):
+    """256 feature counts x {FLOAT, DOUBLE} x 4 predict families = 2,048 overloads (+ 10 other functions).  The
+    extension's side of LOAD must stay a few milliseconds (measured 7 ms here: 265k LogicalType objects built and moved); what a
+    real DuckDB adds on top is its catalog insert per ScalarFunctionSet (4 sets) -- INTEGRATION.md 2.1 discusses `varargs` instead."""
+    import ctypes as C
+
+    from infera_amd import capi
+
+    capi.load_library()
+    L = C.CDLL(os.path.join(ROOT, "tests", "duckdb_stub", "libinfera_duckdb_stub.so"))
+    L.infera_stub_registration_seconds.restype = C.c_double
+    L.infera_stub_registration_seconds.argtypes = [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    n, types = C.c_uint64(), C.c_uint64()
+    sec = L.infera_stub_registration_seconds(3, C.byref(n), C.byref(types))
+    assert n.value == 256 * 2 * 4 + 10, n.value
+    assert types.value == 4 * 2 * sum(f + 1 for f in range(1, 257)) + 2 + 1 + 2 + 1 + 1 + 1, types.value
+    assert sec < 0.25, sec

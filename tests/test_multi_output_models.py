@@ -45,6 +45,11 @@ def test_output_selection_metadata_and_errors(built, tmp_path):
         odd = W.write(str(tmp_path / "v#2.onnx"), _classifier(["hidden"]))
         capi.load_model("clf", odd)
         assert capi.get_model_info("clf")["output_shape"] == [-1, 16]
+        # a mistyped path containing '#' is reported exactly as it was typed, not truncated at the '#'
+        typo = str(tmp_path / "no_such_dir" / "m.onnx") + "#probabilities"
+        with pytest.raises(capi.InferaError) as exc:
+            capi.load_model("typo", typo)
+        assert typo in str(exc.value), str(exc.value)
     finally:
         capi.unload_model("clf")
 

@@ -126,6 +126,18 @@ out["chunked_ok"] = open(cached(base + "/chunked.onnx"), "rb").read() == LINEAR
 capi.load_model("r5", base + "/redir.onnx")
 out["redir_ok"] = open(cached(base + "/redir.onnx"), "rb").read() == LINEAR
 
+# a URL fragment (ADVICE r2): never sent to the server, the cache key is sha256 of the URL AS WRITTEN (the reference's key,
+# http.rs:187-190), and a fragment that names no output of the model leaves output 0 served, as the reference would
+u = base + "/ok.onnx#v2"
+capi.load_model("frag", u)
+out["frag_info"] = capi.get_model_info("frag")["input_shape"]
+out["frag_cached_under_full_url"] = os.path.exists(cached(u))
+out["frag_request_path_hits"] = hits.get("/ok.onnx#v2", 0)
+out["frag_ok_hits"] = hits["/ok.onnx"]
+# ... and one that DOES name an output selects it (multi_output.onnx has the single output "Y": index 0 and the name both work)
+capi.load_model("frag_sel", base + "/etag200.onnx#0")
+out["frag_sel_ok"] = capi.get_model_info("frag_sel")["loaded"]
+
 # https is refused, not attempted
 try:
     capi.load_model("tls", "https://127.0.0.1:1/x.onnx"); out["https"] = "loaded?!"
@@ -199,6 +211,8 @@ def test_remote_fetch_and_lru_cache(built, tmp_path, backend):
     assert (out["drop"].startswith("IO error: ") or out["drop"].startswith("HTTP request failed: ")) and out["drop_clean"]
     assert out["missing"].startswith("HTTP request failed: HTTP status client error (404") and out["missing_clean"]
     assert out["chunked_ok"] and out["redir_ok"]
+    assert out["frag_info"] == [1, 3] and out["frag_cached_under_full_url"] and out["frag_request_path_hits"] == 0 and out["frag_ok_hits"] == 3  # r1, the /redir.onnx target, and this one (a new cache key: its own fetch)
+    assert out["frag_sel_ok"] is True
     for name in ("badchunk", "emptychunk"):  # a malformed chunk-size line is a failed download, never a cached truncated file
         assert (out[name].startswith("IO error: ") or out[name].startswith("HTTP request failed: ")) and out[name + "_clean"], out[name]
     assert out["etag_files_after_evict"] == out["etag_expected"]
