@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <sched.h>
 #include <sys/resource.h>
 #include <cstdio>
 #include <mutex>
@@ -654,7 +655,27 @@ int32_t infera_sql_bench_scan_table_typed(const char *function, const char *mode
   for (int rep = 0; rep < reps; rep++) {
     std::atomic<uint64_t> next{0};
     double total = 0.0;
+    std::atomic<int> worker_id{0};
     auto worker = [&] {
+      // INFERA_BENCH_PIN=spread|pack: EXPERIMENT ONLY -- pins scan worker t to one CPU of the process's affinity mask (spread: every
+      // 8th CPU = one per CCD first; pack: consecutive CPUs).  DuckDB does not pin its workers; this separates what thread
+      // migration costs the gather from what the memory system costs it.
+      if (const char *pin = std::getenv("INFERA_BENCH_PIN")) {
+        cpu_set_t mask;
+        if (sched_getaffinity(0, sizeof mask, &mask) == 0) {
+          std::vector<int> cpus;
+          for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &mask)) cpus.push_back(c);
+          const int me = worker_id.fetch_add(1), n = int(cpus.size());
+          if (n > 0) {
+            const int idx = pin[0] == 's' ? int((int64_t(me) * 8) % n + (int64_t(me) * 8) / n) % n : me % n;
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[size_t(idx)], &one);
+            (void)sched_setaffinity(0, sizeof one, &one);
+          }
+        }
+      }
       std::vector<InferaSqlVector> args(ncols + 1);
       const uint8_t *name_ptr = reinterpret_cast<const uint8_t *>(model);
       uint64_t name_len = std::strlen(model);

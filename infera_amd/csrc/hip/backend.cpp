@@ -101,12 +101,12 @@ struct ThreadCtx {
         if (ts.tv_nsec >= 1000000000L) ts = timespec{ts.tv_nsec / 1000000000L, ts.tv_nsec % 1000000000L};
         (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
       };
-      nap(std::min(wait_ema_ns * 0.75, 2.0e6));
+      nap(std::min(wait_ema_ns * Config::get().host_poll_first, 2.0e6));
       for (;;) {
         const hipError_t e = mode == 2 ? hipEventQuery(poll_ev) : hipStreamQuery(stream);
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery / hipStreamQuery");
-        nap(std::max(3000.0, std::min(wait_ema_ns * 0.1, 50000.0)));
+        nap(std::max(3000.0, std::min(wait_ema_ns * Config::get().host_poll_next, 50000.0)));
       }
       (void)hipGetLastError();  // hipErrorNotReady from the queries must not surface at the next launch check
       const double waited = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
@@ -217,6 +217,7 @@ HostPool &host_pool(int slot) {
   static HostPool pools[64];
   return pools[size_t(slot) % 64];
 }
+thread_local ThreadCtx *t_last_ctx[64];  // per device slot: the staging context this thread leased last (never dereferenced: an identity)
 struct HostLease {
   HostPool &pool;
   ThreadCtx *c = nullptr;
@@ -228,8 +229,21 @@ struct HostLease {
       std::unique_lock<std::mutex> lk(pool.mu);
       pool.cv.wait(lk, [&] { return !pool.free.empty() || pool.created < cap; });
       if (!pool.free.empty()) {
-        c = pool.free.back();
-        pool.free.pop_back();
+        // the context this thread used last, when it is free: its pinned staging lines are (still) in THIS core's caches -- a chunk
+        // gathered into the buffer another core wrote last pays a cache-to-cache transfer per line (gather 42 -> 50 us per chunk
+        // already at 2 caller threads with plain LIFO reuse).  INFERA_HOST_CTX_AFFINITY=0: plain LIFO (A/B)
+        // (Tried on top, INFERA_HOST_CTX_AFFINITY=2 in round 3: prefer a context last filled on this CPU's L3 domain when the thread has
+        // moved to another CCD -- no gain, 80.5 vs 78.5 us of CPU per chunk at 16 threads, profiles/r03_host_cpu_ab_pinning.txt.)
+        size_t pick = pool.free.size() - 1;
+        if (Config::get().host_ctx_affinity && size_t(slot) < 64 && t_last_ctx[slot])
+          for (size_t i = pool.free.size(); i-- > 0;)
+            if (pool.free[i] == t_last_ctx[slot]) {
+              pick = i;
+              break;
+            }
+        c = pool.free[pick];
+        pool.free.erase(pool.free.begin() + long(pick));
+        if (size_t(slot) < 64) t_last_ctx[slot] = c;
         return;
       }
       pool.created++;
@@ -247,6 +261,7 @@ struct HostLease {
       hip_fail(e, "hipStreamCreateWithFlags");
     }
     c = n;
+    if (size_t(slot) < 64) t_last_ctx[slot] = c;
   }
   ~HostLease() {
     if (!c) return;

@@ -1057,6 +1057,237 @@ __global__ __launch_bounds__(POOL ? kPoolBlock : kBlock) void conv2d_patch_kerne
     if (have_p) pool_tile(img_p, pr0_p, pc0_p);  // the workgroup's last tile has no k loop behind it to hide under
 }
 
+// ---- stem + max-pool, TWO half-channel workgroups per CU (round 3) ------------------------------------------------------
+// The 512-thread kernel above keeps one 146 KB workgroup per CU: its eight waves leave the k loop together, write the
+// exchange tile together, park the next patch together and pass two barriers together -- phases in which the matrix pipe idles
+// (mfma_busy 0.70 over the launch, 0.90 inside the k loops).  Here a 64-feature stem runs as TWO independent 256-thread
+// workgroups per CU, each computing 32 of the 64 features for the same tile sequence: wave w of a workgroup owns pixel tiles w
+// and w + 4 of the 17 x 15 tile (two accumulator tiles, ONE weight fragment per unit shared by both), so a workgroup does the
+// same 152 MFMAs per wave per tile as before; 76 KB of LDS each (its half of the weights, ONE patch buffer -- both patch stores
+// of the pooled flow sit between the tile's two barriers, when nobody reads the patch -- and a [256][32 + 4] exchange tile).
+// Max-pooling is per channel, so the halves never talk to each other; the odd half starts half a tile late, so one
+// workgroup's exchange / patch / barrier phase falls into the other's k loop.  Same k order per output element as the other
+// stem kernels -> bit-identical (tests/test_stem_pool_gpu.py).
+constexpr int kPool2Block = 256;
+static size_t patch_pool2_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
+  return (size_t(p.K8) * 256 + size_t(p.K8) * 8 + size_t(g.C) * p.PLANE + 8 + 256 * size_t(32 + 4)) * sizeof(float);
+}
+
+template <int K8C>
+__global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+                                                                          const float *__restrict__ bias, float *__restrict__ Y, int64_t ntiles,
+                                                                          ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync) {
+  constexpr int BS = kPool2Block, PW = 2;
+  static_assert(K8C >= 6, "the pooling runs in the shadow of a compile-time k loop of at least 22 units");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *wl = smem;                                     // [K8][64 lanes][4]: this half's 32 features
+  int *ktab = reinterpret_cast<int *>(smem + K8C * 256);  // [K8][h][4] patch offsets of k = 8g + 4h + j
+  float *patch = smem + K8C * 256 + K8C * 8;             // [C * PLANE] (+ 4 spare floats), then the exchange tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int psz = g.C * pg.PLANE;
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, half = wg & 1, pair = wg >> 1;
+
+  // this half's weight fragments out of the [K8][2][64][4] blob, and the offsets behind it: once per (persistent) workgroup
+  for (int i = threadIdx.x; i < K8C * 64; i += BS)
+    reinterpret_cast<f32x4 *>(wl)[i] = reinterpret_cast<const f32x4 *>(Wp)[((i >> 6) * 2 + half) * 64 + (i & 63)];
+  for (int i = threadIdx.x; i < K8C * 8; i += BS) ktab[i] = reinterpret_cast<const int *>(Wp)[K8C * 2 * 256 + i];
+
+  int e_rel[kPatchMaxE], e_rc[kPatchMaxE], e_lds[kPatchMaxE];
+#pragma unroll
+  for (int i = 0; i < kPatchMaxE; i++) {
+    const int e = threadIdx.x + i * BS;
+    const int c = e / (pg.PR * pg.PC), rem = e - c * (pg.PR * pg.PC), row = rem / pg.PC, col = rem - row * pg.PC;
+    const bool live = c < g.C;
+    e_rel[i] = (c * g.H + row) * g.W + col;
+    e_rc[i] = live ? (row << 16) | col : -1;
+    e_lds[i] = live ? c * pg.PLANE + row * pg.ROWS + (col % g.sw) * pg.HALF + col / g.sw : -1;
+  }
+  const int tiles_per_img = pg.tiles_x * pg.tiles_y;
+  auto tile_origin = [&](int64_t t, int &img, int &oy0, int &ox0) {
+    const unsigned u = unsigned(t), im = u / unsigned(tiles_per_img), rem = u - im * unsigned(tiles_per_img);
+    const unsigned ty = rem / unsigned(pg.tiles_x), tx = rem - ty * unsigned(pg.tiles_x);
+    img = int(im);
+    oy0 = int(ty) * kPoolTR * 2 - pool.pt;
+    ox0 = int(tx) * kPoolTC * 2 - pool.pl;
+  };
+  auto load_slot = [&](int i, const float *image, int iy0, int ix0) -> float {
+    const int iy = iy0 + (e_rc[i] >> 16), ix = ix0 + (e_rc[i] & 0xffff);
+    const bool ok = unsigned(iy) < unsigned(g.H) && unsigned(ix) < unsigned(g.W);
+    const float x = image[ok ? iy0 * g.W + ix0 + e_rel[i] : 0];
+    return ok ? x : 0.f;
+  };
+  auto store_patch = [&](const float(&v)[kPatchMaxE]) {
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++) patch[e_lds[i] >= 0 ? e_lds[i] : psz + (i & 3)] = v[i];
+  };
+
+  int lbase[PW], py[PW], px[PW];
+#pragma unroll
+  for (int p = 0; p < PW; p++) {
+    const int pix = min((wave + 4 * p) * 32 + r, kPoolCR * kPoolCC - 1);
+    py[p] = pix / kPoolCC;
+    px[p] = pix % kPoolCC;
+    lbase[p] = py[p] * g.sh * pg.ROWS + px[p];
+  }
+  const f32x4 *wfrag = reinterpret_cast<const f32x4 *>(wl) + lane;
+  const int4 *ktab4 = reinterpret_cast<const int4 *>(ktab) + h;
+  f32x4 bres[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) bres[q] = bias ? reinterpret_cast<const f32x4 *>(bias)[h + 8 * half + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+  float pv[kPatchMaxE];
+  // XCD x owns the contiguous tile range [x*chunk, (x+1)*chunk); the two halves of a pair walk the same tiles
+  const int64_t chunk = (ntiles + 7) >> 3, t_end = min(ntiles, (int64_t(xcd) + 1) * chunk);
+  const int64_t tstep = ((gridDim.x + 7 - xcd) >> 3) >> 1;  // workgroup PAIRS on this XCD (the launcher keeps that even)
+  int64_t tile = int64_t(xcd) * chunk + pair;
+  int img_n = 0, oy0_n = 0, ox0_n = 0;
+  if (tile < t_end) {
+    tile_origin(tile, img_n, oy0_n, ox0_n);
+    const int iy0 = oy0_n * g.sh - g.pt, ix0 = ox0_n * g.sw - g.pl;
+    const float *image = X + int64_t(img_n) * g.C * g.H * g.W;
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++) pv[i] = load_slot(i, image, iy0, ix0);
+    store_patch(pv);
+  }
+  __syncthreads();
+  if (half)
+    for (int i = 0; i < desync; i++) __builtin_amdgcn_s_sleep(127);  // ~3.5 us each: half a tile behind the even half
+  const int4 ko_first = ktab4[0], ko_second = ktab4[2];
+  const f32x4 a_first = wfrag[0];
+  constexpr int XQ = 9, NQ = 8, PT = kPoolTR * kPoolTC;  // quads per pixel in the exchange tile; this half's quads; pooled pixels
+  f32x4 *exch = reinterpret_cast<f32x4 *>(patch + ((psz + 4 + 3) & ~3));
+  int pwin[2] = {0, 0}, poff[2] = {-1, -1}, ppr[2] = {0, 0}, ppc[2] = {0, 0};
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int it = threadIdx.x + n * BS;
+    const bool ok = it < NQ * PT;
+    const int cq = ok ? it / PT : 0, pp = ok ? it % PT : 0, pr = pp / kPoolTC, pc = pp % kPoolTC;
+    pwin[n] = ((2 * pr) * kPoolCC + 2 * pc) * XQ + cq;
+    ppr[n] = pr;
+    ppc[n] = pc;
+    poff[n] = ok ? (((cq + NQ * half) * pool.OH + pr) * pool.OW + pc) * 16 : -1;
+  }
+  const unsigned pooled_img_bytes = unsigned(g.M / 4) * unsigned(pool.OH) * unsigned(pool.OW) * 16u;
+  auto pooled_rsrc = [&](int img, bool live) {
+    const char *base = reinterpret_cast<const char *>(Y) + int64_t(__builtin_amdgcn_readfirstlane(img)) * pooled_img_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, live ? int(pooled_img_bytes) : 0, 0x00020000);
+  };
+  auto pooled_voff = [&](int n, int pr0, int pc0) {
+    return (poff[n] >= 0 && pr0 + ppr[n] < pool.OH && pc0 + ppc[n] < pool.OW) ? poff[n] + (pr0 * pool.OW + pc0) * 16 : -1;
+  };
+  auto pooled_store = [&](const f32x4 &m, __amdgpu_buffer_rsrc_t rs, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), rs, voff, 0, 0);
+  };
+  int img_p = 0, pr0_p = 0, pc0_p = 0;
+  bool have_p = false;
+  for (; tile < t_end; tile += tstep) {
+    const int64_t next = tile + tstep;
+    const int oy0 = oy0_n, ox0 = ox0_n, img = img_n;
+    const __amdgpu_buffer_rsrc_t rs_p = pooled_rsrc(img_p, have_p);
+    const int voff_p[2] = {pooled_voff(0, pr0_p, pc0_p), pooled_voff(1, pr0_p, pc0_p)};
+    f32x4 ptmp[2], pm;
+    auto shadow_pool = [&](int uu) {  // item 0: units 0..10, item 1: units 11..21
+      const int n = uu / 11, st = uu - 11 * n;
+      if (n > 1) return;
+      if (st < 9) ptmp[st & 1] = exch[pwin[n] + ((st / 3) * kPoolCC + st % 3) * XQ];
+      if (st == 0) pm = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (st >= 1 && st <= 9) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) pm[e] = fmaxf(pm[e], ptmp[(st - 1) & 1][e]);
+      }
+      if (st == 10) pooled_store(pm, rs_p, voff_p[n]);
+    };
+    tile_origin(next < t_end ? next : tile, img_n, oy0_n, ox0_n);
+    const int iy0_n = oy0_n * g.sh - g.pt, ix0_n = ox0_n * g.sw - g.pl;
+    const float *image_n = X + int64_t(img_n) * g.C * g.H * g.W;
+
+    f32x16 acc[PW];
+#pragma unroll
+    for (int p = 0; p < PW; p++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
+    const float *pb0 = patch + lbase[0], *pb1 = patch + lbase[1];
+    int4 ko[3];
+    float b[2][PW][4];
+    f32x4 a[2];
+    ko[0] = ko_first;
+    ko[1] = ko_second;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      b[0][0][j] = pb0[(&ko[0].x)[j]];
+      b[0][1][j] = pb1[(&ko[0].x)[j]];
+    }
+    a[0] = a_first;
+#pragma unroll
+    for (int grp = 0; grp < K8C; grp++) {
+      const int cur = grp & 1, nxt = cur ^ 1;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (grp + 1 < K8C) {
+          b[nxt][0][j] = pb0[(&ko[(grp + 1) % 3].x)[j]];
+          b[nxt][1][j] = pb1[(&ko[(grp + 1) % 3].x)[j]];
+          if (j == 0) a[nxt] = wfrag[(grp + 1) * 64];
+        }
+        if (j == 0 && grp + 2 < K8C) ko[(grp + 2) % 3] = ktab4[(grp + 2) * 2];
+#pragma unroll
+        for (int sl = 0; sl < kPatchMaxE; sl++)
+          if (sl * (4 * K8C) / kPatchMaxE == grp * 4 + j) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
+        shadow_pool(grp * 4 + j);
+#pragma unroll
+        for (int p = 0; p < PW; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][j], b[cur][p][j], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // the unit's first MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // address arithmetic of ...
+        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);   // ... the next group's reads (and one of the pooling's)
+        __builtin_amdgcn_sched_group_barrier(0x020, K8C < 8 ? 2 : 1, 0);  // ... and of this unit's patch slot(s), if any
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // (a pooled store)
+        __builtin_amdgcn_sched_group_barrier(0x008, PW - 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // epilogue: lane (r, h) of pixel tile p holds pixel (oy0 + py[p], ox0 + px[p]), channels 32 half + 8q + 4h + j -> this half's quad 2q + h
+    __syncthreads();  // the previous tile's pooling has read the exchange tile (inside the k loop everybody has just left)
+    dispatch_act(act.kind, [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+      for (int p = 0; p < PW; p++) {
+        const int oy = oy0 + py[p], ox = ox0 + px[p];
+        const bool inside = oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = inside ? apply_act_c<KIND>(acc[p][4 * q + j] + bres[q][j], act.a, act.b) : -INFINITY;
+          exch[((wave + 4 * p) * 32 + r) * XQ + 2 * q + h] = v;
+        }
+      }
+    });
+    store_patch(pv);  // (unconditional: the last tile parks its own re-fetched patch, see conv2d_patch_kernel)
+    __syncthreads();
+    img_p = img;
+    pr0_p = (oy0 + pool.pt) >> 1;
+    pc0_p = (ox0 + pool.pl) >> 1;
+    have_p = true;
+  }
+  if (have_p) {  // the workgroup's last tile has no k loop behind it to hide under
+    const __amdgpu_buffer_rsrc_t rs = pooled_rsrc(img_p, true);
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const f32x4 *win = exch + pwin[n];
+      f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const f32x4 v = win[(i * kPoolCC + j) * XQ];
+#pragma unroll
+          for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
+        }
+      pooled_store(m, rs, pooled_voff(n, pr0_p, pc0_p));
+    }
+  }
+}
+
 // Depthwise convolution (groups == C == M) in channel-quad planes: HBM-bound, no matrix cores.  One thread per
 // (n, channel quad, oh, ow): every tap is one 16-byte load (consecutive lanes walk a plane row) times one
 // 16-byte weight quad [c/4][tap][4] that the whole wave shares.
@@ -1330,8 +1561,26 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
     return;
   }
   const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
+  // 64-feature stems with a compile-time k loop: two half-channel workgroups per CU (INFERA_STEM_POOL2=0: the one-workgroup kernel;
+  // INFERA_STEM_POOL2_DESYNC=n: the odd half starts n x 3.5 us late, default 1)
+  // (read per launch -- two getenv calls against a millisecond kernel -- so that one process can run both kernels: the bit-identity tests do)
+  const int pool2 = getenv("INFERA_STEM_POOL2") ? atoi(getenv("INFERA_STEM_POOL2")) : 1;
+  const int desync = getenv("INFERA_STEM_POOL2_DESYNC") ? atoi(getenv("INFERA_STEM_POOL2_DESYNC")) : 1;
+  const int cus = num_cus > 0 ? num_cus : 256;
+  if (pool2 && g.M == 64 && (p.K8 == 19 || p.K8 == 10) && (g.C * p.PR * p.PC + kPool2Block - 1) / kPool2Block <= kPatchMaxE &&
+      2 * patch_pool2_lds_bytes(g, p) <= 160 * 1024 && cus % 8 == 0 && (pool2 >= 2 || ntiles >= int64_t(cus))) {  // (2: always -- tests)
+    const size_t lds2 = patch_pool2_lds_bytes(g, p);
+    const unsigned grid2 = unsigned(2 * cus);  // a multiple of 16: an even number of workgroups (whole pairs) on every XCD
+    auto launch2 = [&](auto kernel) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(kernel, dim3(grid2), dim3(kPool2Block), lds2, s, X, packed, bias, Y, ntiles, g, p, act, pool, desync);
+    };
+    if (p.K8 == 19) launch2(conv2d_stem_pool2_kernel<19>);
+    else launch2(conv2d_stem_pool2_kernel<10>);
+    return;
+  }
   const size_t lds = patch_pool_lds_bytes(g, p);
-  const unsigned grid = unsigned(std::min<int64_t>(ntiles, int64_t(num_cus > 0 ? num_cus : 256)));
+  const unsigned grid = unsigned(std::min<int64_t>(ntiles, int64_t(cus)));
   auto launch = [&](auto kernel) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kPoolBlock), lds, s, X, packed, bias, Y, ntiles, g, p, act, pool);

@@ -90,6 +90,16 @@ const Config &Config::get() {
     c.host_contexts = std::max(1, int(env_u64("INFERA_HOST_CONTEXTS", 24)));
     const std::string hw = env_or("INFERA_HOST_WAIT", "poll");
     c.host_wait = hw == "spin" ? 1 : hw == "poll" ? 2 : hw == "pollq" ? 3 : hw == "block" ? 0 : 2;
+    auto env_frac = [](const char *k, double d) {
+      const char *v = std::getenv(k);
+      if (!v || !*v) return d;
+      char *end = nullptr;
+      const double x = std::strtod(v, &end);
+      return end && *end == 0 && x >= 0.0 && x <= 4.0 ? x : d;
+    };
+    c.host_poll_first = env_frac("INFERA_HOST_POLL_FIRST", 0.75);
+    c.host_poll_next = env_frac("INFERA_HOST_POLL_NEXT", 0.1);
+    c.host_ctx_affinity = env_flag("INFERA_HOST_CTX_AFFINITY", true);
     const std::string hg = env_or("INFERA_HOST_GATHER", "memcpy");
     c.host_gather = hg == "nt" ? 1 : hg == "ntpf" ? 2 : 0;
     c.max_inflight_total = int(env_u64("INFERA_MAX_INFLIGHT_TOTAL", 0));

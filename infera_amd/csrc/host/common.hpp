@@ -99,6 +99,10 @@ struct Config {
                                       //   blocking-sync event, which on ROCm 7.2 BURNS the core for the whole wait (measured: 277 us of CPU per
                                       //   chunk at 16 threads against 85 with poll, same rows/s; profiles/r03_host_cpu_ab_wait_gather.txt);
                                       //   spin (1) = hipStreamSynchronize
+  double host_poll_first, host_poll_next;  // INFERA_HOST_POLL_FIRST / _NEXT (default 0.75 / 0.1): poll mode naps first for this share of the
+                                      //   context's recent wait, then this share between event queries
+  bool host_ctx_affinity;             // INFERA_HOST_CTX_AFFINITY=0|1 (default 1)  a caller thread re-leases the staging context it used last when free:
+                                      //   its pinned staging lines are still in that core's caches (CPU per chunk 88.9 -> 76.9 us at 16 callers)
   int host_gather;                    // INFERA_HOST_GATHER=memcpy|nt|ntpf  how FLOAT column runs are copied into pinned staging: memcpy (0),
                                       //   non-temporal 64-byte stores (1: no read-for-ownership of the staging lines, which the DMA engine
                                       //   reads from DRAM anyway), the same + software prefetch of the next column run's first lines (2)

@@ -131,3 +131,39 @@ def test_gpu_fused_stem_pool_treats_nan_and_inf_like_the_two_kernels(gpu_api, tm
     finally:
         os.environ.pop("INFERA_STEM_POOL", None)
     assert np.array_equal(out["0"].view(np.uint32), out["1"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["resnet_stem_64", "resnet_stem_224", "odd_extent", "many_tiles", "k5_rgb", "rectangular"])
+def test_gpu_two_half_workgroup_stem_pool_kernel_is_bit_identical(gpu_api, tmp_path, case):
+    """Round 3: 64-feature stems with a compile-time k loop (7x7 and 5x5 over 3 channels) run as TWO half-channel 256-thread
+    workgroups per CU (conv2d_stem_pool2_kernel; INFERA_STEM_POOL2=2 forces it even for launches of a few tiles, 0 = the
+    one-workgroup kernel, read per launch).  Same k order per output element, max-pooling per channel: the pooled tensor must be
+    bit-for-bit that of the one-workgroup fused kernel and of the stem kernel + pooling kernel, with and without the odd half's
+    start delay."""
+    from oracle import oracle
+
+    c = dict(CASES[case])
+    rows = c.pop("rows")
+    path = W.write(str(tmp_path / "stem.onnx"), _net(**c))
+    x = synth.table(41, 0, rows, c["cin"] * c["hw"] * (c.get("hw2") or c["hw"]))
+    out = {}
+    try:
+        for tag, env in (("two_kernels", {"INFERA_STEM_POOL": "0"}), ("one_wg", {"INFERA_STEM_POOL2": "0"}), ("two_half_wgs", {"INFERA_STEM_POOL2": "2"}),
+                         ("two_half_wgs_no_delay", {"INFERA_STEM_POOL2": "2", "INFERA_STEM_POOL2_DESYNC": "0"})):
+            os.environ.update(env)
+            try:
+                gpu_api.load_model("stem", path)
+                out[tag] = gpu_api.predict_from_blob("stem", x.tobytes())
+                assert np.array_equal(out[tag], gpu_api.predict_from_blob("stem", x.tobytes()))
+                gpu_api.unload_model("stem")
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+    finally:
+        for k in ("INFERA_STEM_POOL", "INFERA_STEM_POOL2", "INFERA_STEM_POOL2_DESYNC"):
+            os.environ.pop(k, None)
+    for tag in ("one_wg", "two_half_wgs", "two_half_wgs_no_delay"):
+        assert np.array_equal(out[tag], out["two_kernels"]), (tag, float(np.abs(out[tag] - out["two_kernels"]).max()))
+    want = oracle.Model(path).predict_blob(x.tobytes())
+    assert np.all(np.abs(out["two_half_wgs"] - want) <= 1e-4 * np.abs(want) + 1e-6)
