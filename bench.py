@@ -69,6 +69,7 @@ def parse_args():
                     help="MEASUREMENT ONLY, with --host-path: the host-side ceiling with the link taken out -- H2D copies move a 4 KiB token "
                          "(1), and the kernels run on one 32-row tile (2: for N slots sharing ONE GPU, whose kernel dispatch rate would "
                          "otherwise bound the probe).  Gather, lease, gate, submit and wait machinery are timed unchanged; results are meaningless")
+    ap.add_argument("--no-registered", action="store_true", help="skip the scan over the REGISTERED host table (the opt-in zero-copy path)")
     ap.add_argument("--no-host-probe", action="store_true", help="default run only: skip the 8-slot link-elided host-ceiling probe (a child process)")
     return ap.parse_args()
 
@@ -342,6 +343,37 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
             "device_slots": [{"slot": d["slot"], "ordinal": d["ordinal"], "rows_this_run": d["host_rows"] - before.get(d["slot"], 0)} for d in after]}
 
 
+def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_cols: int, reps: int, budget: dict, world: int, barrier,
+                          max_over_ranks, threads_arg: str = "") -> dict:
+    """The same scan with the host table REGISTERED once (infera_hip_register_host_memory -- an opt-in for an application that owns
+    long-lived column storage; DuckDB's own buffers are not registered by anybody, so this is NOT the drop-in path and never the
+    headline): every chunk's column runs are then read in place by the GPU, the CPU neither gathers nor enqueues a copy.  What it
+    shows is the host cost per chunk without the gather, i.e. what 8 GPUs fed from one small CPU quota could reach."""
+    from infera_amd import capi
+
+    t0 = time.perf_counter()
+    capi.register_host_memory(table)
+    reg_s = time.perf_counter() - t0
+    try:
+        before = capi.zero_copy_calls()
+        top = budget["usable"]
+        share = max(2, top // world)
+        th = threads_arg or ",".join(str(t) for t in sorted({max(2, share // 4), max(2, share // 2), share, 2 * share}))
+        e = end_to_end(fn, model, table, rows, cols, out_cols, th, reps, budget, world, barrier, max_over_ranks)
+        served = capi.zero_copy_calls() - before
+    finally:
+        capi.unregister_host_memory(table)
+    for k in ("h2d_measured_gbs", "frac_of_h2d_measured", "h2d_measured_note", "pcie_achievable_gbs", "frac_of_pcie_achievable", "all_reps_wall_seconds"):
+        e.pop(k, None)
+    e["entry"] = (f"infera_sql_call('{fn}') per 2048-row chunk over a host table registered with infera_hip_register_host_memory: "
+                  "infera_predict_columns -> ONE gather kernel reading the 128 column runs in place over PCIe -> model kernels -> result vector")
+    e["register_seconds"] = reg_s
+    e["zero_copy_calls"] = served
+    e["what"] = ("OPT-IN zero-copy path (include/infera_hip.h), not the drop-in path: shows the host cost per chunk without the CPU gather. "
+                 "`rows_per_s` here is bounded by what a kernel pulling host memory reaches over PCIe, below the copy engines' rate at 1 GPU")
+    return e
+
+
 def host_ceiling_probe(budget: dict, threads: str = "") -> dict:
     """The host side at 8 device slots with the link taken out: a CHILD process (the knobs are read once at
     library load) runs `bench.py --host-path --gpus 8 --share-device <this GPU> --elide-h2d 2` -- the same scan, the same
@@ -363,7 +395,14 @@ def host_ceiling_probe(budget: dict, threads: str = "") -> dict:
         return {"error": f"{type(exc).__name__}: {exc}"}
     e = line["end_to_end"]
     e["host_cpu_cost"] = {k: v for k, v in e["host_cpu_cost"].items() if k in ("cpu_us_per_chunk", "of_which_system_us", "cpus_busy_during_scan", "rows_per_cpu_second")}
+    busy, quota = e["host_cpu_cost"].get("cpus_busy_during_scan") or 0.0, budget["usable"]
+    cap = quota * (e["host_cpu_cost"].get("rows_per_cpu_second") or 0.0)
     return {"rows_per_s": e["rows_per_s"], "threads": e["threads_per_rank"], "thread_sweep_rows_per_s": e["thread_sweep_rows_per_s"],
+            "bound": "cpu quota" if busy >= 0.85 * quota else
+                     f"not the CPUs ({busy:.1f} of {quota} busy): the ONE GPU under the 8 slots still takes a token copy, a one-tile launch and an event per chunk, "
+                     f"and its packet rate bounds the probe -- a LOWER bound of the host side; the CPU cost per chunk measured in the same scan puts the quota's capacity at "
+                     f"{cap / 1e6:.0f} M rows/s",
+            "host_capacity_rows_per_s_on_quota": cap,
             "host_cpu_cost": e["host_cpu_cost"], "us_per_chunk_per_thread": e["us_per_chunk_per_thread"], "device_slots": len(e["device_slots"]),
             "command": " ".join(cmd[1:]),
             "what": "host-side ceiling at 8 device slots, link and kernels elided (4 KiB token per H2D, one 32-row tile per launch); NOT a throughput claim"}
@@ -631,6 +670,17 @@ def main():
                 raise
             e2e_error = f"{type(exc).__name__}: {exc}"
 
+    # ---- the same scan over a REGISTERED table (opt-in zero-copy path): what the host side costs without the gather ----
+    e2e_reg = None
+    if sql_fn and e2e and table is not None and not args.no_end_to_end and not args.no_registered:
+        try:
+            e2e_reg = end_to_end_registered(sql_fn, "bench", table, min(rows, 10_000_000) if args.workload != "mlp" else rows, cols, out_cols,
+                                            max(2, min(args.e2e_reps, 3)), budget, world, barrier, shard.max_over_ranks)
+        except Exception as exc:
+            if world > 1:
+                raise
+            e2e_reg = {"error": f"{type(exc).__name__}: {exc}"}
+
     # ---- C4 / C5 end to end + their CPU baselines, short (default single-GPU run) ----
     if default_run and not args.no_end_to_end and table is not None and e2e:
         trows = min(rows, 10_000_000)
@@ -673,6 +723,8 @@ def main():
         if e2e:
             e2e["numa_binding"] = numa
             line["end_to_end"] = e2e
+            if e2e_reg:
+                line["end_to_end_registered"] = e2e_reg
         elif e2e_error:
             line["end_to_end"] = {"error": e2e_error}
         if world == 1 and not args.no_cpu_baseline and args.workload == "resnet18":

@@ -115,6 +115,22 @@ double infera_hip_h2d_probe(int32_t device, uint64_t bytes, int32_t iters, int32
  * `ticket_global`.  slot_numa[i] = NUMA node of slot i's GPU (-1 unknown); thread_node < 0 = unknown. */
 int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32_t thread_node, uint64_t ticket_on_node,
                                uint64_t ticket_global);
+/* ---- zero-copy host path (round 3; the reference's ROADMAP.md:44 "zero-copy") -------------------------------------------------
+ * An application that OWNS long-lived column storage (an in-memory table, Arrow buffers, a DuckDB build with an allocator hook)
+ * registers it once: [base, base + bytes) is pinned where it lies and mapped into every selected GPU (hipHostRegister; ~15 us per
+ * 480 KB, nothing is copied).  From then on an infera_predict_columns call whose column runs ALL lie inside registered ranges is
+ * served without the CPU touching the data: one GPU kernel reads the runs in place over PCIe (FLOAT as they are; DOUBLE / INTEGER /
+ * BIGINT converted with the reference's static_cast<float> roundings; constant vectors broadcast) into the column-major chunk the
+ * model's first kernel reads.  Results are bit-identical to the staged path.  Chunks with any column outside a registered range, and
+ * calls longer than one staging pass (> 24 MB of features), take the staged path as before.
+ * CONTRACT: a registered range must stay mapped until it is unregistered, and must not be unregistered while a call that reads it is
+ * in flight (calls are synchronous: none is, once they have returned).  The library never registers memory on its own -- a buffer
+ * the caller frees behind a stale registration would fault the GPU.  Ranges must not overlap.  0 / -1 (+ infera_last_error). */
+int32_t infera_hip_register_host_memory(const void *base, uint64_t bytes);
+int32_t infera_hip_unregister_host_memory(const void *base);
+/* infera_predict_columns calls served zero-copy so far (tests, bench) */
+uint64_t infera_hip_zero_copy_calls(void);
+
 /* The load-aware form the library applies to a caller thread's first call (INFERA_NUMA_SLOTS=1, default): the least-loaded slot
  * on the thread's NUMA node unless it already carries more than one thread above the least-loaded slot overall -- then that one.
  * slot_threads[i] = caller threads currently homed on slot i.  Pure function, exposed for tests. */

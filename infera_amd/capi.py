@@ -29,7 +29,7 @@ EXTENSION_SYMBOLS = [
     "infera_hip_free", "infera_hip_memcpy_h2d", "infera_hip_memcpy_d2h", "infera_hip_synth_fill",
     "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch", "infera_gather_columns",
     "infera_hip_sha256_hex", "infera_hip_shape_rows_cols", "infera_hip_h2d_probe", "infera_hip_choose_slot",
-    "infera_hip_choose_slot_balanced",
+    "infera_hip_choose_slot_balanced", "infera_hip_register_host_memory", "infera_hip_unregister_host_memory", "infera_hip_zero_copy_calls",
 ]
 
 
@@ -124,6 +124,12 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.infera_hip_choose_slot.restype = C.c_int32
     L.infera_hip_choose_slot_balanced.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, C.c_int32]
     L.infera_hip_choose_slot_balanced.restype = C.c_int32
+    L.infera_hip_register_host_memory.argtypes = [C.c_void_p, C.c_uint64]
+    L.infera_hip_register_host_memory.restype = C.c_int32
+    L.infera_hip_unregister_host_memory.argtypes = [C.c_void_p]
+    L.infera_hip_unregister_host_memory.restype = C.c_int32
+    L.infera_hip_zero_copy_calls.argtypes = []
+    L.infera_hip_zero_copy_calls.restype = C.c_uint64
     L.infera_hip_h2d_probe.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_int32]
     L.infera_hip_h2d_probe.restype = C.c_double
     _lib = L
@@ -234,6 +240,22 @@ def choose_slot(slot_numa: Sequence[int], thread_node: int, ticket_on_node: int,
     """The thread -> device-slot dealing policy (NUMA-local slots first), as the library applies it."""
     arr = (C.c_int32 * max(len(slot_numa), 1))(*slot_numa)
     return int(load_library().infera_hip_choose_slot(arr, len(slot_numa), thread_node, ticket_on_node, ticket_global))
+
+
+def register_host_memory(arr: np.ndarray) -> None:
+    """Registers a (contiguous) array's bytes for the zero-copy host path; keep the array alive until unregister_host_memory."""
+    assert arr.flags.c_contiguous
+    if load_library().infera_hip_register_host_memory(arr.ctypes.data, arr.nbytes) != 0:
+        raise InferaError(last_error())
+
+
+def unregister_host_memory(arr: np.ndarray) -> None:
+    if load_library().infera_hip_unregister_host_memory(arr.ctypes.data) != 0:
+        raise InferaError(last_error())
+
+
+def zero_copy_calls() -> int:
+    return int(load_library().infera_hip_zero_copy_calls())
 
 
 def choose_slot_balanced(slot_numa: Sequence[int], slot_threads: Sequence[int], thread_node: int) -> int:

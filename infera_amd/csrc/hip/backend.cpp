@@ -1258,9 +1258,24 @@ bool colmajor_direct_ok(const LoadedModel &m, int64_t rows) {
   return nr <= m.in_colmajor_max_rows && rows_per_pass(m, nr) == nr;
 }
 
+namespace {
+bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn *dfill, float *h_out, int64_t rows, bool col_major);
+}
 void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major) {
+  (void)run_host_impl(m, fill, nullptr, h_out, rows, col_major);
+}
+bool run_host_device_fill(const LoadedModel &m, const DeviceFillFn &dfill, float *h_out, int64_t rows) {
+  return run_host_impl(m, FillFn(), &dfill, h_out, rows, /*col_major=*/true);
+}
+
+namespace {
+bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn *dfill, float *h_out, int64_t rows, bool col_major) {
   if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
-  if (rows <= 0) return;
+  if (rows <= 0) return true;
+  if (dfill) {  // zero-copy: one host pass, direct (non-graph) enqueue only -- anything else goes the staging way
+    const size_t widest_row = std::max(size_t(m.plan.in_per_row()), size_t(m.plan.out_per_row())) * 4;
+    if (Config::get().use_hipgraph || size_t(rows) * widest_row > kPipePassBytes + kPipePassBytes / 2) return false;
+  }
   const int slot = home_slot();
   const uint64_t t_entry = now_ns();
   HostLease lease(slot);
@@ -1341,18 +1356,19 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
       (void)hipStreamSynchronize(ctx.stream);  // nothing may still be reading the staging slots when we unwind
       throw;
     }
-    return;
+    return true;
   }
   int64_t rows_pass = std::max<int64_t>(1, int64_t(kHostPassBytes / widest));
   rows_pass = std::min(rows_pass, rows);
   const bool direct_out = m.out_write_once && Config::get().host_direct_out && size_t(rows_pass) * out_row <= (1u << 20);
   const bool cm_graph = use_graph && col_major;  // (implies m.in_colmajor_ok)
-  ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, size_t(rows_pass) * in_row);
+  if (!dfill) ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows_pass) * out_row);
   ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_dev(ctx.dev_out, ctx.dev_out_cap, size_t(rows_pass) * out_row);
   // H2D (or not: small inputs are read from pinned memory by the kernel itself) + the plan's kernels [+ D2H] of ONE pass whose staged
   // input is at `pin`, on ctx.stream; results land at `pout` (a position in the pinned result buffer).  Non-graph mode.
+  int64_t dfill_r0 = 0;  // (zero-copy) first row of the pass being enqueued
   auto enqueue_pass = [&](const float *pin, float *din, float *dout, float *pout, int64_t nr, bool single_pass, int in_flight, bool allow_small) {
     // column-major chunk straight into the model's first kernel when it can read one (no transpose launch)
     const bool cm_direct = col_major && m.in_colmajor_ok && nr <= m.in_colmajor_max_rows && single_pass && Config::get().host_fused_transpose;
@@ -1369,7 +1385,17 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
     const int64_t din_limit = int64_t(Config::get().host_direct_in_bytes) * quiet_mult;
     const bool small_in = allow_small && !elide && int64_t(nr) * int64_t(in_row) <= din_limit;
     const float *kin = din;
-    if (cm_direct) {
+    if (dfill) {
+      // zero-copy: the GPU pulls the caller's (registered) column runs itself -- straight into the chunk the first kernel reads when it
+      // reads column-major chunks, else into the transpose's source
+      if (cm_direct) {
+        (*dfill)(ctx.stream, din, dfill_r0, nr);
+      } else {
+        ctx.ensure_dev(ctx.dev_cm, ctx.dev_cm_cap, size_t(nr) * in_row);
+        (*dfill)(ctx.stream, ctx.dev_cm, dfill_r0, nr);
+        kern::transpose_cm(ctx.stream, ctx.dev_cm, din, nr, int64_t(in_row / 4));
+      }
+    } else if (cm_direct) {
       if (small_in) kin = pin;
       else HIP_TRY(hipMemcpyAsync(din, pin, h2d_bytes(nr), hipMemcpyHostToDevice, ctx.stream));
     } else if (col_major && small_in) {
@@ -1398,7 +1424,7 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
     const int quiet = gate_for_slot(slot).peek();
     int split = split_mode >= 2 ? split_mode : (split_mode == 1 && quiet <= Config::get().host_split_quiet ? 2 : 1);
     const int64_t sub = split > 1 ? ((rows + split - 1) / split + 31) / 32 * 32 : rows;
-    if (!use_graph && split > 1 && rows <= rows_pass && sub < rows && size_t(sub) * in_row >= (256u << 10) && rows_per_pass(m, sub) == sub) {
+    if (!use_graph && !dfill && split > 1 && rows <= rows_pass && sub < rows && size_t(sub) * in_row >= (256u << 10) && rows_per_pass(m, sub) == sub) {
       const uint64_t t_f0 = now_ns();
       uint64_t gather_ns = 0, enq_ns = 0, gate_ns = 0;
       (void)prepare_scratch(m, ctx, sub);
@@ -1431,14 +1457,15 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
       g_phase_ns[kPhCopyOut].fetch_add(t_c - t_w, std::memory_order_relaxed);
       g_phase_calls.fetch_add(1, std::memory_order_relaxed);
       g_split_calls.fetch_add(1, std::memory_order_relaxed);
-      return;
+      return true;
     }
   }
   for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
     const int64_t nr = std::min(rows_pass, rows - r0);
     // The caller's buffer is only borrowed for the call (SURVEY.md 8b "Ownership"): stage it.
     const uint64_t t_f0 = now_ns();
-    fill(ctx.pin_in, r0, nr);
+    if (!dfill) fill(ctx.pin_in, r0, nr);
+    dfill_r0 = r0;
     const uint64_t t_f1 = now_ns();
     GateHold admitted(gate_for_slot(slot), Config::get().max_inflight, Config::get().max_inflight_total);  // until this pass has been synchronised
     const uint64_t t_g = now_ns();
@@ -1508,7 +1535,74 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
     g_phase_ns[kPhCopyOut].fetch_add(t_c - t_w, std::memory_order_relaxed);
     g_phase_calls.fetch_add(1, std::memory_order_relaxed);
   }
+  return true;
 }
+}  // namespace
+
+// ---- registered host memory (zero-copy host path) -----------------------------------------------------------------------
+namespace {
+struct HostRange {
+  uintptr_t base, end;     // as registered by the caller
+  uintptr_t page_base;     // what was handed to hipHostRegister (page-aligned)
+  intptr_t dev_delta;      // device-visible address = host address + dev_delta
+};
+std::shared_mutex g_ranges_mu;
+std::vector<HostRange> g_ranges;  // sorted by base, non-overlapping
+std::atomic<size_t> g_nranges{0};
+}  // namespace
+
+void register_host_memory(const void *base, size_t bytes) {
+  if (!base || !bytes) throw InferaError::null_pointer();
+  const auto &ds = devices();
+  if (ds.ids.empty()) throw InferaError::onnx("HIP backend unavailable: " + ds.why);
+  const uintptr_t b = reinterpret_cast<uintptr_t>(base), e = b + bytes;
+  const uintptr_t pb = b & ~uintptr_t(4095), pe = (e + 4095) & ~uintptr_t(4095);
+  std::unique_lock<std::shared_mutex> lk(g_ranges_mu);
+  for (const auto &r : g_ranges)
+    if (b < r.end && r.base < e) throw InferaError::onnx("host memory range overlaps a registered range");
+  UnsafeOpGuard guard;
+  HIP_TRY(hipSetDevice(ds.ids[0]));
+  // portable + mapped: visible to every selected GPU; the pages stay where they are (no copy), pinned until unregistered
+  HIP_TRY(hipHostRegister(reinterpret_cast<void *>(pb), pe - pb, hipHostRegisterPortable | hipHostRegisterMapped));
+  void *dptr = nullptr;
+  const hipError_t ge = hipHostGetDevicePointer(&dptr, reinterpret_cast<void *>(pb), 0);
+  if (ge != hipSuccess) {
+    (void)hipHostUnregister(reinterpret_cast<void *>(pb));
+    hip_fail(ge, "hipHostGetDevicePointer");
+  }
+  HostRange r{b, e, pb, intptr_t(reinterpret_cast<uintptr_t>(dptr)) - intptr_t(pb)};
+  g_ranges.insert(std::upper_bound(g_ranges.begin(), g_ranges.end(), r, [](const HostRange &x, const HostRange &y) { return x.base < y.base; }), r);
+  g_nranges.store(g_ranges.size(), std::memory_order_release);
+}
+
+bool unregister_host_memory(const void *base) {
+  const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+  std::unique_lock<std::shared_mutex> lk(g_ranges_mu);
+  for (size_t i = 0; i < g_ranges.size(); i++)
+    if (g_ranges[i].base == b) {
+      const uintptr_t pb = g_ranges[i].page_base;
+      g_ranges.erase(g_ranges.begin() + long(i));
+      g_nranges.store(g_ranges.size(), std::memory_order_release);
+      // every GPU read of the range was synchronised by the call that issued it (host-ABI calls return after their stream is idle)
+      UnsafeOpGuard guard;
+      (void)hipHostUnregister(reinterpret_cast<void *>(pb));
+      return true;
+    }
+  return false;
+}
+
+const void *lookup_host_memory(const void *p, size_t bytes) {
+  if (g_nranges.load(std::memory_order_acquire) == 0) return nullptr;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  std::shared_lock<std::shared_mutex> lk(g_ranges_mu);
+  auto it = std::upper_bound(g_ranges.begin(), g_ranges.end(), a, [](uintptr_t v, const HostRange &r) { return v < r.base; });
+  if (it == g_ranges.begin()) return nullptr;
+  --it;
+  if (a < it->base || a + bytes > it->end) return nullptr;
+  return reinterpret_cast<const void *>(intptr_t(a) + it->dev_delta);
+}
+
+size_t registered_host_ranges() { return g_nranges.load(std::memory_order_acquire); }
 
 void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows) {
   const size_t in_per_row = size_t(m.plan.in_per_row());

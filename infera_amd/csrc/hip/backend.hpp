@@ -126,6 +126,18 @@ using FillFn = std::function<void(float *dst, int64_t row0, int64_t nrows)>;
 // col_major: `fill` writes the pass as [in_per_row][nrows] (column-major -- flat columns are copied as they are) and
 // the transpose to the row-major table happens on the GPU.
 void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major = false);
+// Zero-copy host path (round 3): `dfill(stream, dst, row0, nrows)` makes the GPU itself write rows [row0, row0 + nrows) as one
+// column-major chunk [in_per_row][nrows] into `dst` (HBM) on `stream` -- the caller's columns live in REGISTERED host memory and are
+// read in place over PCIe; no CPU copy, no pinned staging, no hipMemcpyAsync.  Calls longer than one host pass fall back (return
+// false: the caller then stages through the CPU as usual).
+using DeviceFillFn = std::function<void(hipStream_t stream, float *dst, int64_t row0, int64_t nrows)>;
+bool run_host_device_fill(const LoadedModel &m, const DeviceFillFn &dfill, float *h_out, int64_t rows);
+// Registered host memory: [base, base + bytes) is pinned and mapped into every selected GPU (hipHostRegister); lookup() returns the
+// device-visible address of `p` when [p, p + bytes) lies inside one registered range, else nullptr.  Thread-safe.
+void register_host_memory(const void *base, size_t bytes);
+bool unregister_host_memory(const void *base);
+const void *lookup_host_memory(const void *p, size_t bytes);
+size_t registered_host_ranges();
 // whether a host call of `rows` rows can be handed to the plan's first kernel as column-major chunks (one device pass per host pass)
 bool colmajor_direct_ok(const LoadedModel &m, int64_t rows);
 

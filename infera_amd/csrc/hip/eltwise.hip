@@ -463,6 +463,50 @@ void pad_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t
   hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for(rows * Kp)), dim3(kBlock), 0, s, src, dst, rows, K, Kp);
 }
 
+// ---- zero-copy column gather (round 3) ---------------------------------------------------------------------------------
+// The caller's column runs live in host memory that the application REGISTERED with the runtime (infera_hip_register_host_memory):
+// the GPU reads them in place over PCIe and writes the column-major f32 chunk [ncols][rows] into HBM -- the CPU never touches the
+// data.  One workgroup per (column, 4096-row block): a wave instruction reads 1 KB of one column run (16 B per lane, contiguous),
+// every load of the workgroup is in flight at once.  Casts as the reference's ExtractFeatures (static_cast<float>,
+// infera_extension.cpp:211-222): f64 -> f32 and i64 -> f32 round to nearest even (v_cvt_f32_f64; __ll2float_rn), i32 -> f32 exact
+// rounding; a constant vector broadcasts its one value.  Runs whose address is not 16-byte aligned are read element-wise.
+__global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, int64_t rows, float *__restrict__ dst) {
+  const int c = blockIdx.x;
+  const int type = tab.type[c] & 7;
+  const bool constant = tab.type[c] & 8;
+  const char *src = static_cast<const char *>(tab.ptr[c]);
+  float *d = dst + int64_t(c) * rows;
+  const int64_t r0 = int64_t(blockIdx.y) * 4096, r1 = min(rows, r0 + 4096);
+  if (constant) {
+    float v;
+    if (type == 0) v = *reinterpret_cast<const float *>(src);
+    else if (type == 1) v = float(*reinterpret_cast<const double *>(src));
+    else if (type == 2) v = float(*reinterpret_cast<const int *>(src));
+    else v = __ll2float_rn(*reinterpret_cast<const long long *>(src));
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += kBlock) d[r] = v;
+    return;
+  }
+  if (type == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(d)) & 15) == 0 && (rows & 3) == 0) {
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(d);
+    for (int64_t i = r0 / 4 + threadIdx.x; i < r1 / 4; i += kBlock) d4[i] = s4[i];
+    return;
+  }
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
+    float v;
+    if (type == 0) v = reinterpret_cast<const float *>(src)[r];
+    else if (type == 1) v = float(reinterpret_cast<const double *>(src)[r]);
+    else if (type == 2) v = float(reinterpret_cast<const int *>(src)[r]);
+    else v = __ll2float_rn(reinterpret_cast<const long long *>(src)[r]);
+    d[r] = v;
+  }
+}
+
+void gather_columns_device(hipStream_t s, const ColumnTable &tab, int ncols, int64_t rows, float *dst) {
+  if (rows <= 0 || ncols <= 0) return;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(unsigned(ncols), unsigned((rows + 4095) / 4096)), dim3(kBlock), 0, s, tab, rows, dst);
+}
+
 void transpose_cm(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t ncols) {
   if (rows <= 0 || ncols <= 0) return;
   hipLaunchKernelGGL(transpose_cm_kernel, dim3(unsigned((rows + 31) / 32), unsigned((ncols + 31) / 32)), dim3(kBlock), 0, s, src, dst, rows, ncols);

@@ -39,6 +39,14 @@ void argmax_rows(hipStream_t s, const float *x, float *y, int64_t rows, int64_t 
 void pad_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t K, int64_t Kp);
 // dst[rows][ncols] = transpose of src[ncols][rows]  (column-major staging of a columnar chunk)
 void transpose_cm(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t ncols);
+// Zero-copy column gather: up to kMaxZeroCopyCols device-visible column-run pointers (registered host memory) -> [ncols][rows] f32
+// in HBM.  type: 0 f32, 1 f64, 2 i32, 3 i64 (+8 = constant vector: one element); passed by value as the kernel argument (2.3 KB).
+constexpr int kMaxZeroCopyCols = 256;
+struct ColumnTable {
+  const void *ptr[kMaxZeroCopyCols];
+  unsigned char type[kMaxZeroCopyCols];
+};
+void gather_columns_device(hipStream_t s, const ColumnTable &tab, int ncols, int64_t rows, float *dst);
 // synthetic table fill (SURVEY.md 8d generator), row-major [rows, ncols]
 void synth_fill(hipStream_t s, float *dst, uint64_t seed, uint64_t row0, uint64_t rows, uint64_t ncols);
 

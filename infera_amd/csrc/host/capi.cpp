@@ -20,7 +20,11 @@
 
 using namespace infera_hip;
 
+#include <atomic>
+
 namespace {
+std::atomic<uint64_t> g_zero_copy_calls{0};  // infera_predict_columns calls served from registered host memory
+
 
 char *dup_cstr(const std::string &s) {
   char *p = static_cast<char *>(std::malloc(s.size() + 1));
@@ -334,6 +338,21 @@ int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32
   return choose_slot(std::vector<int>(slot_numa, slot_numa + (slot_numa ? nslots : 0)), thread_node, ticket_on_node, ticket_global);
 }
 
+int32_t infera_hip_register_host_memory(const void *base, uint64_t bytes) {
+  return guarded([&] { register_host_memory(base, size_t(bytes)); }) ? 0 : -1;
+}
+
+int32_t infera_hip_unregister_host_memory(const void *base) {
+  return guarded([&] {
+           if (!base) throw InferaError::null_pointer();
+           if (!unregister_host_memory(base)) throw InferaError::onnx("host memory range was not registered");
+         })
+             ? 0
+             : -1;
+}
+
+uint64_t infera_hip_zero_copy_calls(void) { return g_zero_copy_calls.load(std::memory_order_relaxed); }
+
 int32_t infera_hip_choose_slot_balanced(const int32_t *slot_numa, const int32_t *slot_threads, uintptr_t nslots, int32_t thread_node) {
   if (!slot_numa || !slot_threads) return 0;
   return choose_slot_balanced(std::vector<int>(slot_numa, slot_numa + nslots), std::vector<int>(slot_threads, slot_threads + nslots), thread_node);
@@ -491,10 +510,40 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
       // (SURVEY.md 7 "hard parts": the host gather is what limits an 8-GPU host).  Plans whose first kernel cannot read a
       // column-major chunk get a GPU transpose in front; only hipGraph mode on such a plan (the transpose path allocates per
       // pass, which a capture cannot contain) falls back to the AVX2 transposing gather into row-major staging.
+      // Zero-copy (round 3): when EVERY column run lies in host memory the application registered (infera_hip_register_host_memory),
+      // the GPU reads the runs in place over PCIe and converts them on the way -- no CPU gather, no pinned staging, no H2D enqueue:
+      // what a chunk costs the host drops from ~78 us of CPU to the launch and the wait.
+      bool served = false;
+      if (ncols > 0 && ncols <= uintptr_t(kern::kMaxZeroCopyCols) && registered_host_ranges() > 0 && Config::get().host_zero_copy) {
+        kern::ColumnTable tab;
+        size_t esz[kern::kMaxZeroCopyCols];
+        bool all = true;
+        for (uintptr_t c = 0; c < ncols && all; c++) {
+          const InferaColumn &col = columns[c];
+          esz[c] = col.type == INFERA_COL_FLOAT || col.type == INFERA_COL_INTEGER ? 4 : 8;
+          const void *d = lookup_host_memory(col.data, (col.is_constant ? 1 : size_t(rows)) * esz[c]);
+          all = d != nullptr;
+          tab.ptr[c] = d;
+          tab.type[c] = static_cast<unsigned char>(int(col.type) | (col.is_constant ? 8 : 0));
+        }
+        if (all)
+          served = run_host_device_fill(*m, [&](hipStream_t stream, float *dst, int64_t r0, int64_t nr) {
+            // (Measured and dropped, round 3: ONE hipMemcpyBatchAsync of the 128 runs on the copy engines instead of this pulling kernel --
+            // 292 us of CPU inside the call and 8.7 GB/s: the runtime issues 128 separate copies.)
+            kern::ColumnTable t = tab;
+            if (r0)
+              for (uintptr_t c = 0; c < ncols; c++)
+                if (!(t.type[c] & 8)) t.ptr[c] = static_cast<const char *>(t.ptr[c]) + size_t(r0) * esz[c];
+            kern::gather_columns_device(stream, t, int(ncols), nr, dst);
+          }, out, int64_t(rows));
+        if (served) g_zero_copy_calls.fetch_add(1, std::memory_order_relaxed);
+      }
       bool col_major = ncols > 0 && (colmajor_direct_ok(*m, int64_t(rows)) || !Config::get().use_hipgraph);
       if (col_major && !Config::get().host_colmajor_typed)  // A/B knob: only all-FLOAT chunks are staged column-major (round-1 rule)
         for (uintptr_t c = 0; c < ncols && col_major; c++) col_major = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
-      if (col_major) {
+      if (served) {
+        // (done: the GPU gathered the registered columns itself)
+      } else if (col_major) {
         run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) { gather_column_major(columns, 0, ncols, size_t(r0), size_t(nr), dst); },
                       out, int64_t(rows), /*col_major=*/true);
       } else {

@@ -104,6 +104,7 @@ const Config &Config::get() {
     c.host_gather = hg == "nt" ? 1 : hg == "ntpf" ? 2 : 0;
     c.max_inflight_total = int(env_u64("INFERA_MAX_INFLIGHT_TOTAL", 0));
     c.probe_elide_h2d = int(env_u64("INFERA_HOST_PROBE_ELIDE_H2D", 0));
+    c.host_zero_copy = env_flag("INFERA_HOST_ZERO_COPY", true);
     c.numa_slots = env_flag("INFERA_NUMA_SLOTS", true);
     c.host_split = int(env_u64("INFERA_HOST_SPLIT", 0));
     c.host_split_quiet = int(env_u64("INFERA_HOST_SPLIT_QUIET", 4));

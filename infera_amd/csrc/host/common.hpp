@@ -112,6 +112,8 @@ struct Config {
                                       //   4 KiB token instead of the chunk, so the gather / lease / gate / submit machinery can be timed with
                                       //   the link taken out; 2 = the kernels also run on one 32-row tile only (8 slots sharing ONE
                                       //   GPU are otherwise bound by that GPU's kernel dispatch rate).  Results are meaningless in this mode
+  bool host_zero_copy;                // INFERA_HOST_ZERO_COPY=0|1 (default 1)  infera_predict_columns chunks whose column runs all lie in host memory
+                                      //   registered with infera_hip_register_host_memory are read in place by the GPU (no CPU gather, no H2D copy)
   bool numa_slots;                    // INFERA_NUMA_SLOTS=0|1 (default 1)  caller threads prefer the device slots on their own NUMA node (bounded by load)
   int host_split;                     // INFERA_HOST_SPLIT=0|1|n  one-DataChunk calls go through as sub-passes on the call's stream, the gather
                                       //   of sub-pass i+1 overlapping H2D + kernels of sub-pass i: 0 never (default), 1 two halves when the GPU

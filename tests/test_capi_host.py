@@ -270,3 +270,20 @@ def test_gather_columns_matches_extract_features(api):
     valid[2] &= ~np.uint64(1 << 5)
     with pytest.raises(api.InferaError, match="^Feature values cannot be NULL$"):
         api.gather_columns(mixed[:3], validity=[None, valid, None])
+
+
+def test_zero_copy_registration_needs_a_gpu_and_fails_loudly(built):
+    """Without a GPU nothing can be mapped into one: infera_hip_register_host_memory fails with the backend's own error text (no silent
+    fallback), unregistering an unknown range is an error, and no call is ever counted as served zero-copy."""
+    import numpy as np
+
+    from infera_amd import capi
+
+    if capi.device_count() > 0:
+        pytest.skip("this is the no-GPU behaviour")
+    a = np.zeros(4096, np.float32)
+    with pytest.raises(capi.InferaError, match="HIP backend unavailable"):
+        capi.register_host_memory(a)
+    with pytest.raises(capi.InferaError, match="not registered"):
+        capi.unregister_host_memory(a)
+    assert capi.zero_copy_calls() == 0

@@ -1,0 +1,147 @@
+"""Zero-copy host path (include/infera_hip.h: infera_hip_register_host_memory; the reference's ROADMAP.md:44 "zero-copy"): when the
+application has registered the memory its column runs live in, `infera_predict_columns` lets the GPU read the runs in place over PCIe --
+no CPU gather, no pinned staging, no H2D copy.  The results must be bit-for-bit those of the staged path (same kernels behind the
+gather, conversions with the reference's static_cast<float> roundings, infera_extension.cpp:211-222), for the BASELINE C2 / C4 models,
+for plans whose first kernel cannot read a column-major chunk (GPU transpose behind the gather), for DOUBLE / INTEGER / BIGINT / constant
+columns, unaligned runs and ragged row counts; a chunk with ANY column outside the registered ranges takes the staged path; registration
+errors are errors.  The oracle is the referee for one case of each model."""
+import threading
+
+import numpy as np
+import pytest
+
+from infera_amd import onnx_writer as W
+from infera_amd import synth
+
+
+def _table(k, n, seed=3):
+    """A [k][n] column-major table in ONE buffer (what gets registered) and its row-major twin."""
+    x = synth.table(seed, 0, n, k)
+    big = np.ascontiguousarray(x.T)
+    return big, x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["c2_mlp", "c4_logreg", "chain_30_100_2", "wide_dense_128_512_8"])
+@pytest.mark.parametrize("rows", [1, 33, 2048, 4099])
+def test_gpu_zero_copy_equals_staged_path(gpu_api, tmp_path, model, rows):
+    from oracle import oracle
+
+    blob, k = {"c2_mlp": (W.mlp((128, 256, 64, 1)), 128), "c4_logreg": (W.logreg_softmax(128, 10), 128),
+               "chain_30_100_2": (W.mlp((30, 100, 2), final_softmax=True), 30),
+               "wide_dense_128_512_8": (W.mlp((128, 512, 8)), 128)}[model]  # (first kernel = tiled Dense: no column-major reader -> GPU transpose)
+    path = W.write(str(tmp_path / "m.onnx"), blob)
+    big, x = _table(k, rows + 5)
+    cols = [big[c, 3:3 + rows] for c in range(k)]  # runs that start 12 bytes into their row: not 16-byte aligned
+    gpu_api.load_model("zc", path)
+    try:
+        staged = gpu_api.predict_columns("zc", cols)
+        before = gpu_api.zero_copy_calls()
+        gpu_api.register_host_memory(big)
+        try:
+            got = gpu_api.predict_columns("zc", cols)
+            assert gpu_api.zero_copy_calls() == before + 1
+            assert np.array_equal(got, staged), float(np.abs(got - staged).max())
+            aligned = [big[c, :rows] for c in range(k)]  # 16-byte aligned runs: the float4 path (when rows % 4 == 0)
+            assert np.array_equal(gpu_api.predict_columns("zc", aligned), gpu_api.predict("zc", x[:rows]))
+            assert gpu_api.zero_copy_calls() == before + 2
+        finally:
+            gpu_api.unregister_host_memory(big)
+        assert np.array_equal(gpu_api.predict_columns("zc", cols), staged) and gpu_api.zero_copy_calls() == before + 2  # staged again
+    finally:
+        gpu_api.unload_model("zc")
+    if rows in (33, 2048):
+        want = oracle.Model(path).predict(x[3:3 + rows])
+        assert np.all(np.abs(staged - want) <= 1e-4 * np.abs(want) + 1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_zero_copy_typed_and_constant_columns(gpu_api, tmp_path):
+    """DOUBLE / INTEGER / BIGINT / constant columns are converted by the GPU exactly as the CPU gather converts them."""
+    k, rows = 16, 3001
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp((k, 32, 1)))
+    rng = np.random.default_rng(9)
+    f64 = np.ascontiguousarray((rng.standard_normal((4, rows)) * (1 + 1e-9)).astype(np.float64))        # values that round on the way to f32
+    i32 = np.ascontiguousarray(rng.integers(-2**31, 2**31 - 1, (4, rows), dtype=np.int64).astype(np.int32))  # beyond 2^24: inexact in f32
+    i64 = np.ascontiguousarray(rng.integers(-2**62, 2**62, (4, rows), dtype=np.int64))
+    f32 = np.ascontiguousarray(rng.standard_normal((3, rows)).astype(np.float32))
+    const = np.array([0.375], np.float64)
+    cols = [f64[0], i32[0], i64[0], f32[0], f64[1], i32[1], i64[1], f32[1], f64[2], i32[2], i64[2], f32[2], f64[3], i32[3], i64[3], const]
+    gpu_api.load_model("zt", path)
+    regs = [f64, i32, i64, f32, const]
+    try:
+        staged = gpu_api.predict_columns("zt", cols, rows=rows)
+        before = gpu_api.zero_copy_calls()
+        for a in regs:
+            gpu_api.register_host_memory(a)
+        try:
+            got = gpu_api.predict_columns("zt", cols, rows=rows)
+            assert gpu_api.zero_copy_calls() == before + 1
+            assert np.array_equal(got.view(np.uint32), staged.view(np.uint32))
+            # one column from memory nobody registered: the whole chunk is staged, same result
+            outsider = list(cols)
+            outsider[3] = f32[0].copy()
+            assert np.array_equal(gpu_api.predict_columns("zt", outsider, rows=rows), staged)
+            assert gpu_api.zero_copy_calls() == before + 1
+        finally:
+            for a in regs:
+                gpu_api.unregister_host_memory(a)
+    finally:
+        gpu_api.unload_model("zt")
+
+
+@pytest.mark.gpu
+def test_gpu_zero_copy_long_call_and_registration_errors(gpu_api, tmp_path):
+    k = 16
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp((k, 8, 520, 1)))  # 300k rows: two device passes behind one gather (ADVICE r2 shape)
+    rows = 300_000
+    big, x = _table(k, rows)
+    cols = [big[c] for c in range(k)]
+    gpu_api.load_model("zl", path)
+    try:
+        staged = gpu_api.predict_columns("zl", cols)
+        gpu_api.register_host_memory(big)
+        try:
+            before = gpu_api.zero_copy_calls()
+            assert np.array_equal(gpu_api.predict_columns("zl", cols), staged)
+            assert gpu_api.zero_copy_calls() == before + 1
+            with pytest.raises(gpu_api.InferaError, match="overlaps"):
+                gpu_api.register_host_memory(big[2:4])
+        finally:
+            gpu_api.unregister_host_memory(big)
+        with pytest.raises(gpu_api.InferaError, match="not registered"):
+            gpu_api.unregister_host_memory(big)
+    finally:
+        gpu_api.unload_model("zl")
+
+
+@pytest.mark.gpu
+def test_gpu_zero_copy_concurrent_callers(gpu_api, tmp_path):
+    """8 threads x 40 chunks each over one registered table: every chunk equals its slice of one big staged call."""
+    k, chunk, nchunks = 128, 2048, 40
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp((128, 256, 64, 1)))
+    big, x = _table(k, chunk * nchunks, seed=11)
+    gpu_api.load_model("zcc", path)
+    try:
+        want = gpu_api.predict("zcc", x)
+        gpu_api.register_host_memory(big)
+        bad = []
+
+        def work(t):
+            for i in range(t, nchunks, 8):
+                cols = [big[c, i * chunk:(i + 1) * chunk] for c in range(k)]
+                got = gpu_api.predict_columns("zcc", cols)
+                if not np.array_equal(got, want[i * chunk:(i + 1) * chunk]):
+                    bad.append(i)
+
+        try:
+            before = gpu_api.zero_copy_calls()
+            th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not bad, bad
+            assert gpu_api.zero_copy_calls() == before + nchunks
+        finally:
+            gpu_api.unregister_host_memory(big)
+    finally:
+        gpu_api.unload_model("zcc")

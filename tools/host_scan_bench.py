@@ -19,6 +19,7 @@ ap.add_argument("--softmax", action="store_true")
 ap.add_argument("--pool", action="store_true", help="cache-resident per-thread chunk pool instead of the materialised table (round-1 behaviour)")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--double", action="store_true", help="DOUBLE columns (DuckDB's default floating type) instead of FLOAT")
+ap.add_argument("--register", action="store_true", help="register the host table (infera_hip_register_host_memory): the opt-in zero-copy path")
 ap.add_argument("--numa", default="off", choices=["auto", "off"], help="auto: bind the process to the CPUs of the (first) GPU's NUMA node before any thread exists")
 a = ap.parse_args()
 if a.numa == "auto":
@@ -44,6 +45,11 @@ print(f"devices={capi.get_devices()['devices']} workload={a.dims or a.workload} 
 import numpy as np  # noqa: E402
 table = None if a.pool else sqlmock.synth_table(a.rows, cols, 42, 16, np.float64 if a.double else np.float32)
 print("column type:", "DOUBLE" if a.double else "FLOAT")
+if a.register and table is not None:
+    import time
+    t0 = time.perf_counter()
+    capi.register_host_memory(table)
+    print(f"host table registered in {time.perf_counter() - t0:.3f} s ({table.nbytes / 1e9:.2f} GB): chunks are read in place by the GPU")
 for t in [int(x) for x in a.threads.split(",")]:
     if a.pool:
         sec, cs = sqlmock.bench_scan(fn, "m", a.rows, cols, t)
@@ -53,3 +59,6 @@ for t in [int(x) for x in a.threads.split(",")]:
     sec = sorted(secs)[len(secs) // 2]
     print(f"threads={t:>3}  {a.rows / sec / 1e6:>9.2f} M rows/s  ({a.rows * cols * 4 / sec / 1e9:.2f} GB/s of features)  "
           f"scans={[round(x, 4) for x in secs]}  checksum={cs:.4f}" + ("" if a.pool else f"\n             us/chunk/thread: {phases}"))
+if a.register and table is not None:
+    print("zero-copy calls:", capi.zero_copy_calls())
+    capi.unregister_host_memory(table)
