@@ -470,13 +470,13 @@ void pad_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t
 // every load of the workgroup is in flight at once.  Casts as the reference's ExtractFeatures (static_cast<float>,
 // infera_extension.cpp:211-222): f64 -> f32 and i64 -> f32 round to nearest even (v_cvt_f32_f64; __ll2float_rn), i32 -> f32 exact
 // rounding; a constant vector broadcasts its one value.  Runs whose address is not 16-byte aligned are read element-wise.
-__global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, int64_t rows, float *__restrict__ dst) {
+__global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, int64_t rows, float *__restrict__ dst, int rowblock) {
   const int c = blockIdx.x;
   const int type = tab.type[c] & 7;
   const bool constant = tab.type[c] & 8;
   const char *src = static_cast<const char *>(tab.ptr[c]);
   float *d = dst + int64_t(c) * rows;
-  const int64_t r0 = int64_t(blockIdx.y) * 4096, r1 = min(rows, r0 + 4096);
+  const int64_t r0 = int64_t(blockIdx.y) * rowblock, r1 = min(rows, r0 + rowblock);
   if (constant) {
     float v;
     if (type == 0) v = *reinterpret_cast<const float *>(src);
@@ -504,7 +504,11 @@ __global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, in
 
 void gather_columns_device(hipStream_t s, const ColumnTable &tab, int ncols, int64_t rows, float *dst) {
   if (rows <= 0 || ncols <= 0) return;
-  hipLaunchKernelGGL(gather_cols_kernel, dim3(unsigned(ncols), unsigned((rows + 4095) / 4096)), dim3(kBlock), 0, s, tab, rows, dst);
+  // (4096-row blocks = one workgroup per column of a DataChunk, two 16-byte loads per lane: 82-83 M rows/s on C2 at 8+ callers; 1024- /
+  // 512-row blocks -- more, thinner workgroups -- 73-75 M; more hardware queues (GPU_MAX_HW_QUEUES=8 / 16) 66-74 M.  One kernel streaming
+  // 1 GiB of registered memory reaches the copy engines' 57 GB/s (tools/ubench/pull_probe.hip): the gap is the per-chunk launch structure.)
+  constexpr int rowblock = 4096;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(unsigned(ncols), unsigned((rows + rowblock - 1) / rowblock)), dim3(kBlock), 0, s, tab, rows, dst, rowblock);
 }
 
 void transpose_cm(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t ncols) {
