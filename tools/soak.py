@@ -21,6 +21,11 @@ capi.load_model("r18s", W.write(f"{d}/r18s.onnx", W.resnet18(in_hw=64)))  # fuse
 imgs64 = synth.table(9, 0, 6, 3 * 64 * 64)
 tables = {k: synth.table(7, 0, 4096, c) for k, c in cols.items()}
 imgs = synth.table(8, 0, 24, 3 * 16 * 16)
+# the same tables column-major in REGISTERED memory: predict_columns over their runs is served zero-copy (the GPU reads them in place)
+# and must give the bits of the row-major host entry on the same rows
+tables_cm = {k: np.ascontiguousarray(t.T) for k, t in tables.items()}
+for t in tables_cm.values():
+    capi.register_host_memory(t)
 ref, ref_mu = {}, threading.Lock()
 errors, counts = [], [0] * nthreads
 stop = time.time() + secs
@@ -38,11 +43,16 @@ def worker(t):
     try:
         while time.time() < stop and not errors:
             r = rng.random()
-            if r < 0.80:
+            if r < 0.60:
                 k = rng.choice(list(cols))
                 lo = rng.randrange(0, 2048, 256)
                 n = rng.choice([1, 33, 500, 2048])
                 check((k, lo, n), capi.predict(k, tables[k][lo:lo + n]))
+            elif r < 0.80:
+                k = rng.choice(list(cols))
+                lo = rng.randrange(0, 2048, 256)
+                n = rng.choice([1, 33, 500, 2048])
+                check((k, lo, n), capi.predict_columns(k, [tables_cm[k][c, lo:lo + n] for c in range(cols[k])], rows=n))
             elif r < 0.88:
                 n = rng.choice([1, 5, 24])
                 check(("zoo", n), capi.predict_from_blob("zoo", imgs[:n].tobytes()))
@@ -77,6 +87,7 @@ th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
 [x.start() for x in th]
 [x.join(timeout=secs + 120) for x in th]
 stuck = sum(x.is_alive() for x in th)
-print(f"calls={sum(counts)} threads={nthreads} stuck={stuck} errors={errors[:3]}")
+print(f"calls={sum(counts)} threads={nthreads} stuck={stuck} errors={errors[:3]} zero_copy_calls={capi.zero_copy_calls()} "
+      f"wait={os.environ.get('INFERA_HOST_WAIT', 'poll')}")
 print("host RSS (s, MB):", samples)
 sys.exit(1 if (errors or stuck) else 0)
