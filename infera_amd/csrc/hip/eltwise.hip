@@ -506,7 +506,10 @@ void gather_columns_device(hipStream_t s, const ColumnTable &tab, int ncols, int
   if (rows <= 0 || ncols <= 0) return;
   // (4096-row blocks = one workgroup per column of a DataChunk, two 16-byte loads per lane: 82-83 M rows/s on C2 at 8+ callers; 1024- /
   // 512-row blocks -- more, thinner workgroups -- 73-75 M; more hardware queues (GPU_MAX_HW_QUEUES=8 / 16) 66-74 M.  One kernel streaming
-  // 1 GiB of registered memory reaches the copy engines' 57 GB/s (tools/ubench/pull_probe.hip): the gap is the per-chunk launch structure.)
+  // 1 GiB of registered memory reaches the copy engines' 57 GB/s (tools/ubench/pull_probe.hip): the gap is the per-chunk launch structure.
+  // Also measured and dropped: the fused MLP's tile kernel reading the column runs ITSELF (each workgroup pulling its own 32 rows of
+  // every column into LDS: one launch per chunk, bit-identical) -- 46 M rows/s against 82: 128-byte pieces per (column, tile) use the
+  // link far worse than this kernel's 1 KB wave instructions.)
   constexpr int rowblock = 4096;
   hipLaunchKernelGGL(gather_cols_kernel, dim3(unsigned(ncols), unsigned((rows + rowblock - 1) / rowblock)), dim3(kBlock), 0, s, tab, rows, dst, rowblock);
 }
