@@ -123,9 +123,10 @@ int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32
  * BIGINT converted with the reference's static_cast<float> roundings; constant vectors broadcast) into the column-major chunk the
  * model's first kernel reads.  Results are bit-identical to the staged path.  Chunks with any column outside a registered range, and
  * calls longer than one staging pass (> 24 MB of features), take the staged path as before.
- * CONTRACT: a registered range must stay mapped until it is unregistered, and must not be unregistered while a call that reads it is
- * in flight (calls are synchronous: none is, once they have returned).  The library never registers memory on its own -- a buffer
- * the caller frees behind a stale registration would fault the GPU.  Ranges must not overlap.  0 / -1 (+ infera_last_error). */
+ * CONTRACT: a registered range must stay mapped until it is unregistered.  The library never registers memory on its own -- a buffer
+ * the caller frees behind a stale registration would fault the GPU.  Ranges must not overlap each other; they MAY share memory pages
+ * (neighbours on the heap): the runtime pins whole pages, so ranges whose page spans touch share one registration, which lives until
+ * the last of them is unregistered.  Both calls wait for zero-copy calls that are in flight.  0 / -1 (+ infera_last_error). */
 int32_t infera_hip_register_host_memory(const void *base, uint64_t bytes);
 int32_t infera_hip_unregister_host_memory(const void *base);
 /* infera_predict_columns calls served zero-copy so far (tests, bench) */

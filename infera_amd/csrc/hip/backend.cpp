@@ -72,45 +72,68 @@ struct ThreadCtx {
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // completion of the pass that last used staging slot 0 / 1
   hipEvent_t done_ev = nullptr;                // blocking-sync event: a host-ABI call sleeps on it instead of spinning
   hipEvent_t poll_ev = nullptr;                // INFERA_HOST_WAIT=poll: queried between naps
-  double wait_ema_ns = 40000.0;                // recent wait of this context's calls (poll mode: length of the first nap)
-  // waits for everything enqueued on `stream` so far
-  void wait_stream() {
+  // Sleep-poll (INFERA_HOST_WAIT=poll): ROCm's blocking event wait spins before it blocks and pays an interrupt + wake-up per chunk; under
+  // a CPU quota (16 CPUs feeding 8 GPUs) CPU time per chunk is what bounds the scan.  Nap for most of what this context's recent waits
+  // OF THE SAME KIND took (`key`: model and row count -- a context that served a 30 ms image batch must not sleep 2 ms on the 50 us table
+  // chunk that follows it), then query between short naps: one or two clock_nanosleep calls and a few queries per chunk.  With no
+  // estimate (first wait of a kind on this context) the naps grow with the time already waited (a quarter of it, 3..200 us).
+  struct WaitEstimate {
+    double ema_ns = 0.0;
+    uint64_t key = 0;
+  };
+  WaitEstimate wait_est, pipe_est;
+  template <class Query>
+  static void poll_until(Query &&query, WaitEstimate &est, uint64_t key) {
+    static thread_local bool slack_set = false;
+    if (!slack_set) {
+      (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // default slack is 50 us: a 20 us nap would last 70
+      slack_set = true;
+    }
+    if (key != est.key || key == 0) {
+      est.key = key;
+      est.ema_ns = 0.0;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto waited_ns = [&] { return std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); };
+    auto nap = [](double ns) {
+      if (ns < 1500.0) return;
+      const long long n = (long long)ns;
+      timespec ts{time_t(n / 1000000000LL), long(n % 1000000000LL)};
+      (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
+    };
+    const bool known = est.ema_ns > 0.0;
+    if (known) nap(std::min(est.ema_ns * Config::get().host_poll_first, 2.0e6));
+    for (;;) {
+      const hipError_t e = query();
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery / hipStreamQuery");
+      nap(known ? std::max(3000.0, std::min(est.ema_ns * Config::get().host_poll_next, 50000.0))
+                : std::max(3000.0, std::min(waited_ns() * 0.25, 200000.0)));
+    }
+    (void)hipGetLastError();  // hipErrorNotReady from the queries must not surface at the next launch check
+    const double waited = waited_ns();
+    est.ema_ns = known ? 0.75 * est.ema_ns + 0.25 * waited : waited;
+  }
+  // waits for `ev` (already recorded) the way INFERA_HOST_WAIT says: poll modes nap and query, the others synchronise
+  void wait_event(hipEvent_t ev, WaitEstimate &est, uint64_t key) {
+    if (Config::get().host_wait >= 2) poll_until([&] { return hipEventQuery(ev); }, est, key);
+    else HIP_TRY(hipEventSynchronize(ev));
+  }
+  // waits for everything enqueued on `stream` so far.  `key` identifies the kind of work (0 = unknown)
+  void wait_stream(uint64_t key = 0) {
     const int mode = Config::get().host_wait;
     if (mode == 1) {
       HIP_TRY(hipStreamSynchronize(stream));
       return;
     }
-    if (mode >= 2) {
-      // Sleep-poll: ROCm's blocking event wait spins before it blocks and pays an interrupt + wake-up per chunk; under a CPU quota
-      // (16 CPUs feeding 8 GPUs) CPU time per chunk is what bounds the scan.  Nap for most of what this context's recent calls
-      // waited, then query between short naps: one or two clock_nanosleep calls and a few event queries per chunk.
-      static thread_local bool slack_set = false;
-      if (!slack_set) {
-        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // default slack is 50 us: a 20 us nap would last 70
-        slack_set = true;
-      }
-      // (mode 3, "pollq": hipStreamQuery instead of a recorded event -- no marker packet on the queue, one API call less per chunk)
-      if (mode == 2) {
-        if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(poll_ev, stream));
-      }
-      const auto t0 = std::chrono::steady_clock::now();
-      auto nap = [](double ns) {
-        if (ns < 1500.0) return;
-        timespec ts{0, long(ns)};
-        if (ts.tv_nsec >= 1000000000L) ts = timespec{ts.tv_nsec / 1000000000L, ts.tv_nsec % 1000000000L};
-        (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
-      };
-      nap(std::min(wait_ema_ns * Config::get().host_poll_first, 2.0e6));
-      for (;;) {
-        const hipError_t e = mode == 2 ? hipEventQuery(poll_ev) : hipStreamQuery(stream);
-        if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery / hipStreamQuery");
-        nap(std::max(3000.0, std::min(wait_ema_ns * Config::get().host_poll_next, 50000.0)));
-      }
-      (void)hipGetLastError();  // hipErrorNotReady from the queries must not surface at the next launch check
-      const double waited = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
-      wait_ema_ns = 0.75 * wait_ema_ns + 0.25 * waited;
+    if (mode == 3) {  // "pollq": hipStreamQuery instead of a recorded event -- no marker packet on the queue, one API call less per chunk
+      poll_until([&] { return hipStreamQuery(stream); }, wait_est, key);
+      return;
+    }
+    if (mode == 2) {
+      if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(poll_ev, stream));
+      poll_until([&] { return hipEventQuery(poll_ev); }, wait_est, key);
       return;
     }
     if (!done_ev) HIP_TRY(hipEventCreateWithFlags(&done_ev, hipEventBlockingSync | hipEventDisableTiming));
@@ -1324,7 +1347,8 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
     auto drain = [&](int k) {
       if (!pend_nr[k]) return;
       const uint64_t t0 = now_ns();
-      HIP_TRY(hipEventSynchronize(ctx.pipe_ev[k]));
+      // (poll mode: nap instead of hipEventSynchronize's spin -- a BLOB batch is milliseconds of GPU time per pass)
+      ctx.wait_event(ctx.pipe_ev[k], ctx.pipe_est, m.uid * 0x9E3779B97F4A7C15ull ^ uint64_t(pend_nr[k]) ^ (uint64_t(1) << 63));
       const uint64_t t1 = now_ns();
       std::memcpy(h_out + size_t(pend_r0[k]) * (out_row / 4), slot_ptr(ctx.pin_out, k, out_row), size_t(pend_nr[k]) * out_row);
       g_phase_ns[kPhWait].fetch_add(t1 - t0, std::memory_order_relaxed);
@@ -1444,7 +1468,7 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
         enq_ns += now_ns() - c;
       }
       const uint64_t t_e = now_ns();
-      ctx.wait_stream();
+      ctx.wait_stream(m.uid * 0x9E3779B97F4A7C15ull ^ uint64_t(rows) ^ (uint64_t(split) << 56));
       const uint64_t t_w = now_ns();
       std::memcpy(h_out, ctx.pin_out, size_t(rows) * out_row);
       const uint64_t t_c = now_ns();
@@ -1523,7 +1547,7 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
       enqueue_pass(ctx.pin_in, ctx.dev_in, ctx.dev_out, ctx.pin_out, nr, single_pass, admitted.in_flight, true);
     }
     const uint64_t t_e = now_ns();
-    ctx.wait_stream();  // (spinning on hipStreamQuery instead measured slower: 41 vs 69 M rows/s at 16 threads)
+    ctx.wait_stream(m.uid * 0x9E3779B97F4A7C15ull ^ uint64_t(nr));  // (spinning on hipStreamQuery instead measured slower: 41 vs 69 M rows/s at 16 threads)
     const uint64_t t_w = now_ns();
     std::memcpy(h_out + size_t(r0) * (out_row / 4), ctx.pin_out, size_t(nr) * out_row);
     const uint64_t t_c = now_ns();
@@ -1540,28 +1564,29 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
 }  // namespace
 
 // ---- registered host memory (zero-copy host path) -----------------------------------------------------------------------
+// The runtime pins whole pages, callers register byte ranges (numpy arrays, malloc'ed buffers: neighbours on the heap share pages).
+// So a registered RANGE (what lookups test against) points at a page BLOCK (what hipHostRegister was called on); ranges whose page
+// spans touch are served by ONE block: the blocks they overlap are replaced by a registration of their union (contiguous, because
+// they overlap), and a block lives until its last range is unregistered.  Replacing a block unmaps it for a moment, so calls that
+// read registered memory hold g_zc_inflight shared from their lookup to their completion and (un)registration takes it exclusively --
+// which also makes unregistering safe against calls that are still in flight.
 namespace {
-struct HostRange {
-  uintptr_t base, end;     // as registered by the caller
-  uintptr_t page_base;     // what was handed to hipHostRegister (page-aligned)
-  intptr_t dev_delta;      // device-visible address = host address + dev_delta
+struct PageBlock {
+  uintptr_t pb, pe;    // page-aligned span handed to hipHostRegister
+  intptr_t dev_delta;  // device-visible address = host address + dev_delta
+  int refs;            // registered ranges inside
 };
-std::shared_mutex g_ranges_mu;
-std::vector<HostRange> g_ranges;  // sorted by base, non-overlapping
+struct HostRange {
+  uintptr_t base, end;  // as registered by the caller
+  PageBlock *block;
+};
+std::shared_mutex g_ranges_mu;      // g_ranges / g_blocks
+std::shared_mutex g_zc_inflight;    // shared: a call reading registered memory is in flight
+std::vector<HostRange> g_ranges;    // sorted by base, non-overlapping
+std::vector<std::unique_ptr<PageBlock>> g_blocks;
 std::atomic<size_t> g_nranges{0};
-}  // namespace
 
-void register_host_memory(const void *base, size_t bytes) {
-  if (!base || !bytes) throw InferaError::null_pointer();
-  const auto &ds = devices();
-  if (ds.ids.empty()) throw InferaError::onnx("HIP backend unavailable: " + ds.why);
-  const uintptr_t b = reinterpret_cast<uintptr_t>(base), e = b + bytes;
-  const uintptr_t pb = b & ~uintptr_t(4095), pe = (e + 4095) & ~uintptr_t(4095);
-  std::unique_lock<std::shared_mutex> lk(g_ranges_mu);
-  for (const auto &r : g_ranges)
-    if (b < r.end && r.base < e) throw InferaError::onnx("host memory range overlaps a registered range");
-  UnsafeOpGuard guard;
-  HIP_TRY(hipSetDevice(ds.ids[0]));
+intptr_t hip_register_span(uintptr_t pb, uintptr_t pe) {
   // portable + mapped: visible to every selected GPU; the pages stay where they are (no copy), pinned until unregistered
   HIP_TRY(hipHostRegister(reinterpret_cast<void *>(pb), pe - pb, hipHostRegisterPortable | hipHostRegisterMapped));
   void *dptr = nullptr;
@@ -1570,22 +1595,77 @@ void register_host_memory(const void *base, size_t bytes) {
     (void)hipHostUnregister(reinterpret_cast<void *>(pb));
     hip_fail(ge, "hipHostGetDevicePointer");
   }
-  HostRange r{b, e, pb, intptr_t(reinterpret_cast<uintptr_t>(dptr)) - intptr_t(pb)};
+  return intptr_t(reinterpret_cast<uintptr_t>(dptr)) - intptr_t(pb);
+}
+}  // namespace
+
+void register_host_memory(const void *base, size_t bytes) {
+  if (!base || !bytes) throw InferaError::null_pointer();
+  const auto &ds = devices();
+  if (ds.ids.empty()) throw InferaError::onnx("HIP backend unavailable: " + ds.why);
+  const uintptr_t b = reinterpret_cast<uintptr_t>(base), e = b + bytes;
+  uintptr_t pb = b & ~uintptr_t(4095), pe = (e + 4095) & ~uintptr_t(4095);
+  std::unique_lock<std::shared_mutex> drained(g_zc_inflight);  // no call is reading registered memory while blocks may be replaced
+  std::unique_lock<std::shared_mutex> lk(g_ranges_mu);
+  for (const auto &r : g_ranges)
+    if (b < r.end && r.base < e) throw InferaError::onnx("host memory range overlaps a registered range");
+  UnsafeOpGuard guard;
+  HIP_TRY(hipSetDevice(ds.ids[0]));
+  std::vector<PageBlock *> hit;  // blocks whose pages the new span touches
+  for (auto &blk : g_blocks)
+    if (pb < blk->pe && blk->pb < pe) hit.push_back(blk.get());
+  PageBlock *target = nullptr;
+  if (hit.size() == 1 && hit[0]->pb <= pb && pe <= hit[0]->pe) {
+    target = hit[0];  // every page is already pinned by a neighbour's block
+    target->refs++;
+  } else {
+    int refs = 1;
+    for (PageBlock *h : hit) {
+      pb = std::min(pb, h->pb);
+      pe = std::max(pe, h->pe);
+      refs += h->refs;
+    }
+    for (PageBlock *h : hit) (void)hipHostUnregister(reinterpret_cast<void *>(h->pb));
+    intptr_t delta = 0;
+    try {
+      delta = hip_register_span(pb, pe);
+    } catch (...) {
+      // put the old blocks back (their pages were registrable a moment ago); ranges keep pointing at them
+      for (PageBlock *h : hit) {
+        try {
+          h->dev_delta = hip_register_span(h->pb, h->pe);
+        } catch (...) {
+        }
+      }
+      throw;
+    }
+    auto fresh = std::make_unique<PageBlock>(PageBlock{pb, pe, delta, refs});
+    target = fresh.get();
+    for (auto &r : g_ranges)
+      if (std::find(hit.begin(), hit.end(), r.block) != hit.end()) r.block = target;
+    g_blocks.erase(std::remove_if(g_blocks.begin(), g_blocks.end(), [&](const std::unique_ptr<PageBlock> &x) { return std::find(hit.begin(), hit.end(), x.get()) != hit.end(); }),
+                   g_blocks.end());
+    g_blocks.push_back(std::move(fresh));
+  }
+  HostRange r{b, e, target};
   g_ranges.insert(std::upper_bound(g_ranges.begin(), g_ranges.end(), r, [](const HostRange &x, const HostRange &y) { return x.base < y.base; }), r);
   g_nranges.store(g_ranges.size(), std::memory_order_release);
 }
 
 bool unregister_host_memory(const void *base) {
   const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+  std::unique_lock<std::shared_mutex> drained(g_zc_inflight);  // (waits for calls that still read the range)
   std::unique_lock<std::shared_mutex> lk(g_ranges_mu);
   for (size_t i = 0; i < g_ranges.size(); i++)
     if (g_ranges[i].base == b) {
-      const uintptr_t pb = g_ranges[i].page_base;
+      PageBlock *blk = g_ranges[i].block;
       g_ranges.erase(g_ranges.begin() + long(i));
       g_nranges.store(g_ranges.size(), std::memory_order_release);
-      // every GPU read of the range was synchronised by the call that issued it (host-ABI calls return after their stream is idle)
-      UnsafeOpGuard guard;
-      (void)hipHostUnregister(reinterpret_cast<void *>(pb));
+      if (--blk->refs == 0) {  // (a block shared with neighbours stays pinned until the last of them goes)
+        UnsafeOpGuard guard;
+        (void)hipHostUnregister(reinterpret_cast<void *>(blk->pb));
+        g_blocks.erase(std::remove_if(g_blocks.begin(), g_blocks.end(), [&](const std::unique_ptr<PageBlock> &x) { return x.get() == blk; }), g_blocks.end());
+      }
       return true;
     }
   return false;
@@ -1599,10 +1679,30 @@ const void *lookup_host_memory(const void *p, size_t bytes) {
   if (it == g_ranges.begin()) return nullptr;
   --it;
   if (a < it->base || a + bytes > it->end) return nullptr;
-  return reinterpret_cast<const void *>(intptr_t(a) + it->dev_delta);
+  return reinterpret_cast<const void *>(intptr_t(a) + it->block->dev_delta);
+}
+
+bool lookup_host_memory_many(size_t n, const void *const *ptrs, const size_t *bytes, const void **out) {
+  if (g_nranges.load(std::memory_order_acquire) == 0) return false;
+  std::shared_lock<std::shared_mutex> lk(g_ranges_mu);  // one lock for the whole chunk's columns
+  const HostRange *hint = nullptr;                      // (columns of one table usually lie in one range)
+  for (size_t i = 0; i < n; i++) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptrs[i]);
+    if (!hint || a < hint->base || a + bytes[i] > hint->end) {
+      auto it = std::upper_bound(g_ranges.begin(), g_ranges.end(), a, [](uintptr_t v, const HostRange &r) { return v < r.base; });
+      if (it == g_ranges.begin()) return false;
+      --it;
+      if (a < it->base || a + bytes[i] > it->end) return false;
+      hint = &*it;
+    }
+    out[i] = reinterpret_cast<const void *>(intptr_t(a) + hint->block->dev_delta);
+  }
+  return true;
 }
 
 size_t registered_host_ranges() { return g_nranges.load(std::memory_order_acquire); }
+
+std::shared_lock<std::shared_mutex> zero_copy_in_flight() { return std::shared_lock<std::shared_mutex>(g_zc_inflight); }
 
 void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows) {
   const size_t in_per_row = size_t(m.plan.in_per_row());

@@ -12,6 +12,7 @@
 
 #include <functional>
 #include <memory>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -132,12 +133,17 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
 // false: the caller then stages through the CPU as usual).
 using DeviceFillFn = std::function<void(hipStream_t stream, float *dst, int64_t row0, int64_t nrows)>;
 bool run_host_device_fill(const LoadedModel &m, const DeviceFillFn &dfill, float *h_out, int64_t rows);
-// Registered host memory: [base, base + bytes) is pinned and mapped into every selected GPU (hipHostRegister); lookup() returns the
-// device-visible address of `p` when [p, p + bytes) lies inside one registered range, else nullptr.  Thread-safe.
+// Registered host memory: [base, base + bytes) is pinned and mapped into every selected GPU (hipHostRegister, whole pages: ranges
+// that share a page share one registration); lookup() returns the device-visible address of `p` when [p, p + bytes) lies inside one
+// registered range, else nullptr.  Thread-safe; (un)registering waits for the zero-copy calls in flight.
 void register_host_memory(const void *base, size_t bytes);
 bool unregister_host_memory(const void *base);
 const void *lookup_host_memory(const void *p, size_t bytes);
+// the same for n runs under ONE lock: false unless every run lies inside a registered range
+bool lookup_host_memory_many(size_t n, const void *const *ptrs, const size_t *bytes, const void **out);
 size_t registered_host_ranges();
+// held (shared) by a call from its lookup until the GPU has finished reading the registered memory: (un)registration waits for it
+std::shared_lock<std::shared_mutex> zero_copy_in_flight();
 // whether a host call of `rows` rows can be handed to the plan's first kernel as column-major chunks (one device pass per host pass)
 bool colmajor_direct_ok(const LoadedModel &m, int64_t rows);
 

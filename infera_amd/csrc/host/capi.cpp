@@ -516,16 +516,17 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
       bool served = false;
       if (ncols > 0 && ncols <= uintptr_t(kern::kMaxZeroCopyCols) && registered_host_ranges() > 0 && Config::get().host_zero_copy) {
         kern::ColumnTable tab;
-        size_t esz[kern::kMaxZeroCopyCols];
-        bool all = true;
-        for (uintptr_t c = 0; c < ncols && all; c++) {
+        size_t esz[kern::kMaxZeroCopyCols], run_bytes[kern::kMaxZeroCopyCols];
+        const void *host_ptr[kern::kMaxZeroCopyCols];
+        for (uintptr_t c = 0; c < ncols; c++) {
           const InferaColumn &col = columns[c];
           esz[c] = col.type == INFERA_COL_FLOAT || col.type == INFERA_COL_INTEGER ? 4 : 8;
-          const void *d = lookup_host_memory(col.data, (col.is_constant ? 1 : size_t(rows)) * esz[c]);
-          all = d != nullptr;
-          tab.ptr[c] = d;
+          host_ptr[c] = col.data;
+          run_bytes[c] = (col.is_constant ? 1 : size_t(rows)) * esz[c];
           tab.type[c] = static_cast<unsigned char>(int(col.type) | (col.is_constant ? 8 : 0));
         }
+        const auto reading = zero_copy_in_flight();  // (un)registration waits until this call has finished with the registered runs
+        const bool all = lookup_host_memory_many(ncols, host_ptr, run_bytes, tab.ptr);
         if (all)
           served = run_host_device_fill(*m, [&](hipStream_t stream, float *dst, int64_t r0, int64_t nr) {
             // (Measured and dropped, round 3: ONE hipMemcpyBatchAsync of the 128 runs on the copy engines instead of this pulling kernel --

@@ -5,6 +5,7 @@ gather, conversions with the reference's static_cast<float> roundings, infera_ex
 for plans whose first kernel cannot read a column-major chunk (GPU transpose behind the gather), for DOUBLE / INTEGER / BIGINT / constant
 columns, unaligned runs and ragged row counts; a chunk with ANY column outside the registered ranges takes the staged path; registration
 errors are errors.  The oracle is the referee for one case of each model."""
+import ctypes as C
 import threading
 
 import numpy as np
@@ -14,10 +15,21 @@ from infera_amd import onnx_writer as W
 from infera_amd import synth
 
 
+def _page_aligned(shape, dtype):
+    """An array that owns whole 4 KiB pages (registration is per page: two registered ranges must not share one)."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.zeros((n + 4095) // 4096 * 4096 + 4096, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    a = raw[off:off + n].view(dtype).reshape(shape)
+    assert a.ctypes.data % 4096 == 0 and a.flags.c_contiguous
+    return a
+
+
 def _table(k, n, seed=3):
-    """A [k][n] column-major table in ONE buffer (what gets registered) and its row-major twin."""
+    """A [k][n] column-major table in ONE page-aligned buffer (what gets registered) and its row-major twin."""
     x = synth.table(seed, 0, n, k)
-    big = np.ascontiguousarray(x.T)
+    big = _page_aligned((k, n), np.float32)
+    big[...] = x.T
     return big, x
 
 
@@ -61,11 +73,13 @@ def test_gpu_zero_copy_typed_and_constant_columns(gpu_api, tmp_path):
     k, rows = 16, 3001
     path = W.write(str(tmp_path / "m.onnx"), W.mlp((k, 32, 1)))
     rng = np.random.default_rng(9)
-    f64 = np.ascontiguousarray((rng.standard_normal((4, rows)) * (1 + 1e-9)).astype(np.float64))        # values that round on the way to f32
-    i32 = np.ascontiguousarray(rng.integers(-2**31, 2**31 - 1, (4, rows), dtype=np.int64).astype(np.int32))  # beyond 2^24: inexact in f32
-    i64 = np.ascontiguousarray(rng.integers(-2**62, 2**62, (4, rows), dtype=np.int64))
-    f32 = np.ascontiguousarray(rng.standard_normal((3, rows)).astype(np.float32))
-    const = np.array([0.375], np.float64)
+    f64, i32, i64, f32, const = (_page_aligned((4, rows), np.float64), _page_aligned((4, rows), np.int32), _page_aligned((4, rows), np.int64),
+                                 _page_aligned((3, rows), np.float32), _page_aligned((1,), np.float64))
+    f64[...] = rng.standard_normal((4, rows)) * (1 + 1e-9)                                 # values that round on the way to f32
+    i32[...] = rng.integers(-2**31, 2**31 - 1, (4, rows), dtype=np.int64).astype(np.int32)  # beyond 2^24: inexact in f32
+    i64[...] = rng.integers(-2**62, 2**62, (4, rows), dtype=np.int64)
+    f32[...] = rng.standard_normal((3, rows)).astype(np.float32)
+    const[0] = 0.375
     cols = [f64[0], i32[0], i64[0], f32[0], f64[1], i32[1], i64[1], f32[1], f64[2], i32[2], i64[2], f32[2], f64[3], i32[3], i64[3], const]
     gpu_api.load_model("zt", path)
     regs = [f64, i32, i64, f32, const]
@@ -107,6 +121,7 @@ def test_gpu_zero_copy_long_call_and_registration_errors(gpu_api, tmp_path):
             assert gpu_api.zero_copy_calls() == before + 1
             with pytest.raises(gpu_api.InferaError, match="overlaps"):
                 gpu_api.register_host_memory(big[2:4])
+            assert np.array_equal(gpu_api.predict_columns("zl", cols), staged)
         finally:
             gpu_api.unregister_host_memory(big)
         with pytest.raises(gpu_api.InferaError, match="not registered"):
@@ -145,3 +160,44 @@ def test_gpu_zero_copy_concurrent_callers(gpu_api, tmp_path):
             gpu_api.unregister_host_memory(big)
     finally:
         gpu_api.unload_model("zcc")
+
+
+@pytest.mark.gpu
+def test_gpu_zero_copy_ranges_that_share_pages(gpu_api, tmp_path):
+    """The runtime pins whole pages, callers register byte ranges: neighbours on the heap (numpy arrays, malloc'ed buffers) share
+    pages.  Ranges whose page spans touch are served by one registration of their union; a shared block lives until its LAST range
+    is unregistered; columns may come from several ranges at once."""
+    k, rows = 16, 1000  # 4000-byte runs: every column shares pages with its neighbours
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp((k, 32, 1)))
+    raw = _page_aligned((k * rows + 64,), np.float32)
+    x = synth.table(21, 0, rows, k)
+    cols = []
+    for c in range(k):
+        run = raw[c * rows + 3:c * rows + 3 + rows - 6]  # k separate, non-overlapping ranges packed into the same pages
+        run[...] = x[:rows - 6, c]
+        cols.append(run)
+    gpu_api.load_model("zp", path)
+    try:
+        staged = gpu_api.predict_columns("zp", cols)
+        before = gpu_api.zero_copy_calls()
+        for run in cols[::-1]:  # (any order)
+            gpu_api.register_host_memory(run)
+        try:
+            assert np.array_equal(gpu_api.predict_columns("zp", cols), staged) and gpu_api.zero_copy_calls() == before + 1
+            for run in cols[:8]:  # half of the ranges go: the shared pages must stay pinned for the others
+                gpu_api.unregister_host_memory(run)
+            assert np.array_equal(gpu_api.predict_columns("zp", cols), staged) and gpu_api.zero_copy_calls() == before + 1  # staged: 8 columns are outside
+            assert np.array_equal(gpu_api.predict_columns("zp", cols[8:] + cols[8:]), gpu_api.predict("zp", np.concatenate([x[:rows - 6, 8:]] * 2, axis=1)))
+            assert gpu_api.zero_copy_calls() == before + 2
+            for run in cols[:8]:  # ... and can come back
+                gpu_api.register_host_memory(run)
+            assert np.array_equal(gpu_api.predict_columns("zp", cols), staged) and gpu_api.zero_copy_calls() == before + 3
+        finally:
+            for run in cols:
+                try:
+                    gpu_api.unregister_host_memory(run)
+                except gpu_api.InferaError:
+                    pass
+        assert np.array_equal(gpu_api.predict_columns("zp", cols), staged) and gpu_api.zero_copy_calls() == before + 3
+    finally:
+        gpu_api.unload_model("zp")
