@@ -100,8 +100,8 @@ const Config &Config::get() {
     c.host_poll_first = env_frac("INFERA_HOST_POLL_FIRST", 0.75);
     c.host_poll_next = env_frac("INFERA_HOST_POLL_NEXT", 0.1);
     c.host_ctx_affinity = env_flag("INFERA_HOST_CTX_AFFINITY", true);
-    const std::string hg = env_or("INFERA_HOST_GATHER", "memcpy");
-    c.host_gather = hg == "nt" ? 1 : hg == "ntpf" ? 2 : 0;
+    const std::string hg = env_or("INFERA_HOST_GATHER", "il");
+    c.host_gather = hg == "memcpy" ? 0 : hg == "nt" ? 1 : hg == "ntpf" ? 2 : hg == "ilnt" ? 4 : 3;
     c.max_inflight_total = int(env_u64("INFERA_MAX_INFLIGHT_TOTAL", 0));
     c.probe_elide_h2d = int(env_u64("INFERA_HOST_PROBE_ELIDE_H2D", 0));
     c.host_zero_copy = env_flag("INFERA_HOST_ZERO_COPY", true);

@@ -103,9 +103,13 @@ struct Config {
                                       //   context's recent wait, then this share between event queries
   bool host_ctx_affinity;             // INFERA_HOST_CTX_AFFINITY=0|1 (default 1)  a caller thread re-leases the staging context it used last when free:
                                       //   its pinned staging lines are still in that core's caches (CPU per chunk 88.9 -> 76.9 us at 16 callers)
-  int host_gather;                    // INFERA_HOST_GATHER=memcpy|nt|ntpf  how FLOAT column runs are copied into pinned staging: memcpy (0),
-                                      //   non-temporal 64-byte stores (1: no read-for-ownership of the staging lines, which the DMA engine
-                                      //   reads from DRAM anyway), the same + software prefetch of the next column run's first lines (2)
+  int host_gather;                    // INFERA_HOST_GATHER=il|memcpy|nt|ntpf|ilnt  how FLOAT column runs are copied into pinned staging.  il (3, default
+                                      //   since round 3): FOUR runs in lockstep, 512 bytes of each in turn -- four sequential streams keep more
+                                      //   line fills in flight than one 8 KiB run after the other (gather 52-58 -> 42-44 us per chunk at 4-24
+                                      //   callers; 2 streams gain little, 8 and 16 lose: the runs are 8 KiB apart in staging and alias in L1;
+                                      //   INFERA_GATHER_IL_STREAMS / _BYTES for A/B).  memcpy (0) one run at a time; nt (1) non-temporal 64-byte
+                                      //   stores, ntpf (2) + prefetch of the next run, ilnt (4) interleaved + non-temporal: all measured worse
+                                      //   at scale (profiles/r03_gather_interleave_sweep.txt, r03_host_cpu_ab_wait_gather.txt)
   int max_inflight_total;             // INFERA_MAX_INFLIGHT_TOTAL=n  host-ABI calls the PROCESS admits between first H2D and sync over all
                                       //   GPUs (0 = no process-wide limit; the per-GPU limit is INFERA_MAX_INFLIGHT)
   int probe_elide_h2d;                // INFERA_HOST_PROBE_ELIDE_H2D=1|2  MEASUREMENT ONLY (bench.py --elide-h2d): host-path H2D copies move a

@@ -174,6 +174,44 @@ __attribute__((target("avx2"))) void stream_copy_f32_avx2(float *d, const float 
 }
 }  // namespace
 
+namespace {
+// INFERA_HOST_GATHER=il (default): several column runs copied in lockstep, a block of each in turn -- independent sequential streams
+// keep more cache-line fills in flight than one (the copy of one 8 KiB run is latency-bound at the start of every run: a new page, a
+// new DRAM row, a hardware prefetcher that has to find the stream again).  Four streams of 512 bytes: C2's gather 52-58 -> 42-44 us per
+// chunk at 4..24 callers, the 8-slot link-elided probe 325 -> 372 M rows/s; two streams gain little, eight and sixteen LOSE (the runs lie
+// 8 KiB apart in staging: their lines alias in the L1).
+constexpr int kMaxIl = 16;
+__attribute__((target("avx2"))) void copy_interleaved_f32(float *const *d, const float *const *s, int ns, size_t n, size_t blk, bool nt) {
+  size_t i = 0;
+  for (; i + blk <= n; i += blk)
+    for (int k = 0; k < ns; k++) {
+      const float *sp = s[k] + i;
+      float *dp = d[k] + i;
+      if (nt && (reinterpret_cast<uintptr_t>(dp) & 31) == 0)
+        for (size_t v = 0; v < blk; v += 8) _mm256_stream_ps(dp + v, _mm256_loadu_ps(sp + v));
+      else
+        for (size_t v = 0; v < blk; v += 8) _mm256_storeu_ps(dp + v, _mm256_loadu_ps(sp + v));
+    }
+  for (int k = 0; k < ns; k++)
+    if (i < n) std::memcpy(d[k] + i, s[k] + i, (n - i) * sizeof(float));
+}
+// the same for DOUBLE runs (DuckDB's default floating type): vcvtpd2ps = static_cast<float>, blk source elements per turn
+__attribute__((target("avx2"))) void convert_interleaved_f64(float *const *d, const double *const *s, int ns, size_t n, size_t blk) {
+  size_t i = 0;
+  for (; i + blk <= n; i += blk)
+    for (int k = 0; k < ns; k++) {
+      const double *sp = s[k] + i;
+      float *dp = d[k] + i;
+      for (size_t v = 0; v < blk; v += 8) {
+        _mm_storeu_ps(dp + v, _mm256_cvtpd_ps(_mm256_loadu_pd(sp + v)));
+        _mm_storeu_ps(dp + v + 4, _mm256_cvtpd_ps(_mm256_loadu_pd(sp + v + 4)));
+      }
+    }
+  for (int k = 0; k < ns; k++)
+    for (size_t r = i; r < n; r++) d[k][r] = static_cast<float>(s[k][r]);
+}
+}  // namespace
+
 // Column-major staging: rows [row0, row0 + nrows) of column c -> dst[c * nrows ...] as f32, the column's own run converted in
 // place of the plain memcpy a FLOAT column gets (static_cast<float> per the reference, infera_extension.cpp:211-222: RNE for
 // DOUBLE -- what vcvtpd2ps does).  DuckDB's default floating type is DOUBLE, so this is the common case of a real table: no
@@ -184,6 +222,36 @@ void gather_column_major(const infera::InferaColumn *cols, size_t c0, size_t c1,
   const int mode = have_avx2 ? Config::get().host_gather : 0;
   bool streamed = false;
   for (size_t c = c0; c < c1; c++) {
+    if (mode >= 3) {  // several plain FLOAT runs in lockstep
+      static const int il_streams = [] { const char *e = getenv("INFERA_GATHER_IL_STREAMS"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : v > kMaxIl ? kMaxIl : v; }();
+      static const size_t il_floats = [] { const char *e = getenv("INFERA_GATHER_IL_BYTES"); const int v = e ? atoi(e) : 512; return size_t(v < 64 ? 64 : v) / 32 * 8; }();
+      int ns = 0;
+      float *dn[kMaxIl];
+      const float *sn[kMaxIl];
+      while (ns < il_streams && c + size_t(ns) < c1 && !cols[c + size_t(ns)].is_constant && cols[c + size_t(ns)].type == infera::INFERA_COL_FLOAT) {
+        dn[ns] = dst + (c + size_t(ns)) * nrows;
+        sn[ns] = static_cast<const float *>(cols[c + size_t(ns)].data) + row0;
+        ns++;
+      }
+      if (ns >= 2) {
+        copy_interleaved_f32(dn, sn, ns, nrows, il_floats, mode == 4);
+        streamed = streamed || mode == 4;
+        c += size_t(ns) - 1;
+        continue;
+      }
+      const double *sd[kMaxIl];
+      ns = 0;
+      while (ns < il_streams && c + size_t(ns) < c1 && !cols[c + size_t(ns)].is_constant && cols[c + size_t(ns)].type == infera::INFERA_COL_DOUBLE) {
+        dn[ns] = dst + (c + size_t(ns)) * nrows;
+        sd[ns] = static_cast<const double *>(cols[c + size_t(ns)].data) + row0;
+        ns++;
+      }
+      if (ns >= 2) {
+        convert_interleaved_f64(dn, sd, ns, nrows, il_floats / 2);  // (the same bytes of source per turn)
+        c += size_t(ns) - 1;
+        continue;
+      }
+    }
     const infera::InferaColumn &col = cols[c];
     float *d = dst + c * nrows;
     if (mode == 2 && c + 1 < c1 && !cols[c + 1].is_constant) {  // the next run's first lines: its page walk and DRAM row open overlap this run's copy
@@ -191,7 +259,7 @@ void gather_column_major(const infera::InferaColumn *cols, size_t c0, size_t c1,
       const char *nx = static_cast<const char *>(cols[c + 1].data) + row0 * esz;
       for (int l = 0; l < 4; l++) _mm_prefetch(nx + 64 * l, _MM_HINT_T0);
     }
-    if (mode && !col.is_constant && col.type == infera::INFERA_COL_FLOAT) {
+    if ((mode == 1 || mode == 2) && !col.is_constant && col.type == infera::INFERA_COL_FLOAT) {
       (have_avx512 ? stream_copy_f32_avx512 : stream_copy_f32_avx2)(d, static_cast<const float *>(col.data) + row0, nrows);
       streamed = true;
       continue;
