@@ -1331,10 +1331,14 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
     // pass i+1 into pinned memory -- the slowest stage, the caller's buffer is only borrowed -- overlaps the
     // H2D / kernels / D2H of pass i instead of following them.
     // Pass size: 16 MB keeps the CPU copy and the H2D of table rows overlapped best; rows as big as images (602 KB) get
-    // at least 96 of them per pass (up to 64 MB), because a 27-image pass leaves the conv kernels half empty
+    // many more of them per pass, because a 27-image pass leaves the conv kernels half empty
     // (ResNet-18, 16 threads x 256-image calls: 18.5k img/s with 16 MB passes, 29.7k -- the resident rate -- with 64 MB).
     const int64_t by_bytes = std::max<int64_t>(1, int64_t(kPipePassBytes / widest));
-    const int64_t by_rows = std::min<int64_t>(96, std::max<int64_t>(1, int64_t(kHostPassBytes / widest)));
+    // (round 3: 256 such rows per pass, up to 256 MB -- 96-image passes left C5 at 0.90 of its resident rate end to end, 256-image passes
+    // reach 0.96: 31.97k -> 34.0k img/s at 16 callers, 33.6k at 192, 34.1k at 384; INFERA_BLOB_PASS_ROWS for A/B.  Costs 2 x 154 MB of
+    // pinned staging per context that serves image batches.)
+    static const int64_t big_row_pass = [] { const char *e = getenv("INFERA_BLOB_PASS_ROWS"); const int v = e ? atoi(e) : 256; return int64_t(v < 1 ? 1 : v); }();
+    const int64_t by_rows = std::min<int64_t>(big_row_pass, std::max<int64_t>(1, int64_t(4 * kHostPassBytes / widest)));
     const int64_t P = std::min<int64_t>(rows, std::max(by_bytes, by_rows));
     ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, 2 * size_t(P) * in_row);
     ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, 2 * size_t(P) * out_row);
