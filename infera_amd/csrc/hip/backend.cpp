@@ -1339,7 +1339,11 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
     // pinned staging per context that serves image batches.)
     static const int64_t big_row_pass = [] { const char *e = getenv("INFERA_BLOB_PASS_ROWS"); const int v = e ? atoi(e) : 256; return int64_t(v < 1 ? 1 : v); }();
     const int64_t by_rows = std::min<int64_t>(big_row_pass, std::max<int64_t>(1, int64_t(4 * kHostPassBytes / widest)));
-    const int64_t P = std::min<int64_t>(rows, std::max(by_bytes, by_rows));
+    // equal passes, at least two when the call is worth cutting: the CPU copy of pass 2 must overlap the GPU's pass 1 also when ONE
+    // caller brings one batch (256 images as 128 + 128, not as a single pass with nothing to overlap)
+    const int64_t p0 = std::min<int64_t>(rows, std::max(by_bytes, by_rows));
+    const int64_t npass = std::max<int64_t>(rows >= 64 ? 2 : 1, (rows + p0 - 1) / p0);
+    const int64_t P = (rows + npass - 1) / npass;
     ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, 2 * size_t(P) * in_row);
     ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, 2 * size_t(P) * out_row);
     ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, 2 * size_t(P) * in_row);
