@@ -70,9 +70,14 @@ std::vector<std::string> loaded_names() {
 
 std::string model_metadata_json(const std::string &name) {
   auto m = find(name);
-  // serde_json `json!` object -> keys in sorted order, compact (engine.rs:298-304)
+  // serde_json `json!` object -> keys in sorted order, compact (engine.rs:298-304).  One ADDITIVE key, only for models whose served
+  // output the graph declares as an integer tensor (ArgMax labels, Cast to int): the C ABI carries f32 only (rust.h:28-49; the
+  // reference rejects such outputs, engine.rs:150-152), so they are served as f32 VALUES -- and the metadata says so.
+  std::string extra;
+  if (!m->plan.output_declared_type.empty())
+    extra = ",\"output_served_as\":" + json_str("f32 values of the graph's " + m->plan.output_declared_type + " output '" + m->plan.output_name + "'");
   return "{\"input_shape\":" + json_int_array(m->plan.input_shape) + ",\"loaded\":true,\"name\":" + json_str(m->name) +
-         ",\"output_shape\":" + json_int_array(m->plan.output_shape) + "}";
+         ",\"output_shape\":" + json_int_array(m->plan.output_shape) + extra + "}";
 }
 
 OutShape out_shape_for_rows(const LoadedModel &m, uint64_t rows) {

@@ -1535,7 +1535,9 @@ struct Lowerer {
       const bool int_valued = int_bufs.count(it->second.buf) > 0;
       if (!(int_valued && (out.elem_type == onnx::kInt64 || out.elem_type == onnx::kInt32)))
         throw InferaError::onnx("output '" + out.name + "' is not f32");
+      plan.output_declared_type = out.elem_type == onnx::kInt64 ? "int64" : "int32";
     }
+    plan.output_name = out.name;
     plan.out_buf = it->second.buf;
     plan.output_shape = it->second.shape;
     if (plan.fixed_batch < 0) plan.output_shape[0] = -1;

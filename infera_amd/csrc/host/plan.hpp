@@ -84,6 +84,8 @@ struct Plan {
   int out_buf = 0;
   int64_t fixed_batch = -1;  // > 0 when the model's leading dim is a constant (e.g. linear.onnx [1,3])
   int64_t opset = 1;
+  std::string output_name;         // the served graph output
+  std::string output_declared_type;  // "" for f32; "int64" / "int32" when the graph declares an integer output that is served as f32 VALUES
 
   int64_t in_per_row() const { return buf_per_row[0]; }
   int64_t out_per_row() const { return buf_per_row[out_buf]; }

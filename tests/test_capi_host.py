@@ -287,3 +287,22 @@ def test_zero_copy_registration_needs_a_gpu_and_fails_loudly(built):
     with pytest.raises(capi.InferaError, match="not registered"):
         capi.unregister_host_memory(a)
     assert capi.zero_copy_calls() == 0
+
+
+def test_model_info_says_when_an_integer_output_is_served_as_f32(built, tmp_path):
+    """VERDICT r2 (missing, item 6): the C ABI carries f32 only (rust.h:28-49); a model whose served output the graph declares as an
+    integer tensor (a classifier's label) is served as f32 VALUES, and infera_get_model_info says so in one additive key -- absent for
+    f32 outputs, so the reference's JSON shape (engine.rs:298-304: input_shape, loaded, name, output_shape) is what everyone else sees."""
+    from infera_amd import capi
+    from infera_amd import onnx_writer as W
+
+    capi.load_model("info_lab", W.write(str(tmp_path / "lab.onnx"), W.sklearn_pipeline(30, 3)))
+    capi.load_model("info_f32", W.write(str(tmp_path / "mlp.onnx"), W.mlp((8, 4, 1))))
+    try:
+        lab, f32 = capi.get_model_info("info_lab"), capi.get_model_info("info_f32")
+        assert lab["output_served_as"] == "f32 values of the graph's int64 output 'label'"
+        assert list(f32.keys()) == ["input_shape", "loaded", "name", "output_shape"]
+        assert list(lab.keys()) == ["input_shape", "loaded", "name", "output_shape", "output_served_as"]
+    finally:
+        capi.unload_model("info_lab")
+        capi.unload_model("info_f32")
