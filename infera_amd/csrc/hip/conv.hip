@@ -170,7 +170,8 @@ __device__ unsigned long long g_conv_stamps[2][12];
 template <int MT, int S, int PROBE = 0, int MODE = 0>
 __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                              const float *__restrict__ bias, const float *__restrict__ residual,
-                                                             float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
+                                                             float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act,
+                                                             unsigned blk0 = 0) {
   constexpr bool DENSE = MODE == 1, PADC = MODE == 2;
   constexpr int NB = 4 * S;   // B fragments (16 B per lane) per stage
   constexpr int U = NB * MT;  // units per stage
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(kBlock) void conv2d_tiled_kernel(const float *__res
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous
   // range of pixel tiles (neighbouring tiles share halo rows -> they share that XCD's L2).
   const unsigned nfull = gridDim.x & ~7u;
-  const unsigned lb = blockIdx.x < nfull ? (blockIdx.x & 7u) * (nfull >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  // (blk0: this launch covers pixel blocks [blk0, blk0 + gridDim.x) of the layer -- the tail of a launch split in two, see conv2d_tiled)
+  const unsigned lb = blk0 + (blockIdx.x < nfull ? (blockIdx.x & 7u) * (nfull >> 3) + (blockIdx.x >> 3) : blockIdx.x);
   const int OHW = g.OH * g.OW;
   const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
   const int CS = g.C / (32 * S), ntaps = g.kh * g.kw, nstages = ntaps * CS;
@@ -1720,7 +1722,7 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
   }
   const unsigned bx = unsigned((total_pix + 127) / 128);
   auto launch = [&](auto kernel, int mt) {
-    hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / (32 * mt))), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+    hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / (32 * mt))), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, 0u);
   };
   // feature tiles per workgroup: the largest of 4, 3, 2, 1 that divides M / 32 (ResNet: 2 or 4; MobileNet-style
   // widths such as 96, 160, 576, 960 take 3, 1, 3, 3)
@@ -1804,6 +1806,29 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
     // 128-channel 3x3 layers: 32-feature slices still fit (144 KB); twice the gathers per MFMA of the 64-feature form, yet
     // 1.76-1.78 ms against the tiled kernel's 1.79-1.81 per 236.8 GFLOP layer, and 0.94 against 0.98 ms on the stride-2 entry
     if (deep && slice32 <= kWsLdsBytes && ws_mode != 3) return launch_ws(conv2d_ws_kernel<1, 2, 8>, 1, 8);
+  }
+  // Tail split (round 3): 128-feature workgroups sit two per CU (64 KB of LDS each); a launch of a little more than a whole number of
+  // rounds -- ResNet's 256 -> 512 stride-2 entry: 1568 workgroups on 512 slots -- ends in a round that is 6 % full yet lasts a whole
+  // lone-workgroup time.  The pixel blocks of that last partial round run as a second launch of 32-feature tiles instead (four times the
+  // workgroups, a quarter of the work each; same sums per output element -> bit-identical).  64-feature tiles for the WHOLE layer lose
+  // on stride-2 layers (more feature slices re-gather more: 1.03 -> 1.18 ms); this re-gathers only the tail's few pixel blocks.
+  if (wide && deep && g.kh * g.kw > 1) {  // (1x1 layers: measured neutral -- 168 us whole, 155 + 13 split)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static int cus2[64] = {};
+    if (!cus2[dev & 63]) (void)hipDeviceGetAttribute(&cus2[dev & 63], hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t slots = int64_t(2) * std::max(1, cus2[dev & 63]), slices = m32 / 4, wgs = int64_t(bx) * slices;
+    const int64_t rounds = wgs / slots, rem = wgs - rounds * slots;
+    const char *tse = getenv("INFERA_CONV_TAIL_SPLIT");  // (read per launch: one process compares both forms in the tests)
+    const bool split_on = !(tse && atoi(tse) == 0);
+    if (split_on && rounds >= 1 && rounds <= 6 && rem > 0 && rem * 4 <= slots) {  // a short last round
+      const unsigned bx_main = unsigned(rounds * slots / slices), bx_tail = bx - bx_main;
+      if (bx_main > 0 && bx_tail > 0) {
+        hipLaunchKernelGGL((conv2d_tiled_kernel<4, 2>), dim3(bx_main, unsigned(slices)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, 0u);
+        hipLaunchKernelGGL((conv2d_tiled_kernel<1, 2>), dim3(bx_tail, unsigned(m32)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, bx_main);
+        return;
+      }
+    }
   }
   if (wide && deep) launch(conv2d_tiled_kernel<4, 2>, 4);
   else if (wide) launch(conv2d_tiled_kernel<4, 1>, 4);

@@ -67,3 +67,29 @@ def test_gpu_weight_stationary_conv_matches_tiled_and_oracle(gpu_api, tmp_path, 
     want = oracle.Model(path).predict_blob(x.tobytes())
     assert out["2"].shape == want.shape
     assert np.all(np.abs(out["2"] - want) <= 1e-4 * np.abs(want) + 1e-6), np.abs(out["2"] - want).max()
+
+
+@pytest.mark.gpu
+def test_gpu_tiled_conv_tail_split_is_bit_identical(gpu_api, tmp_path):
+    """Round 3: a wide tiled launch that ends in a short last round of workgroups (ResNet's 256 -> 512 stride-2 entry: 1568 workgroups on
+    512 slots) runs its last pixel blocks as a second launch of 32-feature tiles (conv2d_tiled, `blk0`).  Same sums per output element:
+    INFERA_CONV_TAIL_SPLIT=0 / 1 (read per launch) must agree bit for bit, and with the oracle.  Shape: 256 -> 128 channels, 3x3 stride 2,
+    32x32 images -> 16x16 outputs, 261 images = 522 pixel blocks x 1 feature slice = one full round of 512 + 10 blocks of tail."""
+    from oracle import oracle
+
+    rows = 261
+    path = W.write(str(tmp_path / "tail.onnx"), _net([(256, 1, 1), (128, 3, 2)], 4, 32))
+    x = synth.table(33, 0, rows, 4 * 32 * 32)
+    gpu_api.load_model("tailnet", path)
+    try:
+        out = {}
+        for mode in ("1", "0"):
+            os.environ["INFERA_CONV_TAIL_SPLIT"] = mode
+            out[mode] = gpu_api.predict_from_blob("tailnet", x.tobytes())
+            assert np.array_equal(out[mode], gpu_api.predict_from_blob("tailnet", x.tobytes()))
+    finally:
+        os.environ.pop("INFERA_CONV_TAIL_SPLIT", None)
+        gpu_api.unload_model("tailnet")
+    assert np.array_equal(out["0"], out["1"]), float(np.abs(out["0"] - out["1"]).max())
+    want = oracle.Model(path).predict_blob(x[:3].tobytes())
+    assert np.all(np.abs(out["1"][:3] - want) <= 1e-4 * np.abs(want) + 1e-6)
