@@ -29,7 +29,7 @@ EXTENSION_SYMBOLS = [
     "infera_hip_free", "infera_hip_memcpy_h2d", "infera_hip_memcpy_d2h", "infera_hip_synth_fill",
     "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch", "infera_gather_columns",
     "infera_hip_sha256_hex", "infera_hip_shape_rows_cols", "infera_hip_h2d_probe", "infera_hip_choose_slot",
-    "infera_hip_choose_slot_balanced", "infera_hip_register_host_memory", "infera_hip_unregister_host_memory", "infera_hip_zero_copy_calls",
+    "infera_gather_columns_colmajor", "infera_hip_choose_slot_balanced", "infera_hip_register_host_memory", "infera_hip_unregister_host_memory", "infera_hip_zero_copy_calls",
 ]
 
 
@@ -116,6 +116,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.infera_predict_columns.restype = InferaInferenceResult
     L.infera_gather_columns.argtypes = [C.POINTER(InferaColumn), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
     L.infera_gather_columns.restype = C.c_int32
+    L.infera_gather_columns_colmajor.argtypes = [C.POINTER(InferaColumn), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.infera_gather_columns_colmajor.restype = C.c_int32
     L.infera_predict_from_blob_batch.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t]
     L.infera_predict_from_blob_batch.restype = InferaInferenceResult
     L.infera_hip_shape_rows_cols.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -395,6 +397,16 @@ def gather_columns(columns: Sequence[np.ndarray], rows: int | None = None, row0:
     nrows = rows - row0 if nrows is None else nrows
     out = np.empty((nrows, n), np.float32)
     if load_library().infera_gather_columns(cols, n, row0, nrows, out.ctypes.data) != 0:
+        raise InferaError(last_error())
+    return out
+
+
+def gather_columns_colmajor(columns: Sequence[np.ndarray], rows: int | None = None, row0: int = 0, nrows: int | None = None) -> np.ndarray:
+    """The staged path's gather step alone (CPU): typed columns -> ONE column-major f32 chunk [ncols, nrows]."""
+    cols, n, rows, _keep = _make_columns(columns, rows, None)
+    nrows = rows - row0 if nrows is None else nrows
+    out = np.empty((n, nrows), np.float32)
+    if load_library().infera_gather_columns_colmajor(cols, n, row0, nrows, out.ctypes.data) != 0:
         raise InferaError(last_error())
     return out
 

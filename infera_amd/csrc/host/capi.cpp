@@ -582,6 +582,24 @@ int32_t infera_gather_columns(const InferaColumn *columns, uintptr_t ncols, uint
              : -1;
 }
 
+int32_t infera_gather_columns_colmajor(const InferaColumn *columns, uintptr_t ncols, uintptr_t row0, uintptr_t nrows, float *dst) {
+  return guarded([&] {
+           if (!columns || !dst) throw InferaError::null_pointer();
+           for (uintptr_t c = 0; c < ncols; c++) {
+             const InferaColumn &col = columns[c];
+             if (!col.data) throw InferaError::null_pointer();
+             if (col.type < INFERA_COL_FLOAT || col.type > INFERA_COL_BIGINT)
+               throw InferaError(ErrKind::Onnx, "Unsupported feature type: " + std::to_string(col.type));
+             if (col.validity)
+               for (uintptr_t r = col.is_constant ? 0 : row0; r < (col.is_constant ? (nrows ? 1 : 0) : row0 + nrows); r++)
+                 if (!((col.validity[r >> 6] >> (r & 63)) & 1)) throw InferaError(ErrKind::Onnx, "Feature values cannot be NULL");
+           }
+           gather_column_major(columns, 0, ncols, row0, nrows, dst);
+         })
+             ? 0
+             : -1;
+}
+
 struct InferaInferenceResult infera_predict_from_blob_batch(const char *model_name, const uint8_t *const *blobs,
                                                             const uintptr_t *lens, uintptr_t n) {
   InferaInferenceResult res = error_result();
