@@ -745,6 +745,32 @@ void schedule(LoadedModel &m) {
     m.slot_per_row[size_t(chosen)] = std::max(m.slot_per_row[size_t(chosen)], m.plan.buf_per_row[size_t(b)]);
     slot_free_after[size_t(chosen)] = last_read[size_t(b)] < 0 ? int(e) : last_read[size_t(b)];
   }
+  // split-fp16 convolutions (INFERA_PRECISION=f16x3) and the per-image maxima they scale their inputs by
+  m.conv_split.assign(n, 0);
+  m.amax_of_buf.assign(nb, -1);
+  m.amax_by_kernel.assign(nb, 0);
+  m.n_amax = 0;
+  m.amax_slot = -1;
+  if (ScheduleKnobs::read().conv_f16x3 && m.cq_mode) {
+    for (size_t i = 0; i < n; i++) {
+      if (m.exec[i] != ExecKind::ConvTiled) continue;
+      const Step &c = st[i];
+      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
+                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
+      if (!kern::conv2d_split_supported(kern::conv2d_tiled_geom(g)) || m.nchw_buf[size_t(c.in0)]) continue;
+      m.conv_split[i] = 1;
+      if (m.amax_of_buf[size_t(c.in0)] < 0) {
+        m.amax_of_buf[size_t(c.in0)] = m.n_amax++;
+        m.amax_by_kernel[size_t(c.in0)] = 1;
+      }
+    }
+    for (size_t i = 0; i < n; i++)  // tensors a split convolution writes: its epilogue tracks the maxima
+      if (m.conv_split[i]) m.amax_by_kernel[size_t(m.conv_fused_add[i] >= 0 ? st[size_t(m.conv_fused_add[i])].out : st[i].out)] = 0;
+    if (m.n_amax > 0) {
+      m.amax_slot = int(m.slot_per_row.size());
+      m.slot_per_row.push_back(m.n_amax);  // one word per image and tracked tensor
+    }
+  }
   m.scratch_per_row = 0;
   for (auto v : m.slot_per_row) m.scratch_per_row += v;
 }
@@ -809,7 +835,13 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
         }
         continue;
       }
-      kern::conv2d_tiled_pack(g, s.W.data(), packed.data());
+      if (m.conv_split[i]) {
+        std::vector<float> winv(size_t(g.M));
+        kern::conv2d_split_pack(g, s.W.data(), packed.data(), winv.data());
+        d.winv = upload(winv, us);
+      } else {
+        kern::conv2d_tiled_pack(g, s.W.data(), packed.data());
+      }
       d.W = upload(packed, us);
     } else if (m.exec[i] == ExecKind::ConvDepthwise) {
       kern::ConvGeom g{int(s.C), int(s.H), int(s.Wd), int(s.Mo), int(s.OH), int(s.OW), int(s.kh), int(s.kw),
@@ -928,6 +960,15 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
       if (b == p.out_buf) return d_out + r0 * p.out_per_row();
       return ctx.scratch + slot_base[size_t(m.slot_of_buf[size_t(b)])];
     };
+    // split-fp16 convolutions: row k of the amax slot = per-image max |x| of tracked tensor k, max-accumulated from zero each pass
+    auto amax = [&](int b) -> unsigned * {
+      return reinterpret_cast<unsigned *>(ctx.scratch + slot_base[size_t(m.amax_slot)]) + int64_t(m.amax_of_buf[size_t(b)]) * rows_pass;
+    };
+    std::vector<char> amax_done;
+    if (m.n_amax > 0) {
+      HIP_TRY(hipMemsetAsync(ctx.scratch + slot_base[size_t(m.amax_slot)], 0, size_t(m.n_amax) * size_t(rows_pass) * 4, s));
+      amax_done.assign(m.amax_of_buf.size(), 0);
+    }
     for (size_t i = 0; i < st.size(); i++) {
       const Step &x = st[i];
       const DeviceStep &d = dm.steps[i];
@@ -970,6 +1011,16 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
           const int fj = m.conv_fused_add[i];
           const kern::ConvGeom gp = kern::conv2d_tiled_geom(g);
+          if (m.conv_split[i]) {
+            if (m.amax_by_kernel[size_t(x.in0)] && !amax_done[size_t(x.in0)]) {
+              kern::absmax_rows(s, buf(x.in0), nr, m.plan.buf_per_row[size_t(x.in0)], amax(x.in0));
+              amax_done[size_t(x.in0)] = 1;
+            }
+            const int ob = fj >= 0 ? st[size_t(fj)].out : x.out;
+            kern::conv2d_split(s, buf(x.in0), d.W, d.bias, d.winv, fj >= 0 ? buf(m.conv_residual_buf[i]) : nullptr, buf(ob), amax(x.in0),
+                               m.amax_of_buf[size_t(ob)] >= 0 ? amax(ob) : nullptr, nr, gp, act_of(fj >= 0 ? st[size_t(fj)] : x));
+            continue;
+          }
           if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]));
           else kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, gp, act_of(x));
           continue;
@@ -1180,7 +1231,7 @@ DeviceModel::~DeviceModel() {
   if (hipSetDevice(device) != hipSuccess) return;
   (void)hipDeviceSynchronize();
   for (auto &d : steps) {
-    for (float *p : {d.W, d.bias, d.cst, d.scale, d.shift})
+    for (float *p : {d.W, d.bias, d.cst, d.scale, d.shift, d.winv})
       if (p) (void)hipFree(p);
   }
   if (mlp3_packed) (void)hipFree(mlp3_packed);
@@ -1737,10 +1788,11 @@ std::string LoadedModel::describe_json() const {
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++)
-    o << (i ? "," : "") << "\"" << (i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : ek[int(exec[i])]) << "\"";
+    o << (i ? "," : "") << "\"" << (i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split.size() && conv_split[i] ? "conv_split_f16x3" : ek[int(exec[i])]) << "\"";
   o << "],\"activation_layout\":\"" << (cq_mode ? "NC/4HW4" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";
+  if (n_amax > 0) o << ",\"conv_precision\":\"f16x3 (fp16 matrix cores, operands split hi + lo, fp32 accumulate)\"";
   for (size_t i = 0; i < exec.size(); i++)
     if (exec[i] == ExecKind::Mlp3Head)
       o << ",\"fused_kernel\":" << json_str(bf16x3 ? kern::mlp3_bf16x3_kernel_name(mlp3_shape) : kern::mlp3_kernel_name(mlp3_shape))

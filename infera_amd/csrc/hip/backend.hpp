@@ -48,6 +48,7 @@ double h2d_probe_gbs(int device_ordinal, size_t bytes, int iters, int threads);
 // Constants of one plan step resident in one GPU's HBM.
 struct DeviceStep {
   float *W = nullptr, *bias = nullptr, *cst = nullptr, *scale = nullptr, *shift = nullptr;
+  float *winv = nullptr;  // split-fp16 convolutions: per-feature inverse weight scales (W then holds fp16 hi / lo fragments)
 };
 
 // How the executor runs a step.
@@ -104,6 +105,13 @@ class LoadedModel {
   std::vector<int> conv_fused_pool;  // per step: the MaxPool 3x3/2 step a ConvPatch stem computes in its own kernel, or -1
   std::vector<int> conv_fused_add;
   std::vector<int> conv_residual_buf;
+  // INFERA_PRECISION=f16x3: ConvTiled steps that run on the fp16 matrix cores with split operands (conv_split.hip).  Each needs the
+  // per-image max |x| of its input tensor: amax_of_buf = index of that tensor's row of maxima in the plan's amax scratch slot (-1: not
+  // needed); amax_by_kernel = the tensor's producer is no split convolution, a reduction kernel computes the maxima before first use.
+  std::vector<char> conv_split;
+  std::vector<int> amax_of_buf;
+  std::vector<char> amax_by_kernel;
+  int n_amax = 0, amax_slot = -1;
   std::vector<int> slot_of_buf;        // scratch slot per activation buffer (-1: external in/out)
   std::vector<int64_t> slot_per_row;   // floats per row of each scratch slot
   int64_t scratch_per_row = 0;         // sum over slots

@@ -162,6 +162,15 @@ void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed);
 // residual (nullable): CQ tensor of the output's shape added before the activation (fused ResNet Add)
 void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y,
                   int64_t rows, const ConvGeom &g, ActParam act);
+// The same convolution on the fp16 matrix cores, every fp32 operand split in two fp16 halves (conv_split.hip; INFERA_PRECISION=f16x3).
+// packed = conv2d_tiled_packed_floats(g) floats' worth of fp16 hi / lo fragments, winv[M] = the per-feature inverse scales.
+// amax_in[rows] = bits of each image's largest |x| over the input tensor (absmax_rows, or a split convolution's amax_out);
+// amax_out (nullable) = the same for the output tensor, max-accumulated: zero it before the producing launch.
+bool conv2d_split_supported(const ConvGeom &g);
+void conv2d_split_pack(const ConvGeom &g, const float *Wt, float *packed, float *winv);
+void absmax_rows(hipStream_t s, const float *X, int64_t rows, int64_t per_row, unsigned *amax);
+void conv2d_split(hipStream_t s, const float *X, const float *packed, const float *bias, const float *winv, const float *residual,
+                  float *Y, const unsigned *amax_in, unsigned *amax_out, int64_t rows, const ConvGeom &g, ActParam act);
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
             int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq);
 // y[n,c,p] = x[n,c,p] / (bias + alpha/size * sum_{c' in window(c)} x[n,c',p]^2)^beta over [rows, C, S] (cq: channel-quad planes)

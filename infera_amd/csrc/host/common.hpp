@@ -153,6 +153,7 @@ struct ScheduleKnobs {
   bool stem_pool;   // INFERA_STEM_POOL=0|1   stem convolution + MaxPool 3x3/2 in one kernel
   bool chain_xcm;   // INFERA_CHAIN_XCM=0|1   the fused small-MLP chain kernel reads column-major host chunks itself (0: transpose launch first)
   bool dense_xcm;   // INFERA_DENSE_XCM=0|1   the same for the as-it-lies streaming kernels of single narrow layers
+  bool conv_f16x3;  // INFERA_PRECISION=f16x3  the tiled convolutions on the fp16 matrix cores, operands split hi + lo (conv_split.hip)
   static ScheduleKnobs read();
 };
 // Read at first use inside the kernel launchers, A/B experiments only (no effect on results; defaults are the shipped paths):

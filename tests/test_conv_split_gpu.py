@@ -1,0 +1,87 @@
+"""INFERA_PRECISION=f16x3 (csrc/hip/conv_split.hip): the tiled convolutions on the fp16 matrix cores, every fp32 operand split
+in two fp16 halves after an exact power-of-two scaling (per output feature for the weights, per IMAGE for the activations --
+the producing kernel's epilogue tracks each image's largest |x|), three MFMAs per product, fp32 accumulation.  The mode is
+read when a model is scheduled, so one process loads the same network both ways.
+
+Checked here: the plan says which steps run split; the results are within the parity tolerance (1e-4 |y| + 1e-6) of the oracle
+AND within a few fp32 roundings of it relative to each row's scale; a row's result does not depend on its batch (bit for bit);
+rows of wildly different magnitude (1e-20 ... 1e+20, all zeros) in one batch each keep their own relative accuracy."""
+import os
+
+import numpy as np
+import pytest
+
+from infera_amd import synth
+from infera_amd import onnx_writer as W
+from tests.test_conv_ws_gpu import CASES, _net
+
+
+def _load_both(gpu_api, path):
+    gpu_api.load_model("conv_fp32", path)
+    os.environ["INFERA_PRECISION"] = "f16x3"
+    try:
+        gpu_api.load_model("conv_split", path)
+    finally:
+        os.environ.pop("INFERA_PRECISION", None)
+
+
+def _unload(gpu_api):
+    for name in ("conv_fp32", "conv_split"):
+        try:
+            gpu_api.unload_model(name)
+        except Exception:
+            pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_gpu_split_fp16_conv_matches_oracle(gpu_api, tmp_path, case):
+    from oracle import oracle
+
+    c = CASES[case]
+    path = W.write(str(tmp_path / "net.onnx"), _net(c["chain"], c["cin"], c["hw"], c["residual_at"]))
+    x = synth.table(31, 0, c["rows"], c["cin"] * c["hw"] * c["hw"])
+    _load_both(gpu_api, path)
+    try:
+        plan = gpu_api.get_plan("conv_split")
+        assert "conv_split_f16x3" in plan["exec"] and "f16x3" in plan["conv_precision"]
+        assert "conv_split_f16x3" not in gpu_api.get_plan("conv_fp32")["exec"] and "conv_precision" not in gpu_api.get_plan("conv_fp32")
+        got = gpu_api.predict_from_blob("conv_split", x.tobytes())
+        assert np.array_equal(got, gpu_api.predict_from_blob("conv_split", x.tobytes()))
+        ref32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
+        # one row alone == the same row inside the batch (the activation scale is per image)
+        for r in (0, c["rows"] - 1):
+            alone = gpu_api.predict_from_blob("conv_split", x[r].tobytes())
+            assert np.array_equal(alone.reshape(-1), got.reshape(c["rows"], -1)[r])
+    finally:
+        _unload(gpu_api)
+    want = oracle.Model(path).predict_blob(x.tobytes())
+    assert got.shape == want.shape
+    err = np.abs(got - want)
+    assert np.all(err <= 1e-4 * np.abs(want) + 1e-6), err.max()
+    # ... and far inside it: a few fp32 roundings of the output scale, like the exact-fp32 kernels' own distance from the oracle
+    scale = np.abs(want).max()
+    assert err.max() <= 4e-6 * scale, (err.max() / scale, np.abs(ref32 - want).max() / scale)
+
+
+@pytest.mark.gpu
+def test_gpu_split_fp16_conv_scales_each_image_on_its_own(gpu_api, tmp_path):
+    from oracle import oracle
+
+    chain = [(64, 3, 1), (64, 3, 1), (128, 3, 2), (128, 1, 1)]
+    cin, hw = 4, 14
+    path = W.write(str(tmp_path / "net.onnx"), _net(chain, cin, hw, residual_at=(1,)))
+    per_row = cin * hw * hw
+    mags = np.array([1.0, 1e-20, 1e20, 0.0, 3e-7, 6.5e4, 1e-30, 1.0], np.float32)
+    base = synth.table(5, 0, len(mags), per_row).reshape(len(mags), per_row)
+    x = (base * mags[:, None]).astype(np.float32)
+    _load_both(gpu_api, path)
+    try:
+        got = gpu_api.predict_from_blob("conv_split", x.tobytes()).reshape(len(mags), -1)
+    finally:
+        _unload(gpu_api)
+    want = oracle.Model(path).predict_blob(x.tobytes()).reshape(len(mags), -1)
+    assert np.all(np.isfinite(got))
+    for r in range(len(mags)):
+        scale = np.abs(want[r]).max()
+        assert np.abs(got[r] - want[r]).max() <= 4e-6 * scale + 1e-37, (r, mags[r], np.abs(got[r] - want[r]).max(), scale)
