@@ -45,13 +45,17 @@ __device__ __attribute__((aligned(256))) float g_split_zero_page[128];
 
 __device__ __forceinline__ f16x8 as_h(const u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
-// two fp32 values (already scaled) -> one dword of fp16 hi halves and one of fp16 lo halves
-__device__ __forceinline__ void split_pair(float v0, float v1, unsigned &hi, unsigned &lo) {
-  const f32x2 pair = {v0, v1};
-  const f16x2 hh = __builtin_convertvector(pair, f16x2);
-  const f32x2 rest = {v0 - float(hh[0]), v1 - float(hh[1])};
-  hi = __builtin_bit_cast(unsigned, hh);
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(rest, f16x2));
+// two fp32 values times the (power-of-two) scale -> one dword of fp16 hi halves and one of fp16 lo halves, five instructions:
+// hi = RNE_f16(x * sc) written half by half (v_fma_mixlo / mixhi_f16), the remainders x * sc - hi as exact fp32 FMAs that read
+// the fp16 halves in place (v_fma_mix_f32), one packed conversion for lo.  (Plain C++ costs eight: the multiply twice, the hi
+// halves widened back by two conversions.)
+__device__ __forceinline__ void split_pair(float x0, float x1, float sc, unsigned &hi, unsigned &lo) {
+  float r0, r1;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hi) : "v"(x0), "v"(sc));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hi) : "v"(x1), "v"(sc));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(sc), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(sc), "v"(hi));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
 }
 
 // scale (a power of two) that brings values of magnitude <= amax (bits of a non-negative float) into [2^14, 2^15),
@@ -65,8 +69,8 @@ __device__ __forceinline__ void scales_of(unsigned amax_bits, float &sc, float &
 
 // packed split weights: [chunk (conv2d_tiled_pack's stage order)][mt][kb (2)][part (hi, lo)][lane (64)][e (8 halves)]
 //   = W[m = 32mt + (lane&31)][tap][c = 32cc + 16kb + 8(e>>2) + 4(lane>>5) + (e&3)] * 2^pw(m)
-template <int MT, int S>
-__global__ __launch_bounds__(kBlock) void conv2d_split_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+template <int MT, int S, int PROBE = 0>
+__global__ __launch_bounds__(kBlock, MT >= 3 ? 2 : 3) void conv2d_split_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                              const float *__restrict__ bias, const float *__restrict__ winv,
                                                              const float *__restrict__ residual, float *__restrict__ Y,
                                                              const unsigned *__restrict__ amax_in, unsigned *__restrict__ amax_out,
@@ -145,45 +149,72 @@ __global__ __launch_bounds__(kBlock) void conv2d_split_kernel(const float *__res
     __syncthreads();
   };
 
+  // 16 channels of this lane's pixel (gathered quads 2q and 2q + 1 of the stage) -> the hi and lo B fragments of k-block q
+  auto convert = [&](const f32x4(&bc)[NB], int q, u32x4 &oh, u32x4 &ol) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const f32x4 &src = bc[2 * q + (e >> 1)];
+      unsigned hi, lo;
+      if constexpr (PROBE == 1) {  // (timing probes, PROBES builds only: wrong results)
+        hi = __float_as_uint(src[2 * (e & 1)]);
+        lo = __float_as_uint(src[2 * (e & 1) + 1]);
+      } else {
+        split_pair(src[2 * (e & 1)], src[2 * (e & 1) + 1], sc, hi, lo);
+      }
+      oh[e] = hi;
+      ol[e] = lo;
+    }
+    // The hazard recogniser does not see VALU writes inside inline asm: a matrix instruction issued within two wait states of the last
+    // one reads the register's OLD contents (gfx90a+: "VALU write VGPR -> MFMA read", normally padded by the compiler).  Found as a 2^-12
+    // per-product error in exactly the instantiations whose first MFMA follows the split directly (S = 1 with one or two feature tiles).
+    asm volatile("s_nop 1" : "+v"(oh), "+v"(ol));
+  };
+  // (Measured and dropped: gathers TWO stages ahead through a third register buffer, the weight slab issued first and `s_waitcnt vmcnt(NB)` at
+  // the end of a stage -- 128-feature tiles then need 256 registers and spill 28, 64-feature tiles fall from 3 to 2 waves per SIMD: 4-20 %
+  // slower.  With three 32-cycle matrix instructions per product the chip is at its power limit long before the matrix pipe is full -- 1.8 to
+  // 2.0 GHz at 41 % busy, against 2.2 GHz at 87 % under the exact-fp32 instruction.)
   auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;
+    constexpr bool probe_gather = PROBE != 2 && PROBE != 4, probe_stage = PROBE != 3 && PROBE != 4;
+    constexpr int Q = 2 * S;  // k-blocks per stage
     const u32x4 *wl = reinterpret_cast<const u32x4 *>(wbuf[stage & 1]) + lane;
-    // unit u -> chunk sl = u / (2 MT), k-block kb = (u / MT) % 2, feature tile t = u % MT; its hi fragment, lo = + 64
-    auto fidx = [](int u) { return (((u / (2 * MT)) * MT + u % MT) * 4 + ((u / MT) % 2) * 2) * 64; };
+    // unit u -> k-block q = u / MT (chunk q / 2, half q % 2), feature tile t = u % MT; its hi fragment, lo = + 64
+    auto fidx = [](int u) { return ((((u / MT) / 2) * MT + u % MT) * 4 + ((u / MT) % 2) * 2) * 64; };
     u32x4 rh[P], rl[P];
 #pragma unroll
     for (int u = 0; u < P && u < U; u++) {
       rh[u] = wl[fidx(u)];
       rl[u] = wl[fidx(u) + 64];
     }
-    u32x4 bh, bl;
+    u32x4 bh[2], bl[2];
+    convert(bc, 0, bh[0], bl[0]);
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int q = u / MT, t = u % MT;  // q = 2 sl + kb: this unit's gathered quads are 2q and 2q + 1
-      if (t == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const f32x4 &src = bc[2 * q + (e >> 1)];
-          unsigned hi, lo;
-          split_pair(src[2 * (e & 1)] * sc, src[2 * (e & 1) + 1] * sc, hi, lo);
-          bh[e] = hi;
-          bl[e] = lo;
-        }
-      }
+      const int q = u / MT, t = u % MT;
       const u32x4 ah = rh[u % P], al = rl[u % P];
       if (u + P < U) {
         rh[u % P] = wl[fidx(u + P)];
         rl[u % P] = wl[fidx(u + P) + 64];
       }
       if constexpr (more) {
-        if (u == 0) gather(bn);
-        if (u == 1) stage_issue(stage + 1, (stage + 1) & 1);
+        if constexpr (probe_gather) {
+          if (u == 0) gather(bn);
+        }
+        if constexpr (probe_stage) {
+          if (u == 1) stage_issue(stage + 1, (stage + 1) & 1);
+        }
       }
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(al), as_h(bh), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bl), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bh), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(al), as_h(bh[q & 1]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bl[q & 1]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bh[q & 1]), acc[t], 0, 0, 0);
+      // the next k-block's fragments are split while this one's matrix instructions run
+      if (t == 0 && q + 1 < Q) convert(bc, q + 1, bh[(q + 1) & 1], bl[(q + 1) & 1]);
     }
-    if constexpr (more) stage_commit();
+    if constexpr (more && probe_stage) stage_commit();
+    if constexpr (!probe_gather) {
+#pragma unroll
+      for (int q = 0; q < NB; q++) bn[q] = bc[q];
+    }
   };
 
   f32x4 b0[NB], b1[NB];
@@ -212,28 +243,24 @@ __global__ __launch_bounds__(kBlock) void conv2d_split_kernel(const float *__res
   const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
   const f32x4 *wq = reinterpret_cast<const f32x4 *>(winv + 32 * mt0 + 4 * h);
   float vmax = 0.f;
-  auto fetch = [&](f32x4(&bv)[4], f32x4(&rv)[4], f32x4(&wv)[4], int t) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
-      wv[q] = wq[8 * t + 2 * q];
-      rv[q] = (rp && pvalid) ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
   dispatch_act(act.kind, [&](auto kind_tag) {
     constexpr int KIND = decltype(kind_tag)::value;
-    f32x4 bv[2][4], rv[2][4], wv[2][4];
-    fetch(bv[0], rv[0], wv[0], 0);
 #pragma unroll
     for (int t = 0; t < MT; t++) {
-      if (t + 1 < MT) fetch(bv[(t + 1) & 1], rv[(t + 1) & 1], wv[(t + 1) & 1], t + 1);
+      f32x4 bv[4], rv[4], wv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        wv[q] = wq[8 * t + 2 * q];
+        rv[q] = (rp && pvalid) ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float y = (acc[t][4 * q + j] * wv[t & 1][q][j]) * sinv;
-          v[j] = apply_act_c<KIND>((y + bv[t & 1][q][j]) + rv[t & 1][q][j], act.a, act.b);
+          const float y = (acc[t][4 * q + j] * wv[q][j]) * sinv;
+          v[j] = apply_act_c<KIND>((y + bv[q][j]) + rv[q][j], act.a, act.b);
           vmax = fmaxf(vmax, fabsf(v[j]));
         }
         if (pvalid) *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
@@ -252,6 +279,215 @@ __global__ __launch_bounds__(kBlock) void conv2d_split_kernel(const float *__res
       if (lane == 0 && pvalid) atomicMax(amax_out + first, __float_as_uint(vmax));
     } else if (pvalid) {
       atomicMax(amax_out + n32, __float_as_uint(vmax));
+    }
+  }
+}
+
+// ---- weight-stationary persistent form (conv2d_ws_kernel's structure, conv.hip) ------------------------------------------------
+// When one M-slice of the packed split weights fits in LDS (the 64-channel 3x3 layers, the 64 -> 128 stride-2 entry in two 64-feature
+// slices, every 1x1 downsample) a persistent workgroup loads it once and each of its NW waves walks 32-pixel tiles on its own: no weight
+// slab per stage, no barrier after the prologue, the stage stream running through tile boundaries (the first stage of the wave's next
+// tile is gathered under the last stage of this one, the epilogue's loads / stores / the max-tracking atomic drain under the next tile).
+// The activation scale belongs to the tile being COMPUTED: the prefetch cursor loads its image's maximum when it enters a tile, and the
+// tile takes it over when it starts (the cursor is then exactly one stage into that tile).
+template <int MT, int S, int NW>
+__global__ __launch_bounds__(NW * 64) void conv2d_split_ws_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+                                                                 const float *__restrict__ bias, const float *__restrict__ winv,
+                                                                 const float *__restrict__ residual, float *__restrict__ Y,
+                                                                 const unsigned *__restrict__ amax_in, unsigned *__restrict__ amax_out,
+                                                                 int64_t total_pix, ConvGeom g, ActParam act) {
+  constexpr int NB = 4 * S, U = 2 * S * MT, P = 2, Q = 2 * S;
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int OHW = g.OH * g.OW;
+  const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
+  const int CS = g.C / (32 * S), ntaps = g.kh * g.kw, nstages = ntaps * CS, nchunks = nstages * S;
+  for (int i = threadIdx.x; i < nchunks * MT * 256; i += NW * 64) {
+    const int chunk = i / (MT * 256), rem = i - chunk * (MT * 256);
+    reinterpret_cast<f32x4 *>(wlds)[i] = reinterpret_cast<const f32x4 *>(Wp + (int64_t(chunk) * MTtot + mt0) * 1024)[rem];
+  }
+  __syncthreads();
+
+  const int64_t ntiles = (total_pix + 31) >> 5;
+  const int64_t tstride = int64_t(gridDim.x) * NW;
+  int64_t tile = int64_t(blockIdx.x) * NW + wave;
+  if (tile >= ntiles) return;
+  const int HW4 = g.H * g.W * 4;
+  const float *zp = g_split_zero_page + 4 * h;
+
+  const float *p_xc = zp;
+  uint64_t p_ok = 0;
+  // image maxima of the last two tiles the cursor has entered: the tile that starts computing takes a_new, or a_old when a tile is a
+  // single stage (the cursor is then a whole tile further on: it entered the next tile while gathering this one's only stage)
+  unsigned a_new = 0, a_old = 0;
+  int p_tap = 0, p_kx = 0, p_off = 0, p_base = 0;
+  auto enter_tile = [&](int64_t t) {
+    const int64_t pix = (t << 5) + r;
+    const bool pvalid = t < ntiles && pix < total_pix;
+    const unsigned pix32 = pvalid ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
+    const int64_t n = n32;
+    const int prem = int(pix32 - n32 * unsigned(OHW));
+    const int oh = int(unsigned(prem) / unsigned(g.OW)), ow = prem - oh * g.OW;
+    const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
+    p_xc = X + n * int64_t(g.H) * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
+    a_old = a_new;
+    a_new = amax_in[n32];
+    p_ok = 0;
+    if (pvalid) {
+      int tap = 0;
+      for (int ky = 0; ky < g.kh; ky++)
+        for (int kx = 0; kx < g.kw; kx++, tap++) {
+          const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
+          if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) p_ok |= uint64_t(1) << tap;
+        }
+    }
+    p_tap = p_kx = p_off = p_base = 0;
+  };
+  int64_t p_tile = tile;
+  auto gather = [&](f32x4(&b)[NB]) {
+    const bool ok = (p_ok >> p_tap) & 1;
+    const float *p = ok ? p_xc + p_off : zp;
+    const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;
+#pragma unroll
+    for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
+    p_tap++;
+    p_kx++;
+    p_off += g.dw * 4;
+    if (p_kx == g.kw) {
+      p_kx = 0;
+      p_off += (g.dh * g.W - g.kw * g.dw) * 4;
+    }
+    if (p_tap == ntaps) {
+      p_tap = 0;
+      p_base += 2 * NB * HW4;
+      p_off = p_base;
+      if (p_base == CS * 2 * NB * HW4) {
+        p_tile += tstride;
+        enter_tile(p_tile);
+      }
+    }
+  };
+
+  f32x16 acc[MT];
+  float sc = 1.f, sinv = 1.f;
+  auto convert = [&](const f32x4(&bc)[NB], int q, u32x4 &oh, u32x4 &ol) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const f32x4 &src = bc[2 * q + (e >> 1)];
+      unsigned hi, lo;
+      split_pair(src[2 * (e & 1)], src[2 * (e & 1) + 1], sc, hi, lo);
+      oh[e] = hi;
+      ol[e] = lo;
+    }
+    // The hazard recogniser does not see VALU writes inside inline asm: a matrix instruction issued within two wait states of the last
+    // one reads the register's OLD contents (gfx90a+: "VALU write VGPR -> MFMA read", normally padded by the compiler).  Found as a 2^-12
+    // per-product error in exactly the instantiations whose first MFMA follows the split directly (S = 1 with one or two feature tiles).
+    asm volatile("s_nop 1" : "+v"(oh), "+v"(ol));
+  };
+  auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage) {
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(wlds + int64_t(stage) * S * MT * 1024) + lane;
+    auto fidx = [](int u) { return ((((u / MT) / 2) * MT + u % MT) * 4 + ((u / MT) % 2) * 2) * 64; };
+    u32x4 rh[P], rl[P];
+#pragma unroll
+    for (int u = 0; u < P && u < U; u++) {
+      rh[u] = wl[fidx(u)];
+      rl[u] = wl[fidx(u) + 64];
+    }
+    u32x4 bh[2], bl[2];
+    convert(bc, 0, bh[0], bl[0]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int q = u / MT, t = u % MT;
+      const u32x4 ah = rh[u % P], al = rl[u % P];
+      if (u + P < U) {
+        rh[u % P] = wl[fidx(u + P)];
+        rl[u % P] = wl[fidx(u + P) + 64];
+      }
+      if (u == 0) gather(bn);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(al), as_h(bh[q & 1]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bl[q & 1]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bh[q & 1]), acc[t], 0, 0, 0);
+      if (t == 0 && q + 1 < Q) convert(bc, q + 1, bh[(q + 1) & 1], bl[(q + 1) & 1]);
+    }
+  };
+  const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
+  const f32x4 *wq = reinterpret_cast<const f32x4 *>(winv + 32 * mt0 + 4 * h);
+  const int64_t OHW4 = int64_t(OHW) * 4;
+  auto epilogue = [&](int64_t t) {
+    const int64_t pix = (t << 5) + r;
+    const bool pvalid = pix < total_pix;
+    const unsigned n32 = (pvalid ? unsigned(pix) : 0u) / unsigned(OHW);
+    const int64_t n = n32;
+    const int prem = int((pvalid ? unsigned(pix) : 0u) - n32 * unsigned(OHW));
+    const int64_t yoff = n * OHW * int64_t(g.M) + int64_t(8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+    float *yp = Y + yoff;
+    const float *rp = residual ? residual + yoff : nullptr;
+    float vmax = 0.f;
+    dispatch_act(act.kind, [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+      for (int t2 = 0; t2 < MT; t2++) {
+        f32x4 bv[4], rv[4], wv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          bv[q] = bq ? bq[8 * t2 + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+          wv[q] = wq[8 * t2 + 2 * q];
+          rv[q] = (rp && pvalid) ? *reinterpret_cast<const f32x4 *>(rp + (8 * t2 + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const float y = (acc[t2][4 * q + j] * wv[q][j]) * sinv;
+            v[j] = apply_act_c<KIND>((y + bv[q][j]) + rv[q][j], act.a, act.b);
+            vmax = fmaxf(vmax, fabsf(v[j]));
+          }
+          if (pvalid) *reinterpret_cast<f32x4 *>(yp + (8 * t2 + 2 * q) * OHW4) = v;
+        }
+      }
+    });
+    if (amax_out) {
+      const unsigned first = __builtin_amdgcn_readfirstlane(n32);
+      const bool uniform = __all(!pvalid || n32 == first);
+      if (!pvalid) vmax = 0.f;
+      if (uniform) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0 && pvalid) atomicMax(amax_out + first, __float_as_uint(vmax));
+      } else if (pvalid) {
+        atomicMax(amax_out + n32, __float_as_uint(vmax));
+      }
+    }
+  };
+  auto run_tile = [&](f32x4(&ba)[NB], f32x4(&bb)[NB], int64_t t) {
+    scales_of(nstages == 1 ? a_old : a_new, sc, sinv);
+#pragma unroll
+    for (int t2 = 0; t2 < MT; t2++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[t2][i] = 0.f;
+    int stage = 0;
+    for (; stage + 2 <= nstages; stage += 2) {
+      step(ba, bb, stage);
+      step(bb, ba, stage + 1);
+    }
+    if (stage < nstages) step(ba, bb, stage);
+    epilogue(t);
+  };
+
+  f32x4 b0[NB], b1[NB];
+  enter_tile(tile);
+  gather(b0);
+  const bool odd = nstages & 1;
+  for (;;) {
+    run_tile(b0, b1, tile);
+    tile += tstride;
+    if (tile >= ntiles) break;
+    if (odd) {
+      run_tile(b1, b0, tile);
+      tile += tstride;
+      if (tile >= ntiles) break;
     }
   }
 }
@@ -381,6 +617,52 @@ void conv2d_split(hipStream_t s, const float *X, const float *packed, const floa
   const int m32 = g.M / 32;
   const int mt_pick = m32 % 4 == 0 ? 4 : m32 % 3 == 0 ? 3 : m32 % 2 == 0 ? 2 : 1;
   const bool deep = g.C % 64 == 0;
+#ifdef INFERA_CONV_PROBES
+  // 1 no operand split, 2 no gathers, 3 no weight staging / barrier, 4 neither (bare matrix stream): timing only, results are wrong
+  static const int probe = getenv("INFERA_SPLIT_PROBE") ? atoi(getenv("INFERA_SPLIT_PROBE")) : 0;
+  if (probe && deep && (mt_pick == 4 || mt_pick == 2)) {
+    switch (probe * 2 + (mt_pick == 4)) {
+      case 2: return launch(conv2d_split_kernel<2, 2, 1>, 2);
+      case 3: return launch(conv2d_split_kernel<4, 2, 1>, 4);
+      case 4: return launch(conv2d_split_kernel<2, 2, 2>, 2);
+      case 5: return launch(conv2d_split_kernel<4, 2, 2>, 4);
+      case 6: return launch(conv2d_split_kernel<2, 2, 3>, 2);
+      case 7: return launch(conv2d_split_kernel<4, 2, 3>, 4);
+      case 8: return launch(conv2d_split_kernel<2, 2, 4>, 2);
+      case 9: return launch(conv2d_split_kernel<4, 2, 4>, 4);
+    }
+  }
+#endif
+  // weight-stationary persistent form when one M-slice of the split weights fits in LDS and the launch fills the persistent grid
+  // (INFERA_CONV_WS as for the exact-fp32 kernels: 0 never, 1 default, 2 whenever it fits -- read per launch, tests compare both)
+  const char *ws_env = getenv("INFERA_CONV_WS");
+  const int ws_mode = ws_env ? atoi(ws_env) : 1;
+  if (ws_mode == 2 || (ws_mode == 1 && total_pix >= 32 * 2048)) {
+    constexpr size_t kWsLdsBytes = 160 * 1024 - 256;
+    const size_t slice32 = size_t(g.kh) * g.kw * g.C * 32 * sizeof(float);  // hi + lo fp16 fragments of 32 features: as many bytes as fp32
+    auto launch_ws = [&](auto kernel, int mt, int nw) {
+      static std::atomic<uint64_t> attr_done[4] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      static int cus[64] = {};
+      if (!cus[dev & 63]) (void)hipDeviceGetAttribute(&cus[dev & 63], hipDeviceAttributeMultiprocessorCount, dev);
+      std::atomic<uint64_t> &done = attr_done[(mt == 4 ? 2 : 0) + (deep ? 1 : 0)];
+      if (!((done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kWsLdsBytes));
+        done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+      }
+      const unsigned slices = unsigned(g.M / (32 * mt));
+      const int64_t ntiles = (total_pix + 31) / 32;
+      unsigned gx = unsigned(std::max(1, cus[dev & 63] / int(slices)));
+      gx = unsigned(std::min<int64_t>(gx, (ntiles + nw - 1) / nw));
+      hipLaunchKernelGGL(kernel, dim3(gx, slices), dim3(unsigned(nw) * 64), slice32 * mt, s, X, packed, bias, winv, residual, Y, amax_in, amax_out,
+                         total_pix, g, act);
+    };
+    // (128-feature slices -- the 1x1 downsamples -- only when forced: 256 registers, 22 spilled, 260 us against the tiled form's 234)
+    if (ws_mode == 2 && m32 % 4 == 0 && slice32 * 4 <= kWsLdsBytes)
+      return deep ? launch_ws(conv2d_split_ws_kernel<4, 2, 8>, 4, 8) : launch_ws(conv2d_split_ws_kernel<4, 1, 8>, 4, 8);
+    if (m32 % 2 == 0 && slice32 * 2 <= kWsLdsBytes) return deep ? launch_ws(conv2d_split_ws_kernel<2, 2, 8>, 2, 8) : launch_ws(conv2d_split_ws_kernel<2, 1, 8>, 2, 8);
+  }
   if (mt_pick == 4) deep ? launch(conv2d_split_kernel<4, 2>, 4) : launch(conv2d_split_kernel<4, 1>, 4);
   else if (mt_pick == 3) deep ? launch(conv2d_split_kernel<3, 2>, 3) : launch(conv2d_split_kernel<3, 1>, 3);
   else if (mt_pick == 2) deep ? launch(conv2d_split_kernel<2, 2>, 2) : launch(conv2d_split_kernel<2, 1>, 2);

@@ -48,6 +48,14 @@ def test_gpu_split_fp16_conv_matches_oracle(gpu_api, tmp_path, case):
         assert "conv_split_f16x3" not in gpu_api.get_plan("conv_fp32")["exec"] and "conv_precision" not in gpu_api.get_plan("conv_fp32")
         got = gpu_api.predict_from_blob("conv_split", x.tobytes())
         assert np.array_equal(got, gpu_api.predict_from_blob("conv_split", x.tobytes()))
+        # the weight-stationary persistent form (forced on for these small inputs) and the tiled form: same fragments, same order of
+        # additions per output element -> bit-identical
+        for mode in ("0", "2"):
+            os.environ["INFERA_CONV_WS"] = mode
+            try:
+                assert np.array_equal(got, gpu_api.predict_from_blob("conv_split", x.tobytes())), mode
+            finally:
+                os.environ.pop("INFERA_CONV_WS", None)
         ref32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
         # one row alone == the same row inside the batch (the activation scale is per image)
         for r in (0, c["rows"] - 1):
@@ -61,7 +69,47 @@ def test_gpu_split_fp16_conv_matches_oracle(gpu_api, tmp_path, case):
     assert np.all(err <= 1e-4 * np.abs(want) + 1e-6), err.max()
     # ... and far inside it: a few fp32 roundings of the output scale, like the exact-fp32 kernels' own distance from the oracle
     scale = np.abs(want).max()
-    assert err.max() <= 4e-6 * scale, (err.max() / scale, np.abs(ref32 - want).max() / scale)
+    # (or the exact-fp32 kernels' own distance where that is larger: the mean over 1600 pixels of `many_tiles` alone is 1.6e-6 off)
+    assert err.max() <= max(1.5e-6 * scale, 1.5 * np.abs(ref32 - want).max()), (err.max() / scale, np.abs(ref32 - want).max() / scale)
+
+
+# every instantiation of both kernels: (feature tiles per workgroup MT) x (32-channel chunks per stage S) x (3x3 | 1x1, i.e. many stages | a
+# SINGLE stage per tile for the weight-stationary form's cursor), image sizes that leave ragged last tiles.  The bound is 1.5e-6 of the output
+# scale: one k-block's lo fragment read stale (an MFMA issued inside the wait states of an inline-asm VALU write, which the compiler's hazard
+# recogniser does not see) showed up as 6e-6 ... 3e-5 here and nowhere else.
+VARIANTS = {
+    "mt1_s1_3x3": [(32, 3, 1), (32, 3, 1)], "mt1_s2_3x3": [(64, 3, 1), (32, 3, 1)], "mt2_s1_3x3": [(32, 3, 1), (64, 3, 1)],
+    "mt2_s1_3blocks": [(96, 3, 1), (64, 3, 1)], "mt2_s2_3x3": [(64, 3, 1), (64, 3, 1)], "mt3_s1_3x3": [(32, 3, 1), (96, 3, 1)],
+    "mt3_s2_3x3": [(64, 3, 1), (96, 3, 1)], "mt4_s1_3x3": [(32, 3, 1), (128, 3, 1)], "mt4_s2_3x3": [(64, 3, 1), (128, 3, 2)],
+    "mt2_s1_1x1": [(32, 3, 1), (64, 1, 1)], "mt4_s2_1x1_s2": [(64, 3, 1), (128, 1, 2)], "mt2_s2_1x1": [(64, 3, 1), (64, 1, 1)],
+    "mt1_s1_1x1": [(32, 3, 1), (32, 1, 1)], "mt4_s2_2stages": [(128, 3, 1), (128, 1, 1)],
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_gpu_split_fp16_conv_every_instantiation_is_accurate(gpu_api, tmp_path, variant):
+    from oracle import oracle
+
+    hw, rows = 17, 7
+    path = W.write(str(tmp_path / "net.onnx"), _net(VARIANTS[variant], 4, hw, residual_at=()))
+    x = synth.table(23, 0, rows, 4 * hw * hw)
+    _load_both(gpu_api, path)
+    try:
+        assert gpu_api.get_plan("conv_split")["exec"].count("conv_split_f16x3") == 1
+        out = {}
+        for mode in ("0", "2"):
+            os.environ["INFERA_CONV_WS"] = mode
+            try:
+                out[mode] = gpu_api.predict_from_blob("conv_split", x.tobytes())
+            finally:
+                os.environ.pop("INFERA_CONV_WS", None)
+    finally:
+        _unload(gpu_api)
+    assert np.array_equal(out["0"], out["2"])
+    want = oracle.Model(path).predict_blob(x.tobytes())
+    scale = np.abs(want).max()
+    assert np.abs(out["0"] - want).max() <= 1.5e-6 * scale, np.abs(out["0"] - want).max() / scale
 
 
 @pytest.mark.gpu
@@ -84,4 +132,4 @@ def test_gpu_split_fp16_conv_scales_each_image_on_its_own(gpu_api, tmp_path):
     assert np.all(np.isfinite(got))
     for r in range(len(mags)):
         scale = np.abs(want[r]).max()
-        assert np.abs(got[r] - want[r]).max() <= 4e-6 * scale + 1e-37, (r, mags[r], np.abs(got[r] - want[r]).max(), scale)
+        assert np.abs(got[r] - want[r]).max() <= 2e-6 * scale + 1e-37, (r, mags[r], np.abs(got[r] - want[r]).max(), scale)
