@@ -49,9 +49,10 @@ def parse_args():
     ap.add_argument("--workload", default="mlp", choices=["mlp", "logreg", "resnet18"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "f16x3"],
                     help="bf16x3 = the OPTIONAL fast mode of the fused MLP (three bf16 MFMAs per product; NOT the parity path, "
-                         "never the default, never the headline): the line is labelled accordingly")
+                         "never the default, never the headline): the line is labelled accordingly.  f16x3 = the tiled convolutions on the fp16 "
+                         "matrix cores with split operands (resnet18 workload; within the parity tolerance, DESIGN.md 3.3b): labelled in dtype / config")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default run only: skip the short device-resident C4 / C5 measurements reported under other_workloads")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-path (PCIe-inclusive) scan")
@@ -433,13 +434,19 @@ def other_model_path(onnx_writer, tmp: str, which: str) -> str:
     return path
 
 
-def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str) -> dict:
+def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str, precision: str = "fp32") -> dict:
     """BASELINE configs C4 / C5 beside the headline, device-resident (2 warm + `passes` timed passes, HIP events on the
     launching stream): the same definitions as `value` / `roofline`, so that the driver's own run records them too."""
     w = OTHER[which]
     rows, cols, out_cols, bound, flops_row, bytes_row = w["rows"], w["cols"], w["out_cols"], w["bound"], w["flops_row"], w["bytes_row"]
-    model = "bench_" + which
-    capi.load_model(model, other_model_path(onnx_writer, tmp, which))
+    model = "bench_" + which + ("_" + precision if precision != "fp32" else "")
+    if precision != "fp32":
+        os.environ["INFERA_PRECISION"] = precision  # (the convolution mode is read when a model is scheduled)
+    try:
+        capi.load_model(model, other_model_path(onnx_writer, tmp, which))
+    finally:
+        if precision != "fp32":
+            os.environ.pop("INFERA_PRECISION", None)
     try:
         d_in = capi.DeviceBuffer(dev, rows * cols * 4)
         d_out = capi.DeviceBuffer(dev, rows * out_cols * 4)
@@ -455,12 +462,17 @@ def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str) -> dict:
         del d_in, d_out
     finally:
         capi.unload_model(model)
-    if bound == "mfma":
+    split = "f16x3" in str(plan.get("conv_precision", ""))
+    if bound == "mfma" and split:
+        achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 3.0, "TFLOP/s"
+    elif bound == "mfma":
         achieved, peak, unit = flops_row * rows / kernel_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
     else:
         achieved, peak, unit = bytes_row * rows / kernel_s / 1e9, HBM_PEAK_GBS, "GB/s"
-    traffic, traffic_source = traffic_for(which, rows)
-    return {"workload": w["name"], "rows": rows, "rows_per_s": rows / kernel_s, "ms_per_pass": kernel_s * 1e3, "passes_timed": iters, "dtype": "f32",
+    traffic, traffic_source = (None, None) if split else traffic_for(which, rows)
+    return {"workload": w["name"] + (" -- INFERA_PRECISION=f16x3 (opt-in: convolutions on the fp16 matrix cores, operands split hi + lo, three MFMAs per "
+                                     "product; peak = dense fp16 / 3)" if split else ""),
+            "rows": rows, "rows_per_s": rows / kernel_s, "ms_per_pass": kernel_s * 1e3, "passes_timed": iters, "dtype": "f16x3" if split else "f32",
             "value_is": "device_resident",
             "kernel": plan.get("fused_kernel", ",".join(sorted(set(plan["exec"]) - {"skipped"}))),
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic,
@@ -613,7 +625,11 @@ def main():
     ms = capi.time_predict_device("bench", d_in, rows, cols, d_out, iters)
     kernel_s = ms / 1e3 / iters
     bf16x3 = "bf16x3" in str(plan.get("precision", ""))
-    if bound == "mfma" and bf16x3:
+    f16x3 = "f16x3" in str(plan.get("conv_precision", ""))
+    if bound == "mfma" and f16x3:
+        # three fp16 MFMAs per product: the algorithmic-flop ceiling is the dense fp16 peak / 3
+        achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 3.0, "TFLOP/s"
+    elif bound == "mfma" and bf16x3:
         # three bf16 MFMAs per product: the algorithmic-flop ceiling is the dense bf16 peak / 3
         achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 3.0, "TFLOP/s"
     elif bound == "mfma":
@@ -641,6 +657,12 @@ def main():
                 others[key] = other_workload(capi, onnx_writer, tmp, dev, which)
             except Exception as exc:  # never at the expense of the headline line
                 others[key] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:  # C5 once more in the opt-in split-fp16 convolution mode (device-resident only)
+            others["C5_f16x3"] = other_workload(capi, onnx_writer, tmp, dev, "resnet18", "f16x3")
+            if "roofline" in others.get("C5", {}):
+                others["C5_f16x3"]["speedup_over_fp32"] = others["C5_f16x3"]["rows_per_s"] / others["C5"]["rows_per_s"]
+        except Exception as exc:
+            others["C5_f16x3"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- the metric as SURVEY 8(d) defines it: the host path, PCIe included (all ranks scan concurrently) ----
     e2e, table = None, None
@@ -708,16 +730,21 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3 products, f32 accumulate -- OPTIONAL fast mode, NOT parity precision" if bf16x3 else "f32",
+            "dtype": "bf16x3 products, f32 accumulate -- OPTIONAL fast mode, NOT parity precision" if bf16x3 else
+                     "f16x3: fp32 operands split hi + lo in fp16 (22 significant bits), three fp16 MFMAs per product, f32 accumulate -- opt-in, inside "
+                     "the parity tolerance (tests/test_conv_split_gpu.py)" if f16x3 else "f32",
             "data": "synthetic (counter-based splitmix64 table, seed 42; random-init weights seed 1234)",
             "config": {"workload": wl_name, "rows_per_gpu": rows, "features": cols, "parallelism": f"row-range x{world}",
-                       "precision": plan.get("precision", "fp32"),
+                       "precision": plan.get("conv_precision", plan.get("precision", "fp32")),
                        "entry": "infera_hip_predict_device (inputs resident in HBM)",
                        "kernel": plan.get("fused_kernel", ",".join(plan["exec"]))},
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": bytes_row * rows,
                          "kernel_ms": kernel_s * 1e3, "rows_per_s": rows / kernel_s, "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}},
         }
+        if f16x3:
+            line["roofline"]["peak_is"] = "dense fp16 MFMA peak / 3 (three matrix instructions per fp32 product); the stem stays on the exact-fp32 instruction"
+            line["roofline"]["vs_fp32_mfma_peak"] = achieved / FP32_MFMA_PEAK_TFLOPS
         if others:
             line["other_workloads"] = others
         if e2e:

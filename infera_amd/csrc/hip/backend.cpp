@@ -764,8 +764,10 @@ void schedule(LoadedModel &m) {
         m.amax_by_kernel[size_t(c.in0)] = 1;
       }
     }
-    for (size_t i = 0; i < n; i++)  // tensors a split convolution writes: its epilogue tracks the maxima
+    for (size_t i = 0; i < n; i++) {  // tensors a split convolution or the stem + max-pool kernel writes: the producer tracks the maxima
       if (m.conv_split[i]) m.amax_by_kernel[size_t(m.conv_fused_add[i] >= 0 ? st[size_t(m.conv_fused_add[i])].out : st[i].out)] = 0;
+      if (m.exec[i] == ExecKind::ConvPatch && m.conv_fused_pool[i] >= 0) m.amax_by_kernel[size_t(st[size_t(m.conv_fused_pool[i])].out)] = 0;
+    }
     if (m.n_amax > 0) {
       m.amax_slot = int(m.slot_per_row.size());
       m.slot_per_row.push_back(m.n_amax);  // one word per image and tracked tensor
@@ -1040,7 +1042,8 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           if (const int fj = m.conv_fused_pool[i]; fj >= 0) {
             const Step &q = st[size_t(fj)];
             kern::conv2d_patch_pool(s, buf(x.in0), d.W, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
-                                    kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus);
+                                    kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus,
+                                    m.n_amax > 0 && m.amax_of_buf[size_t(q.out)] >= 0 ? amax(q.out) : nullptr);
             continue;
           }
           kern::conv2d_patch(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, kern::conv2d_patch_geom(g), act_of(x), dm.num_cus);

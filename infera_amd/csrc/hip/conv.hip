@@ -1078,7 +1078,8 @@ static size_t patch_pool2_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
 template <int K8C>
 __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                           const float *__restrict__ bias, float *__restrict__ Y, int64_t ntiles,
-                                                                          ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync) {
+                                                                          ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync,
+                                                                          unsigned *__restrict__ amax_out) {
   constexpr int BS = kPool2Block, PW = 2;
   static_assert(K8C >= 6, "the pooling runs in the shadow of a compile-time k loop of at least 22 units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1182,6 +1183,19 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
   };
   int img_p = 0, pr0_p = 0, pc0_p = 0;
   bool have_p = false;
+  // amax_out (nullable): bits of each image's largest pooled |y| (max-accumulated; the split-fp16 convolution that reads this tensor scales
+  // its operands by it, conv_split.hip): every thread tracks the quads it stores, one atomic per wave and tile
+  float tmax = 0.f;
+  auto track = [&](const f32x4 &m, int voff) {
+    if (amax_out && voff >= 0) tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(m[0]), fabsf(m[1]))), fmaxf(fabsf(m[2]), fabsf(m[3])));
+  };
+  auto flush_amax = [&](int img) {
+    float m = tmax;
+    tmax = 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && m > 0.f) atomicMax(amax_out + img, __float_as_uint(m));
+  };
   for (; tile < t_end; tile += tstep) {
     const int64_t next = tile + tstep;
     const int oy0 = oy0_n, ox0 = ox0_n, img = img_n;
@@ -1197,7 +1211,10 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
 #pragma unroll
         for (int e = 0; e < 4; e++) pm[e] = fmaxf(pm[e], ptmp[(st - 1) & 1][e]);
       }
-      if (st == 10) pooled_store(pm, rs_p, voff_p[n]);
+      if (st == 10) {
+        pooled_store(pm, rs_p, voff_p[n]);
+        track(pm, voff_p[n]);
+      }
     };
     tile_origin(next < t_end ? next : tile, img_n, oy0_n, ox0_n);
     const int iy0_n = oy0_n * g.sh - g.pt, ix0_n = ox0_n * g.sw - g.pl;
@@ -1266,6 +1283,10 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
     });
     store_patch(pv);  // (unconditional: the last tile parks its own re-fetched patch, see conv2d_patch_kernel)
     __syncthreads();
+    if (amax_out) {
+      if (have_p) flush_amax(img_p);  // the tile pooled under this k loop
+      else tmax = 0.f;                // (first tile: the pooling ran over an empty exchange tile, its stores were dropped)
+    }
     img_p = img;
     pr0_p = (oy0 + pool.pt) >> 1;
     pc0_p = (ox0 + pool.pl) >> 1;
@@ -1285,8 +1306,11 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
 #pragma unroll
           for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
         }
-      pooled_store(m, rs, pooled_voff(n, pr0_p, pc0_p));
+      const int voff = pooled_voff(n, pr0_p, pc0_p);
+      pooled_store(m, rs, voff);
+      track(m, voff);
     }
+    if (amax_out) flush_amax(img_p);
   }
 }
 
@@ -1554,12 +1578,13 @@ void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed, const 
 }
 
 void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
-                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus) {
+                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out) {
   if (rows <= 0) return;
   const PatchGeom p = patch_pool_geom(g, pool);
   if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {  // (the kernel counts tiles in 32 bits)
     for (int64_t r0 = 0; r0 < rows; r0 += cap)
-      conv2d_patch_pool(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus);
+      conv2d_patch_pool(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus,
+                        amax_out ? amax_out + r0 : nullptr);
     return;
   }
   const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
@@ -1575,7 +1600,7 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
     const unsigned grid2 = unsigned(2 * cus);  // a multiple of 16: an even number of workgroups (whole pairs) on every XCD
     auto launch2 = [&](auto kernel) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kernel, dim3(grid2), dim3(kPool2Block), lds2, s, X, packed, bias, Y, ntiles, g, p, act, pool, desync);
+      hipLaunchKernelGGL(kernel, dim3(grid2), dim3(kPool2Block), lds2, s, X, packed, bias, Y, ntiles, g, p, act, pool, desync, amax_out);
     };
     if (p.K8 == 19) launch2(conv2d_stem_pool2_kernel<19>);
     else launch2(conv2d_stem_pool2_kernel<10>);
@@ -1598,6 +1623,7 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
   };
   if (g.M == 32) by_k8(std::integral_constant<int, 1>{});
   else by_k8(std::integral_constant<int, 2>{});
+  if (amax_out) absmax_rows(s, Y, rows, int64_t(g.M) * pool.OH * pool.OW, amax_out);  // (only the two-workgroup kernel tracks the maxima itself)
 }
 
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,

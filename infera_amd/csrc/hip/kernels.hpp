@@ -145,8 +145,9 @@ struct PoolTail {
   int OH = 0, OW = 0, pt = 0, pl = 0;
 };
 bool conv2d_patch_pool_supported(const ConvGeom &g, const PoolTail &pool);
+// amax_out (nullable): bits of each image's largest pooled |y|, max-accumulated (zero it first) -- for a split-fp16 convolution reading Y
 void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
-                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus);
+                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out = nullptr);
 void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail *pool = nullptr);
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                   const ConvGeom &g, ActParam act, int num_cus);

@@ -57,3 +57,8 @@ def test_default_bench_line_has_contract_fields_and_other_workloads():
         assert w["end_to_end"]["rows_per_s"] > 0 and w["cpu_baseline"]["value"] > 0 and w["cpu_baseline"]["best_cpu"]["value"] > 0, w.keys()
         assert w["end_to_end"]["vs_cpu_baseline"] > 0
     assert c5["end_to_end"]["rows_per_s"] > 0.5 * c5["rows_per_s"]  # C5 stays kernel-bound end to end
+    # ... and C5 in the opt-in split-fp16 convolution mode: its own ceiling (dense fp16 / 3), well ahead of the exact-fp32 kernels
+    s5 = o["C5_f16x3"]
+    assert "error" not in s5, s5
+    assert s5["dtype"] == "f16x3" and "conv_split_f16x3" in s5["kernel"] and s5["roofline"]["peak"] == 2500.0 / 3.0 and 0.1 < s5["roofline"]["frac"] < 1.0
+    assert s5["speedup_over_fp32"] > 1.3 and c5["dtype"] == "f32" and "conv_split_f16x3" not in c5["kernel"]

@@ -133,3 +133,38 @@ def test_gpu_split_fp16_conv_scales_each_image_on_its_own(gpu_api, tmp_path):
     for r in range(len(mags)):
         scale = np.abs(want[r]).max()
         assert np.abs(got[r] - want[r]).max() <= 2e-6 * scale + 1e-37, (r, mags[r], np.abs(got[r] - want[r]).max(), scale)
+
+
+@pytest.mark.gpu
+def test_gpu_split_fp16_resnet18_full_width_both_stem_kernels(gpu_api, tmp_path):
+    """The full-width ResNet-18 topology (stem 7x7/2 + MaxPool in one kernel, 64 .. 512 channels, stride-2 entries, 1x1 downsamples, residual
+    adds) in split-fp16 mode.  The first split convolution scales its input by the per-image maxima of the POOLED stem output: tracked by the
+    two-workgroup stem kernel's own stores (one atomic per wave and tile), or -- behind the one-workgroup stem kernel -- by a reduction
+    kernel.  A maximum is a maximum: both routes must give bit-identical logits, and those must sit as close to the oracle as the exact-fp32
+    plan's."""
+    from oracle import oracle
+
+    path = W.write(str(tmp_path / "rn64.onnx"), W.resnet18(classes=10, in_hw=64, width=64))
+    imgs = synth.table(21, 0, 5, 3 * 64 * 64)
+    _load_both(gpu_api, path)
+    try:
+        plan = gpu_api.get_plan("conv_split")
+        assert plan["exec"].count("conv_split_f16x3") == 19 and plan["exec"][0] == "conv_patch_pool"
+        out = {}
+        for mode in ("0", "2"):
+            os.environ["INFERA_STEM_POOL2"] = mode
+            try:
+                out[mode] = gpu_api.predict_from_blob("conv_split", imgs.tobytes())
+            finally:
+                os.environ.pop("INFERA_STEM_POOL2", None)
+        ref32 = gpu_api.predict_from_blob("conv_fp32", imgs.tobytes())
+        one = gpu_api.predict_from_blob("conv_split", imgs[3].tobytes())
+    finally:
+        _unload(gpu_api)
+    assert np.array_equal(out["0"], out["2"])
+    assert np.array_equal(one.reshape(-1), out["2"][3])
+    want = oracle.Model(path).predict_blob(imgs.tobytes())
+    scale = np.abs(want).max()
+    e16, e32 = np.abs(out["2"] - want).max() / scale, np.abs(ref32 - want).max() / scale
+    assert np.all(np.abs(out["2"] - want) <= 1e-4 * np.abs(want) + 1e-6)
+    assert e16 <= max(3e-6, 3 * e32), (e16, e32)
