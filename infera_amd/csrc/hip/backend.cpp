@@ -747,6 +747,7 @@ void schedule(LoadedModel &m) {
   }
   // split-fp16 convolutions (INFERA_PRECISION=f16x3) and the per-image maxima they scale their inputs by
   m.conv_split.assign(n, 0);
+  m.stem_split.assign(n, 0);
   m.amax_of_buf.assign(nb, -1);
   m.amax_by_kernel.assign(nb, 0);
   m.n_amax = 0;
@@ -763,6 +764,14 @@ void schedule(LoadedModel &m) {
         m.amax_of_buf[size_t(c.in0)] = m.n_amax++;
         m.amax_by_kernel[size_t(c.in0)] = 1;
       }
+    }
+    for (size_t i = 0; i < n; i++) {  // the stem + max-pool kernel in the same arithmetic, where its shape has the instantiation
+      if (m.exec[i] != ExecKind::ConvPatch || m.conv_fused_pool[i] < 0) continue;
+      const Step &c = st[i], &q = st[size_t(m.conv_fused_pool[i])];
+      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
+                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
+      const kern::ConvGeom gp = kern::conv2d_patch_geom(g);
+      if (gp.mvalid == 0 && kern::conv2d_stem_split_supported(gp, kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)})) m.stem_split[i] = 1;
     }
     for (size_t i = 0; i < n; i++) {  // tensors a split convolution or the stem + max-pool kernel writes: the producer tracks the maxima
       if (m.conv_split[i]) m.amax_by_kernel[size_t(m.conv_fused_add[i] >= 0 ? st[size_t(m.conv_fused_add[i])].out : st[i].out)] = 0;
@@ -888,6 +897,11 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
         const Step &q = st[size_t(fj)];
         const kern::PoolTail tail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)};
         kern::conv2d_patch_pack(g, s.W.data(), packed.data(), &tail);
+        if (m.stem_split[i]) {  // (the exact-fp32 blob above stays: INFERA_STEM_SPLIT=0 at run time compares the two)
+          std::vector<float> sp(kern::conv2d_stem_split_packed_floats());
+          kern::conv2d_stem_split_pack(g, s.W.data(), sp.data(), tail);
+          d.cst = upload(sp, us);
+        }
       } else {
         kern::conv2d_patch_pack(g, s.W.data(), packed.data());
       }
@@ -904,7 +918,7 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       d.W = upload(s.W, us);
     }
     d.bias = upload(s.bias, us);
-    d.cst = upload(s.cst, us);
+    if (!d.cst) d.cst = upload(s.cst, us);  // (a split stem keeps its fp16 blob there: convolutions have no constants)
     d.scale = upload(s.scale, us);
     d.shift = upload(s.shift, us);
   }
@@ -1041,9 +1055,14 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
           if (const int fj = m.conv_fused_pool[i]; fj >= 0) {
             const Step &q = st[size_t(fj)];
-            kern::conv2d_patch_pool(s, buf(x.in0), d.W, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
-                                    kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus,
-                                    m.n_amax > 0 && m.amax_of_buf[size_t(q.out)] >= 0 ? amax(q.out) : nullptr);
+            unsigned *track = m.n_amax > 0 && m.amax_of_buf[size_t(q.out)] >= 0 ? amax(q.out) : nullptr;
+            const char *sse = getenv("INFERA_STEM_SPLIT");  // 0: the exact-fp32 stem kernels under a split plan (read per launch: tests, A/B)
+            if (m.stem_split[i] && d.cst && !(sse && atoi(sse) == 0))
+              kern::conv2d_stem_split(s, buf(x.in0), d.cst, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
+                                      kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus, track);
+            else
+              kern::conv2d_patch_pool(s, buf(x.in0), d.W, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
+                                      kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus, track);
             continue;
           }
           kern::conv2d_patch(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, kern::conv2d_patch_geom(g), act_of(x), dm.num_cus);
@@ -1791,7 +1810,7 @@ std::string LoadedModel::describe_json() const {
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++)
-    o << (i ? "," : "") << "\"" << (i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split.size() && conv_split[i] ? "conv_split_f16x3" : ek[int(exec[i])]) << "\"";
+    o << (i ? "," : "") << "\"" << (i < stem_split.size() && stem_split[i] ? "conv_patch_pool_f16x3" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split.size() && conv_split[i] ? "conv_split_f16x3" : ek[int(exec[i])]) << "\"";
   o << "],\"activation_layout\":\"" << (cq_mode ? "NC/4HW4" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";

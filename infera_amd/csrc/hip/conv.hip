@@ -25,7 +25,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 #include <type_traits>
 
 namespace infera_hip::kern {
@@ -1314,6 +1317,296 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
   }
 }
 
+// ---- the same stem + max-pool on the fp16 matrix cores with split operands (INFERA_PRECISION=f16x3, round 3) -------------------
+// conv2d_stem_pool2_kernel's tile flow (two half-channel workgroups per CU, patch / exchange tile / pooling in the k loop's shadow) with
+// the inner product of conv_split.hip: every product as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_f16.  K = C*kh*kw = 147 is
+// ten k-blocks of 16 (instead of 152 exact-fp32 k-steps of 64 cycles: 60 MFMAs of 32 cycles per pixel-tile pair).
+//   * The input patch is split ONCE, when it is parked in LDS: a patch word is {hi | lo << 16} of x * 2^p, the scale 2^p taken from the
+//     largest |x| of THIS TILE's patch (each thread's max of the words it fetched -> wave reduction -> four LDS slots, read after the
+//     barrier the flow already has).  Per tile, not per batch: the tile grid of an image is fixed, so a row's result does not depend on
+//     its batch.  The k loop builds B fragments with one v_perm_b32 per dword (eight scalar LDS reads per k-block and pixel tile, like
+//     the fp32 kernel's; no conversion there).
+//   * Weights: hi / lo fp16 fragments per k-block, scaled per output feature at load time (conv2d_stem_split_pack); the epilogue multiplies
+//     by 2^-(p_tile + p_feature), exact.
+constexpr int kStemKB = 10;
+using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
+static size_t stem_split_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
+  return size_t(kStemKB) * 2048 + size_t(kStemKB) * 64 + (size_t(g.C) * p.PLANE + 8) * 4 + 256 * size_t(32 + 4) * 4 + 64;
+}
+
+__global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+                                                                          const float *__restrict__ bias, float *__restrict__ Y, int64_t ntiles,
+                                                                          ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync,
+                                                                          unsigned *__restrict__ amax_out) {
+  constexpr int BS = kPool2Block, PW = 2, KBC = kStemKB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  u32x4_t *wl = reinterpret_cast<u32x4_t *>(smem);                      // [KBC][part][64 lanes]: this half's 32 features
+  int *ktab = reinterpret_cast<int *>(smem + KBC * 512);                // [KBC][h][8] patch offsets of k = 16 kb + 8 h + e
+  unsigned *patch = reinterpret_cast<unsigned *>(smem + KBC * 512 + KBC * 16);  // [C * PLANE] split words (+ 4 spare)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int psz = g.C * pg.PLANE;
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, half = wg & 1, pair = wg >> 1;
+  f32x4 *exch = reinterpret_cast<f32x4 *>(patch + ((psz + 4 + 3) & ~3));
+  float *red = reinterpret_cast<float *>(exch + 256 * 9);               // [4] per-wave patch maxima of the tile being parked
+
+  // blob: [KBC][half][part][64][4 dwords], then ktab16 [KBC][2][8], then winv[64]
+  for (int i = threadIdx.x; i < KBC * 128; i += BS)
+    wl[i] = reinterpret_cast<const u32x4_t *>(Wp)[(((i >> 7) * 2 + half) * 2 + ((i >> 6) & 1)) * 64 + (i & 63)];
+  for (int i = threadIdx.x; i < KBC * 16; i += BS) ktab[i] = reinterpret_cast<const int *>(Wp)[KBC * 1024 + i];
+  const float *winv = Wp + KBC * 1024 + KBC * 16;
+
+  int e_rel[kPatchMaxE], e_rc[kPatchMaxE], e_lds[kPatchMaxE];
+#pragma unroll
+  for (int i = 0; i < kPatchMaxE; i++) {
+    const int e = threadIdx.x + i * BS;
+    const int c = e / (pg.PR * pg.PC), rem = e - c * (pg.PR * pg.PC), row = rem / pg.PC, col = rem - row * pg.PC;
+    const bool live = c < g.C;
+    e_rel[i] = (c * g.H + row) * g.W + col;
+    e_rc[i] = live ? (row << 16) | col : -1;
+    e_lds[i] = live ? c * pg.PLANE + row * pg.ROWS + (col % g.sw) * pg.HALF + col / g.sw : -1;
+  }
+  const int tiles_per_img = pg.tiles_x * pg.tiles_y;
+  auto tile_origin = [&](int64_t t, int &img, int &oy0, int &ox0) {
+    const unsigned u = unsigned(t), im = u / unsigned(tiles_per_img), rem = u - im * unsigned(tiles_per_img);
+    const unsigned ty = rem / unsigned(pg.tiles_x), tx = rem - ty * unsigned(pg.tiles_x);
+    img = int(im);
+    oy0 = int(ty) * kPoolTR * 2 - pool.pt;
+    ox0 = int(tx) * kPoolTC * 2 - pool.pl;
+  };
+  auto load_slot = [&](int i, const float *image, int iy0, int ix0) -> float {
+    const int iy = iy0 + (e_rc[i] >> 16), ix = ix0 + (e_rc[i] & 0xffff);
+    const bool ok = unsigned(iy) < unsigned(g.H) && unsigned(ix) < unsigned(g.W);
+    const float x = image[ok ? iy0 * g.W + ix0 + e_rel[i] : 0];
+    return ok ? x : 0.f;
+  };
+  // this wave's largest |x| among the patch words it fetched -> red[wave] (read by everybody after the next barrier)
+  auto publish_max = [&](const float(&v)[kPatchMaxE]) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+  };
+  // scale (and its inverse) of the tile whose maxima are in red[], then park its patch as split words
+  auto park_patch = [&](const float(&v)[kPatchMaxE], float &sinv) {
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    unsigned e = (__float_as_uint(m) >> 23) & 0xffu;
+    e = e < 15u ? 15u : (e > 254u ? 254u : e);
+    const float sc = __uint_as_float((268u - e) << 23);
+    sinv = __uint_as_float((e - 14u) << 23);
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++) {
+      unsigned d;
+      float rest;
+      asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(v[i]), "v"(sc));
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(rest) : "v"(v[i]), "v"(sc), "v"(d));
+      asm("v_fma_mixhi_f16 %0, %1, 1.0, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(rest));
+      patch[e_lds[i] >= 0 ? e_lds[i] : psz + (i & 3)] = d;
+    }
+  };
+
+  int lbase[PW], py[PW], px[PW];
+#pragma unroll
+  for (int p = 0; p < PW; p++) {
+    const int pix = min((wave + 4 * p) * 32 + r, kPoolCR * kPoolCC - 1);
+    py[p] = pix / kPoolCC;
+    px[p] = pix % kPoolCC;
+    lbase[p] = py[p] * g.sh * pg.ROWS + px[p];
+  }
+  const u32x4_t *wfrag = wl + lane;
+  const int4 *ktab4 = reinterpret_cast<const int4 *>(ktab) + 2 * h;
+  f32x4 bres[4], wres[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    bres[q] = bias ? reinterpret_cast<const f32x4 *>(bias)[h + 8 * half + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    wres[q] = reinterpret_cast<const f32x4 *>(winv)[h + 8 * half + 2 * q];
+  }
+  float pv[kPatchMaxE];
+  const int64_t chunk = (ntiles + 7) >> 3, t_end = min(ntiles, (int64_t(xcd) + 1) * chunk);
+  const int64_t tstep = ((gridDim.x + 7 - xcd) >> 3) >> 1;
+  int64_t tile = int64_t(xcd) * chunk + pair;
+  int img_n = 0, oy0_n = 0, ox0_n = 0;
+  float sinv_cur = 1.f;
+  if (tile < t_end) {
+    tile_origin(tile, img_n, oy0_n, ox0_n);
+    const int iy0 = oy0_n * g.sh - g.pt, ix0 = ox0_n * g.sw - g.pl;
+    const float *image = X + int64_t(img_n) * g.C * g.H * g.W;
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++) pv[i] = load_slot(i, image, iy0, ix0);
+    publish_max(pv);
+  }
+  __syncthreads();
+  if (tile < t_end) park_patch(pv, sinv_cur);
+  __syncthreads();
+  if (half)
+    for (int i = 0; i < desync; i++) __builtin_amdgcn_s_sleep(127);
+  constexpr int XQ = 9, NQ = 8, PT = kPoolTR * kPoolTC;
+  int pwin[2] = {0, 0}, poff[2] = {-1, -1}, ppr[2] = {0, 0}, ppc[2] = {0, 0};
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int it = threadIdx.x + n * BS;
+    const bool ok = it < NQ * PT;
+    const int cq = ok ? it / PT : 0, pp = ok ? it % PT : 0, pr = pp / kPoolTC, pc = pp % kPoolTC;
+    pwin[n] = ((2 * pr) * kPoolCC + 2 * pc) * XQ + cq;
+    ppr[n] = pr;
+    ppc[n] = pc;
+    poff[n] = ok ? (((cq + NQ * half) * pool.OH + pr) * pool.OW + pc) * 16 : -1;
+  }
+  const unsigned pooled_img_bytes = unsigned(g.M / 4) * unsigned(pool.OH) * unsigned(pool.OW) * 16u;
+  auto pooled_rsrc = [&](int img, bool live) {
+    const char *base = reinterpret_cast<const char *>(Y) + int64_t(__builtin_amdgcn_readfirstlane(img)) * pooled_img_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, live ? int(pooled_img_bytes) : 0, 0x00020000);
+  };
+  auto pooled_voff = [&](int n, int pr0, int pc0) {
+    return (poff[n] >= 0 && pr0 + ppr[n] < pool.OH && pc0 + ppc[n] < pool.OW) ? poff[n] + (pr0 * pool.OW + pc0) * 16 : -1;
+  };
+  auto pooled_store = [&](const f32x4 &m, __amdgpu_buffer_rsrc_t rs, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), rs, voff, 0, 0);
+  };
+  int img_p = 0, pr0_p = 0, pc0_p = 0;
+  bool have_p = false;
+  float tmax = 0.f;
+  auto track = [&](const f32x4 &m, int voff) {
+    if (amax_out && voff >= 0) tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(m[0]), fabsf(m[1]))), fmaxf(fabsf(m[2]), fabsf(m[3])));
+  };
+  auto flush_amax = [&](int img) {
+    float m = tmax;
+    tmax = 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && m > 0.f) atomicMax(amax_out + img, __float_as_uint(m));
+  };
+  for (; tile < t_end; tile += tstep) {
+    const int64_t next = tile + tstep;
+    const int oy0 = oy0_n, ox0 = ox0_n, img = img_n;
+    const __amdgpu_buffer_rsrc_t rs_p = pooled_rsrc(img_p, have_p);
+    const int voff_p[2] = {pooled_voff(0, pr0_p, pc0_p), pooled_voff(1, pr0_p, pc0_p)};
+    f32x4 ptmp[2], pm;
+    auto shadow_pool = [&](int uu) {  // item 0: units 0..10, item 1: units 11..21
+      const int n = uu / 11, st = uu - 11 * n;
+      if (n > 1) return;
+      if (st < 9) ptmp[st & 1] = exch[pwin[n] + ((st / 3) * kPoolCC + st % 3) * XQ];
+      if (st == 0) pm = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (st >= 1 && st <= 9) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) pm[e] = fmaxf(pm[e], ptmp[(st - 1) & 1][e]);
+      }
+      if (st == 10) {
+        pooled_store(pm, rs_p, voff_p[n]);
+        track(pm, voff_p[n]);
+      }
+    };
+    tile_origin(next < t_end ? next : tile, img_n, oy0_n, ox0_n);
+    const int iy0_n = oy0_n * g.sh - g.pt, ix0_n = ox0_n * g.sw - g.pl;
+    const float *image_n = X + int64_t(img_n) * g.C * g.H * g.W;
+
+    f32x16 acc[PW];
+#pragma unroll
+    for (int p = 0; p < PW; p++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
+    const unsigned *pb[PW] = {patch + lbase[0], patch + lbase[1]};
+    int4 ko[2][2];
+    unsigned w[2][PW][8];
+    u32x4_t ah[2], al[2];
+    auto fetch_kb = [&](int kb, int buf) {  // k-block kb's patch words and weight fragments (its offsets are in ko[buf])
+#pragma unroll
+      for (int p = 0; p < PW; p++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[buf][p][e] = pb[p][(&ko[buf][e >> 2].x)[e & 3]];
+      ah[buf] = wfrag[(kb * 2 + 0) * 64];
+      al[buf] = wfrag[(kb * 2 + 1) * 64];
+    };
+    ko[0][0] = ktab4[0];
+    ko[0][1] = ktab4[1];
+    ko[1][0] = ktab4[4];
+    ko[1][1] = ktab4[5];
+    fetch_kb(0, 0);
+#pragma unroll
+    for (int kb = 0; kb < KBC; kb++) {
+      const int cur = kb & 1, nxt = cur ^ 1;
+      if (kb + 1 < KBC) fetch_kb(kb + 1, nxt);
+      u32x4_t bh[PW], bl[PW];
+#pragma unroll
+      for (int p = 0; p < PW; p++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          bh[p][i] = __builtin_amdgcn_perm(w[cur][p][2 * i + 1], w[cur][p][2 * i], 0x05040100u);
+          bl[p][i] = __builtin_amdgcn_perm(w[cur][p][2 * i + 1], w[cur][p][2 * i], 0x07060302u);
+        }
+      if (kb + 2 < KBC) {  // (ko[cur] is free once this k-block's words are in registers: they were fetched one block ago)
+        ko[cur][0] = ktab4[(kb + 2) * 4];
+        ko[cur][1] = ktab4[(kb + 2) * 4 + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int unit = kb * 3 + u;
+#pragma unroll
+        for (int sl = 0; sl < kPatchMaxE; sl++)
+          if (sl * (3 * KBC) / kPatchMaxE == unit) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
+        shadow_pool(unit);
+#pragma unroll
+        for (int p = 0; p < PW; p++) {
+          const u32x4_t a = u == 0 ? al[cur] : ah[cur], b = u == 1 ? bl[p] : bh[p];
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc[p], 0, 0, 0);
+        }
+      }
+    }
+
+    publish_max(pv);  // the next tile's patch words are all in registers by now
+    __syncthreads();  // the previous tile's pooling has read the exchange tile; everybody is out of the k loop (patch free)
+    const float sinv = sinv_cur;
+    dispatch_act(act.kind, [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+      for (int p = 0; p < PW; p++) {
+        const int oy = oy0 + py[p], ox = ox0 + px[p];
+        const bool inside = oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            v[j] = inside ? apply_act_c<KIND>((acc[p][4 * q + j] * wres[q][j]) * sinv + bres[q][j], act.a, act.b) : -INFINITY;
+          exch[((wave + 4 * p) * 32 + r) * XQ + 2 * q + h] = v;
+        }
+      }
+    });
+    park_patch(pv, sinv_cur);
+    __syncthreads();
+    if (amax_out) {
+      if (have_p) flush_amax(img_p);
+      else tmax = 0.f;
+    }
+    img_p = img;
+    pr0_p = (oy0 + pool.pt) >> 1;
+    pc0_p = (ox0 + pool.pl) >> 1;
+    have_p = true;
+  }
+  if (have_p) {
+    const __amdgpu_buffer_rsrc_t rs = pooled_rsrc(img_p, true);
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const f32x4 *win = exch + pwin[n];
+      f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const f32x4 v = win[(i * kPoolCC + j) * XQ];
+#pragma unroll
+          for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
+        }
+      const int voff = pooled_voff(n, pr0_p, pc0_p);
+      pooled_store(m, rs, voff);
+      track(m, voff);
+    }
+    if (amax_out) flush_amax(img_p);
+  }
+}
+
 // Depthwise convolution (groups == C == M) in channel-quad planes: HBM-bound, no matrix cores.  One thread per
 // (n, channel quad, oh, ow): every tap is one 16-byte load (consecutive lanes walk a plane row) times one
 // 16-byte weight quad [c/4][tap][4] that the whole wave shares.
@@ -1624,6 +1917,109 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
   if (g.M == 32) by_k8(std::integral_constant<int, 1>{});
   else by_k8(std::integral_constant<int, 2>{});
   if (amax_out) absmax_rows(s, Y, rows, int64_t(g.M) * pool.OH * pool.OW, amax_out);  // (only the two-workgroup kernel tracks the maxima itself)
+}
+
+// ---- split-fp16 stem + max-pool (conv2d_stem_split_kernel) ----
+bool conv2d_stem_split_supported(const ConvGeom &g, const PoolTail &pool) {
+  if (!conv2d_patch_pool_supported(g, pool) || g.M != 64) return false;
+  const PatchGeom p = patch_pool_geom(g, pool);
+  return (p.K8 + 1) / 2 == kStemKB && (g.C * p.PR * p.PC + kPool2Block - 1) / kPool2Block <= kPatchMaxE && 2 * stem_split_lds_bytes(g, p) <= 160 * 1024;
+}
+
+size_t conv2d_stem_split_packed_floats() { return size_t(kStemKB) * 1024 + size_t(kStemKB) * 16 + 64; }
+
+namespace {
+// fp32 -> fp16 bits, round to nearest even (pre-scaled weights: normal range, but every case is handled)
+uint16_t stem_f16_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return uint16_t(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (x >= 0x477ff000u) return uint16_t(sign | 0x7c00u);
+  if (x < 0x33000001u) return uint16_t(sign);
+  if (x < 0x38800000u) {
+    const int shift = 126 - int(x >> 23);
+    const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+    const uint32_t q = mant >> shift, rem = mant & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    return uint16_t(sign | (q + ((rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u)));
+  }
+  const uint32_t q = (x - 0x38000000u) >> 13, rem = x & 0x1fffu;
+  return uint16_t(sign | (q + ((rem > 0x1000u || (rem == 0x1000u && (q & 1u))) ? 1u : 0u)));
+}
+float stem_f16_value(uint16_t hb) {
+  const uint32_t sign = uint32_t(hb & 0x8000u) << 16, e = (hb >> 10) & 0x1fu, mnt = hb & 0x3ffu;
+  float f;
+  if (e == 0) {
+    f = float(mnt) * 5.9604644775390625e-8f;
+    if (sign) f = -f;
+    return f;
+  }
+  const uint32_t x = e == 31 ? (sign | 0x7f800000u | (mnt << 13)) : (sign | ((e + 112u) << 23) | (mnt << 13));
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+}  // namespace
+
+void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail &pool) {
+  const PatchGeom p = patch_pool_geom(g, pool);
+  const int KK = g.C * g.kh * g.kw;
+  float *winv = packed + size_t(kStemKB) * 1024 + size_t(kStemKB) * 16;
+  std::vector<float> scale(64);
+  for (int m = 0; m < 64; m++) {
+    float amax = 0.f;
+    for (int k = 0; k < KK; k++) amax = std::max(amax, std::fabs(Wt[size_t(m) * KK + k]));
+    uint32_t bits;
+    std::memcpy(&bits, &amax, 4);
+    uint32_t e = (bits >> 23) & 0xffu;
+    e = e < 15u ? 15u : (e > 254u ? 254u : e);
+    const uint32_t sb = (268u - e) << 23, ib = (e - 14u) << 23;
+    std::memcpy(&scale[size_t(m)], &sb, 4);
+    std::memcpy(&winv[m], &ib, 4);
+  }
+  uint16_t *out = reinterpret_cast<uint16_t *>(packed);
+  for (int kb = 0; kb < kStemKB; kb++)
+    for (int half = 0; half < 2; half++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int e = 0; e < 8; e++) {
+          const int m = 32 * half + (lane & 31), k = 16 * kb + 8 * (lane >> 5) + e;
+          const float v = k < KK ? Wt[size_t(m) * KK + k] * scale[size_t(m)] : 0.f;
+          const uint16_t hi = stem_f16_bits(v), lo = stem_f16_bits(v - stem_f16_value(hi));
+          const size_t base = (size_t(kb) * 2 + half) * 2;  // fragments of 64 lanes x 8 halves
+          out[(base + 0) * 512 + size_t(lane) * 8 + e] = hi;
+          out[(base + 1) * 512 + size_t(lane) * 8 + e] = lo;
+        }
+  int *kt = reinterpret_cast<int *>(packed + size_t(kStemKB) * 1024);
+  for (int k = 0; k < kStemKB * 16; k++) {
+    int off = 0;  // (padding k: zero weights times a real, finite patch word)
+    if (k < KK) {
+      const int c = k / (g.kh * g.kw), rem = k % (g.kh * g.kw), cy = (rem / g.kw) * g.dh, cx = (rem % g.kw) * g.dw;
+      off = c * p.PLANE + cy * p.ROWS + (cx % g.sw) * p.HALF + cx / g.sw;
+    }
+    kt[k] = off;
+  }
+}
+
+void conv2d_stem_split(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
+                       ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out) {
+  if (rows <= 0) return;
+  const PatchGeom p = patch_pool_geom(g, pool);
+  if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {
+    for (int64_t r0 = 0; r0 < rows; r0 += cap)
+      conv2d_stem_split(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus,
+                        amax_out ? amax_out + r0 : nullptr);
+    return;
+  }
+  const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
+  const int desync = getenv("INFERA_STEM_POOL2_DESYNC") ? atoi(getenv("INFERA_STEM_POOL2_DESYNC")) : 1;
+  // the grid is whole workgroup PAIRS on each of 8 XCD queues: a multiple of 16 (one precision per plan: this kernel runs for every
+  // batch size, a single image included -- the exact-fp32 stem kernels are not bit-compatible with it)
+  const int cus = std::max(8, (num_cus > 0 ? num_cus : 256) / 8 * 8);
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done.exchange(true))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_stem_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(conv2d_stem_split_kernel, dim3(unsigned(2 * cus)), dim3(kPool2Block), stem_split_lds_bytes(g, p), s, X, packed, bias, Y, ntiles, g, p,
+                     act, pool, desync, amax_out);
 }
 
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,

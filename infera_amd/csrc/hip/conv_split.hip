@@ -661,7 +661,8 @@ void conv2d_split(hipStream_t s, const float *X, const float *packed, const floa
     // (128-feature slices -- the 1x1 downsamples -- only when forced: 256 registers, 22 spilled, 260 us against the tiled form's 234)
     if (ws_mode == 2 && m32 % 4 == 0 && slice32 * 4 <= kWsLdsBytes)
       return deep ? launch_ws(conv2d_split_ws_kernel<4, 2, 8>, 4, 8) : launch_ws(conv2d_split_ws_kernel<4, 1, 8>, 4, 8);
-    if (m32 % 2 == 0 && slice32 * 2 <= kWsLdsBytes) return deep ? launch_ws(conv2d_split_ws_kernel<2, 2, 8>, 2, 8) : launch_ws(conv2d_split_ws_kernel<2, 1, 8>, 2, 8);
+    // (1x1 layers stay on the tiled form unless forced: a single stage per tile, 298 us against 234 for the 64 -> 128 downsample)
+    if (m32 % 2 == 0 && slice32 * 2 <= kWsLdsBytes && (g.kh * g.kw > 1 || ws_mode == 2)) return deep ? launch_ws(conv2d_split_ws_kernel<2, 2, 8>, 2, 8) : launch_ws(conv2d_split_ws_kernel<2, 1, 8>, 2, 8);
   }
   if (mt_pick == 4) deep ? launch(conv2d_split_kernel<4, 2>, 4) : launch(conv2d_split_kernel<4, 1>, 4);
   else if (mt_pick == 3) deep ? launch(conv2d_split_kernel<3, 2>, 3) : launch(conv2d_split_kernel<3, 1>, 3);

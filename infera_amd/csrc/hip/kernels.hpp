@@ -149,6 +149,13 @@ bool conv2d_patch_pool_supported(const ConvGeom &g, const PoolTail &pool);
 void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                        const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out = nullptr);
 void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail *pool = nullptr);
+// The 64-feature 7x7x3 stem + MaxPool on the fp16 matrix cores with split operands (INFERA_PRECISION=f16x3): the patch is split once, when
+// it is parked in LDS, scaled by its own tile's maximum; weights split and scaled per feature at load time.  Runs for every batch size.
+bool conv2d_stem_split_supported(const ConvGeom &g, const PoolTail &pool);
+size_t conv2d_stem_split_packed_floats();
+void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail &pool);
+void conv2d_stem_split(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
+                       ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out);
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                   const ConvGeom &g, ActParam act, int num_cus);
 // Depthwise convolution (groups == C == M, C % 4 == 0) in channel-quad planes; packed = [C/4][tap][4].

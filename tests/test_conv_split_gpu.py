@@ -136,12 +136,14 @@ def test_gpu_split_fp16_conv_scales_each_image_on_its_own(gpu_api, tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_split_fp16_resnet18_full_width_both_stem_kernels(gpu_api, tmp_path):
+def test_gpu_split_fp16_resnet18_full_width(gpu_api, tmp_path):
     """The full-width ResNet-18 topology (stem 7x7/2 + MaxPool in one kernel, 64 .. 512 channels, stride-2 entries, 1x1 downsamples, residual
-    adds) in split-fp16 mode.  The first split convolution scales its input by the per-image maxima of the POOLED stem output: tracked by the
-    two-workgroup stem kernel's own stores (one atomic per wave and tile), or -- behind the one-workgroup stem kernel -- by a reduction
-    kernel.  A maximum is a maximum: both routes must give bit-identical logits, and those must sit as close to the oracle as the exact-fp32
-    plan's."""
+    adds) in split-fp16 mode: the stem runs conv2d_stem_split_kernel (patch split once per tile, scaled by the tile's own maximum), every
+    other convolution the split tiled kernels.  The first of those scales its input by the per-image maxima of the POOLED stem output, which
+    the stem kernel tracks over its own stores.  With INFERA_STEM_SPLIT=0 the exact-fp32 stem kernels run under the same plan -- the
+    two-workgroup one tracks the maxima like the split one, behind the one-workgroup one a reduction kernel computes them: a maximum is a
+    maximum, those two must agree bit for bit.  Every route sits as close to the oracle as the exact-fp32 plan; a row alone == the row in a
+    batch (the split stem runs for every batch size)."""
     from oracle import oracle
 
     path = W.write(str(tmp_path / "rn64.onnx"), W.resnet18(classes=10, in_hw=64, width=64))
@@ -149,22 +151,64 @@ def test_gpu_split_fp16_resnet18_full_width_both_stem_kernels(gpu_api, tmp_path)
     _load_both(gpu_api, path)
     try:
         plan = gpu_api.get_plan("conv_split")
-        assert plan["exec"].count("conv_split_f16x3") == 19 and plan["exec"][0] == "conv_patch_pool"
-        out = {}
-        for mode in ("0", "2"):
-            os.environ["INFERA_STEM_POOL2"] = mode
-            try:
-                out[mode] = gpu_api.predict_from_blob("conv_split", imgs.tobytes())
-            finally:
-                os.environ.pop("INFERA_STEM_POOL2", None)
-        ref32 = gpu_api.predict_from_blob("conv_fp32", imgs.tobytes())
+        assert plan["exec"].count("conv_split_f16x3") == 19 and plan["exec"][0] == "conv_patch_pool_f16x3"
+        got = gpu_api.predict_from_blob("conv_split", imgs.tobytes())
         one = gpu_api.predict_from_blob("conv_split", imgs[3].tobytes())
+        out = {}
+        os.environ["INFERA_STEM_SPLIT"] = "0"
+        try:
+            for mode in ("0", "2"):
+                os.environ["INFERA_STEM_POOL2"] = mode
+                out[mode] = gpu_api.predict_from_blob("conv_split", imgs.tobytes())
+        finally:
+            os.environ.pop("INFERA_STEM_SPLIT", None)
+            os.environ.pop("INFERA_STEM_POOL2", None)
+        ref32 = gpu_api.predict_from_blob("conv_fp32", imgs.tobytes())
     finally:
         _unload(gpu_api)
     assert np.array_equal(out["0"], out["2"])
-    assert np.array_equal(one.reshape(-1), out["2"][3])
+    assert np.array_equal(one.reshape(-1), got[3])
     want = oracle.Model(path).predict_blob(imgs.tobytes())
     scale = np.abs(want).max()
-    e16, e32 = np.abs(out["2"] - want).max() / scale, np.abs(ref32 - want).max() / scale
-    assert np.all(np.abs(out["2"] - want) <= 1e-4 * np.abs(want) + 1e-6)
-    assert e16 <= max(3e-6, 3 * e32), (e16, e32)
+    e32 = np.abs(ref32 - want).max() / scale
+    for y in (got, out["2"]):
+        assert np.all(np.abs(y - want) <= 1e-4 * np.abs(want) + 1e-6)
+        assert np.abs(y - want).max() / scale <= max(3e-6, 3 * e32), (np.abs(y - want).max() / scale, e32)
+
+
+@pytest.mark.gpu
+def test_gpu_split_fp16_stem_alone_and_ranges(gpu_api, tmp_path):
+    """The split stem + max-pool kernel by itself (7x7/2 stem, MaxPool 3x3/2, global average, nothing else): images of wildly different
+    magnitude and an all-zero image in one batch, image sizes that leave ragged tiles on both axes."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(3)
+    for hw in (64, 50, 37):
+        w = (rng.standard_normal((64, 3, 7, 7)) / np.sqrt(147)).astype(np.float32)
+        b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+        nodes = [W.node("Conv", ["X", "w", "b"], ["c"], [W.attr_ints("kernel_shape", [7, 7]), W.attr_ints("strides", [2, 2]), W.attr_ints("pads", [3] * 4)]),
+                 W.node("Relu", ["c"], ["r"]),
+                 W.node("MaxPool", ["r"], ["p"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("strides", [2, 2]), W.attr_ints("pads", [1] * 4)]),
+                 W.node("GlobalAveragePool", ["p"], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
+        path = W.write(str(tmp_path / f"stem{hw}.onnx"), W.model("stem", nodes, [W.tensor("w", w), W.tensor("b", b)], [W.value_info("X", ["N", 3, hw, hw])],
+                                                           [W.value_info("Y", ["N", 64])]))
+        mags = np.array([1.0, 1e-15, 1e15, 0.0, 255.0, 1.0], np.float32)
+        x = (synth.table(9, 0, len(mags), 3 * hw * hw) * mags[:, None]).astype(np.float32)
+        _load_both(gpu_api, path)
+        try:
+            assert gpu_api.get_plan("conv_split")["exec"][0] == "conv_patch_pool_f16x3"
+            got = gpu_api.predict_from_blob("conv_split", x.tobytes())
+            assert np.array_equal(got[5], gpu_api.predict_from_blob("conv_split", x[5].tobytes()).reshape(-1))
+            ref32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
+            os.environ["INFERA_STEM_SPLIT"] = "0"  # the exact-fp32 stem under the same plan: a different kernel, so different bits somewhere
+            try:
+                assert not np.array_equal(got, gpu_api.predict_from_blob("conv_split", x.tobytes()))
+            finally:
+                os.environ.pop("INFERA_STEM_SPLIT", None)
+        finally:
+            _unload(gpu_api)
+        want = oracle.Model(path).predict_blob(x.tobytes())
+        assert np.all(np.isfinite(got))
+        for r in range(len(mags)):  # (or 1.5x the exact-fp32 plan's own distance: the mean over 256 pooled pixels alone is 2e-6 off)
+            scale = np.abs(want[r]).max()
+            assert np.abs(got[r] - want[r]).max() <= max(2e-6 * scale, 1.5 * np.abs(ref32[r] - want[r]).max()) + 1e-37, (hw, r, np.abs(got[r] - want[r]).max() / scale)
