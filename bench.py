@@ -480,16 +480,22 @@ def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str, precision:
                          "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}}}
 
 
-def other_workload_host(capi, onnx_writer, tmp: str, which: str, table, trows: int, budget: dict, threads: int, no_cpu: bool) -> dict:
+def other_workload_host(capi, onnx_writer, tmp: str, which: str, table, trows: int, budget: dict, threads: int, no_cpu: bool, precision: str = "fp32") -> dict:
     """The same two configs END TO END and beside their CPU baselines, short: C4 over the host table C2's
     scan used (first 10M rows, list output of 10, 3 scans); C5 through infera_predict_from_blob over 512 host images (2 scans);
     CPU legs capped at ~2 s each."""
     from infera_amd import sqlmock
 
     w = OTHER[which]
-    model = "bench_" + which
+    model = "bench_" + which + ("_" + precision if precision != "fp32" else "")
     path = other_model_path(onnx_writer, tmp, which)
-    capi.load_model(model, path)
+    if precision != "fp32":
+        os.environ["INFERA_PRECISION"] = precision  # (read when the model is scheduled)
+    try:
+        capi.load_model(model, path)
+    finally:
+        if precision != "fp32":
+            os.environ.pop("INFERA_PRECISION", None)
     out = {}
     try:
         if which == "logreg":
@@ -713,6 +719,16 @@ def main():
                 others[key].update(other_workload_host(capi, onnx_writer, tmp, which, table, trows, budget, e2e["threads_per_rank"], args.no_cpu_baseline))
             except Exception as exc:
                 others[key]["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if "error" not in others.get("C5_f16x3", {"error": 1}):  # the same images through the same entry in the opt-in mode; ratios against C5's CPU legs
+            try:
+                e5 = other_workload_host(capi, onnx_writer, tmp, "resnet18", table, trows, budget, e2e["threads_per_rank"], True, "f16x3")["end_to_end"]
+                cb = others.get("C5", {}).get("cpu_baseline")
+                if cb:
+                    e5["vs_cpu_baseline"] = e5["rows_per_s"] / max(cb["value"], cb["best_cpu"]["value"])
+                    e5["vs_cpu_reference_shaped"] = e5["rows_per_s"] / cb["value"]
+                others["C5_f16x3"]["end_to_end"] = e5
+            except Exception as exc:
+                others["C5_f16x3"]["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         total_rows = rows * world * args.steps

@@ -62,3 +62,4 @@ def test_default_bench_line_has_contract_fields_and_other_workloads():
     assert "error" not in s5, s5
     assert s5["dtype"] == "f16x3" and "conv_split_f16x3" in s5["kernel"] and s5["roofline"]["peak"] == 2500.0 / 3.0 and 0.1 < s5["roofline"]["frac"] < 1.0
     assert s5["speedup_over_fp32"] > 1.3 and c5["dtype"] == "f32" and "conv_split_f16x3" not in c5["kernel"]
+    assert s5["end_to_end"]["rows_per_s"] > 1.2 * c5["end_to_end"]["rows_per_s"] and s5["end_to_end"]["vs_cpu_baseline"] > c5["end_to_end"]["vs_cpu_baseline"]
