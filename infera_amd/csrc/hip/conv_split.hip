@@ -169,6 +169,12 @@ __global__ __launch_bounds__(kBlock, MT >= 3 ? 2 : 3) void conv2d_split_kernel(c
     // per-product error in exactly the instantiations whose first MFMA follows the split directly (S = 1 with one or two feature tiles).
     asm volatile("s_nop 1" : "+v"(oh), "+v"(ol));
   };
+  // (Measured and dropped: a PATCH form for stride-1 layers -- per 32-channel chunk the workgroup's whole receptive field parked in LDS already
+  // split and scaled (rows of the zero-padded input, a tap = a slot offset, eight fragment planes, every element fetched and split once instead
+  // of once per tap), weight slabs per (tap, chunk) stage as here.  Correct (within 1.5e-6 of the oracle, images of different scale sharing a
+  // tile) and slower: 128 / 256 / 512-channel layers 0.68-0.77 ms against 0.59-0.72, 64-channel layers 1.20-1.28 against 0.81-0.92.  With the
+  // patch in LDS (up to 59 KB) only one 32-channel slab pair fits beside it at two workgroups per CU, so a stage is 12-24 matrix instructions
+  // -- half of this form's -- and the per-stage barrier + slab latency cost more than the nine-fold gathers and splits they replaced.)
   // (Measured and dropped: gathers TWO stages ahead through a third register buffer, the weight slab issued first and `s_waitcnt vmcnt(NB)` at
   // the end of a stage -- 128-feature tiles then need 256 registers and spill 28, 64-feature tiles fall from 3 to 2 waves per SIMD: 4-20 %
   // slower.  With three 32-cycle matrix instructions per product the chip is at its power limit long before the matrix pipe is full -- 1.8 to
