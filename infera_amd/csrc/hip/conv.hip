@@ -21,6 +21,7 @@
 //   * conv2d_generic_kernel -- any geometry / groups / layouts (the C=3 stem reads the caller's NCHW
 //     blob and writes CQ); scalar gathers, weights straight from L2.
 #include "device_common.hpp"
+#include "f16_split.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -1928,39 +1929,6 @@ bool conv2d_stem_split_supported(const ConvGeom &g, const PoolTail &pool) {
 
 size_t conv2d_stem_split_packed_floats() { return size_t(kStemKB) * 1024 + size_t(kStemKB) * 16 + 64; }
 
-namespace {
-// fp32 -> fp16 bits, round to nearest even (pre-scaled weights: normal range, but every case is handled)
-uint16_t stem_f16_bits(float f) {
-  uint32_t x;
-  std::memcpy(&x, &f, 4);
-  const uint32_t sign = (x >> 16) & 0x8000u;
-  x &= 0x7fffffffu;
-  if (x >= 0x7f800000u) return uint16_t(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
-  if (x >= 0x477ff000u) return uint16_t(sign | 0x7c00u);
-  if (x < 0x33000001u) return uint16_t(sign);
-  if (x < 0x38800000u) {
-    const int shift = 126 - int(x >> 23);
-    const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
-    const uint32_t q = mant >> shift, rem = mant & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
-    return uint16_t(sign | (q + ((rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u)));
-  }
-  const uint32_t q = (x - 0x38000000u) >> 13, rem = x & 0x1fffu;
-  return uint16_t(sign | (q + ((rem > 0x1000u || (rem == 0x1000u && (q & 1u))) ? 1u : 0u)));
-}
-float stem_f16_value(uint16_t hb) {
-  const uint32_t sign = uint32_t(hb & 0x8000u) << 16, e = (hb >> 10) & 0x1fu, mnt = hb & 0x3ffu;
-  float f;
-  if (e == 0) {
-    f = float(mnt) * 5.9604644775390625e-8f;
-    if (sign) f = -f;
-    return f;
-  }
-  const uint32_t x = e == 31 ? (sign | 0x7f800000u | (mnt << 13)) : (sign | ((e + 112u) << 23) | (mnt << 13));
-  std::memcpy(&f, &x, 4);
-  return f;
-}
-}  // namespace
-
 void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail &pool) {
   const PatchGeom p = patch_pool_geom(g, pool);
   const int KK = g.C * g.kh * g.kw;
@@ -1969,11 +1937,8 @@ void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, c
   for (int m = 0; m < 64; m++) {
     float amax = 0.f;
     for (int k = 0; k < KK; k++) amax = std::max(amax, std::fabs(Wt[size_t(m) * KK + k]));
-    uint32_t bits;
-    std::memcpy(&bits, &amax, 4);
-    uint32_t e = (bits >> 23) & 0xffu;
-    e = e < 15u ? 15u : (e > 254u ? 254u : e);
-    const uint32_t sb = (268u - e) << 23, ib = (e - 14u) << 23;
+    uint32_t sb, ib;
+    f16_split_scale_bits(amax, sb, ib);
     std::memcpy(&scale[size_t(m)], &sb, 4);
     std::memcpy(&winv[m], &ib, 4);
   }
@@ -1984,7 +1949,7 @@ void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, c
         for (int e = 0; e < 8; e++) {
           const int m = 32 * half + (lane & 31), k = 16 * kb + 8 * (lane >> 5) + e;
           const float v = k < KK ? Wt[size_t(m) * KK + k] * scale[size_t(m)] : 0.f;
-          const uint16_t hi = stem_f16_bits(v), lo = stem_f16_bits(v - stem_f16_value(hi));
+          const uint16_t hi = f16_bits_rne(v), lo = f16_bits_rne(v - f16_bits_to_float(hi));
           const size_t base = (size_t(kb) * 2 + half) * 2;  // fragments of 64 lanes x 8 halves
           out[(base + 0) * 512 + size_t(lane) * 8 + e] = hi;
           out[(base + 1) * 512 + size_t(lane) * 8 + e] = lo;

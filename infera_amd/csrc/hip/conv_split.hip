@@ -21,6 +21,7 @@
 // fragment format and the inner product differ.  K-block kb (16 channels) of a 32-channel chunk pairs the gathered quads
 // 2kb and 2kb+1: lane (r, h) feeds k = 8h + e  <->  channel 16kb + 8(e >> 2) + 4h + (e & 3) of pixel r.
 #include "device_common.hpp"
+#include "f16_split.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -514,46 +515,6 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restric
   if ((threadIdx.x & 63) == 0) atomicMax(amax + blockIdx.y, __float_as_uint(m));
 }
 
-// fp32 -> fp16 bits, round to nearest even (host; values are pre-scaled into fp16's range, but every case is handled)
-uint16_t f16_bits_rne(float f) {
-  uint32_t x;
-  std::memcpy(&x, &f, 4);
-  const uint32_t sign = (x >> 16) & 0x8000u;
-  x &= 0x7fffffffu;
-  if (x >= 0x7f800000u) return uint16_t(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));  // NaN / inf
-  if (x >= 0x477ff000u) return uint16_t(sign | 0x7c00u);                                   // rounds to >= 65520 -> inf
-  if (x < 0x33000001u) return uint16_t(sign);                                              // <= 2^-25 -> 0 (ties to even)
-  if (x < 0x38800000u) {  // subnormal half: value = m * 2^-24, m = RNE(f * 2^24)
-    const int shift = 126 - int(x >> 23);  // f = 1.mant * 2^(e-127); m = (1.mant * 2^23) >> (shift) with 14 <= shift <= 24
-    const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
-    const uint32_t q = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
-    return uint16_t(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
-  }
-  const uint32_t q = ((x - 0x38000000u) >> 13), rem = x & 0x1fffu;  // exponent rebased, 10 mantissa bits kept
-  return uint16_t(sign | (q + ((rem > 0x1000u || (rem == 0x1000u && (q & 1u))) ? 1u : 0u)));  // a carry walks into the exponent
-}
-
-float f16_bits_to_float(uint16_t hbits) {
-  const uint32_t sign = uint32_t(hbits & 0x8000u) << 16, e = (hbits >> 10) & 0x1fu, m = hbits & 0x3ffu;
-  uint32_t x;
-  if (e == 0) {
-    if (m == 0) {
-      x = sign;
-    } else {  // subnormal: m * 2^-24
-      float v = float(m) * 5.9604644775390625e-8f;
-      std::memcpy(&x, &v, 4);
-      x |= sign;
-    }
-  } else if (e == 31) {
-    x = sign | 0x7f800000u | (m << 13);
-  } else {
-    x = sign | ((e + 112u) << 23) | (m << 13);
-  }
-  float f;
-  std::memcpy(&f, &x, 4);
-  return f;
-}
-
 }  // namespace
 
 bool conv2d_split_supported(const ConvGeom &g) {
@@ -570,11 +531,8 @@ void conv2d_split_pack(const ConvGeom &g, const float *Wt, float *packed, float 
       const float a = std::fabs(Wt[size_t(m) * K + k]);
       if (a > amax) amax = a;  // (NaN weights: compare false, the feature's outputs are NaN either way)
     }
-    uint32_t bits;
-    std::memcpy(&bits, &amax, 4);
-    uint32_t e = (bits >> 23) & 0xffu;
-    e = e < 15u ? 15u : (e > 254u ? 254u : e);
-    const uint32_t sb = (268u - e) << 23, ib = (e - 14u) << 23;
+    uint32_t sb, ib;
+    f16_split_scale_bits(amax, sb, ib);
     std::memcpy(&scale[size_t(m)], &sb, 4);
     std::memcpy(&winv[m], &ib, 4);
   }
