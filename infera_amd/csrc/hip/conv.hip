@@ -1325,14 +1325,18 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
 //   * The input patch is split ONCE, when it is parked in LDS: a patch word is {hi | lo << 16} of x * 2^p, the scale 2^p taken from the
 //     largest |x| of THIS TILE's patch (each thread's max of the words it fetched -> wave reduction -> four LDS slots, read after the
 //     barrier the flow already has).  Per tile, not per batch: the tile grid of an image is fixed, so a row's result does not depend on
-//     its batch.  The k loop builds B fragments with one v_perm_b32 per dword (eight scalar LDS reads per k-block and pixel tile, like
-//     the fp32 kernel's; no conversion there).
+//     its batch.
+//   * k order: a lane half's eight k-values of a k-block are ONE filter row (c, ky), kx in the order 0 2 4 6 1 3 5 7 (kx = 7: zero weight).
+//     The patch rows are de-interleaved by column parity (stride 2), so those are four consecutive words of the row's even half and four of
+//     its odd half: one row offset per k-block (eleven registers for the kernel's lifetime, no offset table), four ds_read2_b32 per pixel
+//     tile, one v_perm_b32 per fragment dword.  21 filter rows = 11 k-blocks (the 22nd row has zero weights).  (First version: k in ONNX
+//     order through a per-k offset table -- 16 scalar reads and 16 address computations per k-block and tile: 1.74 ms against ~1.3.)
 //   * Weights: hi / lo fp16 fragments per k-block, scaled per output feature at load time (conv2d_stem_split_pack); the epilogue multiplies
 //     by 2^-(p_tile + p_feature), exact.
-constexpr int kStemKB = 10;
+constexpr int kStemKB = 11;
 using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
 static size_t stem_split_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
-  return size_t(kStemKB) * 2048 + size_t(kStemKB) * 64 + (size_t(g.C) * p.PLANE + 8) * 4 + 256 * size_t(32 + 4) * 4 + 64;
+  return size_t(kStemKB) * 2048 + (size_t(g.C) * p.PLANE + 8) * 4 + 256 * size_t(32 + 4) * 4 + 64;
 }
 
 __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
@@ -1342,8 +1346,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split_kernel(const
   constexpr int BS = kPool2Block, PW = 2, KBC = kStemKB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   u32x4_t *wl = reinterpret_cast<u32x4_t *>(smem);                      // [KBC][part][64 lanes]: this half's 32 features
-  int *ktab = reinterpret_cast<int *>(smem + KBC * 512);                // [KBC][h][8] patch offsets of k = 16 kb + 8 h + e
-  unsigned *patch = reinterpret_cast<unsigned *>(smem + KBC * 512 + KBC * 16);  // [C * PLANE] split words (+ 4 spare)
+  unsigned *patch = reinterpret_cast<unsigned *>(smem + KBC * 512);     // [C * PLANE] split words (+ 4 spare)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int psz = g.C * pg.PLANE;
@@ -1351,11 +1354,20 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split_kernel(const
   f32x4 *exch = reinterpret_cast<f32x4 *>(patch + ((psz + 4 + 3) & ~3));
   float *red = reinterpret_cast<float *>(exch + 256 * 9);               // [4] per-wave patch maxima of the tile being parked
 
-  // blob: [KBC][half][part][64][4 dwords], then ktab16 [KBC][2][8], then winv[64]
+  // blob: [KBC][half][part][64][4 dwords], then winv[64]
   for (int i = threadIdx.x; i < KBC * 128; i += BS)
     wl[i] = reinterpret_cast<const u32x4_t *>(Wp)[(((i >> 7) * 2 + half) * 2 + ((i >> 6) & 1)) * 64 + (i & 63)];
-  for (int i = threadIdx.x; i < KBC * 16; i += BS) ktab[i] = reinterpret_cast<const int *>(Wp)[KBC * 1024 + i];
-  const float *winv = Wp + KBC * 1024 + KBC * 16;
+  const float *winv = Wp + KBC * 1024;
+  // words nobody parks (the odd half's fourth word of the last pixels: kx = 7, weight zero) must still be finite
+  for (int i = threadIdx.x; i < psz + 8; i += BS) patch[i] = 0u;
+  // the patch offset of every filter row (c, ky) = 0 .. 21 (row 21: zero weights, any row): wave-uniform, so they live in scalar registers;
+  // lane half h of k-block kb reads row 2 kb + h
+  int soff[2 * KBC];
+#pragma unroll
+  for (int rr = 0; rr < 2 * KBC; rr++) {
+    const int c = rr / g.kh, ky = rr - c * g.kh;
+    soff[rr] = rr < g.C * g.kh ? c * pg.PLANE + ky * g.dh * pg.ROWS : 0;
+  }
 
   int e_rel[kPatchMaxE], e_rc[kPatchMaxE], e_lds[kPatchMaxE];
 #pragma unroll
@@ -1417,7 +1429,6 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split_kernel(const
     lbase[p] = py[p] * g.sh * pg.ROWS + px[p];
   }
   const u32x4_t *wfrag = wl + lane;
-  const int4 *ktab4 = reinterpret_cast<const int4 *>(ktab) + 2 * h;
   f32x4 bres[4], wres[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -1509,51 +1520,47 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split_kernel(const
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
     const unsigned *pb[PW] = {patch + lbase[0], patch + lbase[1]};
-    int4 ko[2][2];
-    unsigned w[2][PW][8];
+    // a step = (k-block, pixel tile): eight patch words (even half: kx 0 2 4 6, odd half: kx 1 3 5 7), fetched one step ahead; the
+    // k-block's weight fragments one k-block ahead
+    unsigned w[2][8];
     u32x4_t ah[2], al[2];
-    auto fetch_kb = [&](int kb, int buf) {  // k-block kb's patch words and weight fragments (its offsets are in ko[buf])
+    auto fetch_words = [&](int step, int buf) {
+      const int kb = step / PW, p = step % PW;
+      const unsigned *row = pb[p] + (h ? soff[2 * kb + 1] : soff[2 * kb]), *rowh = row + pg.HALF;
 #pragma unroll
-      for (int p = 0; p < PW; p++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) w[buf][p][e] = pb[p][(&ko[buf][e >> 2].x)[e & 3]];
-      ah[buf] = wfrag[(kb * 2 + 0) * 64];
-      al[buf] = wfrag[(kb * 2 + 1) * 64];
-    };
-    ko[0][0] = ktab4[0];
-    ko[0][1] = ktab4[1];
-    ko[1][0] = ktab4[4];
-    ko[1][1] = ktab4[5];
-    fetch_kb(0, 0);
-#pragma unroll
-    for (int kb = 0; kb < KBC; kb++) {
-      const int cur = kb & 1, nxt = cur ^ 1;
-      if (kb + 1 < KBC) fetch_kb(kb + 1, nxt);
-      u32x4_t bh[PW], bl[PW];
-#pragma unroll
-      for (int p = 0; p < PW; p++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          bh[p][i] = __builtin_amdgcn_perm(w[cur][p][2 * i + 1], w[cur][p][2 * i], 0x05040100u);
-          bl[p][i] = __builtin_amdgcn_perm(w[cur][p][2 * i + 1], w[cur][p][2 * i], 0x07060302u);
-        }
-      if (kb + 2 < KBC) {  // (ko[cur] is free once this k-block's words are in registers: they were fetched one block ago)
-        ko[cur][0] = ktab4[(kb + 2) * 4];
-        ko[cur][1] = ktab4[(kb + 2) * 4 + 1];
+      for (int e = 0; e < 4; e++) {
+        w[buf][e] = row[e];
+        w[buf][4 + e] = rowh[e];
       }
+    };
+    fetch_words(0, 0);
+    ah[0] = wfrag[0];
+    al[0] = wfrag[64];
 #pragma unroll
-      for (int u = 0; u < 3; u++) {
-        const int unit = kb * 3 + u;
+    for (int step = 0; step < KBC * PW; step++) {
+      const int kb = step / PW, p = step % PW, cur = step & 1, kc = kb & 1;
+      if (step + 1 < KBC * PW) fetch_words(step + 1, cur ^ 1);
+      if (p == 0 && kb + 1 < KBC) {
+        ah[kc ^ 1] = wfrag[((kb + 1) * 2 + 0) * 64];
+        al[kc ^ 1] = wfrag[((kb + 1) * 2 + 1) * 64];
+      }
+      u32x4_t bh, bl;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        bh[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1], w[cur][2 * i], 0x05040100u);
+        bl[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1], w[cur][2 * i], 0x07060302u);
+      }
+      // the tile's other work rides along: one and a half units of pooling / patch prefetch per step
+#pragma unroll
+      for (int unit = (step * 3) / 2; unit < ((step + 1) * 3) / 2; unit++) {
 #pragma unroll
         for (int sl = 0; sl < kPatchMaxE; sl++)
           if (sl * (3 * KBC) / kPatchMaxE == unit) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
         shadow_pool(unit);
-#pragma unroll
-        for (int p = 0; p < PW; p++) {
-          const u32x4_t a = u == 0 ? al[cur] : ah[cur], b = u == 1 ? bl[p] : bh[p];
-          acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc[p], 0, 0, 0);
-        }
       }
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al[kc]), __builtin_bit_cast(f16x8_t, bh), acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah[kc]), __builtin_bit_cast(f16x8_t, bl), acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah[kc]), __builtin_bit_cast(f16x8_t, bh), acc[p], 0, 0, 0);
     }
 
     publish_max(pv);  // the next tile's patch words are all in registers by now
@@ -1924,15 +1931,17 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
 bool conv2d_stem_split_supported(const ConvGeom &g, const PoolTail &pool) {
   if (!conv2d_patch_pool_supported(g, pool) || g.M != 64) return false;
   const PatchGeom p = patch_pool_geom(g, pool);
-  return (p.K8 + 1) / 2 == kStemKB && (g.C * p.PR * p.PC + kPool2Block - 1) / kPool2Block <= kPatchMaxE && 2 * stem_split_lds_bytes(g, p) <= 160 * 1024;
+  // (the k loop reads four consecutive words of each half of a de-interleaved patch row: 7 columns, stride 2)
+  return g.kw == 7 && g.sw == 2 && g.dw == 1 && (g.C * g.kh + 1) / 2 == kStemKB && p.HALF >= kPoolCC + 3 &&
+         (g.C * p.PR * p.PC + kPool2Block - 1) / kPool2Block <= kPatchMaxE && 2 * stem_split_lds_bytes(g, p) <= 160 * 1024;
 }
 
-size_t conv2d_stem_split_packed_floats() { return size_t(kStemKB) * 1024 + size_t(kStemKB) * 16 + 64; }
+size_t conv2d_stem_split_packed_floats() { return size_t(kStemKB) * 1024 + 64; }
 
 void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail &pool) {
   const PatchGeom p = patch_pool_geom(g, pool);
   const int KK = g.C * g.kh * g.kw;
-  float *winv = packed + size_t(kStemKB) * 1024 + size_t(kStemKB) * 16;
+  float *winv = packed + size_t(kStemKB) * 1024;
   std::vector<float> scale(64);
   for (int m = 0; m < 64; m++) {
     float amax = 0.f;
@@ -1947,22 +1956,16 @@ void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, c
     for (int half = 0; half < 2; half++)
       for (int lane = 0; lane < 64; lane++)
         for (int e = 0; e < 8; e++) {
-          const int m = 32 * half + (lane & 31), k = 16 * kb + 8 * (lane >> 5) + e;
-          const float v = k < KK ? Wt[size_t(m) * KK + k] * scale[size_t(m)] : 0.f;
+          // lane half h of k-block kb = filter row (c, ky) = 2 kb + h; element e = kx in the order 0 2 4 6 1 3 5 7
+          const int m = 32 * half + (lane & 31), rr = 2 * kb + (lane >> 5), kx = e < 4 ? 2 * e : 2 * (e - 4) + 1;
+          const bool real = rr < g.C * g.kh && kx < g.kw;
+          const float v = real ? Wt[size_t(m) * KK + size_t(rr) * g.kw + kx] * scale[size_t(m)] : 0.f;
           const uint16_t hi = f16_bits_rne(v), lo = f16_bits_rne(v - f16_bits_to_float(hi));
           const size_t base = (size_t(kb) * 2 + half) * 2;  // fragments of 64 lanes x 8 halves
           out[(base + 0) * 512 + size_t(lane) * 8 + e] = hi;
           out[(base + 1) * 512 + size_t(lane) * 8 + e] = lo;
         }
-  int *kt = reinterpret_cast<int *>(packed + size_t(kStemKB) * 1024);
-  for (int k = 0; k < kStemKB * 16; k++) {
-    int off = 0;  // (padding k: zero weights times a real, finite patch word)
-    if (k < KK) {
-      const int c = k / (g.kh * g.kw), rem = k % (g.kh * g.kw), cy = (rem / g.kw) * g.dh, cx = (rem % g.kw) * g.dw;
-      off = c * p.PLANE + cy * p.ROWS + (cx % g.sw) * p.HALF + cx / g.sw;
-    }
-    kt[k] = off;
-  }
+  (void)p;
 }
 
 void conv2d_stem_split(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
