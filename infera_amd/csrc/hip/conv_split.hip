@@ -628,6 +628,9 @@ void conv2d_split(hipStream_t s, const float *X, const float *packed, const floa
     // (1x1 layers stay on the tiled form unless forced: a single stage per tile, 298 us against 234 for the 64 -> 128 downsample)
     if (m32 % 2 == 0 && slice32 * 2 <= kWsLdsBytes && (g.kh * g.kw > 1 || ws_mode == 2)) return deep ? launch_ws(conv2d_split_ws_kernel<2, 2, 8>, 2, 8) : launch_ws(conv2d_split_ws_kernel<2, 1, 8>, 2, 8);
   }
+  // (Measured and dropped: conv2d_tiled's tail split -- the last partial round of a 128-feature launch as a second launch of 32- or 64-feature
+  // tiles.  Every workgroup here gathers and splits its whole input whatever its feature count, so a quarter of the features costs nearly a
+  // whole workgroup time: 567 + 212 us (32-feature tail) or 580 + 72 ... 646 + 155 us (64-feature tail) against 640-705 unsplit.)
   if (mt_pick == 4) deep ? launch(conv2d_split_kernel<4, 2>, 4) : launch(conv2d_split_kernel<4, 1>, 4);
   else if (mt_pick == 3) deep ? launch(conv2d_split_kernel<3, 2>, 3) : launch(conv2d_split_kernel<3, 1>, 3);
   else if (mt_pick == 2) deep ? launch(conv2d_split_kernel<2, 2>, 2) : launch(conv2d_split_kernel<2, 1>, 2);

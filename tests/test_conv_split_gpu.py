@@ -212,3 +212,4 @@ def test_gpu_split_fp16_stem_alone_and_ranges(gpu_api, tmp_path):
         for r in range(len(mags)):  # (or 1.5x the exact-fp32 plan's own distance: the mean over 256 pooled pixels alone is 2e-6 off)
             scale = np.abs(want[r]).max()
             assert np.abs(got[r] - want[r]).max() <= max(2e-6 * scale, 1.5 * np.abs(ref32[r] - want[r]).max()) + 1e-37, (hw, r, np.abs(got[r] - want[r]).max() / scale)
+
