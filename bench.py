@@ -509,7 +509,8 @@ def other_workload_host(capi, onnx_writer, tmp: str, which: str, table, trows: i
             from infera_amd import synth
 
             images = synth.table(7, 0, 512, w["cols"])  # 512 images = 308 MB of host BLOBs
-            out["end_to_end"] = end_to_end_blobs(model, images, w["cols"] * 4, w["out_cols"], "8", 2, budget)
+            # (the exact-fp32 plan is kernel-bound at 8 callers; the split-fp16 plan is twice as fast and needs 16 to stay fed)
+            out["end_to_end"] = end_to_end_blobs(model, images, w["cols"] * 4, w["out_cols"], "8" if precision == "fp32" else "16", 2, budget)
             del images
             if not no_cpu:
                 out["cpu_baseline"] = cpu_baseline_blobs(path, w["cols"], budget, seconds=2.0, flops_row=w["flops_row"])
