@@ -1983,9 +1983,13 @@ void conv2d_stem_split(hipStream_t s, const float *X, const float *packed, const
   // the grid is whole workgroup PAIRS on each of 8 XCD queues: a multiple of 16 (one precision per plan: this kernel runs for every
   // batch size, a single image included -- the exact-fp32 stem kernels are not bit-compatible with it)
   const int cus = std::max(8, (num_cus > 0 ? num_cus : 256) / 8 * 8);
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.exchange(true))
+  static std::atomic<uint64_t> attr_done{0};  // once per device: function attributes belong to the device's code object
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_stem_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+  }
   hipLaunchKernelGGL(conv2d_stem_split_kernel, dim3(unsigned(2 * cus)), dim3(kPool2Block), stem_split_lds_bytes(g, p), s, X, packed, bias, Y, ntiles, g, p,
                      act, pool, desync, amax_out);
 }
