@@ -213,3 +213,32 @@ def test_gpu_split_fp16_stem_alone_and_ranges(gpu_api, tmp_path):
             scale = np.abs(want[r]).max()
             assert np.abs(got[r] - want[r]).max() <= max(2e-6 * scale, 1.5 * np.abs(ref32[r] - want[r]).max()) + 1e-37, (hw, r, np.abs(got[r] - want[r]).max() / scale)
 
+
+
+@pytest.mark.gpu
+def test_gpu_split_fp16_c5_full_width_error_against_float64(gpu_api, tmp_path):
+    """BASELINE config C5 itself (ResNet-18, full width, 224x224, 1000 classes) in split-fp16 mode against a float64 evaluation of the same
+    graph (PyTorch's CPU operators in double precision, rebuilt from the writer's weight stream -- tests/test_oracle_vs_torch.py): every logit
+    within the parity tolerance 1e-4 |y| + 1e-6 of the float64 value, and the largest error no more than twice the exact-fp32 plan's own."""
+    import torch
+
+    from tests.test_oracle_vs_torch import torch_resnet18
+
+    rows = 4
+    path = W.write(str(tmp_path / "rn224.onnx"), W.resnet18())
+    x = synth.table(5, 0, rows, 3 * 224 * 224)
+    _load_both(gpu_api, path)
+    try:
+        assert gpu_api.get_plan("conv_split")["exec"].count("conv_split_f16x3") == 19
+        y16 = gpu_api.predict_from_blob("conv_split", x.tobytes())
+        y32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
+    finally:
+        _unload(gpu_api)
+    with torch.no_grad():
+        ref = torch_resnet18(torch.from_numpy(x.reshape(rows, 3, 224, 224)).double(), 1000, 64, torch.float64).numpy()
+    scale = np.abs(ref).max()
+    e16, e32 = np.abs(y16 - ref), np.abs(y32 - ref)
+    print(f"C5 vs float64: f16x3 max {e16.max() / scale:.3e} of scale (worst |err|/(1e-4|y|+1e-6) = {(e16 / (1e-4 * np.abs(ref) + 1e-6)).max():.3f}); "
+          f"fp32 plan max {e32.max() / scale:.3e} ({(e32 / (1e-4 * np.abs(ref) + 1e-6)).max():.3f})")
+    assert np.all(e16 <= 1e-4 * np.abs(ref) + 1e-6) and np.all(e32 <= 1e-4 * np.abs(ref) + 1e-6)
+    assert e16.max() <= 2.0 * e32.max() + 1e-7 * scale, (e16.max() / scale, e32.max() / scale)
