@@ -242,3 +242,59 @@ def test_gpu_split_fp16_c5_full_width_error_against_float64(gpu_api, tmp_path):
           f"fp32 plan max {e32.max() / scale:.3e} ({(e32 / (1e-4 * np.abs(ref) + 1e-6)).max():.3f})")
     assert np.all(e16 <= 1e-4 * np.abs(ref) + 1e-6) and np.all(e32 <= 1e-4 * np.abs(ref) + 1e-6)
     assert e16.max() <= 2.0 * e32.max() + 1e-7 * scale, (e16.max() / scale, e32.max() / scale)
+
+
+def _random_conv_case(seed):
+    """stem 4 -> C (3x3, padded-channel fp32 kernel) + ReLU, then ONE random split-eligible convolution C -> M, global average."""
+    rng = np.random.default_rng(seed)
+    C = int(rng.choice([32, 64, 96, 128, 160])); M = int(rng.choice([32, 64, 96, 128, 192, 256]))
+    kh, kw = int(rng.choice([1, 2, 3, 5])), int(rng.choice([1, 2, 3, 5]))
+    sh, sw = int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2]))
+    dh, dw = int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2]))
+    hw = int(rng.integers(max(5, (kh - 1) * dh + 1, (kw - 1) * dw + 1), 25))
+    pads = [int(rng.integers(0, (kh - 1) * dh // 2 + 2)), int(rng.integers(0, (kw - 1) * dw // 2 + 2)),
+            int(rng.integers(0, (kh - 1) * dh // 2 + 2)), int(rng.integers(0, (kw - 1) * dw // 2 + 2))]
+    rows = int(rng.integers(1, 10))
+    w0 = (rng.standard_normal((C, 4, 3, 3)) / 6.0).astype(np.float32)
+    b0 = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    w1 = (rng.standard_normal((M, C, kh, kw)) / np.sqrt(C * kh * kw)).astype(np.float32)
+    b1 = (rng.standard_normal(M) * 0.1).astype(np.float32)
+    nodes = [W.node("Conv", ["X", "w0", "b0"], ["c0"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("pads", [1] * 4)]), W.node("Relu", ["c0"], ["r0"]),
+             W.node("Conv", ["r0", "w1", "b1"], ["c1"], [W.attr_ints("kernel_shape", [kh, kw]), W.attr_ints("strides", [sh, sw]), W.attr_ints("dilations", [dh, dw]),
+                                                         W.attr_ints("pads", pads)]),
+             W.node("Relu", ["c1"], ["r1"]), W.node("GlobalAveragePool", ["r1"], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
+    blob = W.model(f"rc{seed}", nodes, [W.tensor("w0", w0), W.tensor("b0", b0), W.tensor("w1", w1), W.tensor("b1", b1)],
+                   [W.value_info("X", ["N", 4, hw, hw])], [W.value_info("Y", ["N", M])])
+    return blob, hw, rows, dict(C=C, M=M, k=(kh, kw), s=(sh, sw), d=(dh, dw), pads=pads, hw=hw, rows=rows)
+
+
+@pytest.mark.gpu
+def test_gpu_split_fp16_random_geometries(gpu_api, tmp_path):
+    """Sixty random geometries of one split-eligible convolution (channels 32 .. 160, features 32 .. 256, 1 .. 5 taps per axis, strides 1 / 2,
+    dilations 1 / 2, asymmetric pads, 5 .. 24 pixel images, 1 .. 9 rows) in both forms against the oracle."""
+    from oracle import oracle
+
+    for seed in range(60):
+        blob, hw, rows, desc = _random_conv_case(seed)
+        path = W.write(str(tmp_path / f"rc{seed}.onnx"), blob)
+        x = synth.table(100 + seed, 0, rows, 4 * hw * hw)
+        try:
+            want = oracle.Model(path).predict_blob(x.tobytes())
+        except Exception:  # (a geometry with an empty output: nothing to compare)
+            continue
+        _load_both(gpu_api, path)
+        try:
+            assert gpu_api.get_plan("conv_split")["exec"].count("conv_split_f16x3") == 1, desc
+            out = {}
+            for mode in ("0", "2"):
+                os.environ["INFERA_CONV_WS"] = mode
+                try:
+                    out[mode] = gpu_api.predict_from_blob("conv_split", x.tobytes())
+                finally:
+                    os.environ.pop("INFERA_CONV_WS", None)
+            ref32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
+        finally:
+            _unload(gpu_api)
+        assert np.array_equal(out["0"], out["2"]), desc
+        scale = np.abs(want).max()
+        assert np.abs(out["0"] - want).max() <= max(1.5e-6 * scale, 1.5 * np.abs(ref32 - want).max()) + 1e-30, (desc, np.abs(out["0"] - want).max() / scale)
