@@ -760,7 +760,7 @@ def main():
                          "kernel_ms": kernel_s * 1e3, "rows_per_s": rows / kernel_s, "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}},
         }
         if f16x3:
-            line["roofline"]["peak_is"] = "dense fp16 MFMA peak / 3 (three matrix instructions per fp32 product); the stem stays on the exact-fp32 instruction"
+            line["roofline"]["peak_is"] = "dense fp16 MFMA peak / 3 (three matrix instructions per fp32 product; the stem + max-pool kernel and every tiled convolution run that way, the 512 -> 1000 head on the exact-fp32 instruction)"
             line["roofline"]["vs_fp32_mfma_peak"] = achieved / FP32_MFMA_PEAK_TFLOPS
         if others:
             line["other_workloads"] = others
