@@ -1,0 +1,63 @@
+"""The split-fp16 convolution mode's HOST logic, without a GPU (the plan is made at infera_load_model): which steps INFERA_PRECISION=f16x3
+moves to the fp16 matrix cores, that the knob is read when a model is scheduled (models loaded without it are untouched), and which layers
+stay on the exact-fp32 kernels because the split kernels do not take their shape."""
+import os
+
+import numpy as np
+
+from infera_amd import capi
+from infera_amd import onnx_writer as W
+
+
+def _plan(tmp_path, name, blob, precision=None):
+    path = W.write(str(tmp_path / f"{name}.onnx"), blob)
+    if precision:
+        os.environ["INFERA_PRECISION"] = precision
+    try:
+        capi.load_model("splitplan_" + name, path)
+    finally:
+        os.environ.pop("INFERA_PRECISION", None)
+    try:
+        return capi.get_plan("splitplan_" + name)
+    finally:
+        capi.unload_model("splitplan_" + name)
+
+
+def test_resnet18_plan_in_split_mode_and_without(built, tmp_path):
+    blob = W.resnet18()
+    split = _plan(tmp_path, "rn_split", blob, "f16x3")
+    plain = _plan(tmp_path, "rn_plain", blob)
+    assert split["exec"][0] == "conv_patch_pool_f16x3" and split["exec"].count("conv_split_f16x3") == 19 and "f16x3" in split["conv_precision"]
+    assert plain["exec"][0] == "conv_patch_pool" and plain["exec"].count("conv_tiled_cq") == 19 and "conv_precision" not in plain
+    # same steps, same fusions (residual adds in the epilogues, the head on the exact-fp32 tiled kernel): only the names of the moved steps differ
+    moved = {"conv_patch_pool_f16x3": "conv_patch_pool", "conv_split_f16x3": "conv_tiled_cq"}
+    assert [moved.get(e, e) for e in split["exec"]] == plain["exec"]
+    # one word of scratch per image and tracked tensor on top of the activations
+    assert 0 < split["scratch_floats_per_row"] - plain["scratch_floats_per_row"] <= 19
+    # bf16x3 is the fused MLP's mode: a convolutional plan ignores it
+    assert _plan(tmp_path, "rn_bf", blob, "bf16x3")["exec"] == plain["exec"]
+
+
+def test_layers_the_split_kernels_do_not_take_stay_exact(built, tmp_path):
+    rng = np.random.default_rng(1)
+
+    def net(c_in, convs, hw=12):
+        nodes, inits, x, c = [], [], "X", c_in
+        for i, (cout, k, groups) in enumerate(convs):
+            w = (rng.standard_normal((cout, c // groups, k, k)) * 0.1).astype(np.float32)
+            inits.append(W.tensor(f"w{i}", w))
+            nodes.append(W.node("Conv", [x, f"w{i}"], [f"c{i}"], [W.attr_ints("kernel_shape", [k, k]), W.attr_ints("pads", [k // 2] * 4), W.attr_i("group", groups)]))
+            nodes.append(W.node("Relu", [f"c{i}"], [f"r{i}"]))
+            x, c = f"r{i}", cout
+        nodes += [W.node("GlobalAveragePool", [x], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
+        return W.model("n", nodes, inits, [W.value_info("X", ["N", c_in, hw, hw])], [W.value_info("Y", ["N", c])])
+
+    # 4 -> 24 (padded-channel kernel), 24 -> 48 (channels not multiples of 32: padded-channel kernel), depthwise 48, 48 -> 64 1x1 (C % 32 != 0)
+    p = _plan(tmp_path, "mobile", net(4, [(24, 3, 1), (48, 3, 1), (48, 3, 48), (64, 1, 1)]), "f16x3")
+    assert "conv_split_f16x3" not in p["exec"] and "conv_precision" not in p
+    # 4 -> 64, then 64 -> 64 in two groups (generic kernel), then 64 -> 96 3x3 (split)
+    p = _plan(tmp_path, "grouped", net(4, [(64, 3, 1), (64, 3, 2), (96, 3, 1)]), "f16x3")
+    assert p["exec"][:3] == ["conv_patch", "normal", "conv_split_f16x3"] and p["exec"].count("conv_split_f16x3") == 1  # (activations ride in the conv steps)
+    # a model whose INPUT already has 32 channels: the caller's tensor is NCHW, its first convolution is not a channel-quad one
+    p = _plan(tmp_path, "wide_in", net(32, [(64, 3, 1), (64, 3, 1)]), "f16x3")
+    assert p["exec"][0] != "conv_split_f16x3" and p["exec"].count("conv_split_f16x3") == 1
