@@ -298,3 +298,26 @@ def test_gpu_split_fp16_random_geometries(gpu_api, tmp_path):
         assert np.array_equal(out["0"], out["2"]), desc
         scale = np.abs(want).max()
         assert np.abs(out["0"] - want).max() <= max(1.5e-6 * scale, 1.5 * np.abs(ref32 - want).max()) + 1e-30, (desc, np.abs(out["0"] - want).max() / scale)
+
+
+@pytest.mark.gpu
+def test_gpu_split_fp16_non_finite_images_stay_in_their_rows(gpu_api, tmp_path):
+    """A NaN or an infinity in one image: every OTHER image of the batch is bit for bit what it is without the poisoned neighbour -- the
+    scales are per image (per tile in the stem), nothing of one row reaches another.  (What the poisoned image itself returns is not
+    specified in this mode: an infinity takes the scale of its tile / image to the floor, and Relu maps NaN to 0 here as in the exact-fp32
+    kernels and the oracle -- DESIGN.md 3.3b.)"""
+    path = W.write(str(tmp_path / "rn64.onnx"), W.resnet18(classes=10, in_hw=64, width=64))
+    clean = synth.table(21, 0, 6, 3 * 64 * 64)
+    bad = clean.copy()
+    bad[1, 5000] = np.nan
+    bad[4, 77] = np.inf
+    _load_both(gpu_api, path)
+    try:
+        y_clean = gpu_api.predict_from_blob("conv_split", clean.tobytes())
+        y_bad = gpu_api.predict_from_blob("conv_split", bad.tobytes())
+    finally:
+        _unload(gpu_api)
+    assert np.all(np.isfinite(y_clean))
+    for r in (0, 2, 3, 5):
+        assert np.array_equal(y_bad[r], y_clean[r]), r
+    assert not np.array_equal(y_bad[4], y_clean[4])
