@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock, MT >= 3 ? 2 : 3) void conv2d_split_kernel(c
                                                              int64_t total_pix, ConvGeom g, ActParam act, unsigned blk0) {
   constexpr int NB = 4 * S;       // gathered quads (16 B per lane) per stage
   constexpr int U = 2 * S * MT;   // units per stage: (chunk, k-block, feature tile) = 2 A fragments + 3 MFMAs
-  constexpr int P = (PROBE == 10 || PROBE == 15) ? 3 : 2;  // A-fragment ring depth (units)
+  constexpr int P = 2;            // A-fragment ring depth (units)
   __shared__ __attribute__((aligned(16))) float wbuf[2][S * MT * 1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -176,6 +176,9 @@ __global__ __launch_bounds__(kBlock, MT >= 3 ? 2 : 3) void conv2d_split_kernel(c
   // tile) and slower: 128 / 256 / 512-channel layers 0.68-0.77 ms against 0.59-0.72, 64-channel layers 1.20-1.28 against 0.81-0.92.  With the
   // patch in LDS (up to 59 KB) only one 32-channel slab pair fits beside it at two workgroups per CU, so a stage is 12-24 matrix instructions
   // -- half of this form's -- and the per-stage barrier + slab latency cost more than the nine-fold gathers and splits they replaced.)
+  // (Tuning variants measured neutral to -4 % and removed again: a three-deep A-fragment ring; sched_group_barrier pinning of the split's VALU
+  // work between the matrix instructions; s_setprio around them; the weight slab issued before the gathers with `s_waitcnt vmcnt(NB)` at the end
+  // of the stage, so that the gathers stay in flight across the barrier.)
   // (Measured and dropped: gathers TWO stages ahead through a third register buffer, the weight slab issued first and `s_waitcnt vmcnt(NB)` at
   // the end of a stage -- 128-feature tiles then need 256 registers and spill 28, 64-feature tiles fall from 3 to 2 waves per SIMD: 4-20 %
   // slower.  With three 32-cycle matrix instructions per product the chip is at its power limit long before the matrix pipe is full -- 1.8 to
@@ -211,22 +214,11 @@ __global__ __launch_bounds__(kBlock, MT >= 3 ? 2 : 3) void conv2d_split_kernel(c
           if (u == 1) stage_issue(stage + 1, (stage + 1) & 1);
         }
       }
-      if constexpr (PROBE == 12) __builtin_amdgcn_s_setprio(1);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(al), as_h(bh[q & 1]), acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bl[q & 1]), acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bh[q & 1]), acc[t], 0, 0, 0);
-      if constexpr (PROBE == 12) __builtin_amdgcn_s_setprio(0);
       // the next k-block's fragments are split while this one's matrix instructions run
       if (t == 0 && q + 1 < Q) convert(bc, q + 1, bh[(q + 1) & 1], bl[(q + 1) & 1]);
-      if constexpr (PROBE == 11 || PROBE == 15) {  // pin: each matrix instruction followed by a share of the unit's other work
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
-        }
-      }
     }
     if constexpr (more && probe_stage) stage_commit();
     if constexpr (!probe_gather) {
@@ -593,7 +585,7 @@ void conv2d_split(hipStream_t s, const float *X, const float *packed, const floa
   const int mt_pick = m32 % 4 == 0 ? 4 : m32 % 3 == 0 ? 3 : m32 % 2 == 0 ? 2 : 1;
   const bool deep = g.C % 64 == 0;
 #ifdef INFERA_CONV_PROBES
-  // 1 no operand split, 2 no gathers, 3 no weight staging / barrier, 4 neither (bare matrix stream): timing only, results are wrong; 10 / 11 / 12 / 15: tuning variants (correct results)
+  // 1 no operand split, 2 no gathers, 3 no weight staging / barrier, 4 neither (bare matrix stream): timing only, results are wrong
   static const int probe = getenv("INFERA_SPLIT_PROBE") ? atoi(getenv("INFERA_SPLIT_PROBE")) : 0;
   if (probe && deep && (mt_pick == 4 || mt_pick == 2)) {
     switch (probe * 2 + (mt_pick == 4)) {
@@ -605,14 +597,6 @@ void conv2d_split(hipStream_t s, const float *X, const float *packed, const floa
       case 7: return launch(conv2d_split_kernel<4, 2, 3>, 4);
       case 8: return launch(conv2d_split_kernel<2, 2, 4>, 2);
       case 9: return launch(conv2d_split_kernel<4, 2, 4>, 4);
-      case 20: return launch(conv2d_split_kernel<2, 2, 10>, 2);
-      case 21: return launch(conv2d_split_kernel<4, 2, 10>, 4);
-      case 22: return launch(conv2d_split_kernel<2, 2, 11>, 2);
-      case 23: return launch(conv2d_split_kernel<4, 2, 11>, 4);
-      case 24: return launch(conv2d_split_kernel<2, 2, 12>, 2);
-      case 25: return launch(conv2d_split_kernel<4, 2, 12>, 4);
-      case 30: return launch(conv2d_split_kernel<2, 2, 15>, 2);
-      case 31: return launch(conv2d_split_kernel<4, 2, 15>, 4);
     }
   }
 #endif
