@@ -175,7 +175,12 @@ __global__ __launch_bounds__(kBlock, MT >= 3 ? 2 : 3) void conv2d_split_kernel(c
   // of once per tap), weight slabs per (tap, chunk) stage as here.  Correct (within 1.5e-6 of the oracle, images of different scale sharing a
   // tile) and slower: 128 / 256 / 512-channel layers 0.68-0.77 ms against 0.59-0.72, 64-channel layers 1.20-1.28 against 0.81-0.92.  With the
   // patch in LDS (up to 59 KB) only one 32-channel slab pair fits beside it at two workgroups per CU, so a stage is 12-24 matrix instructions
-  // -- half of this form's -- and the per-stage barrier + slab latency cost more than the nine-fold gathers and splits they replaced.)
+  // -- half of this form's -- and the per-stage barrier + slab latency cost more than the nine-fold gathers and splits they replaced.  A second
+  // version -- eight waves on 256 pixels, TWO taps per stage (this form's 16 MT units between barriers, one slab pair for eight waves) -- ran at
+  // 2.2 GHz instead of 2.0 (less VALU and L1 work per matrix instruction) and still only tied: 0.65-0.76 ms on the 128 / 256 / 512-channel layers,
+  // 1.05-1.14 on the 64-channel ones.  Counters: 22 % of its LDS cycles are bank conflicts (a wave's 32 pixels wrap over padded rows, so their
+  // 16-byte slots are no longer 32 consecutive ones) and the per-tile item tables cost three integer divisions per item -- as much VALU work per
+  // tile as the 64-channel layers' whole matrix stream.)
   // (Tuning variants measured neutral to -4 % and removed again: a three-deep A-fragment ring; sched_group_barrier pinning of the split's VALU
   // work between the matrix instructions; s_setprio around them; the weight slab issued before the gathers with `s_waitcnt vmcnt(NB)` at the end
   // of the stage, so that the gathers stay in flight across the barrier.)
