@@ -8,7 +8,7 @@ bash tools/profile_bench.sh r03_final_mlp --steps 10 --warmup 2 --no-cpu-baselin
 bash tools/profile_bench.sh r03_final_logreg --workload logreg --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end > gpurun_out/r03_lines/prof_logreg.log 2>&1
 for w in resnet18 mlp logreg; do
   d=gpurun_out/r03_final_$w
-  python tools/rocpd_summary.py $d/trace/*/*.db $d/trace/*.db 2>/dev/null | head -60 > gpurun_out/r03_final_${w}_bench.txt
+  python tools/rocpd_summary.py $(find $d/trace -name "*.db") 2>/dev/null | head -60 > gpurun_out/r03_final_${w}_bench.txt
   cp $d/bench_line.json gpurun_out/r03_final_${w}_bench_line.json
   python tools/pmc_table.py $(find $d/pmc_sq $d/pmc_grbm -name "*.db") > gpurun_out/r03_final_${w}_pmc_table.txt 2>&1
 done
