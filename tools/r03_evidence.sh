@@ -12,8 +12,8 @@ for w in resnet18 mlp logreg; do
   cp $d/bench_line.json gpurun_out/r03_final_${w}_bench_line.json
   python tools/pmc_table.py $(find $d/pmc_sq $d/pmc_grbm -name "*.db") > gpurun_out/r03_final_${w}_pmc_table.txt 2>&1
 done
-python tools/traffic_json.py gpurun_out/r03_final_mlp mlp3_split > gpurun_out/traffic_mlp.json
-python tools/traffic_json.py gpurun_out/r03_final_logreg dense_narrow16 > gpurun_out/traffic_logreg.json
+python tools/traffic_json.py gpurun_out/r03_final_mlp mlp3_split 10000000 mlp "r03 final" > gpurun_out/traffic_mlp.json
+python tools/traffic_json.py gpurun_out/r03_final_logreg dense_narrow16 50000000 logreg "r03 final" > gpurun_out/traffic_logreg.json
 python tools/traffic_pass_json.py gpurun_out/r03_final_resnet18 global_avgpool 1024 "r03 final" > gpurun_out/traffic_resnet18.json
 ls -la gpurun_out/ | tail -20
 find gpurun_out/r03_final_mlp -name "*.db" | head

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """HBM traffic per launch of the dominant kernel from the FETCH_SIZE / WRITE_SIZE PMC passes.
 
-usage: tools/traffic_json.py <prof_dir> <kernel-substring> > profiles/<tag>_traffic.json
+usage: tools/traffic_json.py <prof_dir> <kernel-substring> [<rows> <workload> <round tag>] > profiles/traffic_<workload>.json
+(rows / workload / round are what bench.py and tests/test_traffic_profiles.py match the file against)
 FETCH_SIZE / WRITE_SIZE are in KiB... (rocprofv3 derives them as bytes/1024); on gfx950 FETCH_SIZE
 reports exactly half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM
 section: 128-B requests tallied at 64 B) -> the read side is doubled.  WRITE_SIZE is taken as is (the
@@ -25,7 +26,10 @@ def main():
     w, nw = per_dispatch(f"{d}/pmc_write/bench_results.db", "WRITE_SIZE", sub)
     read_bytes = f * 1024 * 2  # gfx950 correction
     write_bytes = w * 1024
-    print(json.dumps({"kernel": sub, "dispatches": [nf, nw], "fetch_size_kib_raw": f, "write_size_kib_raw": w,
+    extra = {}
+    if len(sys.argv) >= 6:
+        extra = {"rows": int(sys.argv[3]), "workload": sys.argv[4], "round": sys.argv[5]}
+    print(json.dumps({**extra, "kernel": sub, "dispatches": [nf, nw], "fetch_size_kib_raw": f, "write_size_kib_raw": w,
                       "read_bytes": read_bytes, "write_bytes": write_bytes, "traffic_bytes_per_launch": read_bytes + write_bytes,
                       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)"}))
 
