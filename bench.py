@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--workload", default="mlp", choices=["mlp", "logreg", "resnet18"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "f16x3"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "f16x3", "bf16x6"],
                     help="bf16x3 = the OPTIONAL fast mode of the fused MLP (three bf16 MFMAs per product; NOT the parity path, "
                          "never the default, never the headline): the line is labelled accordingly.  f16x3 = the tiled convolutions on the fp16 "
                          "matrix cores with split operands (resnet18 workload; within the parity tolerance, DESIGN.md 3.3b): labelled in dtype / config")

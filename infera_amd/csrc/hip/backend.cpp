@@ -747,11 +747,21 @@ void schedule(LoadedModel &m) {
   }
   // split-fp16 convolutions (INFERA_PRECISION=f16x3) and the per-image maxima they scale their inputs by
   m.conv_split.assign(n, 0);
+  m.conv_split6.assign(n, 0);
   m.stem_split.assign(n, 0);
   m.amax_of_buf.assign(nb, -1);
   m.amax_by_kernel.assign(nb, 0);
   m.n_amax = 0;
   m.amax_slot = -1;
+  if (ScheduleKnobs::read().conv_bf16x6 && m.cq_mode) {
+    for (size_t i = 0; i < n; i++) {
+      if (m.exec[i] != ExecKind::ConvTiled) continue;
+      const Step &c = st[i];
+      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
+                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
+      if (kern::conv2d_split6_supported(kern::conv2d_tiled_geom(g)) && !m.nchw_buf[size_t(c.in0)]) m.conv_split6[i] = 1;
+    }
+  }
   if (ScheduleKnobs::read().conv_f16x3 && m.cq_mode) {
     for (size_t i = 0; i < n; i++) {
       if (m.exec[i] != ExecKind::ConvTiled) continue;
@@ -846,7 +856,10 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
         }
         continue;
       }
-      if (m.conv_split[i]) {
+      if (m.conv_split6[i]) {
+        packed.resize(kern::conv2d_split6_packed_floats(g));
+        kern::conv2d_split6_pack(g, s.W.data(), packed.data());
+      } else if (m.conv_split[i]) {
         std::vector<float> winv(size_t(g.M));
         kern::conv2d_split_pack(g, s.W.data(), packed.data(), winv.data());
         d.winv = upload(winv, us);
@@ -1027,6 +1040,11 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
           const int fj = m.conv_fused_add[i];
           const kern::ConvGeom gp = kern::conv2d_tiled_geom(g);
+          if (m.conv_split6[i]) {
+            if (fj >= 0) kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]));
+            else kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, gp, act_of(x));
+            continue;
+          }
           if (m.conv_split[i]) {
             if (m.amax_by_kernel[size_t(x.in0)] && !amax_done[size_t(x.in0)]) {
               kern::absmax_rows(s, buf(x.in0), nr, m.plan.buf_per_row[size_t(x.in0)], amax(x.in0));
@@ -1810,11 +1828,13 @@ std::string LoadedModel::describe_json() const {
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++)
-    o << (i ? "," : "") << "\"" << (i < stem_split.size() && stem_split[i] ? "conv_patch_pool_f16x3" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split.size() && conv_split[i] ? "conv_split_f16x3" : ek[int(exec[i])]) << "\"";
+    o << (i ? "," : "") << "\"" << (i < stem_split.size() && stem_split[i] ? "conv_patch_pool_f16x3" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split.size() && conv_split[i] ? "conv_split_f16x3" : i < conv_split6.size() && conv_split6[i] ? "conv_split_bf16x6" : ek[int(exec[i])]) << "\"";
   o << "],\"activation_layout\":\"" << (cq_mode ? "NC/4HW4" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";
   if (n_amax > 0) o << ",\"conv_precision\":\"f16x3 (fp16 matrix cores, operands split hi + lo, fp32 accumulate)\"";
+  else if (std::find(conv_split6.begin(), conv_split6.end(), char(1)) != conv_split6.end())
+    o << ",\"conv_precision\":\"bf16x6 (bf16 matrix cores, operands cut exactly into three parts, six partial products, fp32 accumulate)\"";
   for (size_t i = 0; i < exec.size(); i++)
     if (exec[i] == ExecKind::Mlp3Head)
       o << ",\"fused_kernel\":" << json_str(bf16x3 ? kern::mlp3_bf16x3_kernel_name(mlp3_shape) : kern::mlp3_kernel_name(mlp3_shape))

@@ -222,6 +222,11 @@ __global__ __launch_bounds__(kBlock, MT >= 3 ? 2 : 3) void conv2d_split_kernel(c
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(al), as_h(bh[q & 1]), acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bl[q & 1]), acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bh[q & 1]), acc[t], 0, 0, 0);
+      if constexpr (PROBE == 6) {  // (timing probe: six matrix instructions per unit -- what a three-part bf16 split would issue)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(al), as_h(bl[q & 1]), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(al), as_h(bh[q & 1]), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ah), as_h(bl[q & 1]), acc[t], 0, 0, 0);
+      }
       // the next k-block's fragments are split while this one's matrix instructions run
       if (t == 0 && q + 1 < Q) convert(bc, q + 1, bh[(q + 1) & 1], bl[(q + 1) & 1]);
     }
@@ -507,6 +512,193 @@ __global__ __launch_bounds__(NW * 64) void conv2d_split_ws_kernel(const float *_
   }
 }
 
+// ---- bf16 x 3 parts: the precondition-free sibling (INFERA_PRECISION=bf16x6) -------------------------------------------------------
+// Every fp32 operand is cut EXACTLY into three bf16 parts by truncation -- hi = top 16 bits, mid = top 16 bits of (v - hi), lo = v - hi - mid:
+// 8 + 8 + 8 = all 24 significant bits, no rounding, no scales, no maxima, and bf16 has fp32's exponent range, so nothing about the data has to
+// hold.  A product is six of the nine partial products on v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped
+// mid*lo, lo*mid, lo*lo are below 2^-23 of the product), smallest first, fp32 accumulate: 6 x 32 cycles per 16 k-values against the exact-fp32
+// instruction's 8 x 64.  Tiled geometry with ONE 32-channel chunk per stage (a chunk's fragments are 6 KB per 32 features: 2 k-blocks x 3 parts),
+// 64 or 128 features per workgroup; everything else -- gathers, tile order, epilogue without any scaling -- is conv2d_tiled_kernel's.
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ bf16x8_t as_b(const u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+// two fp32 values -> the dwords {part(v0) | part(v1) << 16} of their hi, mid and lo bf16 parts
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned &hi, unsigned &mid, unsigned &lo) {
+  const unsigned x0 = __float_as_uint(v0), x1 = __float_as_uint(v1);
+  const float r0 = v0 - __uint_as_float(x0 & 0xffff0000u), r1 = v1 - __uint_as_float(x1 & 0xffff0000u);  // exact: 16 bits left
+  const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+  const float s0 = r0 - __uint_as_float(y0 & 0xffff0000u), s1 = r1 - __uint_as_float(y1 & 0xffff0000u);  // exact: 8 bits left
+  hi = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+  mid = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+// packed: [chunk (conv2d_tiled_pack's order)][mt][kb (2)][part (hi, mid, lo)][lane (64)][e (8 bf16)]
+template <int MT>
+__global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+                                                                 const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                 float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
+  static_assert(MT == 2 || MT == 4, "a stage's fragments (MT x 6 KB) are whole 4 KB pieces of the workgroup's copy");
+  constexpr int NB = 4, U = 2 * MT, P = 2, SLAB = MT * 1536;  // floats per stage
+  __shared__ __attribute__((aligned(16))) float wbuf[2][SLAB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const unsigned nfull = gridDim.x & ~7u;
+  const unsigned lb = blockIdx.x < nfull ? (blockIdx.x & 7u) * (nfull >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int OHW = g.OH * g.OW;
+  const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
+  const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = ntaps * CC, SB = g.C % 64 == 0 ? 2 : 1;
+  const int64_t pix = (int64_t(lb) * 4 + wave) * 32 + r;
+  const bool pvalid = pix < total_pix;
+  const unsigned pix32 = pvalid ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
+  const int64_t n = n32;
+  const int prem = int(pix32 - n32 * unsigned(OHW));
+  const int oh = int(unsigned(prem) / unsigned(g.OW)), ow = prem - oh * g.OW;
+  const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
+  const int HW4 = g.H * g.W * 4;
+  const float *xc = X + n * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
+  const float *zp = g_split_zero_page + 4 * h;
+  uint64_t okmask = 0;
+  if (pvalid) {
+    int tap = 0;
+    for (int ky = 0; ky < g.kh; ky++)
+      for (int kx = 0; kx < g.kw; kx++, tap++) {
+        const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
+        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) okmask |= uint64_t(1) << tap;
+      }
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+
+  // stage order: channel block (SB chunks) outermost, then the tap, then the chunk inside the block -- conv2d_tiled_pack's chunk order, one
+  // chunk per stage
+  int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0, n_sl = 0;
+  auto gather = [&](f32x4(&b)[NB]) {
+    const bool ok = (okmask >> n_tap) & 1;
+    const float *p = ok ? xc + n_off + n_sl * (2 * NB * HW4) : zp;
+    const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;
+#pragma unroll
+    for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
+    if (++n_sl == SB) {  // next tap of this channel block
+      n_sl = 0;
+      n_tap++;
+      n_kx++;
+      n_off += g.dw * 4;
+      if (n_kx == g.kw) {
+        n_kx = 0;
+        n_off += (g.dh * g.W - g.kw * g.dw) * 4;
+      }
+      if (n_tap == ntaps) {
+        n_tap = 0;
+        n_base += SB * 2 * NB * HW4;
+        n_off = n_base;
+      }
+    }
+  };
+  auto stage_issue = [&](int stage, int buf) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(Wp + (int64_t(stage) * MTtot + mt0) * 1536) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < SLAB / 1024; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 256),
+                                       (__attribute__((address_space(3))) void *)(wbuf[buf] + i * 1024 + wave * 256), 16, 0, 0);
+  };
+  auto stage_commit = [] {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  auto convert = [&](const f32x4(&bc)[NB], int kb, u32x4 &oh, u32x4 &om, u32x4 &ol) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const f32x4 &src = bc[2 * kb + (e >> 1)];
+      unsigned a, b, c;
+      split3_pair(src[2 * (e & 1)], src[2 * (e & 1) + 1], a, b, c);
+      oh[e] = a;
+      om[e] = b;
+      ol[e] = c;
+    }
+  };
+  auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(wbuf[stage & 1]) + lane;
+    auto fidx = [](int u) { return (((u % MT) * 2 + u / MT) * 3) * 64; };  // unit u: k-block u / MT, feature tile u % MT; hi, mid = +64, lo = +128
+    u32x4 ra[P][3], bb[2][3];
+#pragma unroll
+    for (int u = 0; u < P && u < U; u++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) ra[u][k] = wl[fidx(u) + 64 * k];
+    convert(bc, 0, bb[0][0], bb[0][1], bb[0][2]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int kb = u / MT, t = u % MT;
+      const u32x4 ah = ra[u % P][0], am = ra[u % P][1], al = ra[u % P][2];
+      if (u + P < U) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) ra[u % P][k] = wl[fidx(u + P) + 64 * k];
+      }
+      if constexpr (more) {
+        if (u == 0) gather(bn);
+        if (u == 1) stage_issue(stage + 1, (stage + 1) & 1);
+      }
+      const u32x4 &bh = bb[kb][0], &bm = bb[kb][1], &bl = bb[kb][2];
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(al), as_b(bh), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bl), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bm), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bh), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bm), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bh), acc[t], 0, 0, 0);
+      if (t == 0 && kb == 0) convert(bc, 1, bb[1][0], bb[1][1], bb[1][2]);
+    }
+    if constexpr (more) stage_commit();
+  };
+
+  f32x4 b0[NB], b1[NB];
+  gather(b0);
+  stage_issue(0, 0);
+  stage_commit();
+  constexpr std::true_type kMore{};
+  constexpr std::false_type kLast{};
+  int stage = 0;
+  for (; stage + 2 < nstages; stage += 2) {
+    step(b0, b1, stage, kMore);
+    step(b1, b0, stage + 1, kMore);
+  }
+  if (stage + 2 == nstages) {
+    step(b0, b1, stage, kMore);
+    step(b1, b0, stage + 1, kLast);
+  } else {
+    step(b0, b1, stage, kLast);
+  }
+
+  if (!pvalid) return;
+  const int64_t OHW4 = int64_t(OHW) * 4;
+  const int64_t yoff = n * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+  float *yp = Y + yoff;
+  const float *rp = residual ? residual + yoff : nullptr;
+  const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
+  dispatch_act(act.kind, [&](auto kind_tag) {
+    constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+      f32x4 bv[4], rv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[t][4 * q + j] + bv[q][j]) + rv[q][j], act.a, act.b);
+        *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
+      }
+    }
+  });
+}
+
 // per-image max |x| of a tensor some other kernel produced: grid (chunks, rows); bits of a non-negative float, atomic max
 __global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restrict__ X, int64_t per_row, unsigned *__restrict__ amax) {
   const float *x = X + int64_t(blockIdx.y) * per_row;
@@ -569,6 +761,60 @@ void absmax_rows(hipStream_t s, const float *X, int64_t rows, int64_t per_row, u
     hipLaunchKernelGGL(absmax_rows_kernel, dim3(chunks, unsigned(std::min<int64_t>(65535, rows - r0))), dim3(256), 0, s, X + r0 * per_row, per_row, amax + r0);
 }
 
+// ---- bf16 x 3 parts (conv2d_split6_kernel) ----
+bool conv2d_split6_supported(const ConvGeom &g) { return conv2d_split_supported(g) && g.M % 64 == 0; }
+
+size_t conv2d_split6_packed_floats(const ConvGeom &g) { return size_t(g.kh) * g.kw * g.C * g.M * 3 / 2; }
+
+void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed) {
+  const int CC = g.C / 32, MTtot = g.M / 32, ntaps = g.kh * g.kw, S = g.C % 64 == 0 ? 2 : 1;
+  uint16_t *out = reinterpret_cast<uint16_t *>(packed);
+  for (int tap = 0; tap < ntaps; tap++)
+    for (int cc = 0; cc < CC; cc++)
+      for (int mt = 0; mt < MTtot; mt++)
+        for (int kb = 0; kb < 2; kb++)
+          for (int lane = 0; lane < 64; lane++)
+            for (int e = 0; e < 8; e++) {
+              const int m = 32 * mt + (lane & 31), c = 32 * cc + 16 * kb + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+              const size_t chunk = (size_t(cc / S) * ntaps + tap) * S + cc % S;
+              const float v = Wt[(size_t(m) * g.C + c) * ntaps + tap];
+              uint32_t x, y, z;  // exact truncation split: v = hi + mid + lo
+              std::memcpy(&x, &v, 4);
+              const uint32_t xh = x & 0xffff0000u;
+              float fh;
+              std::memcpy(&fh, &xh, 4);
+              const float r1 = v - fh;
+              std::memcpy(&y, &r1, 4);
+              const uint32_t yh = y & 0xffff0000u;
+              float fm;
+              std::memcpy(&fm, &yh, 4);
+              const float r2 = r1 - fm;
+              std::memcpy(&z, &r2, 4);
+              const size_t base = ((chunk * MTtot + mt) * 2 + kb) * 3;  // fragments of 64 lanes x 8 bf16
+              out[(base + 0) * 512 + size_t(lane) * 8 + e] = uint16_t(x >> 16);
+              out[(base + 1) * 512 + size_t(lane) * 8 + e] = uint16_t(y >> 16);
+              out[(base + 2) * 512 + size_t(lane) * 8 + e] = uint16_t(z >> 16);
+            }
+}
+
+void conv2d_split6(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y, int64_t rows,
+                   const ConvGeom &g, ActParam act) {
+  const int64_t total_pix = rows * g.OH * g.OW;
+  if (total_pix <= 0) return;
+  if (total_pix >= (int64_t(1) << 31)) {
+    const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(g.OH) * g.OW);
+    const int64_t in_row = int64_t(g.C) * g.H * g.W, out_row = int64_t(g.M) * g.OH * g.OW;
+    for (int64_t r0 = 0; r0 < rows; r0 += cap)
+      conv2d_split6(s, X + r0 * in_row, packed, bias, residual ? residual + r0 * out_row : nullptr, Y + r0 * out_row, std::min(cap, rows - r0), g, act);
+    return;
+  }
+  const unsigned bx = unsigned((total_pix + 127) / 128);
+  if (g.M % 128 == 0)
+    hipLaunchKernelGGL((conv2d_split6_kernel<4>), dim3(bx, unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+  else
+    hipLaunchKernelGGL((conv2d_split6_kernel<2>), dim3(bx, unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+}
+
 void conv2d_split(hipStream_t s, const float *X, const float *packed, const float *bias, const float *winv, const float *residual,
                   float *Y, const unsigned *amax_in, unsigned *amax_out, int64_t rows, const ConvGeom &g, ActParam act) {
   const int64_t total_pix = rows * g.OH * g.OW;
@@ -590,7 +836,7 @@ void conv2d_split(hipStream_t s, const float *X, const float *packed, const floa
   const int mt_pick = m32 % 4 == 0 ? 4 : m32 % 3 == 0 ? 3 : m32 % 2 == 0 ? 2 : 1;
   const bool deep = g.C % 64 == 0;
 #ifdef INFERA_CONV_PROBES
-  // 1 no operand split, 2 no gathers, 3 no weight staging / barrier, 4 neither (bare matrix stream): timing only, results are wrong
+  // 1 no operand split, 2 no gathers, 3 no weight staging / barrier, 4 neither (bare matrix stream), 6 six matrix instructions per unit (a three-part bf16 split's count): timing only, results are wrong
   static const int probe = getenv("INFERA_SPLIT_PROBE") ? atoi(getenv("INFERA_SPLIT_PROBE")) : 0;
   if (probe && deep && (mt_pick == 4 || mt_pick == 2)) {
     switch (probe * 2 + (mt_pick == 4)) {
@@ -602,6 +848,8 @@ void conv2d_split(hipStream_t s, const float *X, const float *packed, const floa
       case 7: return launch(conv2d_split_kernel<4, 2, 3>, 4);
       case 8: return launch(conv2d_split_kernel<2, 2, 4>, 2);
       case 9: return launch(conv2d_split_kernel<4, 2, 4>, 4);
+      case 12: return launch(conv2d_split_kernel<2, 2, 6>, 2);
+      case 13: return launch(conv2d_split_kernel<4, 2, 6>, 4);
     }
   }
 #endif

@@ -179,6 +179,13 @@ void conv2d_split_pack(const ConvGeom &g, const float *Wt, float *packed, float 
 void absmax_rows(hipStream_t s, const float *X, int64_t rows, int64_t per_row, unsigned *amax);
 void conv2d_split(hipStream_t s, const float *X, const float *packed, const float *bias, const float *winv, const float *residual,
                   float *Y, const unsigned *amax_in, unsigned *amax_out, int64_t rows, const ConvGeom &g, ActParam act);
+// ... and with every operand cut exactly into three bf16 parts, six partial products per product (INFERA_PRECISION=bf16x6): no scales, no maxima,
+// no precondition on the data.  M % 64 == 0; packed = conv2d_split6_packed_floats(g) floats' worth of bf16 hi / mid / lo fragments.
+bool conv2d_split6_supported(const ConvGeom &g);
+size_t conv2d_split6_packed_floats(const ConvGeom &g);
+void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed);
+void conv2d_split6(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y, int64_t rows,
+                   const ConvGeom &g, ActParam act);
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
             int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq);
 // y[n,c,p] = x[n,c,p] / (bias + alpha/size * sum_{c' in window(c)} x[n,c',p]^2)^beta over [rows, C, S] (cq: channel-quad planes)

@@ -125,7 +125,7 @@ const Config &Config::get() {
 
 ScheduleKnobs ScheduleKnobs::read() {
   return ScheduleKnobs{env_flag("INFERA_STEM_POOL", true), env_flag("INFERA_CHAIN_XCM", true), env_flag("INFERA_DENSE_XCM", true),
-                       env_or("INFERA_PRECISION", "fp32") == "f16x3"};
+                       env_or("INFERA_PRECISION", "fp32") == "bf16x6", env_or("INFERA_PRECISION", "fp32") == "f16x3"};
 }
 
 void log_msg(int level, const std::string &msg) {

@@ -321,3 +321,72 @@ def test_gpu_split_fp16_non_finite_images_stay_in_their_rows(gpu_api, tmp_path):
     for r in (0, 2, 3, 5):
         assert np.array_equal(y_bad[r], y_clean[r]), r
     assert not np.array_equal(y_bad[4], y_clean[4])
+
+
+# ---- INFERA_PRECISION=bf16x6: operands cut exactly into three bf16 parts, six partial products; no scales, no maxima, no precondition --------
+def _load_mode(gpu_api, path, name, precision):
+    os.environ["INFERA_PRECISION"] = precision
+    try:
+        gpu_api.load_model(name, path)
+    finally:
+        os.environ.pop("INFERA_PRECISION", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["mt2_s1_3x3", "mt2_s1_3blocks", "mt2_s2_3x3", "mt4_s1_3x3", "mt4_s2_3x3", "mt2_s1_1x1", "mt4_s2_1x1_s2", "mt2_s2_1x1",
+                                     "mt4_s2_2stages"])
+def test_gpu_bf16x6_conv_every_instantiation_is_accurate(gpu_api, tmp_path, variant):
+    from oracle import oracle
+
+    hw, rows = 17, 7
+    path = W.write(str(tmp_path / "net.onnx"), _net(VARIANTS[variant], 4, hw, residual_at=()))
+    # rows of wildly different magnitude: this mode has no scales, so nothing about the data's range can matter
+    mags = np.array([1.0, 1e-30, 1e25, 0.0, 3e-12, 1.0, 65504.0], np.float32)
+    x = (synth.table(23, 0, rows, 4 * hw * hw) * mags[:, None]).astype(np.float32)
+    gpu_api.load_model("conv_fp32", path)
+    _load_mode(gpu_api, path, "conv_bf6", "bf16x6")
+    try:
+        plan = gpu_api.get_plan("conv_bf6")
+        assert plan["exec"].count("conv_split_bf16x6") == 1 and "bf16x6" in plan["conv_precision"]
+        got = gpu_api.predict_from_blob("conv_bf6", x.tobytes())
+        assert np.array_equal(got, gpu_api.predict_from_blob("conv_bf6", x.tobytes()))
+        assert np.array_equal(got[5], gpu_api.predict_from_blob("conv_bf6", x[5].tobytes()).reshape(-1))
+        ref32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
+    finally:
+        gpu_api.unload_model("conv_bf6")
+        gpu_api.unload_model("conv_fp32")
+    want = oracle.Model(path).predict_blob(x.tobytes())
+    assert np.all(np.isfinite(got))
+    for r in range(rows):  # (or 1.5x the exact-fp32 plan's own distance: the mean over 289 pixels that follows is itself ~2e-6 off on flat rows)
+        scale = np.abs(want[r]).max()
+        assert np.abs(got[r] - want[r]).max() <= max(1.5e-6 * scale, 1.5 * np.abs(ref32[r] - want[r]).max()) + 1e-37, (r, np.abs(got[r] - want[r]).max() / scale)
+
+
+@pytest.mark.gpu
+def test_gpu_bf16x6_c5_full_width_error_against_float64(gpu_api, tmp_path):
+    import torch
+
+    from tests.test_oracle_vs_torch import torch_resnet18
+
+    rows = 4
+    path = W.write(str(tmp_path / "rn224.onnx"), W.resnet18())
+    x = synth.table(5, 0, rows, 3 * 224 * 224)
+    gpu_api.load_model("conv_fp32", path)
+    _load_mode(gpu_api, path, "conv_bf6", "bf16x6")
+    try:
+        plan = gpu_api.get_plan("conv_bf6")
+        assert plan["exec"].count("conv_split_bf16x6") == 19 and plan["exec"][0] == "conv_patch_pool"  # (the stem stays on the exact-fp32 kernel)
+        y6 = gpu_api.predict_from_blob("conv_bf6", x.tobytes())
+        y32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
+        assert np.array_equal(y6[2], gpu_api.predict_from_blob("conv_bf6", x[2].tobytes()).reshape(-1))
+    finally:
+        gpu_api.unload_model("conv_bf6")
+        gpu_api.unload_model("conv_fp32")
+    with torch.no_grad():
+        ref = torch_resnet18(torch.from_numpy(x.reshape(rows, 3, 224, 224)).double(), 1000, 64, torch.float64).numpy()
+    scale = np.abs(ref).max()
+    e6, e32 = np.abs(y6 - ref), np.abs(y32 - ref)
+    print(f"C5 vs float64: bf16x6 max {e6.max() / scale:.3e} of scale (worst |err|/(1e-4|y|+1e-6) = {(e6 / (1e-4 * np.abs(ref) + 1e-6)).max():.3f}); "
+          f"fp32 plan max {e32.max() / scale:.3e} ({(e32 / (1e-4 * np.abs(ref) + 1e-6)).max():.3f})")
+    assert np.all(e6 <= 1e-4 * np.abs(ref) + 1e-6)
+    assert e6.max() <= 2.0 * e32.max() + 1e-7 * scale, (e6.max() / scale, e32.max() / scale)
