@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--workload", default="mlp", choices=["mlp", "logreg", "resnet18"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "f16x3", "bf16x6"],
+    ap.add_argument("--precision", default="default", choices=["default", "fp32", "bf16x3", "f16x3", "bf16x6"],
                     help="bf16x3 = the OPTIONAL fast mode of the fused MLP (three bf16 MFMAs per product; NOT the parity path, "
                          "never the default, never the headline): the line is labelled accordingly.  f16x3 = the tiled convolutions on the fp16 "
                          "matrix cores with split operands (resnet18 workload; within the parity tolerance, DESIGN.md 3.3b): labelled in dtype / config")
@@ -434,18 +434,18 @@ def other_model_path(onnx_writer, tmp: str, which: str) -> str:
     return path
 
 
-def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str, precision: str = "fp32") -> dict:
+def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str, precision: str = "default") -> dict:
     """BASELINE configs C4 / C5 beside the headline, device-resident (2 warm + `passes` timed passes, HIP events on the
     launching stream): the same definitions as `value` / `roofline`, so that the driver's own run records them too."""
     w = OTHER[which]
     rows, cols, out_cols, bound, flops_row, bytes_row = w["rows"], w["cols"], w["out_cols"], w["bound"], w["flops_row"], w["bytes_row"]
-    model = "bench_" + which + ("_" + precision if precision != "fp32" else "")
-    if precision != "fp32":
+    model = "bench_" + which + ("_" + precision if precision != "default" else "")
+    if precision != "default":
         os.environ["INFERA_PRECISION"] = precision  # (the convolution mode is read when a model is scheduled)
     try:
         capi.load_model(model, other_model_path(onnx_writer, tmp, which))
     finally:
-        if precision != "fp32":
+        if precision != "default":
             os.environ.pop("INFERA_PRECISION", None)
     try:
         d_in = capi.DeviceBuffer(dev, rows * cols * 4)
@@ -463,16 +463,21 @@ def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str, precision:
     finally:
         capi.unload_model(model)
     split = "f16x3" in str(plan.get("conv_precision", ""))
+    six = "bf16x6" in str(plan.get("conv_precision", ""))
     if bound == "mfma" and split:
         achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 3.0, "TFLOP/s"
+    elif bound == "mfma" and six:
+        achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 6.0, "TFLOP/s"
     elif bound == "mfma":
         achieved, peak, unit = flops_row * rows / kernel_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
     else:
         achieved, peak, unit = bytes_row * rows / kernel_s / 1e9, HBM_PEAK_GBS, "GB/s"
-    traffic, traffic_source = (None, None) if split else traffic_for(which, rows)
+    traffic, traffic_source = (None, None) if split or (bound == "mfma" and not six) else traffic_for(which, rows)
     return {"workload": w["name"] + (" -- INFERA_PRECISION=f16x3 (opt-in: convolutions on the fp16 matrix cores, operands split hi + lo, three MFMAs per "
                                      "product; peak = dense fp16 / 3)" if split else ""),
-            "rows": rows, "rows_per_s": rows / kernel_s, "ms_per_pass": kernel_s * 1e3, "passes_timed": iters, "dtype": "f16x3" if split else "f32",
+            "rows": rows, "rows_per_s": rows / kernel_s, "ms_per_pass": kernel_s * 1e3, "passes_timed": iters,
+            "dtype": "f16x3" if split else "bf16x6 (f32 operands as three exact bf16 parts, six MFMAs per product, f32 accumulate)" if six else "f32",
+            **({"vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS, "peak_is": "dense bf16 MFMA peak / 6"} if six else {}),
             "value_is": "device_resident",
             "kernel": plan.get("fused_kernel", ",".join(sorted(set(plan["exec"]) - {"skipped"}))),
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic,
@@ -480,21 +485,21 @@ def other_workload(capi, onnx_writer, tmp: str, dev: int, which: str, precision:
                          "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}}}
 
 
-def other_workload_host(capi, onnx_writer, tmp: str, which: str, table, trows: int, budget: dict, threads: int, no_cpu: bool, precision: str = "fp32") -> dict:
+def other_workload_host(capi, onnx_writer, tmp: str, which: str, table, trows: int, budget: dict, threads: int, no_cpu: bool, precision: str = "default") -> dict:
     """The same two configs END TO END and beside their CPU baselines, short: C4 over the host table C2's
     scan used (first 10M rows, list output of 10, 3 scans); C5 through infera_predict_from_blob over 512 host images (2 scans);
     CPU legs capped at ~2 s each."""
     from infera_amd import sqlmock
 
     w = OTHER[which]
-    model = "bench_" + which + ("_" + precision if precision != "fp32" else "")
+    model = "bench_" + which + ("_" + precision if precision != "default" else "")
     path = other_model_path(onnx_writer, tmp, which)
-    if precision != "fp32":
+    if precision != "default":
         os.environ["INFERA_PRECISION"] = precision  # (read when the model is scheduled)
     try:
         capi.load_model(model, path)
     finally:
-        if precision != "fp32":
+        if precision != "default":
             os.environ.pop("INFERA_PRECISION", None)
     out = {}
     try:
@@ -548,8 +553,8 @@ def main():
         # One process per GPU: this rank's library instance must only create a context / upload weights on
         # ITS device (read once at library load, so set before importing the binding).
         os.environ.setdefault("INFERA_DEVICES", str(dev))
-    if args.precision != "fp32":
-        os.environ["INFERA_PRECISION"] = args.precision  # read once at library load
+    if args.precision != "default":
+        os.environ["INFERA_PRECISION"] = args.precision  # (the MLP mode is read once at library load, the convolution mode when a model is scheduled)
     if world > 1:
         # control plane only (barrier + max-reduce of one float); the data path has no collective
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -633,9 +638,13 @@ def main():
     kernel_s = ms / 1e3 / iters
     bf16x3 = "bf16x3" in str(plan.get("precision", ""))
     f16x3 = "f16x3" in str(plan.get("conv_precision", ""))
+    bf16x6 = "bf16x6" in str(plan.get("conv_precision", ""))
     if bound == "mfma" and f16x3:
         # three fp16 MFMAs per product: the algorithmic-flop ceiling is the dense fp16 peak / 3
         achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 3.0, "TFLOP/s"
+    elif bound == "mfma" and bf16x6:
+        # six bf16 MFMAs per product (three exact parts per operand): the dense bf16 peak / 6
+        achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 6.0, "TFLOP/s"
     elif bound == "mfma" and bf16x3:
         # three bf16 MFMAs per product: the algorithmic-flop ceiling is the dense bf16 peak / 3
         achieved, peak, unit = flops_row * rows / kernel_s / 1e12, BF16_MFMA_PEAK_TFLOPS / 3.0, "TFLOP/s"
@@ -648,7 +657,7 @@ def main():
     # tools/profile_bench.sh (separate rocprofv3 --pmc passes of this same command) and committed as
     # profiles/traffic_<workload>.json.  Reported only when that file matches this workload, row count AND the kernel the
     # plan reports (tests/test_traffic_profiles.py guards the constant against a kernel change).
-    traffic, traffic_source = traffic_for(args.workload, rows, bf16x3)  # HBM bytes per launch, a plain number as the contract asks
+    traffic, traffic_source = (None, None) if f16x3 or (args.precision == "fp32" and args.workload == "resnet18") else traffic_for(args.workload, rows, bf16x3)  # HBM bytes per launch, a plain number as the contract asks
 
     # a cheap end-of-run sanity check so a silently wrong kernel cannot post a number
     y = d_out.download((4, out_cols))
@@ -664,12 +673,15 @@ def main():
                 others[key] = other_workload(capi, onnx_writer, tmp, dev, which)
             except Exception as exc:  # never at the expense of the headline line
                 others[key] = {"error": f"{type(exc).__name__}: {exc}"}
-        try:  # C5 once more in the opt-in split-fp16 convolution mode (device-resident only)
-            others["C5_f16x3"] = other_workload(capi, onnx_writer, tmp, dev, "resnet18", "f16x3")
-            if "roofline" in others.get("C5", {}):
-                others["C5_f16x3"]["speedup_over_fp32"] = others["C5_f16x3"]["rows_per_s"] / others["C5"]["rows_per_s"]
-        except Exception as exc:
-            others["C5_f16x3"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # C5 twice more: on the exact-fp32 matrix instruction (INFERA_PRECISION=fp32) and in the opt-in split-fp16 mode
+        for key, prec in (("C5_fp32", "fp32"), ("C5_f16x3", "f16x3")):
+            try:
+                others[key] = other_workload(capi, onnx_writer, tmp, dev, "resnet18", prec)
+            except Exception as exc:
+                others[key] = {"error": f"{type(exc).__name__}: {exc}"}
+        if all("rows_per_s" in others.get(k, {}) for k in ("C5", "C5_fp32", "C5_f16x3")):
+            others["C5"]["speedup_over_fp32"] = others["C5"]["rows_per_s"] / others["C5_fp32"]["rows_per_s"]
+            others["C5_f16x3"]["speedup_over_fp32"] = others["C5_f16x3"]["rows_per_s"] / others["C5_fp32"]["rows_per_s"]
 
     # ---- the metric as SURVEY 8(d) defines it: the host path, PCIe included (all ranks scan concurrently) ----
     e2e, table = None, None
@@ -749,7 +761,9 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16x3 products, f32 accumulate -- OPTIONAL fast mode, NOT parity precision" if bf16x3 else
                      "f16x3: fp32 operands split hi + lo in fp16 (22 significant bits), three fp16 MFMAs per product, f32 accumulate -- opt-in, inside "
-                     "the parity tolerance (tests/test_conv_split_gpu.py)" if f16x3 else "f32",
+                     "the parity tolerance (tests/test_conv_split_gpu.py)" if f16x3 else
+                     "f32 operands cut exactly into three bf16 parts, six bf16 MFMAs per product, f32 accumulate (the default form of the tiled "
+                     "convolutions; the stem and the head on the exact-f32 instruction)" if bf16x6 else "f32",
             "data": "synthetic (counter-based splitmix64 table, seed 42; random-init weights seed 1234)",
             "config": {"workload": wl_name, "rows_per_gpu": rows, "features": cols, "parallelism": f"row-range x{world}",
                        "precision": plan.get("conv_precision", plan.get("precision", "fp32")),
@@ -759,6 +773,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": bytes_row * rows,
                          "kernel_ms": kernel_s * 1e3, "rows_per_s": rows / kernel_s, "algorithmic_per_row": {"flop": flops_row, "bytes": bytes_row}},
         }
+        if bf16x6:
+            line["roofline"]["peak_is"] = "dense bf16 MFMA peak / 6 (six matrix instructions per fp32 product: three exact bf16 parts per operand, the three smallest partial products dropped); the stem + max-pool kernel and the 512 -> 1000 head run on the exact-fp32 instruction"
+            line["roofline"]["vs_fp32_mfma_peak"] = achieved / FP32_MFMA_PEAK_TFLOPS
         if f16x3:
             line["roofline"]["peak_is"] = "dense fp16 MFMA peak / 3 (three matrix instructions per fp32 product; the stem + max-pool kernel and every tiled convolution run that way, the 512 -> 1000 head on the exact-fp32 instruction)"
             line["roofline"]["vs_fp32_mfma_peak"] = achieved / FP32_MFMA_PEAK_TFLOPS

@@ -125,7 +125,10 @@ const Config &Config::get() {
 
 ScheduleKnobs ScheduleKnobs::read() {
   return ScheduleKnobs{env_flag("INFERA_STEM_POOL", true), env_flag("INFERA_CHAIN_XCM", true), env_flag("INFERA_DENSE_XCM", true),
-                       env_or("INFERA_PRECISION", "fp32") == "bf16x6", env_or("INFERA_PRECISION", "fp32") == "f16x3"};
+                       // convolutions: bf16x6 unless told otherwise ("fp32" = the exact-fp32 matrix instruction, "f16x3" = the fastest form, with
+                       // its dynamic-range precondition; "bf16x3" is the fused MLP's optional mode and leaves convolutions on their default)
+                       env_or("INFERA_PRECISION", "bf16x6") != "fp32" && env_or("INFERA_PRECISION", "bf16x6") != "f16x3",
+                       env_or("INFERA_PRECISION", "bf16x6") == "f16x3"};
 }
 
 void log_msg(int level, const std::string &msg) {

@@ -153,7 +153,9 @@ struct ScheduleKnobs {
   bool stem_pool;   // INFERA_STEM_POOL=0|1   stem convolution + MaxPool 3x3/2 in one kernel
   bool chain_xcm;   // INFERA_CHAIN_XCM=0|1   the fused small-MLP chain kernel reads column-major host chunks itself (0: transpose launch first)
   bool dense_xcm;   // INFERA_DENSE_XCM=0|1   the same for the as-it-lies streaming kernels of single narrow layers
-  bool conv_bf16x6; // INFERA_PRECISION=bf16x6 the same convolutions with operands cut exactly into three bf16 parts, six partial products (no precondition)
+  bool conv_bf16x6; // DEFAULT (INFERA_PRECISION unset / bf16x6): the tiled convolutions on the bf16 matrix cores, every fp32 operand cut EXACTLY into
+                    //   three bf16 parts, six partial products per product, fp32 accumulate (conv_split.hip) -- no scales, no precondition on the data.
+                    //   INFERA_PRECISION=fp32: the exact-fp32 matrix instruction instead (conv.hip's tiled / weight-stationary kernels)
   bool conv_f16x3;  // INFERA_PRECISION=f16x3  the tiled convolutions on the fp16 matrix cores, operands split hi + lo (conv_split.hip)
   static ScheduleKnobs read();
 };

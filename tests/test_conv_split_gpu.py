@@ -17,12 +17,12 @@ from tests.test_conv_ws_gpu import CASES, _net
 
 
 def _load_both(gpu_api, path):
-    gpu_api.load_model("conv_fp32", path)
-    os.environ["INFERA_PRECISION"] = "f16x3"
-    try:
-        gpu_api.load_model("conv_split", path)
-    finally:
-        os.environ.pop("INFERA_PRECISION", None)
+    for name, precision in (("conv_fp32", "fp32"), ("conv_split", "f16x3")):  # (read when a model is scheduled; the default is bf16x6)
+        os.environ["INFERA_PRECISION"] = precision
+        try:
+            gpu_api.load_model(name, path)
+        finally:
+            os.environ.pop("INFERA_PRECISION", None)
 
 
 def _unload(gpu_api):
@@ -323,7 +323,7 @@ def test_gpu_split_fp16_non_finite_images_stay_in_their_rows(gpu_api, tmp_path):
     assert not np.array_equal(y_bad[4], y_clean[4])
 
 
-# ---- INFERA_PRECISION=bf16x6: operands cut exactly into three bf16 parts, six partial products; no scales, no maxima, no precondition --------
+# ---- the DEFAULT convolution form (bf16x6): operands cut exactly into three bf16 parts, six partial products; no scales, no maxima, no precondition ----
 def _load_mode(gpu_api, path, name, precision):
     os.environ["INFERA_PRECISION"] = precision
     try:
@@ -343,8 +343,8 @@ def test_gpu_bf16x6_conv_every_instantiation_is_accurate(gpu_api, tmp_path, vari
     # rows of wildly different magnitude: this mode has no scales, so nothing about the data's range can matter
     mags = np.array([1.0, 1e-30, 1e25, 0.0, 3e-12, 1.0, 65504.0], np.float32)
     x = (synth.table(23, 0, rows, 4 * hw * hw) * mags[:, None]).astype(np.float32)
-    gpu_api.load_model("conv_fp32", path)
-    _load_mode(gpu_api, path, "conv_bf6", "bf16x6")
+    _load_mode(gpu_api, path, "conv_fp32", "fp32")
+    gpu_api.load_model("conv_bf6", path)  # the default
     try:
         plan = gpu_api.get_plan("conv_bf6")
         assert plan["exec"].count("conv_split_bf16x6") == 1 and "bf16x6" in plan["conv_precision"]
@@ -371,8 +371,8 @@ def test_gpu_bf16x6_c5_full_width_error_against_float64(gpu_api, tmp_path):
     rows = 4
     path = W.write(str(tmp_path / "rn224.onnx"), W.resnet18())
     x = synth.table(5, 0, rows, 3 * 224 * 224)
-    gpu_api.load_model("conv_fp32", path)
-    _load_mode(gpu_api, path, "conv_bf6", "bf16x6")
+    _load_mode(gpu_api, path, "conv_fp32", "fp32")
+    gpu_api.load_model("conv_bf6", path)  # the default
     try:
         plan = gpu_api.get_plan("conv_bf6")
         assert plan["exec"].count("conv_split_bf16x6") == 19 and plan["exec"][0] == "conv_patch_pool"  # (the stem stays on the exact-fp32 kernel)

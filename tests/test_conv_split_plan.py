@@ -26,16 +26,21 @@ def _plan(tmp_path, name, blob, precision=None):
 def test_resnet18_plan_in_split_mode_and_without(built, tmp_path):
     blob = W.resnet18()
     split = _plan(tmp_path, "rn_split", blob, "f16x3")
-    plain = _plan(tmp_path, "rn_plain", blob)
+    plain = _plan(tmp_path, "rn_plain", blob, "fp32")
+    default = _plan(tmp_path, "rn_default", blob)
     assert split["exec"][0] == "conv_patch_pool_f16x3" and split["exec"].count("conv_split_f16x3") == 19 and "f16x3" in split["conv_precision"]
     assert plain["exec"][0] == "conv_patch_pool" and plain["exec"].count("conv_tiled_cq") == 19 and "conv_precision" not in plain
+    # the default: the same 19 layers on the bf16 matrix cores with three exact parts per operand; no maxima, so no extra scratch; the stem exact-fp32
+    assert default["exec"][0] == "conv_patch_pool" and default["exec"].count("conv_split_bf16x6") == 19 and "bf16x6" in default["conv_precision"]
+    assert default["scratch_floats_per_row"] == plain["scratch_floats_per_row"]
+    assert [{"conv_split_bf16x6": "conv_tiled_cq"}.get(e, e) for e in default["exec"]] == plain["exec"]
     # same steps, same fusions (residual adds in the epilogues, the head on the exact-fp32 tiled kernel): only the names of the moved steps differ
     moved = {"conv_patch_pool_f16x3": "conv_patch_pool", "conv_split_f16x3": "conv_tiled_cq"}
     assert [moved.get(e, e) for e in split["exec"]] == plain["exec"]
     # one word of scratch per image and tracked tensor on top of the activations
     assert 0 < split["scratch_floats_per_row"] - plain["scratch_floats_per_row"] <= 19
-    # bf16x3 is the fused MLP's mode: a convolutional plan ignores it
-    assert _plan(tmp_path, "rn_bf", blob, "bf16x3")["exec"] == plain["exec"]
+    # bf16x3 is the fused MLP's mode: a convolutional plan keeps its default under it
+    assert _plan(tmp_path, "rn_bf", blob, "bf16x3")["exec"] == default["exec"]
 
 
 def test_layers_the_split_kernels_do_not_take_stay_exact(built, tmp_path):
@@ -54,7 +59,8 @@ def test_layers_the_split_kernels_do_not_take_stay_exact(built, tmp_path):
 
     # 4 -> 24 (padded-channel kernel), 24 -> 48 (channels not multiples of 32: padded-channel kernel), depthwise 48, 48 -> 64 1x1 (C % 32 != 0)
     p = _plan(tmp_path, "mobile", net(4, [(24, 3, 1), (48, 3, 1), (48, 3, 48), (64, 1, 1)]), "f16x3")
-    assert "conv_split_f16x3" not in p["exec"] and "conv_precision" not in p
+    assert "conv_split_f16x3" not in p["exec"] and "conv_split_bf16x6" not in p["exec"] and "conv_precision" not in p
+    assert "conv_split_bf16x6" not in _plan(tmp_path, "mobile_d", net(4, [(24, 3, 1), (48, 3, 1), (48, 3, 48), (64, 1, 1)]))["exec"]
     # 4 -> 64, then 64 -> 64 in two groups (generic kernel), then 64 -> 96 3x3 (split)
     p = _plan(tmp_path, "grouped", net(4, [(64, 3, 1), (64, 3, 2), (96, 3, 1)]), "f16x3")
     assert p["exec"][:3] == ["conv_patch", "normal", "conv_split_f16x3"] and p["exec"].count("conv_split_f16x3") == 1  # (activations ride in the conv steps)

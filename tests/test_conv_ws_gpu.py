@@ -51,7 +51,11 @@ def test_gpu_weight_stationary_conv_matches_tiled_and_oracle(gpu_api, tmp_path, 
     c = CASES[case]
     path = W.write(str(tmp_path / "ws.onnx"), _net(c["chain"], c["cin"], c["hw"], c["residual_at"]))
     x = synth.table(31, 0, c["rows"], c["cin"] * c["hw"] * c["hw"])
-    gpu_api.load_model("wsnet", path)
+    os.environ["INFERA_PRECISION"] = "fp32"  # (read when the model is scheduled: the exact-fp32 kernels are what this test is about)
+    try:
+        gpu_api.load_model("wsnet", path)
+    finally:
+        os.environ.pop("INFERA_PRECISION", None)
     try:
         assert gpu_api.get_plan("wsnet")["activation_layout"] == "NC/4HW4"
         out = {}
@@ -80,7 +84,11 @@ def test_gpu_tiled_conv_tail_split_is_bit_identical(gpu_api, tmp_path):
     rows = 261
     path = W.write(str(tmp_path / "tail.onnx"), _net([(256, 1, 1), (128, 3, 2)], 4, 32))
     x = synth.table(33, 0, rows, 4 * 32 * 32)
-    gpu_api.load_model("tailnet", path)
+    os.environ["INFERA_PRECISION"] = "fp32"
+    try:
+        gpu_api.load_model("tailnet", path)
+    finally:
+        os.environ.pop("INFERA_PRECISION", None)
     try:
         out = {}
         for mode in ("1", "0"):

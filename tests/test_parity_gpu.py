@@ -535,7 +535,8 @@ def test_resnet18_full_width_vs_oracle(api, tmp_path):
     path = W.write(str(tmp_path / "rn64.onnx"), W.resnet18(classes=10, in_hw=64, width=64))
     api.load_model("rn64", path)
     plan = api.get_plan("rn64")
-    assert plan["activation_layout"] == "NC/4HW4" and plan["exec"].count("conv_tiled_cq") == 19
+    # (default plan: every tiled convolution on the bf16 matrix cores, operands cut exactly into three parts -- DESIGN.md 3.3c)
+    assert plan["activation_layout"] == "NC/4HW4" and plan["exec"].count("conv_split_bf16x6") == 19 and "bf16x6" in plan["conv_precision"]
     imgs = synth.table(21, 0, 3, 3 * 64 * 64)
     got = api.predict_from_blob("rn64", imgs.tobytes())
     want = oracle.Model(path).predict_blob(imgs.tobytes())
@@ -563,7 +564,13 @@ def test_tiled_conv_feature_tile_variants(api, tmp_path):
         x, cin = f"r{i}", cout
     nodes += [W.node("GlobalAveragePool", [x], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
     path = W.write(str(tmp_path / "widths.onnx"), W.model("widths", nodes, inits, [W.value_info("X", ["N", 4, 20, 20])], [W.value_info("Y", ["N", 32])]))
-    api.load_model("widths", path)
+    import os
+
+    os.environ["INFERA_PRECISION"] = "fp32"  # (read when the model is scheduled: this test is about the exact-fp32 tiled kernel's instantiations)
+    try:
+        api.load_model("widths", path)
+    finally:
+        os.environ.pop("INFERA_PRECISION", None)
     plan = api.get_plan("widths")
     assert plan["activation_layout"] == "NC/4HW4" and plan["exec"].count("conv_tiled_cq") == 6, plan["exec"]
     imgs = synth.table(13, 0, 7, 4 * 20 * 20)
