@@ -390,3 +390,32 @@ def test_gpu_bf16x6_c5_full_width_error_against_float64(gpu_api, tmp_path):
           f"fp32 plan max {e32.max() / scale:.3e} ({(e32 / (1e-4 * np.abs(ref) + 1e-6)).max():.3f})")
     assert np.all(e6 <= 1e-4 * np.abs(ref) + 1e-6)
     assert e6.max() <= 2.0 * e32.max() + 1e-7 * scale, (e6.max() / scale, e32.max() / scale)
+
+
+@pytest.mark.gpu
+def test_gpu_bf16x6_random_geometries(gpu_api, tmp_path):
+    """The same sixty random geometries on the DEFAULT plan: layers with a multiple of 64 features run conv2d_split6_kernel, the others the
+    exact-fp32 tiled kernel; every one against the oracle, a row alone == the row in its batch."""
+    from oracle import oracle
+
+    split = 0
+    for seed in range(60):
+        blob, hw, rows, desc = _random_conv_case(seed)
+        path = W.write(str(tmp_path / f"rc{seed}.onnx"), blob)
+        x = synth.table(100 + seed, 0, rows, 4 * hw * hw)
+        want = oracle.Model(path).predict_blob(x.tobytes())
+        _load_mode(gpu_api, path, "conv_fp32", "fp32")
+        gpu_api.load_model("conv_bf6", path)
+        try:
+            n6 = gpu_api.get_plan("conv_bf6")["exec"].count("conv_split_bf16x6")
+            assert n6 == (1 if desc["M"] % 64 == 0 else 0), desc
+            split += n6
+            got = gpu_api.predict_from_blob("conv_bf6", x.tobytes())
+            assert np.array_equal(got[rows - 1], gpu_api.predict_from_blob("conv_bf6", x[rows - 1].tobytes()).reshape(-1)), desc
+            ref32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
+        finally:
+            gpu_api.unload_model("conv_bf6")
+            gpu_api.unload_model("conv_fp32")
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= max(1.5e-6 * scale, 1.5 * np.abs(ref32 - want).max()) + 1e-30, (desc, np.abs(got - want).max() / scale)
+    assert split >= 20
