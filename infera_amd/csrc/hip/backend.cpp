@@ -748,6 +748,7 @@ void schedule(LoadedModel &m) {
   // split-fp16 convolutions (INFERA_PRECISION=f16x3) and the per-image maxima they scale their inputs by
   m.conv_split.assign(n, 0);
   m.conv_split6.assign(n, 0);
+  m.stem_split6.assign(n, 0);
   m.stem_split.assign(n, 0);
   m.amax_of_buf.assign(nb, -1);
   m.amax_by_kernel.assign(nb, 0);
@@ -760,6 +761,14 @@ void schedule(LoadedModel &m) {
       const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
                              int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
       if (kern::conv2d_split6_supported(kern::conv2d_tiled_geom(g)) && !m.nchw_buf[size_t(c.in0)]) m.conv_split6[i] = 1;
+    }
+    for (size_t i = 0; i < n; i++) {  // the 7x7 / stride-2 stem + max-pool in the same arithmetic
+      if (m.exec[i] != ExecKind::ConvPatch || m.conv_fused_pool[i] < 0) continue;
+      const Step &c = st[i], &q = st[size_t(m.conv_fused_pool[i])];
+      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
+                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
+      const kern::ConvGeom gp = kern::conv2d_patch_geom(g);
+      if (gp.mvalid == 0 && kern::conv2d_stem_split6_supported(gp, kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)})) m.stem_split6[i] = 1;
     }
   }
   if (ScheduleKnobs::read().conv_f16x3 && m.cq_mode) {
@@ -910,6 +919,11 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
         const Step &q = st[size_t(fj)];
         const kern::PoolTail tail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)};
         kern::conv2d_patch_pack(g, s.W.data(), packed.data(), &tail);
+        if (m.stem_split6[i]) {
+          std::vector<float> sp(kern::conv2d_stem_split6_packed_floats());
+          kern::conv2d_stem_split6_pack(g, s.W.data(), sp.data());
+          d.cst = upload(sp, us);
+        }
         if (m.stem_split[i]) {  // (the exact-fp32 blob above stays: INFERA_STEM_SPLIT=0 at run time compares the two)
           std::vector<float> sp(kern::conv2d_stem_split_packed_floats());
           kern::conv2d_stem_split_pack(g, s.W.data(), sp.data(), tail);
@@ -1075,7 +1089,10 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
             const Step &q = st[size_t(fj)];
             unsigned *track = m.n_amax > 0 && m.amax_of_buf[size_t(q.out)] >= 0 ? amax(q.out) : nullptr;
             const char *sse = getenv("INFERA_STEM_SPLIT");  // 0: the exact-fp32 stem kernels under a split plan (read per launch: tests, A/B)
-            if (m.stem_split[i] && d.cst && !(sse && atoi(sse) == 0))
+            if (m.stem_split6[i] && d.cst && !(sse && atoi(sse) == 0))
+              kern::conv2d_stem_split6(s, buf(x.in0), d.cst, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
+                                       kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus);
+            else if (m.stem_split[i] && d.cst && !(sse && atoi(sse) == 0))
               kern::conv2d_stem_split(s, buf(x.in0), d.cst, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
                                       kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus, track);
             else
@@ -1828,7 +1845,7 @@ std::string LoadedModel::describe_json() const {
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++)
-    o << (i ? "," : "") << "\"" << (i < stem_split.size() && stem_split[i] ? "conv_patch_pool_f16x3" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split.size() && conv_split[i] ? "conv_split_f16x3" : i < conv_split6.size() && conv_split6[i] ? "conv_split_bf16x6" : ek[int(exec[i])]) << "\"";
+    o << (i ? "," : "") << "\"" << (i < stem_split6.size() && stem_split6[i] ? "conv_patch_pool_bf16x6" : i < stem_split.size() && stem_split[i] ? "conv_patch_pool_f16x3" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split.size() && conv_split[i] ? "conv_split_f16x3" : i < conv_split6.size() && conv_split6[i] ? "conv_split_bf16x6" : ek[int(exec[i])]) << "\"";
   o << "],\"activation_layout\":\"" << (cq_mode ? "NC/4HW4" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";

@@ -110,6 +110,7 @@ class LoadedModel {
   // needed); amax_by_kernel = the tensor's producer is no split convolution, a reduction kernel computes the maxima before first use.
   std::vector<char> conv_split;
   std::vector<char> conv_split6; // ConvTiled steps on conv2d_split6 (INFERA_PRECISION=bf16x6: three bf16 parts per operand, no maxima needed)
+  std::vector<char> stem_split6; // ConvPatch + fused MaxPool steps that run conv2d_stem_split6 (default plan)
   std::vector<char> stem_split;  // ConvPatch + fused MaxPool steps that run conv2d_stem_split (same mode)
   std::vector<int> amax_of_buf;
   std::vector<char> amax_by_kernel;

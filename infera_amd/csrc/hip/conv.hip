@@ -1615,6 +1615,226 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split_kernel(const
   }
 }
 
+// ---- the stem + max-pool in the DEFAULT arithmetic: bf16 x three exact parts, six MFMAs per product (round 3) ----------------------
+// conv2d_stem_split_kernel's k order (a lane half's eight k-values = one filter row, kx 0 2 4 6 1 3 5 7 = four consecutive words of each half of a
+// de-interleaved patch row) with the inner product of conv2d_split6_kernel (conv_split.hip): no scales, nothing to track, nothing about the input
+// has to hold.  The patch is cut ONCE, when it is parked: a patch word is the pair {hi | mid << 16}, {lo} (8 bytes), so the k loop assembles its
+// three B fragments with three v_perm_b32 per pair of words (first version: fp32 patch, cut in the k loop -- 44 VALU instructions per k-block and
+// pixel tile: 2.24 ms against 1.9).  The weights are three bf16 fragments per k-block (33 KB for this half's 32 features), and to fit two
+// workgroups per CU the exchange tile ALIASES the patch (37 KB each): the pooling runs
+// between the k loops (four barriers per tile instead of two: out of the k loop -> exchange tile written -> pooled and stored -> next patch parked)
+// rather than in the next tile's shadow.  Same tile flow otherwise (two half-channel workgroups per CU, the odd half half a tile late).
+static size_t stem_split6_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
+  const size_t patch_b = (size_t(g.C) * p.PLANE + 8) * 8, exch_b = 256 * size_t(32 + 4) * 4;
+  return size_t(kStemKB) * 3072 + std::max(patch_b, exch_b) + 64;
+}
+using bf16x8_s = __attribute__((ext_vector_type(8))) __bf16;
+
+__global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+                                                                           const float *__restrict__ bias, float *__restrict__ Y, int64_t ntiles,
+                                                                           ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync) {
+  constexpr int BS = kPool2Block, PW = 2, KBC = kStemKB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  u32x4_t *wl = reinterpret_cast<u32x4_t *>(smem);           // [KBC][hi, mid, lo][64 lanes]: this half's 32 features
+  uint2 *patch = reinterpret_cast<uint2 *>(smem + KBC * 768);  // [C * PLANE] cut words {hi | mid << 16, lo} (+ 8 spare) ...
+  f32x4 *exch = reinterpret_cast<f32x4 *>(patch);            // ... and, between the k loops, the exchange tile [256][9 quads]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int psz = g.C * pg.PLANE;
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, half = wg & 1, pair = wg >> 1;
+
+  // blob: [KBC][half][part][64][4 dwords]
+  for (int i = threadIdx.x; i < KBC * 192; i += BS)
+    wl[i] = reinterpret_cast<const u32x4_t *>(Wp)[(((i / 192) * 2 + half) * 3 + (i % 192) / 64) * 64 + (i & 63)];
+  int soff[2 * KBC];
+#pragma unroll
+  for (int rr = 0; rr < 2 * KBC; rr++) {
+    const int c = rr / g.kh, ky = rr - c * g.kh;
+    soff[rr] = rr < g.C * g.kh ? c * pg.PLANE + ky * g.dh * pg.ROWS : 0;
+  }
+  int e_rel[kPatchMaxE], e_rc[kPatchMaxE], e_lds[kPatchMaxE];
+#pragma unroll
+  for (int i = 0; i < kPatchMaxE; i++) {
+    const int e = threadIdx.x + i * BS;
+    const int c = e / (pg.PR * pg.PC), rem = e - c * (pg.PR * pg.PC), row = rem / pg.PC, col = rem - row * pg.PC;
+    const bool live = c < g.C;
+    e_rel[i] = (c * g.H + row) * g.W + col;
+    e_rc[i] = live ? (row << 16) | col : -1;
+    e_lds[i] = live ? c * pg.PLANE + row * pg.ROWS + (col % g.sw) * pg.HALF + col / g.sw : -1;
+  }
+  const int tiles_per_img = pg.tiles_x * pg.tiles_y;
+  auto tile_origin = [&](int64_t t, int &img, int &oy0, int &ox0) {
+    const unsigned u = unsigned(t), im = u / unsigned(tiles_per_img), rem = u - im * unsigned(tiles_per_img);
+    const unsigned ty = rem / unsigned(pg.tiles_x), tx = rem - ty * unsigned(pg.tiles_x);
+    img = int(im);
+    oy0 = int(ty) * kPoolTR * 2 - pool.pt;
+    ox0 = int(tx) * kPoolTC * 2 - pool.pl;
+  };
+  auto load_slot = [&](int i, const float *image, int iy0, int ix0) -> float {
+    const int iy = iy0 + (e_rc[i] >> 16), ix = ix0 + (e_rc[i] & 0xffff);
+    const bool ok = unsigned(iy) < unsigned(g.H) && unsigned(ix) < unsigned(g.W);
+    const float x = image[ok ? iy0 * g.W + ix0 + e_rel[i] : 0];
+    return ok ? x : 0.f;
+  };
+  // park a patch: first every word of the region nobody parks (the odd half's fourth word of the last pixels: kx = 7, weight zero -- and what
+  // the exchange tile left there) is made finite again, then the fetched words
+  auto park_patch = [&](const float(&v)[kPatchMaxE]) {
+    // (one word per patch row is read but never parked -- the odd half's word HALF - 1 = column 2 HALF - 1 past the patch, kx = 7 of the last
+    //  pixels, weight zero: it must be finite, and the exchange tile has been there)
+    for (int i = threadIdx.x; i < g.C * pg.PR; i += BS) patch[(i / pg.PR) * pg.PLANE + (i % pg.PR) * pg.ROWS + 2 * pg.HALF - 1] = uint2{0u, 0u};
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++) {  // exact cut: hi = top 16 bits, mid = top 16 bits of the rest, lo = what is left (8 bits: exact in bf16)
+      const unsigned x = __float_as_uint(v[i]);
+      const float r1 = v[i] - __uint_as_float(x & 0xffff0000u);
+      const unsigned y = __float_as_uint(r1);
+      const float r2 = r1 - __uint_as_float(y & 0xffff0000u);
+      patch[e_lds[i] >= 0 ? e_lds[i] : psz + (i & 3)] = uint2{__builtin_amdgcn_perm(y, x, 0x07060302u), __float_as_uint(r2) >> 16};
+    }
+  };
+
+  int lbase[PW], py[PW], px[PW];
+#pragma unroll
+  for (int p = 0; p < PW; p++) {
+    const int pix = min((wave + 4 * p) * 32 + r, kPoolCR * kPoolCC - 1);
+    py[p] = pix / kPoolCC;
+    px[p] = pix % kPoolCC;
+    lbase[p] = py[p] * g.sh * pg.ROWS + px[p];
+  }
+  const u32x4_t *wfrag = wl + lane;
+  f32x4 bres[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) bres[q] = bias ? reinterpret_cast<const f32x4 *>(bias)[h + 8 * half + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+  float pv[kPatchMaxE];
+  const int64_t chunk = (ntiles + 7) >> 3, t_end = min(ntiles, (int64_t(xcd) + 1) * chunk);
+  const int64_t tstep = ((gridDim.x + 7 - xcd) >> 3) >> 1;
+  int64_t tile = int64_t(xcd) * chunk + pair;
+  int img_n = 0, oy0_n = 0, ox0_n = 0;
+  if (tile < t_end) {
+    tile_origin(tile, img_n, oy0_n, ox0_n);
+    const int iy0 = oy0_n * g.sh - g.pt, ix0 = ox0_n * g.sw - g.pl;
+    const float *image = X + int64_t(img_n) * g.C * g.H * g.W;
+#pragma unroll
+    for (int i = 0; i < kPatchMaxE; i++) pv[i] = load_slot(i, image, iy0, ix0);
+  }
+  __syncthreads();  // (the weights)
+  if (tile < t_end) park_patch(pv);
+  __syncthreads();
+  if (half)
+    for (int i = 0; i < desync; i++) __builtin_amdgcn_s_sleep(127);
+  constexpr int XQ = 9, NQ = 8, PT = kPoolTR * kPoolTC;
+  int pwin[2] = {0, 0}, poff[2] = {-1, -1}, ppr[2] = {0, 0}, ppc[2] = {0, 0};
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int it = threadIdx.x + n * BS;
+    const bool ok = it < NQ * PT;
+    const int cq = ok ? it / PT : 0, pp = ok ? it % PT : 0, pr = pp / kPoolTC, pc = pp % kPoolTC;
+    pwin[n] = ((2 * pr) * kPoolCC + 2 * pc) * XQ + cq;
+    ppr[n] = pr;
+    ppc[n] = pc;
+    poff[n] = ok ? (((cq + NQ * half) * pool.OH + pr) * pool.OW + pc) * 16 : -1;
+  }
+  const unsigned pooled_img_bytes = unsigned(g.M / 4) * unsigned(pool.OH) * unsigned(pool.OW) * 16u;
+
+  for (; tile < t_end; tile += tstep) {
+    const int64_t next = tile + tstep;
+    const int oy0 = oy0_n, ox0 = ox0_n, img = img_n;
+    tile_origin(next < t_end ? next : tile, img_n, oy0_n, ox0_n);
+    const int iy0_n = oy0_n * g.sh - g.pt, ix0_n = ox0_n * g.sw - g.pl;
+    const float *image_n = X + int64_t(img_n) * g.C * g.H * g.W;
+
+    f32x16 acc[PW];
+#pragma unroll
+    for (int p = 0; p < PW; p++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
+    const uint2 *pb[PW] = {patch + lbase[0], patch + lbase[1]};
+    // a step = (k-block, pixel tile): eight cut patch words (even half: kx 0 2 4 6, odd half: kx 1 3 5 7), fetched one step ahead; the
+    // k-block's three weight fragments one k-block ahead
+    uint2 w[2][8];
+    u32x4_t a3[2][3];
+    auto fetch_words = [&](int step, int buf) {
+      const int kb = step / PW, p = step % PW;
+      const uint2 *row = pb[p] + (h ? soff[2 * kb + 1] : soff[2 * kb]), *rowh = row + pg.HALF;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        w[buf][e] = row[e];
+        w[buf][4 + e] = rowh[e];
+      }
+    };
+    fetch_words(0, 0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) a3[0][k] = wfrag[k * 64];
+#pragma unroll
+    for (int step = 0; step < KBC * PW; step++) {
+      const int kb = step / PW, p = step % PW, cur = step & 1, kc = kb & 1;
+      if (step + 1 < KBC * PW) fetch_words(step + 1, cur ^ 1);
+      if (p == 0 && kb + 1 < KBC) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) a3[kc ^ 1][k] = wfrag[((kb + 1) * 3 + k) * 64];
+      }
+      u32x4_t bh, bm, bl;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // elements 2i, 2i + 1 of the fragment: hi halves, mid halves, lo halves of two cut words
+        bh[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1].x, w[cur][2 * i].x, 0x05040100u);
+        bm[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1].x, w[cur][2 * i].x, 0x07060302u);
+        bl[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1].y, w[cur][2 * i].y, 0x05040100u);
+      }
+      // the next tile's patch words ride along: sixteen fetches over the 22 steps
+#pragma unroll
+      for (int sl = 0; sl < kPatchMaxE; sl++)
+        if (sl * (KBC * PW) / kPatchMaxE == step) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
+      auto B = [](const u32x4_t &v) { return __builtin_bit_cast(bf16x8_s, v); };
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][2]), B(bh), acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bl), acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][1]), B(bm), acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][1]), B(bh), acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bm), acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bh), acc[p], 0, 0, 0);
+    }
+
+    __syncthreads();  // everybody is out of the k loop: the patch region becomes the exchange tile
+    dispatch_act(act.kind, [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
+#pragma unroll
+      for (int p = 0; p < PW; p++) {
+        const int oy = oy0 + py[p], ox = ox0 + px[p];
+        const bool inside = oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = inside ? apply_act_c<KIND>(acc[p][4 * q + j] + bres[q][j], act.a, act.b) : -INFINITY;
+          exch[((wave + 4 * p) * 32 + r) * XQ + 2 * q + h] = v;
+        }
+      }
+    });
+    __syncthreads();
+    {  // pooling: every thread its (at most two) pooled (pixel, channel quad) items
+      const char *base = reinterpret_cast<const char *>(Y) + int64_t(__builtin_amdgcn_readfirstlane(img)) * pooled_img_bytes;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, int(pooled_img_bytes), 0x00020000);
+      const int pr0 = (oy0 + pool.pt) >> 1, pc0 = (ox0 + pool.pl) >> 1;
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        const f32x4 *win = exch + pwin[n];
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const f32x4 v = win[(i * kPoolCC + j) * XQ];
+#pragma unroll
+            for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
+          }
+        const int voff = (poff[n] >= 0 && pr0 + ppr[n] < pool.OH && pc0 + ppc[n] < pool.OW) ? poff[n] + (pr0 * pool.OW + pc0) * 16 : -1;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), rs, voff, 0, 0);
+      }
+    }
+    __syncthreads();  // the exchange tile has been read: the region is the patch again
+    park_patch(pv);   // (unconditional: the last tile parks its own re-fetched patch)
+    __syncthreads();
+  }
+}
+
 // Depthwise convolution (groups == C == M) in channel-quad planes: HBM-bound, no matrix cores.  One thread per
 // (n, channel quad, oh, ow): every tap is one 16-byte load (consecutive lanes walk a plane row) times one
 // 16-byte weight quad [c/4][tap][4] that the whole wave shares.
@@ -1992,6 +2212,64 @@ void conv2d_stem_split(hipStream_t s, const float *X, const float *packed, const
   }
   hipLaunchKernelGGL(conv2d_stem_split_kernel, dim3(unsigned(2 * cus)), dim3(kPool2Block), stem_split_lds_bytes(g, p), s, X, packed, bias, Y, ntiles, g, p,
                      act, pool, desync, amax_out);
+}
+
+// ---- bf16 x three parts stem + max-pool (conv2d_stem_split6_kernel) ----
+bool conv2d_stem_split6_supported(const ConvGeom &g, const PoolTail &pool) {
+  if (!conv2d_stem_split_supported(g, pool)) return false;
+  return 2 * stem_split6_lds_bytes(g, patch_pool_geom(g, pool)) <= 160 * 1024;
+}
+
+size_t conv2d_stem_split6_packed_floats() { return size_t(kStemKB) * 1536; }
+
+void conv2d_stem_split6_pack(const ConvGeom &g, const float *Wt, float *packed) {
+  const int KK = g.C * g.kh * g.kw;
+  uint16_t *out = reinterpret_cast<uint16_t *>(packed);
+  for (int kb = 0; kb < kStemKB; kb++)
+    for (int half = 0; half < 2; half++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int e = 0; e < 8; e++) {
+          const int m = 32 * half + (lane & 31), rr = 2 * kb + (lane >> 5), kx = e < 4 ? 2 * e : 2 * (e - 4) + 1;
+          const float v = rr < g.C * g.kh && kx < g.kw ? Wt[size_t(m) * KK + size_t(rr) * g.kw + kx] : 0.f;
+          uint32_t x, y, z;  // exact truncation cut: v = hi + mid + lo
+          std::memcpy(&x, &v, 4);
+          const uint32_t xh = x & 0xffff0000u;
+          float fh, fm;
+          std::memcpy(&fh, &xh, 4);
+          const float r1 = v - fh;
+          std::memcpy(&y, &r1, 4);
+          const uint32_t yh = y & 0xffff0000u;
+          std::memcpy(&fm, &yh, 4);
+          const float r2 = r1 - fm;
+          std::memcpy(&z, &r2, 4);
+          const size_t base = (size_t(kb) * 2 + half) * 3;  // fragments of 64 lanes x 8 bf16
+          out[(base + 0) * 512 + size_t(lane) * 8 + e] = uint16_t(x >> 16);
+          out[(base + 1) * 512 + size_t(lane) * 8 + e] = uint16_t(y >> 16);
+          out[(base + 2) * 512 + size_t(lane) * 8 + e] = uint16_t(z >> 16);
+        }
+}
+
+void conv2d_stem_split6(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
+                        ActParam act, const PoolTail &pool, int num_cus) {
+  if (rows <= 0) return;
+  const PatchGeom p = patch_pool_geom(g, pool);
+  if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {
+    for (int64_t r0 = 0; r0 < rows; r0 += cap)
+      conv2d_stem_split6(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus);
+    return;
+  }
+  const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
+  const int desync = getenv("INFERA_STEM_POOL2_DESYNC") ? atoi(getenv("INFERA_STEM_POOL2_DESYNC")) : 1;
+  const int cus = std::max(8, (num_cus > 0 ? num_cus : 256) / 8 * 8);  // whole workgroup pairs on each of 8 XCD queues; runs for every batch size
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_stem_split6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+  }
+  hipLaunchKernelGGL(conv2d_stem_split6_kernel, dim3(unsigned(2 * cus)), dim3(kPool2Block), stem_split6_lds_bytes(g, p), s, X, packed, bias, Y, ntiles, g,
+                     p, act, pool, desync);
 }
 
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,

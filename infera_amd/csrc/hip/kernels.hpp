@@ -145,6 +145,12 @@ struct PoolTail {
   int OH = 0, OW = 0, pt = 0, pl = 0;
 };
 bool conv2d_patch_pool_supported(const ConvGeom &g, const PoolTail &pool);
+// ... and in the default arithmetic (bf16 x three exact parts, six MFMAs per product: no scales, nothing to track)
+bool conv2d_stem_split6_supported(const ConvGeom &g, const PoolTail &pool);
+size_t conv2d_stem_split6_packed_floats();
+void conv2d_stem_split6_pack(const ConvGeom &g, const float *Wt, float *packed);
+void conv2d_stem_split6(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
+                        ActParam act, const PoolTail &pool, int num_cus);
 // amax_out (nullable): bits of each image's largest pooled |y|, max-accumulated (zero it first) -- for a split-fp16 convolution reading Y
 void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                        const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out = nullptr);

@@ -375,7 +375,7 @@ def test_gpu_bf16x6_c5_full_width_error_against_float64(gpu_api, tmp_path):
     gpu_api.load_model("conv_bf6", path)  # the default
     try:
         plan = gpu_api.get_plan("conv_bf6")
-        assert plan["exec"].count("conv_split_bf16x6") == 19 and plan["exec"][0] == "conv_patch_pool"  # (the stem stays on the exact-fp32 kernel)
+        assert plan["exec"].count("conv_split_bf16x6") == 19 and plan["exec"][0] == "conv_patch_pool_bf16x6"
         y6 = gpu_api.predict_from_blob("conv_bf6", x.tobytes())
         y32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
         assert np.array_equal(y6[2], gpu_api.predict_from_blob("conv_bf6", x[2].tobytes()).reshape(-1))
@@ -419,3 +419,45 @@ def test_gpu_bf16x6_random_geometries(gpu_api, tmp_path):
         scale = np.abs(want).max()
         assert np.abs(got - want).max() <= max(1.5e-6 * scale, 1.5 * np.abs(ref32 - want).max()) + 1e-30, (desc, np.abs(got - want).max() / scale)
     assert split >= 20
+
+
+@pytest.mark.gpu
+def test_gpu_bf16x6_stem_alone_and_ranges(gpu_api, tmp_path):
+    """The default plan's stem + max-pool kernel by itself (7x7/2 stem, MaxPool 3x3/2, global average): images of wildly different magnitude and an
+    all-zero image in one batch (no scales in this arithmetic: nothing about the range can matter), image sizes that leave ragged tiles on both
+    axes, a row alone == the row in its batch, and INFERA_STEM_SPLIT=0 (the exact-fp32 stem under the same plan) as the A/B."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(3)
+    for hw in (64, 50, 37, 224):
+        w = (rng.standard_normal((64, 3, 7, 7)) / np.sqrt(147)).astype(np.float32)
+        b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+        nodes = [W.node("Conv", ["X", "w", "b"], ["c"], [W.attr_ints("kernel_shape", [7, 7]), W.attr_ints("strides", [2, 2]), W.attr_ints("pads", [3] * 4)]),
+                 W.node("Relu", ["c"], ["r"]),
+                 W.node("MaxPool", ["r"], ["p"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("strides", [2, 2]), W.attr_ints("pads", [1] * 4)]),
+                 W.node("GlobalAveragePool", ["p"], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
+        path = W.write(str(tmp_path / f"stem{hw}.onnx"), W.model("stem", nodes, [W.tensor("w", w), W.tensor("b", b)], [W.value_info("X", ["N", 3, hw, hw])],
+                                                           [W.value_info("Y", ["N", 64])]))
+        mags = np.array([1.0, 1e-30, 1e25, 0.0, 255.0, 1.0], np.float32)
+        x = (synth.table(9, 0, len(mags), 3 * hw * hw) * mags[:, None]).astype(np.float32)
+        _load_mode(gpu_api, path, "conv_fp32", "fp32")
+        gpu_api.load_model("conv_bf6", path)
+        try:
+            assert gpu_api.get_plan("conv_bf6")["exec"][0] == "conv_patch_pool_bf16x6" and gpu_api.get_plan("conv_fp32")["exec"][0] == "conv_patch_pool"
+            got = gpu_api.predict_from_blob("conv_bf6", x.tobytes())
+            assert np.array_equal(got, gpu_api.predict_from_blob("conv_bf6", x.tobytes()))
+            assert np.array_equal(got[5], gpu_api.predict_from_blob("conv_bf6", x[5].tobytes()).reshape(-1))
+            ref32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
+            os.environ["INFERA_STEM_SPLIT"] = "0"
+            try:
+                assert np.array_equal(ref32, gpu_api.predict_from_blob("conv_bf6", x.tobytes()))  # (nothing else in this net: the fp32 stem == the fp32 plan)
+            finally:
+                os.environ.pop("INFERA_STEM_SPLIT", None)
+        finally:
+            gpu_api.unload_model("conv_bf6")
+            gpu_api.unload_model("conv_fp32")
+        want = oracle.Model(path).predict_blob(x.tobytes())
+        assert np.all(np.isfinite(got))
+        for r in range(len(mags)):
+            scale = np.abs(want[r]).max()
+            assert np.abs(got[r] - want[r]).max() <= max(1.5e-6 * scale, 1.5 * np.abs(ref32[r] - want[r]).max()) + 1e-37, (hw, r, np.abs(got[r] - want[r]).max() / scale)

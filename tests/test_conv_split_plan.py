@@ -30,10 +30,10 @@ def test_resnet18_plan_in_split_mode_and_without(built, tmp_path):
     default = _plan(tmp_path, "rn_default", blob)
     assert split["exec"][0] == "conv_patch_pool_f16x3" and split["exec"].count("conv_split_f16x3") == 19 and "f16x3" in split["conv_precision"]
     assert plain["exec"][0] == "conv_patch_pool" and plain["exec"].count("conv_tiled_cq") == 19 and "conv_precision" not in plain
-    # the default: the same 19 layers on the bf16 matrix cores with three exact parts per operand; no maxima, so no extra scratch; the stem exact-fp32
-    assert default["exec"][0] == "conv_patch_pool" and default["exec"].count("conv_split_bf16x6") == 19 and "bf16x6" in default["conv_precision"]
+    # the default: the stem and the same 19 layers on the bf16 matrix cores with three exact parts per operand; no maxima, so no extra scratch
+    assert default["exec"][0] == "conv_patch_pool_bf16x6" and default["exec"].count("conv_split_bf16x6") == 19 and "bf16x6" in default["conv_precision"]
     assert default["scratch_floats_per_row"] == plain["scratch_floats_per_row"]
-    assert [{"conv_split_bf16x6": "conv_tiled_cq"}.get(e, e) for e in default["exec"]] == plain["exec"]
+    assert [{"conv_split_bf16x6": "conv_tiled_cq", "conv_patch_pool_bf16x6": "conv_patch_pool"}.get(e, e) for e in default["exec"]] == plain["exec"]
     # same steps, same fusions (residual adds in the epilogues, the head on the exact-fp32 tiled kernel): only the names of the moved steps differ
     moved = {"conv_patch_pool_f16x3": "conv_patch_pool", "conv_split_f16x3": "conv_tiled_cq"}
     assert [moved.get(e, e) for e in split["exec"]] == plain["exec"]

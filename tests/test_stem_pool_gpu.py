@@ -13,6 +13,13 @@ from infera_amd import onnx_writer as W
 from infera_amd import synth
 
 
+@pytest.fixture(autouse=True)
+def _exact_fp32_kernels(monkeypatch):
+    """This module is about the exact-fp32 stem kernels (fused or not, one workgroup or two per CU: bit-identical).  The default plan runs the stem
+    in bf16 x three parts since round 3 (tests/test_conv_split_gpu.py); INFERA_PRECISION is read when a model is scheduled."""
+    monkeypatch.setenv("INFERA_PRECISION", "fp32")
+
+
 def _net(cin, hw, m, k, stride, pad, pool_pad, ceil, relu=True, hw2=None):
     rng = np.random.default_rng(23)
     w = (rng.standard_normal((m, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)

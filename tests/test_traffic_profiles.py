@@ -46,8 +46,8 @@ def test_traffic_resnet18_lists_the_planned_kernel_families(tmp_path):
     assert t["rows"] == 1024
     kinds = set(plan["exec"]) - {"skipped"}
     named = " ".join(t["read_bytes_by_kernel"].keys())
-    # (the 64-feature 7x7 stem runs as two half-channel workgroups per CU since round 3; the tiled convolutions' default form is the bf16 x 3-part kernel)
-    want = {"conv_patch_pool": "conv2d_stem_pool2_kernel", "conv_split_bf16x6": "conv2d_split6_kernel"}
+    # (default plan since round 3: the stem + max-pool and the tiled convolutions in bf16 x three exact parts)
+    want = {"conv_patch_pool_bf16x6": "conv2d_stem_split6_kernel", "conv_split_bf16x6": "conv2d_split6_kernel"}
     for kind, stem in want.items():
         assert kind in kinds, kinds
         assert stem in named, (stem, named[:300])
