@@ -161,7 +161,7 @@ struct ScheduleKnobs {
 };
 // Read at first use inside the kernel launchers, A/B experiments only (no effect on results; defaults are the shipped paths):
 //   INFERA_CONV_WS (0 tiled kernel only | 1 default | 2 force the weight-stationary kernel; the split-fp16 forms of conv_split.hip follow it too),
-//   INFERA_STEM_SPLIT (0: the exact-fp32 stem kernels under an INFERA_PRECISION=f16x3 plan -- tests / A/B only, the two are not bit-compatible),
+//   INFERA_STEM_SPLIT (0: the exact-fp32 stem kernels under a default (bf16x6) or f16x3 plan -- tests / A/B only, the forms are not bit-compatible),
 //   INFERA_SPLIT_PROBE (PROBES builds: timing probes of the split convolution, wrong results), INFERA_DENSE16W, INFERA_DENSE16_STAGED,
 //   INFERA_DENSE16G_MIN_M, INFERA_SOFTMAX_ROWS, INFERA_POOL_FAST, INFERA_CHAIN_WAVES, INFERA_MLP3_VARIANT (PROBES builds), INFERA_CONV_PROBE.
 
