@@ -145,11 +145,6 @@ int32_t infera_hip_choose_slot_balanced(const int32_t *slot_numa, const int32_t 
  * remote model (`<cache_dir>/<sha256(url)>.onnx`, reference http.rs:186-190).  Free with infera_free. */
 char *infera_hip_sha256_hex(const char *data, uintptr_t len);
 
-/* Test hook (host arithmetic only, no GPU): how the split-fp16 convolution mode (INFERA_PRECISION=f16x3) prepares a weight.  `amax` = the
- * largest magnitude of the weight's output feature; *scale = the power of two that brings amax into [2^14, 2^15), *inv_scale its inverse;
- * *hi_bits = RNE_f16(v * scale), *lo_bits = RNE_f16(v * scale - hi) as IEEE binary16 bit patterns. */
-void infera_hip_f16_split(float v, float amax, uint16_t *hi_bits, uint16_t *lo_bits, float *scale, float *inv_scale);
-
 #ifdef __cplusplus
 } /* extern "C" */
 } /* namespace infera */

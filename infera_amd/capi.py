@@ -29,7 +29,7 @@ EXTENSION_SYMBOLS = [
     "infera_hip_free", "infera_hip_memcpy_h2d", "infera_hip_memcpy_d2h", "infera_hip_synth_fill",
     "infera_predict_into", "infera_predict_columns", "infera_predict_from_blob_batch", "infera_gather_columns",
     "infera_hip_sha256_hex", "infera_hip_shape_rows_cols", "infera_hip_h2d_probe", "infera_hip_choose_slot",
-    "infera_gather_columns_colmajor", "infera_hip_f16_split", "infera_hip_choose_slot_balanced", "infera_hip_register_host_memory", "infera_hip_unregister_host_memory", "infera_hip_zero_copy_calls",
+    "infera_gather_columns_colmajor", "infera_hip_choose_slot_balanced", "infera_hip_register_host_memory", "infera_hip_unregister_host_memory", "infera_hip_zero_copy_calls",
 ]
 
 
@@ -399,16 +399,6 @@ def gather_columns(columns: Sequence[np.ndarray], rows: int | None = None, row0:
     if load_library().infera_gather_columns(cols, n, row0, nrows, out.ctypes.data) != 0:
         raise InferaError(last_error())
     return out
-
-
-def f16_split(v: float, amax: float):
-    """(hi_bits, lo_bits, scale, inv_scale): the split-fp16 mode's host arithmetic for one weight (test hook, no GPU)."""
-    L = load_library()
-    L.infera_hip_f16_split.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    L.infera_hip_f16_split.restype = None
-    hi, lo, sc, inv = C.c_uint16(), C.c_uint16(), C.c_float(), C.c_float()
-    L.infera_hip_f16_split(v, amax, C.byref(hi), C.byref(lo), C.byref(sc), C.byref(inv))
-    return hi.value, lo.value, sc.value, inv.value
 
 
 def gather_columns_colmajor(columns: Sequence[np.ndarray], rows: int | None = None, row0: int = 0, nrows: int | None = None) -> np.ndarray:

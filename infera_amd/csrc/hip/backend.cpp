@@ -70,28 +70,39 @@ struct ThreadCtx {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // completion of the pass that last used staging slot 0 / 1
-  hipEvent_t done_ev = nullptr;                // blocking-sync event: a host-ABI call sleeps on it instead of spinning
-  hipEvent_t poll_ev = nullptr;                // INFERA_HOST_WAIT=poll: queried between naps
-  // Sleep-poll (INFERA_HOST_WAIT=poll): ROCm's blocking event wait spins before it blocks and pays an interrupt + wake-up per chunk; under
-  // a CPU quota (16 CPUs feeding 8 GPUs) CPU time per chunk is what bounds the scan.  Nap for most of what this context's recent waits
-  // OF THE SAME KIND took (`key`: model and row count -- a context that served a 30 ms image batch must not sleep 2 ms on the 50 us table
-  // chunk that follows it), then query between short naps: one or two clock_nanosleep calls and a few queries per chunk.  With no
-  // estimate (first wait of a kind on this context) the naps grow with the time already waited (a quarter of it, 3..200 us).
+  hipEvent_t poll_ev = nullptr;                // completion marker of a host-ABI call, queried between naps
+  // How a host-ABI call waits for its chunk: it NAPS.  ROCm 7.2's "blocking" event wait (hipEventSynchronize on a hipEventBlockingSync event)
+  // burns the core for the whole wait, and so does hipStreamSynchronize: 277 us of CPU per chunk at 16 callers against 85 with naps at the same
+  // rows/s (profiles/r03_host_cpu_ab_wait_gather.txt) -- under a CPU quota (16 CPUs feeding 8 GPUs) CPU time per chunk is what bounds the
+  // scan.  Nap for most of what this context's recent waits OF THE SAME KIND took (`key`: model and row count -- a context that served a
+  // 30 ms image batch must not sleep 2 ms on the 50 us table chunk that follows it), then query between short naps: one or two
+  // clock_nanosleep calls and a few queries per chunk.  The first nap is bounded by the SHORTEST of the recent waits as well as by their
+  // average (a call that finishes faster than the average must not oversleep).  With no estimate (first wait of a kind on this context)
+  // the naps grow with the time already waited (a quarter of it, 3..200 us).
   struct WaitEstimate {
-    double ema_ns = 0.0;
+    double ema_ns = 0.0, min_ns = 0.0;  // average and (slowly rising) minimum of the recent waits
     uint64_t key = 0;
   };
   WaitEstimate wait_est, pipe_est;
+  static constexpr double kPollFirst = 0.75, kPollNext = 0.1;  // shares of the expected wait (0.6-0.9 / 0.05-0.2 measured equal)
+  // The naps need a timer slack of ~1 us (the default 50 us would turn a 20 us nap into 70).  The slack belongs to the CALLER's thread -- a
+  // DuckDB worker -- so it is set for the duration of the wait only and restored afterwards.
+  struct TimerSlack {
+    long saved = -1;
+    TimerSlack() {
+      saved = prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL);
+      if (saved > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+      else saved = -1;
+    }
+    ~TimerSlack() {
+      if (saved > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)saved, 0UL, 0UL, 0UL);
+    }
+  };
   template <class Query>
   static void poll_until(Query &&query, WaitEstimate &est, uint64_t key) {
-    static thread_local bool slack_set = false;
-    if (!slack_set) {
-      (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // default slack is 50 us: a 20 us nap would last 70
-      slack_set = true;
-    }
     if (key != est.key || key == 0) {
       est.key = key;
-      est.ema_ns = 0.0;
+      est.ema_ns = est.min_ns = 0.0;
     }
     const auto t0 = std::chrono::steady_clock::now();
     auto waited_ns = [&] { return std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); };
@@ -102,43 +113,30 @@ struct ThreadCtx {
       (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
     };
     const bool known = est.ema_ns > 0.0;
-    if (known) nap(std::min(est.ema_ns * Config::get().host_poll_first, 2.0e6));
-    for (;;) {
-      const hipError_t e = query();
-      if (e == hipSuccess) break;
-      if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery / hipStreamQuery");
-      nap(known ? std::max(3000.0, std::min(est.ema_ns * Config::get().host_poll_next, 50000.0))
-                : std::max(3000.0, std::min(waited_ns() * 0.25, 200000.0)));
+    {
+      TimerSlack slack;
+      if (known) nap(std::min({est.ema_ns * kPollFirst, est.min_ns * 0.9, 2.0e6}));
+      for (;;) {
+        const hipError_t e = query();
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery");
+        nap(known ? std::max(3000.0, std::min(est.ema_ns * kPollNext, 50000.0)) : std::max(3000.0, std::min(waited_ns() * 0.25, 200000.0)));
+      }
     }
     (void)hipGetLastError();  // hipErrorNotReady from the queries must not surface at the next launch check
     const double waited = waited_ns();
     est.ema_ns = known ? 0.75 * est.ema_ns + 0.25 * waited : waited;
+    est.min_ns = known ? std::min(waited, est.min_ns * 1.05) : waited;
   }
-  // waits for `ev` (already recorded) the way INFERA_HOST_WAIT says: poll modes nap and query, the others synchronise
+  // waits for `ev` (already recorded)
   void wait_event(hipEvent_t ev, WaitEstimate &est, uint64_t key) {
-    if (Config::get().host_wait >= 2) poll_until([&] { return hipEventQuery(ev); }, est, key);
-    else HIP_TRY(hipEventSynchronize(ev));
+    poll_until([&] { return hipEventQuery(ev); }, est, key);
   }
   // waits for everything enqueued on `stream` so far.  `key` identifies the kind of work (0 = unknown)
   void wait_stream(uint64_t key = 0) {
-    const int mode = Config::get().host_wait;
-    if (mode == 1) {
-      HIP_TRY(hipStreamSynchronize(stream));
-      return;
-    }
-    if (mode == 3) {  // "pollq": hipStreamQuery instead of a recorded event -- no marker packet on the queue, one API call less per chunk
-      poll_until([&] { return hipStreamQuery(stream); }, wait_est, key);
-      return;
-    }
-    if (mode == 2) {
-      if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(poll_ev, stream));
-      poll_until([&] { return hipEventQuery(poll_ev); }, wait_est, key);
-      return;
-    }
-    if (!done_ev) HIP_TRY(hipEventCreateWithFlags(&done_ev, hipEventBlockingSync | hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(done_ev, stream));
-    HIP_TRY(hipEventSynchronize(done_ev));
+    if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(poll_ev, stream));
+    poll_until([&] { return hipEventQuery(poll_ev); }, wait_est, key);
   }
   void drop_graphs() {
     for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
@@ -167,7 +165,6 @@ struct ThreadCtx {
     cap = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), bytes));
     cap = bytes;
-    if (Config::get().probe_elide_h2d > 0) HIP_TRY(hipMemset(p, 0, bytes));  // (measurement mode: the kernels read this buffer without it ever being filled)
   }
 };
 
@@ -254,11 +251,9 @@ struct HostLease {
       if (!pool.free.empty()) {
         // the context this thread used last, when it is free: its pinned staging lines are (still) in THIS core's caches -- a chunk
         // gathered into the buffer another core wrote last pays a cache-to-cache transfer per line (gather 42 -> 50 us per chunk
-        // already at 2 caller threads with plain LIFO reuse).  INFERA_HOST_CTX_AFFINITY=0: plain LIFO (A/B)
-        // (Tried on top, INFERA_HOST_CTX_AFFINITY=2 in round 3: prefer a context last filled on this CPU's L3 domain when the thread has
-        // moved to another CCD -- no gain, 80.5 vs 78.5 us of CPU per chunk at 16 threads, profiles/r03_host_cpu_ab_pinning.txt.)
+        // already at 2 caller threads with plain LIFO reuse; CPU per chunk 88.9 -> 76.9 us at 16 callers, profiles/r03_host_cpu_ab_ctx_affinity.txt).
         size_t pick = pool.free.size() - 1;
-        if (Config::get().host_ctx_affinity && size_t(slot) < 64 && t_last_ctx[slot])
+        if (size_t(slot) < 64 && t_last_ctx[slot])
           for (size_t i = pool.free.size(); i-- > 0;)
             if (pool.free[i] == t_last_ctx[slot]) {
               pick = i;
@@ -307,7 +302,7 @@ std::atomic<uint64_t> g_slot_calls[64], g_slot_rows[64];
 // (H2D + kernels [+ D2H] API calls), wait (until the device is done), copy_out (pinned -> result buffer).
 // Seven steady_clock reads per call (~0.2 us) -- always on, reported by infera_hip_get_devices.
 enum HostPhase { kPhLease, kPhGather, kPhGate, kPhEnqueue, kPhWait, kPhCopyOut, kPhCount };
-std::atomic<uint64_t> g_phase_ns[kPhCount], g_phase_calls, g_split_calls;
+std::atomic<uint64_t> g_phase_ns[kPhCount], g_phase_calls;
 inline uint64_t now_ns() { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
 
 // NUMA node of the CPU the calling thread runs on right now (-1 = unknown), from /sys/devices/system/node/node*/cpulist
@@ -447,7 +442,6 @@ void schedule(LoadedModel &m) {
         m.exec[i] = ExecKind::Mlp3Head;
         m.exec[i + 1] = m.exec[i + 2] = ExecKind::Skipped;
         m.mlp3_shape = sh;
-        m.bf16x3 = Config::get().precision_bf16x3 && kern::mlp3_bf16x3_supported(sh);
         have_mlp3 = true;
         i += 2;
         continue;
@@ -669,6 +663,49 @@ void schedule(LoadedModel &m) {
     }
   }
 
+  // the default arithmetic of the tiled convolutions and the 7x7 / stride-2 stem: bf16 x three exact parts (conv_split.hip)
+  m.conv_split6.assign(n, 0);
+  m.stem_split6.assign(n, 0);
+  if (ScheduleKnobs::read().conv_bf16x6 && m.cq_mode) {
+    for (size_t i = 0; i < n; i++) {
+      if (m.exec[i] != ExecKind::ConvTiled) continue;
+      const Step &c = st[i];
+      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
+                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
+      if (kern::conv2d_split6_supported(kern::conv2d_tiled_geom(g)) && !m.nchw_buf[size_t(c.in0)]) m.conv_split6[i] = 1;
+    }
+    for (size_t i = 0; i < n; i++) {  // the 7x7 / stride-2 stem + max-pool in the same arithmetic
+      if (m.exec[i] != ExecKind::ConvPatch || m.conv_fused_pool[i] < 0) continue;
+      const Step &c = st[i], &q = st[size_t(m.conv_fused_pool[i])];
+      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
+                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
+      const kern::ConvGeom gp = kern::conv2d_patch_geom(g);
+      if (gp.mvalid == 0 && kern::conv2d_stem_split6_supported(gp, kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)})) m.stem_split6[i] = 1;
+    }
+  }
+  // Activations stored PRE-SPLIT (round 4; conv_split.hip "S3"): a tensor written by a split convolution and read ONLY by split convolutions
+  // -- as their input, or as the residual their epilogue adds -- and by at least one of them as its input is stored as three bf16 planes per
+  // 16-channel group (1.5x the floats) by its producer's epilogue; its consumers load matrix-instruction operands instead of cutting every
+  // activation once per tap and feature slice.  Exact both ways, so the plan's results do not change by a bit.  Residual-only tensors (a
+  // downsample branch) stay fp32: 4 bytes per value instead of 6.  INFERA_CONV_PRESPLIT=0 (read when a model is scheduled): fp32 everywhere.
+  m.buf_s3.assign(m.plan.buf_per_row.size(), 0);
+  if (ScheduleKnobs::read().conv_presplit) {
+    const auto eff0 = effective_steps(m);
+    std::vector<int> writer(m.plan.buf_per_row.size(), -1), as_input(m.plan.buf_per_row.size(), 0), other(m.plan.buf_per_row.size(), 0);
+    for (const auto &e : eff0) {
+      if (writer[size_t(e.writes)] >= 0) other[size_t(e.writes)] = 1;  // (several writers: a Concat output)
+      writer[size_t(e.writes)] = e.idx;
+      const bool split = m.exec[size_t(e.idx)] == ExecKind::ConvTiled && m.conv_split6[size_t(e.idx)];
+      for (size_t k = 0; k < e.reads.size(); k++) {
+        if (!split) other[size_t(e.reads[k])] = 1;
+        else if (k == 0) as_input[size_t(e.reads[k])] = 1;
+      }
+    }
+    for (size_t b = 1; b < m.buf_s3.size(); b++)
+      m.buf_s3[b] = int(b) != m.plan.out_buf && writer[b] >= 0 && m.exec[size_t(writer[b])] == ExecKind::ConvTiled && m.conv_split6[size_t(writer[b])] &&
+                    as_input[b] && !other[b];
+  }
+
   // scratch slots by liveness: a slot is reused once its buffer has been read for the last time
   auto eff = effective_steps(m);
   {  // the served output: one writer (a fused streaming kernel that only stores it), no reader
@@ -703,7 +740,7 @@ void schedule(LoadedModel &m) {
       }
     m.in_colmajor_max_rows = INT64_MAX;
     m.in_colmajor_ok = !eff.empty() && in_readers == 1 && m.exec[size_t(eff[0].idx)] == ExecKind::Mlp3Head && eff[0].reads[0] == 0 &&
-                       kern::mlp3_colmajor_supported(m.mlp3_shape) && !m.bf16x3;
+                       kern::mlp3_colmajor_supported(m.mlp3_shape);
     if (m.in_colmajor_ok) m.in_colmajor_max_rows = kern::mlp3_colmajor_max_rows(m.mlp3_shape);
     // the fused small-MLP chain reads a column-major chunk too (a run-time flag of the same kernel); INFERA_CHAIN_XCM=0: transpose first
     const ScheduleKnobs knobs = ScheduleKnobs::read();
@@ -742,64 +779,8 @@ void schedule(LoadedModel &m) {
       m.slot_per_row.push_back(0);
     }
     m.slot_of_buf[size_t(b)] = chosen;
-    m.slot_per_row[size_t(chosen)] = std::max(m.slot_per_row[size_t(chosen)], m.plan.buf_per_row[size_t(b)]);
+    m.slot_per_row[size_t(chosen)] = std::max(m.slot_per_row[size_t(chosen)], m.plan.buf_per_row[size_t(b)] / (m.buf_s3[size_t(b)] ? 2 : 1) * (m.buf_s3[size_t(b)] ? 3 : 1));
     slot_free_after[size_t(chosen)] = last_read[size_t(b)] < 0 ? int(e) : last_read[size_t(b)];
-  }
-  // split-fp16 convolutions (INFERA_PRECISION=f16x3) and the per-image maxima they scale their inputs by
-  m.conv_split.assign(n, 0);
-  m.conv_split6.assign(n, 0);
-  m.stem_split6.assign(n, 0);
-  m.stem_split.assign(n, 0);
-  m.amax_of_buf.assign(nb, -1);
-  m.amax_by_kernel.assign(nb, 0);
-  m.n_amax = 0;
-  m.amax_slot = -1;
-  if (ScheduleKnobs::read().conv_bf16x6 && m.cq_mode) {
-    for (size_t i = 0; i < n; i++) {
-      if (m.exec[i] != ExecKind::ConvTiled) continue;
-      const Step &c = st[i];
-      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
-                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
-      if (kern::conv2d_split6_supported(kern::conv2d_tiled_geom(g)) && !m.nchw_buf[size_t(c.in0)]) m.conv_split6[i] = 1;
-    }
-    for (size_t i = 0; i < n; i++) {  // the 7x7 / stride-2 stem + max-pool in the same arithmetic
-      if (m.exec[i] != ExecKind::ConvPatch || m.conv_fused_pool[i] < 0) continue;
-      const Step &c = st[i], &q = st[size_t(m.conv_fused_pool[i])];
-      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
-                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
-      const kern::ConvGeom gp = kern::conv2d_patch_geom(g);
-      if (gp.mvalid == 0 && kern::conv2d_stem_split6_supported(gp, kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)})) m.stem_split6[i] = 1;
-    }
-  }
-  if (ScheduleKnobs::read().conv_f16x3 && m.cq_mode) {
-    for (size_t i = 0; i < n; i++) {
-      if (m.exec[i] != ExecKind::ConvTiled) continue;
-      const Step &c = st[i];
-      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
-                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
-      if (!kern::conv2d_split_supported(kern::conv2d_tiled_geom(g)) || m.nchw_buf[size_t(c.in0)]) continue;
-      m.conv_split[i] = 1;
-      if (m.amax_of_buf[size_t(c.in0)] < 0) {
-        m.amax_of_buf[size_t(c.in0)] = m.n_amax++;
-        m.amax_by_kernel[size_t(c.in0)] = 1;
-      }
-    }
-    for (size_t i = 0; i < n; i++) {  // the stem + max-pool kernel in the same arithmetic, where its shape has the instantiation
-      if (m.exec[i] != ExecKind::ConvPatch || m.conv_fused_pool[i] < 0) continue;
-      const Step &c = st[i], &q = st[size_t(m.conv_fused_pool[i])];
-      const kern::ConvGeom g{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
-                             int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
-      const kern::ConvGeom gp = kern::conv2d_patch_geom(g);
-      if (gp.mvalid == 0 && kern::conv2d_stem_split_supported(gp, kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)})) m.stem_split[i] = 1;
-    }
-    for (size_t i = 0; i < n; i++) {  // tensors a split convolution or the stem + max-pool kernel writes: the producer tracks the maxima
-      if (m.conv_split[i]) m.amax_by_kernel[size_t(m.conv_fused_add[i] >= 0 ? st[size_t(m.conv_fused_add[i])].out : st[i].out)] = 0;
-      if (m.exec[i] == ExecKind::ConvPatch && m.conv_fused_pool[i] >= 0) m.amax_by_kernel[size_t(st[size_t(m.conv_fused_pool[i])].out)] = 0;
-    }
-    if (m.n_amax > 0) {
-      m.amax_slot = int(m.slot_per_row.size());
-      m.slot_per_row.push_back(m.n_amax);  // one word per image and tracked tensor
-    }
   }
   m.scratch_per_row = 0;
   for (auto v : m.slot_per_row) m.scratch_per_row += v;
@@ -821,15 +802,6 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
                       s2.bias.empty() ? nullptr : s2.bias.data(), s3.W.data(), s3.bias.empty() ? nullptr : s3.bias.data(),
                       packed.data());
       dm.mlp3_packed = upload(packed, us);
-      if (m.bf16x3) {
-        std::vector<unsigned char> pb(kern::mlp3_bf16x3_packed_bytes(m.mlp3_shape));
-        kern::mlp3_bf16x3_pack(m.mlp3_shape, s1.W.data(), s1.bias.empty() ? nullptr : s1.bias.data(), s2.W.data(),
-                               s2.bias.empty() ? nullptr : s2.bias.data(), s3.W.data(), s3.bias.empty() ? nullptr : s3.bias.data(), pb.data());
-        HIP_TRY(hipMalloc(&dm.mlp3_bf16x3_packed, pb.size()));
-        hipError_t e = hipMemcpyAsync(dm.mlp3_bf16x3_packed, pb.data(), pb.size(), hipMemcpyHostToDevice, us);
-        if (e == hipSuccess) e = hipStreamSynchronize(us);
-        if (e != hipSuccess) hip_fail(e, "hipMemcpy(bf16x3 weights)");
-      }
       continue;
     }
     if (m.exec[i] == ExecKind::ChainHead) {
@@ -868,10 +840,6 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       if (m.conv_split6[i]) {
         packed.resize(kern::conv2d_split6_packed_floats(g));
         kern::conv2d_split6_pack(g, s.W.data(), packed.data());
-      } else if (m.conv_split[i]) {
-        std::vector<float> winv(size_t(g.M));
-        kern::conv2d_split_pack(g, s.W.data(), packed.data(), winv.data());
-        d.winv = upload(winv, us);
       } else {
         kern::conv2d_tiled_pack(g, s.W.data(), packed.data());
       }
@@ -919,14 +887,9 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
         const Step &q = st[size_t(fj)];
         const kern::PoolTail tail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)};
         kern::conv2d_patch_pack(g, s.W.data(), packed.data(), &tail);
-        if (m.stem_split6[i]) {
+        if (m.stem_split6[i]) {  // (the exact-fp32 blob above stays: INFERA_STEM_SPLIT=0 at run time compares the two)
           std::vector<float> sp(kern::conv2d_stem_split6_packed_floats());
           kern::conv2d_stem_split6_pack(g, s.W.data(), sp.data());
-          d.cst = upload(sp, us);
-        }
-        if (m.stem_split[i]) {  // (the exact-fp32 blob above stays: INFERA_STEM_SPLIT=0 at run time compares the two)
-          std::vector<float> sp(kern::conv2d_stem_split_packed_floats());
-          kern::conv2d_stem_split_pack(g, s.W.data(), sp.data(), tail);
           d.cst = upload(sp, us);
         }
       } else {
@@ -945,7 +908,7 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
       d.W = upload(s.W, us);
     }
     d.bias = upload(s.bias, us);
-    if (!d.cst) d.cst = upload(s.cst, us);  // (a split stem keeps its fp16 blob there: convolutions have no constants)
+    if (!d.cst) d.cst = upload(s.cst, us);  // (a split stem keeps its bf16 blob there: convolutions have no constants)
     d.scale = upload(s.scale, us);
     d.shift = upload(s.shift, us);
   }
@@ -1003,15 +966,6 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
       if (b == p.out_buf) return d_out + r0 * p.out_per_row();
       return ctx.scratch + slot_base[size_t(m.slot_of_buf[size_t(b)])];
     };
-    // split-fp16 convolutions: row k of the amax slot = per-image max |x| of tracked tensor k, max-accumulated from zero each pass
-    auto amax = [&](int b) -> unsigned * {
-      return reinterpret_cast<unsigned *>(ctx.scratch + slot_base[size_t(m.amax_slot)]) + int64_t(m.amax_of_buf[size_t(b)]) * rows_pass;
-    };
-    std::vector<char> amax_done;
-    if (m.n_amax > 0) {
-      HIP_TRY(hipMemsetAsync(ctx.scratch + slot_base[size_t(m.amax_slot)], 0, size_t(m.n_amax) * size_t(rows_pass) * 4, s));
-      amax_done.assign(m.amax_of_buf.size(), 0);
-    }
     for (size_t i = 0; i < st.size(); i++) {
       const Step &x = st[i];
       const DeviceStep &d = dm.steps[i];
@@ -1021,11 +975,6 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
         {
           std::string why;
           const bool cm = in_colmajor && x.in0 == 0;
-          if (dm.mlp3_bf16x3_packed && !cm) {
-            if (!kern::mlp3_bf16x3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_bf16x3_packed, buf(st[i + 2].out), nr, dm.num_cus))
-              throw InferaError::onnx("bf16x3 MLP kernel launch failed");
-            continue;
-          }
           if (!kern::mlp3(s, m.mlp3_shape, buf(x.in0), dm.mlp3_packed, buf(st[i + 2].out), nr, dm.num_cus, &why, cm))
             throw InferaError::onnx("fused MLP kernel launch failed: " + why);
           continue;
@@ -1055,18 +1004,9 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           const int fj = m.conv_fused_add[i];
           const kern::ConvGeom gp = kern::conv2d_tiled_geom(g);
           if (m.conv_split6[i]) {
-            if (fj >= 0) kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]));
-            else kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, gp, act_of(x));
-            continue;
-          }
-          if (m.conv_split[i]) {
-            if (m.amax_by_kernel[size_t(x.in0)] && !amax_done[size_t(x.in0)]) {
-              kern::absmax_rows(s, buf(x.in0), nr, m.plan.buf_per_row[size_t(x.in0)], amax(x.in0));
-              amax_done[size_t(x.in0)] = 1;
-            }
-            const int ob = fj >= 0 ? st[size_t(fj)].out : x.out;
-            kern::conv2d_split(s, buf(x.in0), d.W, d.bias, d.winv, fj >= 0 ? buf(m.conv_residual_buf[i]) : nullptr, buf(ob), amax(x.in0),
-                               m.amax_of_buf[size_t(ob)] >= 0 ? amax(ob) : nullptr, nr, gp, act_of(fj >= 0 ? st[size_t(fj)] : x));
+            const int ob = fj >= 0 ? st[size_t(fj)].out : x.out, rb = fj >= 0 ? m.conv_residual_buf[i] : -1;
+            kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, rb >= 0 ? buf(rb) : nullptr, buf(ob), nr, gp, act_of(fj >= 0 ? st[size_t(fj)] : x),
+                                m.buf_s3[size_t(x.in0)], m.buf_s3[size_t(ob)], rb >= 0 && m.buf_s3[size_t(rb)]);
             continue;
           }
           if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]));
@@ -1087,17 +1027,13 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
           if (const int fj = m.conv_fused_pool[i]; fj >= 0) {
             const Step &q = st[size_t(fj)];
-            unsigned *track = m.n_amax > 0 && m.amax_of_buf[size_t(q.out)] >= 0 ? amax(q.out) : nullptr;
             const char *sse = getenv("INFERA_STEM_SPLIT");  // 0: the exact-fp32 stem kernels under a split plan (read per launch: tests, A/B)
             if (m.stem_split6[i] && d.cst && !(sse && atoi(sse) == 0))
               kern::conv2d_stem_split6(s, buf(x.in0), d.cst, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
                                        kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus);
-            else if (m.stem_split[i] && d.cst && !(sse && atoi(sse) == 0))
-              kern::conv2d_stem_split(s, buf(x.in0), d.cst, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
-                                      kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus, track);
             else
               kern::conv2d_patch_pool(s, buf(x.in0), d.W, d.bias, buf(q.out), nr, kern::conv2d_patch_geom(g), act_of(x),
-                                      kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus, track);
+                                      kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)}, dm.num_cus);
             continue;
           }
           kern::conv2d_patch(s, buf(x.in0), d.W, d.bias, buf(x.out), nr, kern::conv2d_patch_geom(g), act_of(x), dm.num_cus);
@@ -1201,8 +1137,7 @@ double h2d_probe_gbs(int device_ordinal, size_t bytes, int iters, int threads) {
 
 std::string host_phase_json() {
   static const char *names[kPhCount] = {"lease", "gather", "gate", "enqueue", "wait", "copy_out"};
-  std::string o = "{\"passes\":" + std::to_string(g_phase_calls.load(std::memory_order_relaxed)) +
-                  ",\"split_calls\":" + std::to_string(g_split_calls.load(std::memory_order_relaxed));
+  std::string o = "{\"passes\":" + std::to_string(g_phase_calls.load(std::memory_order_relaxed));
   for (int i = 0; i < kPhCount; i++) o += std::string(",\"") + names[i] + "_ns\":" + std::to_string(g_phase_ns[i].load(std::memory_order_relaxed));
   return o + "}";
 }
@@ -1288,11 +1223,10 @@ DeviceModel::~DeviceModel() {
   if (hipSetDevice(device) != hipSuccess) return;
   (void)hipDeviceSynchronize();
   for (auto &d : steps) {
-    for (float *p : {d.W, d.bias, d.cst, d.scale, d.shift, d.winv})
+    for (float *p : {d.W, d.bias, d.cst, d.scale, d.shift})
       if (p) (void)hipFree(p);
   }
   if (mlp3_packed) (void)hipFree(mlp3_packed);
-  if (mlp3_bf16x3_packed) (void)hipFree(mlp3_bf16x3_packed);
   for (float *p : chain_packed)
     if (p) (void)hipFree(p);
 }
@@ -1422,9 +1356,7 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
   // transposing path allocates per pass, which a capture cannot contain)
   if (col_major && use_graph && !m.in_colmajor_ok) throw InferaError::onnx("internal: column-major staging is not captured in hipGraph mode for this plan");
   // H2D of one pass; a column-major pass lands in dev_cm first and is transposed into the row-major table on the GPU
-  // (INFERA_HOST_PROBE_ELIDE_H2D, measurement only: a 4 KiB token crosses the link instead of the chunk)
-  const bool elide = Config::get().probe_elide_h2d > 0, elide_kernel = Config::get().probe_elide_h2d > 1;
-  auto h2d_bytes = [&](int64_t nr) { return elide ? std::min<size_t>(size_t(nr) * in_row, 4096) : size_t(nr) * in_row; };
+  auto h2d_bytes = [&](int64_t nr) { return size_t(nr) * in_row; };
   auto upload_pass = [&](const float *pin, float *din, int64_t nr) {
     if (col_major) {
       ctx.ensure_dev(ctx.dev_cm, ctx.dev_cm_cap, size_t(nr) * in_row);
@@ -1500,7 +1432,7 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
   }
   int64_t rows_pass = std::max<int64_t>(1, int64_t(kHostPassBytes / widest));
   rows_pass = std::min(rows_pass, rows);
-  const bool direct_out = m.out_write_once && Config::get().host_direct_out && size_t(rows_pass) * out_row <= (1u << 20);
+  const bool direct_out = m.out_write_once && size_t(rows_pass) * out_row <= (1u << 20);
   const bool cm_graph = use_graph && col_major;  // (implies m.in_colmajor_ok)
   if (!dfill) ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows_pass) * out_row);
@@ -1509,9 +1441,9 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
   // H2D (or not: small inputs are read from pinned memory by the kernel itself) + the plan's kernels [+ D2H] of ONE pass whose staged
   // input is at `pin`, on ctx.stream; results land at `pout` (a position in the pinned result buffer).  Non-graph mode.
   int64_t dfill_r0 = 0;  // (zero-copy) first row of the pass being enqueued
-  auto enqueue_pass = [&](const float *pin, float *din, float *dout, float *pout, int64_t nr, bool single_pass, int in_flight, bool allow_small) {
+  auto enqueue_pass = [&](const float *pin, float *din, float *dout, float *pout, int64_t nr, bool single_pass, int in_flight) {
     // column-major chunk straight into the model's first kernel when it can read one (no transpose launch)
-    const bool cm_direct = col_major && m.in_colmajor_ok && nr <= m.in_colmajor_max_rows && single_pass && Config::get().host_fused_transpose;
+    const bool cm_direct = col_major && m.in_colmajor_ok && nr <= m.in_colmajor_max_rows && single_pass;
     // Small inputs (a narrow table's chunk, a point query; INFERA_HOST_DIRECT_IN bytes, default 128 KB) are not copied to HBM first:
     // the kernel that reads them -- the plan's first kernel, or the transpose in front of it -- loads them from the pinned
     // (host-coherent) buffer over PCIe itself.  One submission less per call, and a DMA engine's start-up latency is as long as
@@ -1520,10 +1452,9 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
     // (a quiet GPU reads larger chunks this way -- twice that size with at most four calls in flight, four times with at most two: a
     // few kernels pulling over PCIe do not yet compete with each other, and the copy engine's latency is the larger part of such a
     // call.  30 -> 100 -> 2, 245 KB chunks: +17 / +8 / +6 / +4 % at 1 / 2 / 4 / 8 threads; 64 -> 128 -> 64 -> 1, 512 KB: +13 / +6 % at 1 / 2)
-    const bool quiet_on = Config::get().host_direct_in_quiet;  // (0: A/B)
-    const int quiet_mult = !quiet_on ? 1 : in_flight <= 2 ? 4 : in_flight <= 4 ? 2 : 1;
+    const int quiet_mult = in_flight <= 2 ? 4 : in_flight <= 4 ? 2 : 1;
     const int64_t din_limit = int64_t(Config::get().host_direct_in_bytes) * quiet_mult;
-    const bool small_in = allow_small && !elide && int64_t(nr) * int64_t(in_row) <= din_limit;
+    const bool small_in = int64_t(nr) * int64_t(in_row) <= din_limit;
     const float *kin = din;
     if (dfill) {
       // zero-copy: the GPU pulls the caller's (registered) column runs itself -- straight into the chunk the first kernel reads when it
@@ -1545,61 +1476,18 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
     } else {
       upload_pass(pin, din, nr);
     }
-    const int64_t kr = elide_kernel ? std::min<int64_t>(nr, 32) : nr;  // (probe level 2: a one-tile launch instead of the chunk's)
     if (direct_out) {
       // the plan's only writer of the result stores it straight into the pinned (host-coherent) buffer: a few KB per
       // chunk over PCIe from the kernel's epilogue instead of one more enqueue + blit kernel + dependency per chunk
-      exec_plan(m, dm, ctx, kin, pout, kr, cm_direct);
+      exec_plan(m, dm, ctx, kin, pout, nr, cm_direct);
     } else {
-      exec_plan(m, dm, ctx, kin, dout, kr, cm_direct);
+      exec_plan(m, dm, ctx, kin, dout, nr, cm_direct);
       HIP_TRY(hipMemcpyAsync(pout, dout, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
     }
   };
-  // One call = one DataChunk (the usual case): a quiet GPU -- few callers, what each of 8 GPUs sees when 16 CPUs feed them --
-  // is not kept busy by calls that gather, THEN transfer, THEN compute: the chunk goes through as `split` sub-passes on the
-  // call's stream, the gather of sub-pass i+1 overlapping the H2D + kernels of sub-pass i, one wait at the end.  Row-independent
-  // plans give the same bits whatever the split (sub-passes are multiples of 32 rows: whole MFMA tiles).
-  {
-    const int split_mode = Config::get().host_split;  // 0 never (default: measured a loss, see common.hpp), 1 auto, n >= 2 always n sub-passes
-    const int quiet = gate_for_slot(slot).peek();
-    int split = split_mode >= 2 ? split_mode : (split_mode == 1 && quiet <= Config::get().host_split_quiet ? 2 : 1);
-    const int64_t sub = split > 1 ? ((rows + split - 1) / split + 31) / 32 * 32 : rows;
-    if (!use_graph && !dfill && split > 1 && rows <= rows_pass && sub < rows && size_t(sub) * in_row >= (256u << 10) && rows_per_pass(m, sub) == sub) {
-      const uint64_t t_f0 = now_ns();
-      uint64_t gather_ns = 0, enq_ns = 0, gate_ns = 0;
-      (void)prepare_scratch(m, ctx, sub);
-      std::unique_ptr<GateHold> admitted;
-      for (int64_t r0 = 0; r0 < rows; r0 += sub) {
-        const int64_t nr = std::min(sub, rows - r0);
-        const uint64_t a = now_ns();
-        float *pin = ctx.pin_in + size_t(r0) * (in_row / 4);
-        fill(pin, r0, nr);
-        const uint64_t b = now_ns();
-        if (!admitted) admitted = std::make_unique<GateHold>(gate_for_slot(slot), Config::get().max_inflight, Config::get().max_inflight_total);
-        const uint64_t c = now_ns();
-        enqueue_pass(pin, ctx.dev_in + size_t(r0) * (in_row / 4), ctx.dev_out + size_t(r0) * (out_row / 4), ctx.pin_out + size_t(r0) * (out_row / 4), nr,
-                     true, admitted->in_flight, false);
-        gather_ns += b - a;
-        gate_ns += c - b;
-        enq_ns += now_ns() - c;
-      }
-      const uint64_t t_e = now_ns();
-      ctx.wait_stream(m.uid * 0x9E3779B97F4A7C15ull ^ uint64_t(rows) ^ (uint64_t(split) << 56));
-      const uint64_t t_w = now_ns();
-      std::memcpy(h_out, ctx.pin_out, size_t(rows) * out_row);
-      const uint64_t t_c = now_ns();
-      (void)t_f0;
-      g_phase_ns[kPhLease].fetch_add(t_leased - t_entry, std::memory_order_relaxed);
-      g_phase_ns[kPhGather].fetch_add(gather_ns, std::memory_order_relaxed);
-      g_phase_ns[kPhGate].fetch_add(gate_ns, std::memory_order_relaxed);
-      g_phase_ns[kPhEnqueue].fetch_add(enq_ns, std::memory_order_relaxed);
-      g_phase_ns[kPhWait].fetch_add(t_w - t_e, std::memory_order_relaxed);
-      g_phase_ns[kPhCopyOut].fetch_add(t_c - t_w, std::memory_order_relaxed);
-      g_phase_calls.fetch_add(1, std::memory_order_relaxed);
-      g_split_calls.fetch_add(1, std::memory_order_relaxed);
-      return true;
-    }
-  }
+  // (Measured and dropped in round 3: one chunk as two sub-passes on the call's stream, the gather of the second overlapping the H2D + kernels
+  // of the first -- a loss at every caller count: a chunk's 45-50 us in flight are fixed latencies, not its 20 us of transfer, and halves pay
+  // them twice; profiles/r03_host_cpu_ab_split_pollq.txt.)
   for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
     const int64_t nr = std::min(rows_pass, rows - r0);
     // The caller's buffer is only borrowed for the call (SURVEY.md 8b "Ownership"): stage it.
@@ -1660,7 +1548,7 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
         continue;  // this chunk's result is already in h_out
       }
     } else {
-      enqueue_pass(ctx.pin_in, ctx.dev_in, ctx.dev_out, ctx.pin_out, nr, single_pass, admitted.in_flight, true);
+      enqueue_pass(ctx.pin_in, ctx.dev_in, ctx.dev_out, ctx.pin_out, nr, single_pass, admitted.in_flight);
     }
     const uint64_t t_e = now_ns();
     ctx.wait_stream(m.uid * 0x9E3779B97F4A7C15ull ^ uint64_t(nr));  // (spinning on hipStreamQuery instead measured slower: 41 vs 69 M rows/s at 16 threads)
@@ -1845,17 +1733,25 @@ std::string LoadedModel::describe_json() const {
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++)
-    o << (i ? "," : "") << "\"" << (i < stem_split6.size() && stem_split6[i] ? "conv_patch_pool_bf16x6" : i < stem_split.size() && stem_split[i] ? "conv_patch_pool_f16x3" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split.size() && conv_split[i] ? "conv_split_f16x3" : i < conv_split6.size() && conv_split6[i] ? "conv_split_bf16x6" : ek[int(exec[i])]) << "\"";
+    o << (i ? "," : "") << "\"" << (i < stem_split6.size() && stem_split6[i] ? "conv_patch_pool_bf16x6" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split6.size() && conv_split6[i] ? "conv_split_bf16x6" : ek[int(exec[i])]) << "\"";
   o << "],\"activation_layout\":\"" << (cq_mode ? "NC/4HW4" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";
-  if (n_amax > 0) o << ",\"conv_precision\":\"f16x3 (fp16 matrix cores, operands split hi + lo, fp32 accumulate)\"";
-  else if (std::find(conv_split6.begin(), conv_split6.end(), char(1)) != conv_split6.end())
+  if (std::find(conv_split6.begin(), conv_split6.end(), char(1)) != conv_split6.end())
     o << ",\"conv_precision\":\"bf16x6 (bf16 matrix cores, operands cut exactly into three parts, six partial products, fp32 accumulate)\"";
+  if (std::find(buf_s3.begin(), buf_s3.end(), char(1)) != buf_s3.end()) {
+    o << ",\"presplit_buffers\":[";
+    bool first = true;
+    for (size_t b = 0; b < buf_s3.size(); b++)
+      if (buf_s3[b]) {
+        o << (first ? "" : ",") << b;
+        first = false;
+      }
+    o << "]";
+  }
   for (size_t i = 0; i < exec.size(); i++)
     if (exec[i] == ExecKind::Mlp3Head)
-      o << ",\"fused_kernel\":" << json_str(bf16x3 ? kern::mlp3_bf16x3_kernel_name(mlp3_shape) : kern::mlp3_kernel_name(mlp3_shape))
-        << ",\"precision\":" << json_str(bf16x3 ? "bf16x3 (NOT parity precision)" : "fp32");
+      o << ",\"fused_kernel\":" << json_str(kern::mlp3_kernel_name(mlp3_shape)) << ",\"precision\":\"fp32\"";
   {  // kernel family of every Dense layer that runs on the streaming / generic Dense kernels, for a large aligned device-resident scan
     std::string dk;
     for (size_t i = 0; i < exec.size(); i++) {

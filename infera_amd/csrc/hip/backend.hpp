@@ -48,7 +48,6 @@ double h2d_probe_gbs(int device_ordinal, size_t bytes, int iters, int threads);
 // Constants of one plan step resident in one GPU's HBM.
 struct DeviceStep {
   float *W = nullptr, *bias = nullptr, *cst = nullptr, *scale = nullptr, *shift = nullptr;
-  float *winv = nullptr;  // split-fp16 convolutions: per-feature inverse weight scales (W then holds fp16 hi / lo fragments)
 };
 
 // How the executor runs a step.
@@ -59,7 +58,6 @@ struct DeviceModel {
   int num_cus = 0;
   std::vector<DeviceStep> steps;
   float *mlp3_packed = nullptr;
-  void *mlp3_bf16x3_packed = nullptr;  // INFERA_PRECISION=bf16x3 only: hi/lo bf16 fragments of the same chain
   std::vector<float *> chain_packed;  // parameter block per LoadedModel::chains entry
   ~DeviceModel();
 };
@@ -95,8 +93,6 @@ class LoadedModel {
   bool in_colmajor_ok = false;
   int64_t in_colmajor_max_rows = 0;  // longest column-major chunk the first kernel reads itself (load-time specialised MLP chains: their tile kernel's range)
   bool in_single_reader = false;  // the input buffer is read by exactly one kernel of the plan (small host inputs: straight from pinned memory)
-  // INFERA_PRECISION=bf16x3 and the fused chain has a bf16x3 instantiation: NOT parity precision
-  bool bf16x3 = false;
   // ... except the caller's input and what elementwise preprocessing makes of it (x/255, (x - mean) / std in the graph):
   // those few-channel tensors stay NCHW and the first convolution reads them with the patch kernel.
   std::vector<char> nchw_buf;
@@ -105,16 +101,9 @@ class LoadedModel {
   std::vector<int> conv_fused_pool;  // per step: the MaxPool 3x3/2 step a ConvPatch stem computes in its own kernel, or -1
   std::vector<int> conv_fused_add;
   std::vector<int> conv_residual_buf;
-  // INFERA_PRECISION=f16x3: ConvTiled steps that run on the fp16 matrix cores with split operands (conv_split.hip).  Each needs the
-  // per-image max |x| of its input tensor: amax_of_buf = index of that tensor's row of maxima in the plan's amax scratch slot (-1: not
-  // needed); amax_by_kernel = the tensor's producer is no split convolution, a reduction kernel computes the maxima before first use.
-  std::vector<char> conv_split;
-  std::vector<char> conv_split6; // ConvTiled steps on conv2d_split6 (INFERA_PRECISION=bf16x6: three bf16 parts per operand, no maxima needed)
-  std::vector<char> stem_split6; // ConvPatch + fused MaxPool steps that run conv2d_stem_split6 (default plan)
-  std::vector<char> stem_split;  // ConvPatch + fused MaxPool steps that run conv2d_stem_split (same mode)
-  std::vector<int> amax_of_buf;
-  std::vector<char> amax_by_kernel;
-  int n_amax = 0, amax_slot = -1;
+  std::vector<char> conv_split6;  // ConvTiled steps on conv2d_split6 (default; INFERA_PRECISION=fp32 leaves them on the exact-fp32 kernels)
+  std::vector<char> stem_split6;  // ConvPatch + fused MaxPool steps that run conv2d_stem_split6 (same arithmetic)
+  std::vector<char> buf_s3;       // per activation buffer: stored pre-split (three bf16 planes per 16-channel group, 1.5x the floats) -- schedule()
   std::vector<int> slot_of_buf;        // scratch slot per activation buffer (-1: external in/out)
   std::vector<int64_t> slot_per_row;   // floats per row of each scratch slot
   int64_t scratch_per_row = 0;         // sum over slots

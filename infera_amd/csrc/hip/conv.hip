@@ -21,7 +21,6 @@
 //   * conv2d_generic_kernel -- any geometry / groups / layouts (the C=3 stem reads the caller's NCHW
 //     blob and writes CQ); scalar gathers, weights straight from L2.
 #include "device_common.hpp"
-#include "f16_split.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -1082,8 +1081,7 @@ static size_t patch_pool2_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
 template <int K8C>
 __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                           const float *__restrict__ bias, float *__restrict__ Y, int64_t ntiles,
-                                                                          ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync,
-                                                                          unsigned *__restrict__ amax_out) {
+                                                                          ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync) {
   constexpr int BS = kPool2Block, PW = 2;
   static_assert(K8C >= 6, "the pooling runs in the shadow of a compile-time k loop of at least 22 units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1187,19 +1185,6 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
   };
   int img_p = 0, pr0_p = 0, pc0_p = 0;
   bool have_p = false;
-  // amax_out (nullable): bits of each image's largest pooled |y| (max-accumulated; the split-fp16 convolution that reads this tensor scales
-  // its operands by it, conv_split.hip): every thread tracks the quads it stores, one atomic per wave and tile
-  float tmax = 0.f;
-  auto track = [&](const f32x4 &m, int voff) {
-    if (amax_out && voff >= 0) tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(m[0]), fabsf(m[1]))), fmaxf(fabsf(m[2]), fabsf(m[3])));
-  };
-  auto flush_amax = [&](int img) {
-    float m = tmax;
-    tmax = 0.f;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0 && m > 0.f) atomicMax(amax_out + img, __float_as_uint(m));
-  };
   for (; tile < t_end; tile += tstep) {
     const int64_t next = tile + tstep;
     const int oy0 = oy0_n, ox0 = ox0_n, img = img_n;
@@ -1217,7 +1202,6 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
       }
       if (st == 10) {
         pooled_store(pm, rs_p, voff_p[n]);
-        track(pm, voff_p[n]);
       }
     };
     tile_origin(next < t_end ? next : tile, img_n, oy0_n, ox0_n);
@@ -1287,10 +1271,6 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
     });
     store_patch(pv);  // (unconditional: the last tile parks its own re-fetched patch, see conv2d_patch_kernel)
     __syncthreads();
-    if (amax_out) {
-      if (have_p) flush_amax(img_p);  // the tile pooled under this k loop
-      else tmax = 0.f;                // (first tile: the pooling ran over an empty exchange tile, its stores were dropped)
-    }
     img_p = img;
     pr0_p = (oy0 + pool.pt) >> 1;
     pc0_p = (ox0 + pool.pl) >> 1;
@@ -1312,312 +1292,18 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_pool2_kernel(const
         }
       const int voff = pooled_voff(n, pr0_p, pc0_p);
       pooled_store(m, rs, voff);
-      track(m, voff);
     }
-    if (amax_out) flush_amax(img_p);
   }
 }
 
-// ---- the same stem + max-pool on the fp16 matrix cores with split operands (INFERA_PRECISION=f16x3, round 3) -------------------
-// conv2d_stem_pool2_kernel's tile flow (two half-channel workgroups per CU, patch / exchange tile / pooling in the k loop's shadow) with
-// the inner product of conv_split.hip: every product as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_f16.  K = C*kh*kw = 147 is
-// ten k-blocks of 16 (instead of 152 exact-fp32 k-steps of 64 cycles: 60 MFMAs of 32 cycles per pixel-tile pair).
-//   * The input patch is split ONCE, when it is parked in LDS: a patch word is {hi | lo << 16} of x * 2^p, the scale 2^p taken from the
-//     largest |x| of THIS TILE's patch (each thread's max of the words it fetched -> wave reduction -> four LDS slots, read after the
-//     barrier the flow already has).  Per tile, not per batch: the tile grid of an image is fixed, so a row's result does not depend on
-//     its batch.
-//   * k order: a lane half's eight k-values of a k-block are ONE filter row (c, ky), kx in the order 0 2 4 6 1 3 5 7 (kx = 7: zero weight).
-//     The patch rows are de-interleaved by column parity (stride 2), so those are four consecutive words of the row's even half and four of
-//     its odd half: one row offset per k-block (eleven registers for the kernel's lifetime, no offset table), four ds_read2_b32 per pixel
-//     tile, one v_perm_b32 per fragment dword.  21 filter rows = 11 k-blocks (the 22nd row has zero weights).  (First version: k in ONNX
-//     order through a per-k offset table -- 16 scalar reads and 16 address computations per k-block and tile: 1.74 ms against ~1.3.)
-//   * Weights: hi / lo fp16 fragments per k-block, scaled per output feature at load time (conv2d_stem_split_pack); the epilogue multiplies
-//     by 2^-(p_tile + p_feature), exact.
 constexpr int kStemKB = 11;
-using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
-static size_t stem_split_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
-  return size_t(kStemKB) * 2048 + (size_t(g.C) * p.PLANE + 8) * 4 + 256 * size_t(32 + 4) * 4 + 64;
-}
-
-__global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
-                                                                          const float *__restrict__ bias, float *__restrict__ Y, int64_t ntiles,
-                                                                          ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync,
-                                                                          unsigned *__restrict__ amax_out) {
-  constexpr int BS = kPool2Block, PW = 2, KBC = kStemKB;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  u32x4_t *wl = reinterpret_cast<u32x4_t *>(smem);                      // [KBC][part][64 lanes]: this half's 32 features
-  unsigned *patch = reinterpret_cast<unsigned *>(smem + KBC * 512);     // [C * PLANE] split words (+ 4 spare)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int psz = g.C * pg.PLANE;
-  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, half = wg & 1, pair = wg >> 1;
-  f32x4 *exch = reinterpret_cast<f32x4 *>(patch + ((psz + 4 + 3) & ~3));
-  float *red = reinterpret_cast<float *>(exch + 256 * 9);               // [4] per-wave patch maxima of the tile being parked
-
-  // blob: [KBC][half][part][64][4 dwords], then winv[64]
-  for (int i = threadIdx.x; i < KBC * 128; i += BS)
-    wl[i] = reinterpret_cast<const u32x4_t *>(Wp)[(((i >> 7) * 2 + half) * 2 + ((i >> 6) & 1)) * 64 + (i & 63)];
-  const float *winv = Wp + KBC * 1024;
-  // words nobody parks (the odd half's fourth word of the last pixels: kx = 7, weight zero) must still be finite
-  for (int i = threadIdx.x; i < psz + 8; i += BS) patch[i] = 0u;
-  // the patch offset of every filter row (c, ky) = 0 .. 21 (row 21: zero weights, any row): wave-uniform, so they live in scalar registers;
-  // lane half h of k-block kb reads row 2 kb + h
-  int soff[2 * KBC];
-#pragma unroll
-  for (int rr = 0; rr < 2 * KBC; rr++) {
-    const int c = rr / g.kh, ky = rr - c * g.kh;
-    soff[rr] = rr < g.C * g.kh ? c * pg.PLANE + ky * g.dh * pg.ROWS : 0;
-  }
-
-  int e_rel[kPatchMaxE], e_rc[kPatchMaxE], e_lds[kPatchMaxE];
-#pragma unroll
-  for (int i = 0; i < kPatchMaxE; i++) {
-    const int e = threadIdx.x + i * BS;
-    const int c = e / (pg.PR * pg.PC), rem = e - c * (pg.PR * pg.PC), row = rem / pg.PC, col = rem - row * pg.PC;
-    const bool live = c < g.C;
-    e_rel[i] = (c * g.H + row) * g.W + col;
-    e_rc[i] = live ? (row << 16) | col : -1;
-    e_lds[i] = live ? c * pg.PLANE + row * pg.ROWS + (col % g.sw) * pg.HALF + col / g.sw : -1;
-  }
-  const int tiles_per_img = pg.tiles_x * pg.tiles_y;
-  auto tile_origin = [&](int64_t t, int &img, int &oy0, int &ox0) {
-    const unsigned u = unsigned(t), im = u / unsigned(tiles_per_img), rem = u - im * unsigned(tiles_per_img);
-    const unsigned ty = rem / unsigned(pg.tiles_x), tx = rem - ty * unsigned(pg.tiles_x);
-    img = int(im);
-    oy0 = int(ty) * kPoolTR * 2 - pool.pt;
-    ox0 = int(tx) * kPoolTC * 2 - pool.pl;
-  };
-  auto load_slot = [&](int i, const float *image, int iy0, int ix0) -> float {
-    const int iy = iy0 + (e_rc[i] >> 16), ix = ix0 + (e_rc[i] & 0xffff);
-    const bool ok = unsigned(iy) < unsigned(g.H) && unsigned(ix) < unsigned(g.W);
-    const float x = image[ok ? iy0 * g.W + ix0 + e_rel[i] : 0];
-    return ok ? x : 0.f;
-  };
-  // this wave's largest |x| among the patch words it fetched -> red[wave] (read by everybody after the next barrier)
-  auto publish_max = [&](const float(&v)[kPatchMaxE]) {
-    float m = 0.f;
-#pragma unroll
-    for (int i = 0; i < kPatchMaxE; i++) m = fmaxf(m, fabsf(v[i]));
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) red[wave] = m;
-  };
-  // scale (and its inverse) of the tile whose maxima are in red[], then park its patch as split words
-  auto park_patch = [&](const float(&v)[kPatchMaxE], float &sinv) {
-    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    unsigned e = (__float_as_uint(m) >> 23) & 0xffu;
-    e = e < 15u ? 15u : (e > 254u ? 254u : e);
-    const float sc = __uint_as_float((268u - e) << 23);
-    sinv = __uint_as_float((e - 14u) << 23);
-#pragma unroll
-    for (int i = 0; i < kPatchMaxE; i++) {
-      unsigned d;
-      float rest;
-      asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(v[i]), "v"(sc));
-      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(rest) : "v"(v[i]), "v"(sc), "v"(d));
-      asm("v_fma_mixhi_f16 %0, %1, 1.0, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(rest));
-      patch[e_lds[i] >= 0 ? e_lds[i] : psz + (i & 3)] = d;
-    }
-  };
-
-  int lbase[PW], py[PW], px[PW];
-#pragma unroll
-  for (int p = 0; p < PW; p++) {
-    const int pix = min((wave + 4 * p) * 32 + r, kPoolCR * kPoolCC - 1);
-    py[p] = pix / kPoolCC;
-    px[p] = pix % kPoolCC;
-    lbase[p] = py[p] * g.sh * pg.ROWS + px[p];
-  }
-  const u32x4_t *wfrag = wl + lane;
-  f32x4 bres[4], wres[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    bres[q] = bias ? reinterpret_cast<const f32x4 *>(bias)[h + 8 * half + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
-    wres[q] = reinterpret_cast<const f32x4 *>(winv)[h + 8 * half + 2 * q];
-  }
-  float pv[kPatchMaxE];
-  const int64_t chunk = (ntiles + 7) >> 3, t_end = min(ntiles, (int64_t(xcd) + 1) * chunk);
-  const int64_t tstep = ((gridDim.x + 7 - xcd) >> 3) >> 1;
-  int64_t tile = int64_t(xcd) * chunk + pair;
-  int img_n = 0, oy0_n = 0, ox0_n = 0;
-  float sinv_cur = 1.f;
-  if (tile < t_end) {
-    tile_origin(tile, img_n, oy0_n, ox0_n);
-    const int iy0 = oy0_n * g.sh - g.pt, ix0 = ox0_n * g.sw - g.pl;
-    const float *image = X + int64_t(img_n) * g.C * g.H * g.W;
-#pragma unroll
-    for (int i = 0; i < kPatchMaxE; i++) pv[i] = load_slot(i, image, iy0, ix0);
-    publish_max(pv);
-  }
-  __syncthreads();
-  if (tile < t_end) park_patch(pv, sinv_cur);
-  __syncthreads();
-  if (half)
-    for (int i = 0; i < desync; i++) __builtin_amdgcn_s_sleep(127);
-  constexpr int XQ = 9, NQ = 8, PT = kPoolTR * kPoolTC;
-  int pwin[2] = {0, 0}, poff[2] = {-1, -1}, ppr[2] = {0, 0}, ppc[2] = {0, 0};
-#pragma unroll
-  for (int n = 0; n < 2; n++) {
-    const int it = threadIdx.x + n * BS;
-    const bool ok = it < NQ * PT;
-    const int cq = ok ? it / PT : 0, pp = ok ? it % PT : 0, pr = pp / kPoolTC, pc = pp % kPoolTC;
-    pwin[n] = ((2 * pr) * kPoolCC + 2 * pc) * XQ + cq;
-    ppr[n] = pr;
-    ppc[n] = pc;
-    poff[n] = ok ? (((cq + NQ * half) * pool.OH + pr) * pool.OW + pc) * 16 : -1;
-  }
-  const unsigned pooled_img_bytes = unsigned(g.M / 4) * unsigned(pool.OH) * unsigned(pool.OW) * 16u;
-  auto pooled_rsrc = [&](int img, bool live) {
-    const char *base = reinterpret_cast<const char *>(Y) + int64_t(__builtin_amdgcn_readfirstlane(img)) * pooled_img_bytes;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, live ? int(pooled_img_bytes) : 0, 0x00020000);
-  };
-  auto pooled_voff = [&](int n, int pr0, int pc0) {
-    return (poff[n] >= 0 && pr0 + ppr[n] < pool.OH && pc0 + ppc[n] < pool.OW) ? poff[n] + (pr0 * pool.OW + pc0) * 16 : -1;
-  };
-  auto pooled_store = [&](const f32x4 &m, __amdgpu_buffer_rsrc_t rs, int voff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), rs, voff, 0, 0);
-  };
-  int img_p = 0, pr0_p = 0, pc0_p = 0;
-  bool have_p = false;
-  float tmax = 0.f;
-  auto track = [&](const f32x4 &m, int voff) {
-    if (amax_out && voff >= 0) tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(m[0]), fabsf(m[1]))), fmaxf(fabsf(m[2]), fabsf(m[3])));
-  };
-  auto flush_amax = [&](int img) {
-    float m = tmax;
-    tmax = 0.f;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0 && m > 0.f) atomicMax(amax_out + img, __float_as_uint(m));
-  };
-  for (; tile < t_end; tile += tstep) {
-    const int64_t next = tile + tstep;
-    const int oy0 = oy0_n, ox0 = ox0_n, img = img_n;
-    const __amdgpu_buffer_rsrc_t rs_p = pooled_rsrc(img_p, have_p);
-    const int voff_p[2] = {pooled_voff(0, pr0_p, pc0_p), pooled_voff(1, pr0_p, pc0_p)};
-    f32x4 ptmp[2], pm;
-    auto shadow_pool = [&](int uu) {  // item 0: units 0..10, item 1: units 11..21
-      const int n = uu / 11, st = uu - 11 * n;
-      if (n > 1) return;
-      if (st < 9) ptmp[st & 1] = exch[pwin[n] + ((st / 3) * kPoolCC + st % 3) * XQ];
-      if (st == 0) pm = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (st >= 1 && st <= 9) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) pm[e] = fmaxf(pm[e], ptmp[(st - 1) & 1][e]);
-      }
-      if (st == 10) {
-        pooled_store(pm, rs_p, voff_p[n]);
-        track(pm, voff_p[n]);
-      }
-    };
-    tile_origin(next < t_end ? next : tile, img_n, oy0_n, ox0_n);
-    const int iy0_n = oy0_n * g.sh - g.pt, ix0_n = ox0_n * g.sw - g.pl;
-    const float *image_n = X + int64_t(img_n) * g.C * g.H * g.W;
-
-    f32x16 acc[PW];
-#pragma unroll
-    for (int p = 0; p < PW; p++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
-    const unsigned *pb[PW] = {patch + lbase[0], patch + lbase[1]};
-    // a step = (k-block, pixel tile): eight patch words (even half: kx 0 2 4 6, odd half: kx 1 3 5 7), fetched one step ahead; the
-    // k-block's weight fragments one k-block ahead
-    unsigned w[2][8];
-    u32x4_t ah[2], al[2];
-    auto fetch_words = [&](int step, int buf) {
-      const int kb = step / PW, p = step % PW;
-      const unsigned *row = pb[p] + (h ? soff[2 * kb + 1] : soff[2 * kb]), *rowh = row + pg.HALF;
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        w[buf][e] = row[e];
-        w[buf][4 + e] = rowh[e];
-      }
-    };
-    fetch_words(0, 0);
-    ah[0] = wfrag[0];
-    al[0] = wfrag[64];
-#pragma unroll
-    for (int step = 0; step < KBC * PW; step++) {
-      const int kb = step / PW, p = step % PW, cur = step & 1, kc = kb & 1;
-      if (step + 1 < KBC * PW) fetch_words(step + 1, cur ^ 1);
-      if (p == 0 && kb + 1 < KBC) {
-        ah[kc ^ 1] = wfrag[((kb + 1) * 2 + 0) * 64];
-        al[kc ^ 1] = wfrag[((kb + 1) * 2 + 1) * 64];
-      }
-      u32x4_t bh, bl;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        bh[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1], w[cur][2 * i], 0x05040100u);
-        bl[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1], w[cur][2 * i], 0x07060302u);
-      }
-      // the tile's other work rides along: one and a half units of pooling / patch prefetch per step
-#pragma unroll
-      for (int unit = (step * 3) / 2; unit < ((step + 1) * 3) / 2; unit++) {
-#pragma unroll
-        for (int sl = 0; sl < kPatchMaxE; sl++)
-          if (sl * (3 * KBC) / kPatchMaxE == unit) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
-        shadow_pool(unit);
-      }
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al[kc]), __builtin_bit_cast(f16x8_t, bh), acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah[kc]), __builtin_bit_cast(f16x8_t, bl), acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah[kc]), __builtin_bit_cast(f16x8_t, bh), acc[p], 0, 0, 0);
-    }
-
-    publish_max(pv);  // the next tile's patch words are all in registers by now
-    __syncthreads();  // the previous tile's pooling has read the exchange tile; everybody is out of the k loop (patch free)
-    const float sinv = sinv_cur;
-    dispatch_act(act.kind, [&](auto kind_tag) {
-      constexpr int KIND = decltype(kind_tag)::value;
-#pragma unroll
-      for (int p = 0; p < PW; p++) {
-        const int oy = oy0 + py[p], ox = ox0 + px[p];
-        const bool inside = oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            v[j] = inside ? apply_act_c<KIND>((acc[p][4 * q + j] * wres[q][j]) * sinv + bres[q][j], act.a, act.b) : -INFINITY;
-          exch[((wave + 4 * p) * 32 + r) * XQ + 2 * q + h] = v;
-        }
-      }
-    });
-    park_patch(pv, sinv_cur);
-    __syncthreads();
-    if (amax_out) {
-      if (have_p) flush_amax(img_p);
-      else tmax = 0.f;
-    }
-    img_p = img;
-    pr0_p = (oy0 + pool.pt) >> 1;
-    pc0_p = (ox0 + pool.pl) >> 1;
-    have_p = true;
-  }
-  if (have_p) {
-    const __amdgpu_buffer_rsrc_t rs = pooled_rsrc(img_p, true);
-#pragma unroll
-    for (int n = 0; n < 2; n++) {
-      const f32x4 *win = exch + pwin[n];
-      f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const f32x4 v = win[(i * kPoolCC + j) * XQ];
-#pragma unroll
-          for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
-        }
-      const int voff = pooled_voff(n, pr0_p, pc0_p);
-      pooled_store(m, rs, voff);
-      track(m, voff);
-    }
-    if (amax_out) flush_amax(img_p);
-  }
-}
-
 // ---- the stem + max-pool in the DEFAULT arithmetic: bf16 x three exact parts, six MFMAs per product (round 3) ----------------------
-// conv2d_stem_split_kernel's k order (a lane half's eight k-values = one filter row, kx 0 2 4 6 1 3 5 7 = four consecutive words of each half of a
-// de-interleaved patch row) with the inner product of conv2d_split6_kernel (conv_split.hip): no scales, nothing to track, nothing about the input
+// conv2d_stem_pool2_kernel's tile flow (two half-channel workgroups per CU) with the inner product of conv2d_split6_kernel (conv_split.hip).
+// K = C*kh*kw = 147 as eleven k-blocks of 16 (instead of 152 exact-fp32 k-steps of 64 cycles).  k order: a lane half's eight k-values of a
+// k-block are ONE filter row (c, ky), kx in the order 0 2 4 6 1 3 5 7 (kx = 7: zero weight).  The patch rows are de-interleaved by column
+// parity (stride 2), so those are four consecutive words of the row's even half and four of its odd half: one row offset per k-block (eleven
+// registers for the kernel's lifetime, no offset table).  21 filter rows = 11 k-blocks (the 22nd row has zero weights).
+// No scales, nothing to track, nothing about the input
 // has to hold.  The patch is cut ONCE, when it is parked: a patch word is the pair {hi | mid << 16}, {lo} (8 bytes), so the k loop assembles its
 // three B fragments with three v_perm_b32 per pair of words (first version: fp32 patch, cut in the k loop -- 44 VALU instructions per k-block and
 // pixel tile: 2.24 ms against 1.9).  The weights are three bf16 fragments per k-block (33 KB for this half's 32 features), and to fit two
@@ -2099,13 +1785,12 @@ void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed, const 
 }
 
 void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
-                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out) {
+                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus) {
   if (rows <= 0) return;
   const PatchGeom p = patch_pool_geom(g, pool);
   if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {  // (the kernel counts tiles in 32 bits)
     for (int64_t r0 = 0; r0 < rows; r0 += cap)
-      conv2d_patch_pool(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus,
-                        amax_out ? amax_out + r0 : nullptr);
+      conv2d_patch_pool(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus);
     return;
   }
   const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
@@ -2121,7 +1806,7 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
     const unsigned grid2 = unsigned(2 * cus);  // a multiple of 16: an even number of workgroups (whole pairs) on every XCD
     auto launch2 = [&](auto kernel) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kernel, dim3(grid2), dim3(kPool2Block), lds2, s, X, packed, bias, Y, ntiles, g, p, act, pool, desync, amax_out);
+      hipLaunchKernelGGL(kernel, dim3(grid2), dim3(kPool2Block), lds2, s, X, packed, bias, Y, ntiles, g, p, act, pool, desync);
     };
     if (p.K8 == 19) launch2(conv2d_stem_pool2_kernel<19>);
     else launch2(conv2d_stem_pool2_kernel<10>);
@@ -2144,80 +1829,15 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
   };
   if (g.M == 32) by_k8(std::integral_constant<int, 1>{});
   else by_k8(std::integral_constant<int, 2>{});
-  if (amax_out) absmax_rows(s, Y, rows, int64_t(g.M) * pool.OH * pool.OW, amax_out);  // (only the two-workgroup kernel tracks the maxima itself)
-}
-
-// ---- split-fp16 stem + max-pool (conv2d_stem_split_kernel) ----
-bool conv2d_stem_split_supported(const ConvGeom &g, const PoolTail &pool) {
-  if (!conv2d_patch_pool_supported(g, pool) || g.M != 64) return false;
-  const PatchGeom p = patch_pool_geom(g, pool);
-  // (the k loop reads four consecutive words of each half of a de-interleaved patch row: 7 columns, stride 2)
-  return g.kw == 7 && g.sw == 2 && g.dw == 1 && (g.C * g.kh + 1) / 2 == kStemKB && p.HALF >= kPoolCC + 3 &&
-         (g.C * p.PR * p.PC + kPool2Block - 1) / kPool2Block <= kPatchMaxE && 2 * stem_split_lds_bytes(g, p) <= 160 * 1024;
-}
-
-size_t conv2d_stem_split_packed_floats() { return size_t(kStemKB) * 1024 + 64; }
-
-void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail &pool) {
-  const PatchGeom p = patch_pool_geom(g, pool);
-  const int KK = g.C * g.kh * g.kw;
-  float *winv = packed + size_t(kStemKB) * 1024;
-  std::vector<float> scale(64);
-  for (int m = 0; m < 64; m++) {
-    float amax = 0.f;
-    for (int k = 0; k < KK; k++) amax = std::max(amax, std::fabs(Wt[size_t(m) * KK + k]));
-    uint32_t sb, ib;
-    f16_split_scale_bits(amax, sb, ib);
-    std::memcpy(&scale[size_t(m)], &sb, 4);
-    std::memcpy(&winv[m], &ib, 4);
-  }
-  uint16_t *out = reinterpret_cast<uint16_t *>(packed);
-  for (int kb = 0; kb < kStemKB; kb++)
-    for (int half = 0; half < 2; half++)
-      for (int lane = 0; lane < 64; lane++)
-        for (int e = 0; e < 8; e++) {
-          // lane half h of k-block kb = filter row (c, ky) = 2 kb + h; element e = kx in the order 0 2 4 6 1 3 5 7
-          const int m = 32 * half + (lane & 31), rr = 2 * kb + (lane >> 5), kx = e < 4 ? 2 * e : 2 * (e - 4) + 1;
-          const bool real = rr < g.C * g.kh && kx < g.kw;
-          const float v = real ? Wt[size_t(m) * KK + size_t(rr) * g.kw + kx] * scale[size_t(m)] : 0.f;
-          const uint16_t hi = f16_bits_rne(v), lo = f16_bits_rne(v - f16_bits_to_float(hi));
-          const size_t base = (size_t(kb) * 2 + half) * 2;  // fragments of 64 lanes x 8 halves
-          out[(base + 0) * 512 + size_t(lane) * 8 + e] = hi;
-          out[(base + 1) * 512 + size_t(lane) * 8 + e] = lo;
-        }
-  (void)p;
-}
-
-void conv2d_stem_split(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
-                       ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out) {
-  if (rows <= 0) return;
-  const PatchGeom p = patch_pool_geom(g, pool);
-  if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {
-    for (int64_t r0 = 0; r0 < rows; r0 += cap)
-      conv2d_stem_split(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus,
-                        amax_out ? amax_out + r0 : nullptr);
-    return;
-  }
-  const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
-  const int desync = getenv("INFERA_STEM_POOL2_DESYNC") ? atoi(getenv("INFERA_STEM_POOL2_DESYNC")) : 1;
-  // the grid is whole workgroup PAIRS on each of 8 XCD queues: a multiple of 16 (one precision per plan: this kernel runs for every
-  // batch size, a single image included -- the exact-fp32 stem kernels are not bit-compatible with it)
-  const int cus = std::max(8, (num_cus > 0 ? num_cus : 256) / 8 * 8);
-  static std::atomic<uint64_t> attr_done{0};  // once per device: function attributes belong to the device's code object
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_stem_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
-  }
-  hipLaunchKernelGGL(conv2d_stem_split_kernel, dim3(unsigned(2 * cus)), dim3(kPool2Block), stem_split_lds_bytes(g, p), s, X, packed, bias, Y, ntiles, g, p,
-                     act, pool, desync, amax_out);
 }
 
 // ---- bf16 x three parts stem + max-pool (conv2d_stem_split6_kernel) ----
 bool conv2d_stem_split6_supported(const ConvGeom &g, const PoolTail &pool) {
-  if (!conv2d_stem_split_supported(g, pool)) return false;
-  return 2 * stem_split6_lds_bytes(g, patch_pool_geom(g, pool)) <= 160 * 1024;
+  if (!conv2d_patch_pool_supported(g, pool) || g.M != 64) return false;
+  const PatchGeom p = patch_pool_geom(g, pool);
+  // (the k loop reads four consecutive words of each half of a de-interleaved patch row: 7 columns, stride 2)
+  return g.kw == 7 && g.sw == 2 && g.dw == 1 && (g.C * g.kh + 1) / 2 == kStemKB && p.HALF >= kPoolCC + 3 &&
+         (g.C * p.PR * p.PC + kPool2Block - 1) / kPool2Block <= kPatchMaxE && 2 * stem_split6_lds_bytes(g, p) <= 160 * 1024;
 }
 
 size_t conv2d_stem_split6_packed_floats() { return size_t(kStemKB) * 1536; }

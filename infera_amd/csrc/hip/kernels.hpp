@@ -87,15 +87,6 @@ bool mlp3_colmajor_supported(const Mlp3Shape &sh);
 int64_t mlp3_colmajor_max_rows(const Mlp3Shape &sh);  // longest column-major chunk the chain's kernels read themselves (0: none)
 std::string mlp3_kernel_name(const Mlp3Shape &sh);
 
-// OPTIONAL fast mode (INFERA_PRECISION=bf16x3, never the parity path): every fp32 product as hi*hi + hi*lo + lo*hi on the
-// bf16 matrix cores (mlp_bf16x3.hip).  Ahead-of-time configurations only (the BASELINE trunk, heads <= 4 wide).
-bool mlp3_bf16x3_supported(const Mlp3Shape &sh);
-size_t mlp3_bf16x3_packed_bytes(const Mlp3Shape &sh);
-void mlp3_bf16x3_pack(const Mlp3Shape &sh, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
-                      const float *b3, void *packed);
-bool mlp3_bf16x3(hipStream_t s, const Mlp3Shape &sh, const float *X, const void *packed, float *Y, int64_t rows, int num_cus);
-std::string mlp3_bf16x3_kernel_name(const Mlp3Shape &sh);
-
 // ---- fused chain of small Dense layers over tables of any width (chain_device.inc, specialised with hipRTC) ----
 // k0 table columns; layer l maps dims[l-1] (dims[-1] = k0) -> dims[l] and applies acts[l] (plan.hpp Act 0..5) with
 // parameters pa/pb; sm: 0 plain, 1 softmax, 2 log-softmax, 3 argmax (label only) over the last layer's <= 16 outputs.
@@ -151,17 +142,9 @@ size_t conv2d_stem_split6_packed_floats();
 void conv2d_stem_split6_pack(const ConvGeom &g, const float *Wt, float *packed);
 void conv2d_stem_split6(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
                         ActParam act, const PoolTail &pool, int num_cus);
-// amax_out (nullable): bits of each image's largest pooled |y|, max-accumulated (zero it first) -- for a split-fp16 convolution reading Y
 void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
-                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out = nullptr);
+                       const ConvGeom &g, ActParam act, const PoolTail &pool, int num_cus);
 void conv2d_patch_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail *pool = nullptr);
-// The 64-feature 7x7x3 stem + MaxPool on the fp16 matrix cores with split operands (INFERA_PRECISION=f16x3): the patch is split once, when
-// it is parked in LDS, scaled by its own tile's maximum; weights split and scaled per feature at load time.  Runs for every batch size.
-bool conv2d_stem_split_supported(const ConvGeom &g, const PoolTail &pool);
-size_t conv2d_stem_split_packed_floats();
-void conv2d_stem_split_pack(const ConvGeom &g, const float *Wt, float *packed, const PoolTail &pool);
-void conv2d_stem_split(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
-                       ActParam act, const PoolTail &pool, int num_cus, unsigned *amax_out);
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
                   const ConvGeom &g, ActParam act, int num_cus);
 // Depthwise convolution (groups == C == M, C % 4 == 0) in channel-quad planes; packed = [C/4][tap][4].
@@ -176,22 +159,16 @@ void conv2d_tiled_pack(const ConvGeom &g, const float *Wt, float *packed);
 // residual (nullable): CQ tensor of the output's shape added before the activation (fused ResNet Add)
 void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y,
                   int64_t rows, const ConvGeom &g, ActParam act);
-// The same convolution on the fp16 matrix cores, every fp32 operand split in two fp16 halves (conv_split.hip; INFERA_PRECISION=f16x3).
-// packed = conv2d_tiled_packed_floats(g) floats' worth of fp16 hi / lo fragments, winv[M] = the per-feature inverse scales.
-// amax_in[rows] = bits of each image's largest |x| over the input tensor (absmax_rows, or a split convolution's amax_out);
-// amax_out (nullable) = the same for the output tensor, max-accumulated: zero it before the producing launch.
-bool conv2d_split_supported(const ConvGeom &g);
-void conv2d_split_pack(const ConvGeom &g, const float *Wt, float *packed, float *winv);
-void absmax_rows(hipStream_t s, const float *X, int64_t rows, int64_t per_row, unsigned *amax);
-void conv2d_split(hipStream_t s, const float *X, const float *packed, const float *bias, const float *winv, const float *residual,
-                  float *Y, const unsigned *amax_in, unsigned *amax_out, int64_t rows, const ConvGeom &g, ActParam act);
-// ... and with every operand cut exactly into three bf16 parts, six partial products per product (INFERA_PRECISION=bf16x6): no scales, no maxima,
+// The same convolution on the bf16 matrix cores with every fp32 operand cut exactly into three bf16 parts, six partial products per product (the default;
+// conv_split.hip): no scales, no maxima,
 // no precondition on the data.  M % 64 == 0; packed = conv2d_split6_packed_floats(g) floats' worth of bf16 hi / mid / lo fragments.
 bool conv2d_split6_supported(const ConvGeom &g);
 size_t conv2d_split6_packed_floats(const ConvGeom &g);
 void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed);
+// in_s3 / out_s3 / res_s3: the tensor is stored PRE-SPLIT (three bf16 planes per 16-channel group, 1.5x the floats of the fp32 channel-quad
+// tensor; conv_split.hip) -- what a split convolution writes for readers that are all split convolutions.
 void conv2d_split6(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y, int64_t rows,
-                   const ConvGeom &g, ActParam act);
+                   const ConvGeom &g, ActParam act, bool in_s3 = false, bool out_s3 = false, bool res_s3 = false);
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
             int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq);
 // y[n,c,p] = x[n,c,p] / (bias + alpha/size * sum_{c' in window(c)} x[n,c',p]^2)^beta over [rows, C, S] (cq: channel-quad planes)

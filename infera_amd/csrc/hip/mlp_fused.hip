@@ -218,10 +218,7 @@ void launch_tile(hipStream_t s, const float *X, const float *packed, float *Y, i
   const int64_t ntiles = (rows + 31) / 32;
   hipLaunchKernelGGL((mlp3_tile_kernel<C, XCM>), dim3(unsigned(ntiles)), dim3(256), 0, s, X, packed, Y, rows);
 }
-bool tile_kernel_enabled() {
-  const bool on = infera_hip::Config::get().mlp3_tile;
-  return on;
-}
+bool tile_kernel_enabled() { return true; }
 }  // namespace
 
 bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,

@@ -268,8 +268,7 @@ Compiled &compile_locked(const Mlp3Shape &s, std::unique_lock<std::mutex> &held)
   c.ok = jit_compile(kMlpDeviceSrc, "infera_mlp_jit.hip", c.expr, c.code, c.lowered, c.why);
   // the tile kernel's preconditions (mlp_device.inc: VALU head, at most four layer-2 tiles, at most six layer-1 tiles per wave, its
   // 32 x (D1+4) activation tile in static LDS); a failed compile of a variant only means short launches keep the persistent kernel
-  const bool tile_on = Config::get().mlp3_tile;
-  if (c.ok && tile_on && L.l3v && L.MT2 <= 4 && 32 * (s.d1 + 4) * 4 <= 60 * 1024 && (L.MT1 % 4 == 0 ? L.MT1 / 4 : L.MT1 % 2 == 0 ? L.MT1 / 2 : L.MT1) <= 6) {
+  if (c.ok && L.l3v && L.MT2 <= 4 && 32 * (s.d1 + 4) * 4 <= 60 * 1024 && (L.MT1 % 4 == 0 ? L.MT1 / 4 : L.MT1 % 2 == 0 ? L.MT1 / 2 : L.MT1) <= 6) {
     for (Variant *v : {&c.tile, &c.tile_xcm}) {
       v->expr = "infera_hip::kern::mlpdev::mlp3_tile_kernel<" + c.cfg + "," + (v == &c.tile_xcm ? "true" : "false") + ">";
       v->ok = jit_compile(kMlpDeviceSrc, "infera_mlp_jit.hip", v->expr, v->code, v->lowered, v->why);

@@ -3,7 +3,6 @@
 // Each wrapper follows the shape of the reference's FFI functions in lib.rs: null checks ->
 // UTF-8 check -> delegate -> map failure to (status | -1) + thread-local last error
 // (lib.rs:38-64, 81-102, 127-149, 174-195, 215-233, 245-260, 275-285, 299-308, 326-366, 388-425).
-#include "../hip/f16_split.hpp"
 #include <dirent.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -354,20 +353,6 @@ int32_t infera_hip_unregister_host_memory(const void *base) {
 
 uint64_t infera_hip_zero_copy_calls(void) { return g_zero_copy_calls.load(std::memory_order_relaxed); }
 
-void infera_hip_f16_split(float v, float amax, uint16_t *hi_bits, uint16_t *lo_bits, float *scale, float *inv_scale) {
-  uint32_t sb, ib;
-  infera_hip::kern::f16_split_scale_bits(amax, sb, ib);
-  float sc, inv;
-  std::memcpy(&sc, &sb, 4);
-  std::memcpy(&inv, &ib, 4);
-  const float x = v * sc;
-  const uint16_t hi = infera_hip::kern::f16_bits_rne(x);
-  *hi_bits = hi;
-  *lo_bits = infera_hip::kern::f16_bits_rne(x - infera_hip::kern::f16_bits_to_float(hi));
-  *scale = sc;
-  *inv_scale = inv;
-}
-
 int32_t infera_hip_choose_slot_balanced(const int32_t *slot_numa, const int32_t *slot_threads, uintptr_t nslots, int32_t thread_node) {
   if (!slot_numa || !slot_threads) return 0;
   return choose_slot_balanced(std::vector<int>(slot_numa, slot_numa + nslots), std::vector<int>(slot_threads, slot_threads + nslots), thread_node);
@@ -555,8 +540,6 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
         if (served) g_zero_copy_calls.fetch_add(1, std::memory_order_relaxed);
       }
       bool col_major = ncols > 0 && (colmajor_direct_ok(*m, int64_t(rows)) || !Config::get().use_hipgraph);
-      if (col_major && !Config::get().host_colmajor_typed)  // A/B knob: only all-FLOAT chunks are staged column-major (round-1 rule)
-        for (uintptr_t c = 0; c < ncols && col_major; c++) col_major = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
       if (served) {
         // (done: the GPU gathered the registered columns itself)
       } else if (col_major) {

@@ -88,33 +88,10 @@ const Config &Config::get() {
     c.use_hipgraph = env_flag("INFERA_HIPGRAPH", false);
     c.max_inflight = int(env_u64("INFERA_MAX_INFLIGHT", 12));
     c.host_contexts = std::max(1, int(env_u64("INFERA_HOST_CONTEXTS", 24)));
-    const std::string hw = env_or("INFERA_HOST_WAIT", "poll");
-    c.host_wait = hw == "spin" ? 1 : hw == "poll" ? 2 : hw == "pollq" ? 3 : hw == "block" ? 0 : 2;
-    auto env_frac = [](const char *k, double d) {
-      const char *v = std::getenv(k);
-      if (!v || !*v) return d;
-      char *end = nullptr;
-      const double x = std::strtod(v, &end);
-      return end && *end == 0 && x >= 0.0 && x <= 4.0 ? x : d;
-    };
-    c.host_poll_first = env_frac("INFERA_HOST_POLL_FIRST", 0.75);
-    c.host_poll_next = env_frac("INFERA_HOST_POLL_NEXT", 0.1);
-    c.host_ctx_affinity = env_flag("INFERA_HOST_CTX_AFFINITY", true);
-    const std::string hg = env_or("INFERA_HOST_GATHER", "il");
-    c.host_gather = hg == "memcpy" ? 0 : hg == "nt" ? 1 : hg == "ntpf" ? 2 : hg == "ilnt" ? 4 : 3;
     c.max_inflight_total = int(env_u64("INFERA_MAX_INFLIGHT_TOTAL", 0));
-    c.probe_elide_h2d = int(env_u64("INFERA_HOST_PROBE_ELIDE_H2D", 0));
     c.host_zero_copy = env_flag("INFERA_HOST_ZERO_COPY", true);
     c.numa_slots = env_flag("INFERA_NUMA_SLOTS", true);
-    c.host_split = int(env_u64("INFERA_HOST_SPLIT", 0));
-    c.host_split_quiet = int(env_u64("INFERA_HOST_SPLIT_QUIET", 4));
-    c.host_direct_out = env_flag("INFERA_HOST_DIRECT_OUT", true);
-    c.host_colmajor_typed = env_flag("INFERA_HOST_COLMAJOR_TYPED", true);
-    c.host_fused_transpose = env_flag("INFERA_HOST_FUSED_TRANSPOSE", true);
     c.host_direct_in_bytes = (long long)env_u64("INFERA_HOST_DIRECT_IN", 128 * 1024);
-    c.host_direct_in_quiet = env_flag("INFERA_HOST_DIRECT_IN_QUIET", true);
-    c.mlp3_tile = env_flag("INFERA_MLP3_TILE", true);
-    c.precision_bf16x3 = env_or("INFERA_PRECISION", "fp32") == "bf16x3";
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);
     c.max_rows_per_pass = env_u64("INFERA_MAX_ROWS_PER_PASS", 1ull << 18);
     c.batch_split = env_flag("INFERA_BATCH_SPLIT", false);
@@ -124,11 +101,12 @@ const Config &Config::get() {
 }
 
 ScheduleKnobs ScheduleKnobs::read() {
-  return ScheduleKnobs{env_flag("INFERA_STEM_POOL", true), env_flag("INFERA_CHAIN_XCM", true), env_flag("INFERA_DENSE_XCM", true),
-                       // convolutions: bf16x6 unless told otherwise ("fp32" = the exact-fp32 matrix instruction, "f16x3" = the fastest form, with
-                       // its dynamic-range precondition; "bf16x3" is the fused MLP's optional mode and leaves convolutions on their default)
-                       env_or("INFERA_PRECISION", "bf16x6") != "fp32" && env_or("INFERA_PRECISION", "bf16x6") != "f16x3",
-                       env_or("INFERA_PRECISION", "bf16x6") == "f16x3"};
+  // INFERA_PRECISION: unset / "bf16x6" = the default convolution arithmetic, "fp32" = the exact-fp32 matrix instruction; anything else is a
+  // typo (or a mode of an earlier round) and must not silently select one or the other: warn and keep the default
+  const std::string prec = env_or("INFERA_PRECISION", "bf16x6");
+  if (prec != "bf16x6" && prec != "fp32") log_msg(1, "INFERA_PRECISION='" + prec + "' is not one of bf16x6 | fp32: using the default (bf16x6)");
+  return ScheduleKnobs{env_flag("INFERA_STEM_POOL", true), env_flag("INFERA_CHAIN_XCM", true), env_flag("INFERA_DENSE_XCM", true), prec != "fp32",
+                       env_flag("INFERA_CONV_PRESPLIT", true)};
 }
 
 void log_msg(int level, const std::string &msg) {

@@ -148,54 +148,27 @@ __attribute__((target("avx2"))) void convert_i32_avx2(const int32_t *src, float 
 }  // namespace
 
 namespace {
-// One FLOAT column run into pinned staging with non-temporal 64-byte stores (INFERA_HOST_GATHER=nt|ntpf): the staging lines are
-// not read for ownership and do not displace the caller's working set; the DMA engine reads them from DRAM.  Measured on the
-// round-3 boxes (tools/ubench/gather_probe, 2x EPYC 9575F): 29-30 us per 1 MiB chunk against memcpy's 41 with 1-2 gathering
-// threads, but SLOWER than memcpy from 8 threads on (137 vs 210 GB/s at 16: the reused staging buffer stays cache-resident under
-// regular stores) -- so the default stays memcpy and this is the A/B knob.
-__attribute__((target("avx512f"))) void stream_copy_f32_avx512(float *d, const float *s, size_t n) {
-  size_t i = 0;
-  while (i < n && (reinterpret_cast<uintptr_t>(d + i) & 63)) d[i] = s[i], i++;
-  for (; i + 64 <= n; i += 64) {
-    const __m512i a = _mm512_loadu_si512(s + i), b = _mm512_loadu_si512(s + i + 16), c = _mm512_loadu_si512(s + i + 32), e = _mm512_loadu_si512(s + i + 48);
-    _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i), a);
-    _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i + 16), b);
-    _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i + 32), c);
-    _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i + 48), e);
-  }
-  for (; i + 16 <= n; i += 16) _mm512_stream_si512(reinterpret_cast<__m512i *>(d + i), _mm512_loadu_si512(s + i));
-  for (; i < n; i++) d[i] = s[i];
-}
-__attribute__((target("avx2"))) void stream_copy_f32_avx2(float *d, const float *s, size_t n) {
-  size_t i = 0;
-  while (i < n && (reinterpret_cast<uintptr_t>(d + i) & 31)) d[i] = s[i], i++;
-  for (; i + 8 <= n; i += 8) _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i)));
-  for (; i < n; i++) d[i] = s[i];
-}
-}  // namespace
-
-namespace {
-// INFERA_HOST_GATHER=il (default): several column runs copied in lockstep, a block of each in turn -- independent sequential streams
-// keep more cache-line fills in flight than one (the copy of one 8 KiB run is latency-bound at the start of every run: a new page, a
-// new DRAM row, a hardware prefetcher that has to find the stream again).  Four streams of 512 bytes: C2's gather 52-58 -> 42-44 us per
-// chunk at 4..24 callers, the 8-slot link-elided probe 325 -> 372 M rows/s; two streams gain little, eight and sixteen LOSE (the runs lie
-// 8 KiB apart in staging: their lines alias in the L1).
-constexpr int kMaxIl = 16;
-__attribute__((target("avx2"))) void copy_interleaved_f32(float *const *d, const float *const *s, int ns, size_t n, size_t blk, bool nt) {
+// Several column runs are copied in lockstep, a block of each in turn -- independent sequential streams keep more cache-line fills in
+// flight than one (the copy of one 8 KiB run is latency-bound at the start of every run: a new page, a new DRAM row, a hardware
+// prefetcher that has to find the stream again).  FOUR streams of 512 bytes: C2's gather 52-58 -> 42-44 us per chunk at 4..24 callers;
+// two streams gain little, eight and sixteen LOSE (the runs lie 8 KiB apart in staging: their lines alias in the L1).  Measured and
+// dropped (round 3, profiles/r03_gather_interleave_sweep.txt, r03_host_cpu_ab_wait_gather.txt, r03_gather_probe.txt): one run at a
+// time (memcpy), non-temporal stores with and without a prefetch of the next run (a reused staging buffer under regular stores stays
+// cache-resident; NT stores stop at ~140 GB/s of DRAM writes at 16 threads), interleaved + non-temporal.
+constexpr int kIlStreams = 4;
+constexpr size_t kIlFloats = 128;  // 512 bytes of a FLOAT run (and of a DOUBLE run: 64 elements) per turn; a multiple of 16
+__attribute__((target("avx2"))) void copy_interleaved_f32(float *const *d, const float *const *s, int ns, size_t n, size_t blk) {
   size_t i = 0;
   for (; i + blk <= n; i += blk)
     for (int k = 0; k < ns; k++) {
       const float *sp = s[k] + i;
       float *dp = d[k] + i;
-      if (nt && (reinterpret_cast<uintptr_t>(dp) & 31) == 0)
-        for (size_t v = 0; v < blk; v += 8) _mm256_stream_ps(dp + v, _mm256_loadu_ps(sp + v));
-      else
-        for (size_t v = 0; v < blk; v += 8) _mm256_storeu_ps(dp + v, _mm256_loadu_ps(sp + v));
+      for (size_t v = 0; v < blk; v += 8) _mm256_storeu_ps(dp + v, _mm256_loadu_ps(sp + v));
     }
   for (int k = 0; k < ns; k++)
     if (i < n) std::memcpy(d[k] + i, s[k] + i, (n - i) * sizeof(float));
 }
-// the same for DOUBLE runs (DuckDB's default floating type): vcvtpd2ps = static_cast<float>, blk source elements per turn
+// the same for DOUBLE runs (DuckDB's default floating type): vcvtpd2ps = static_cast<float>, blk source elements per turn (blk % 8 == 0)
 __attribute__((target("avx2"))) void convert_interleaved_f64(float *const *d, const double *const *s, int ns, size_t n, size_t blk) {
   size_t i = 0;
   for (; i + blk <= n; i += blk)
@@ -218,52 +191,36 @@ __attribute__((target("avx2"))) void convert_interleaved_f64(float *const *d, co
 // transposing gather on the CPU, the GPU kernel reads the chunk column-major.
 void gather_column_major(const infera::InferaColumn *cols, size_t c0, size_t c1, size_t row0, size_t nrows, float *dst) {
   static const bool have_avx2 = __builtin_cpu_supports("avx2");
-  static const bool have_avx512 = __builtin_cpu_supports("avx512f");
-  const int mode = have_avx2 ? Config::get().host_gather : 0;
-  bool streamed = false;
   for (size_t c = c0; c < c1; c++) {
-    if (mode >= 3) {  // several plain FLOAT runs in lockstep
-      static const int il_streams = [] { const char *e = getenv("INFERA_GATHER_IL_STREAMS"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : v > kMaxIl ? kMaxIl : v; }();
-      static const size_t il_floats = [] { const char *e = getenv("INFERA_GATHER_IL_BYTES"); const int v = e ? atoi(e) : 512; return size_t(v < 64 ? 64 : v) / 32 * 8; }();
+    if (have_avx2) {  // several plain FLOAT (or DOUBLE) runs in lockstep
       int ns = 0;
-      float *dn[kMaxIl];
-      const float *sn[kMaxIl];
-      while (ns < il_streams && c + size_t(ns) < c1 && !cols[c + size_t(ns)].is_constant && cols[c + size_t(ns)].type == infera::INFERA_COL_FLOAT) {
+      float *dn[kIlStreams];
+      const float *sn[kIlStreams];
+      while (ns < kIlStreams && c + size_t(ns) < c1 && !cols[c + size_t(ns)].is_constant && cols[c + size_t(ns)].type == infera::INFERA_COL_FLOAT) {
         dn[ns] = dst + (c + size_t(ns)) * nrows;
         sn[ns] = static_cast<const float *>(cols[c + size_t(ns)].data) + row0;
         ns++;
       }
       if (ns >= 2) {
-        copy_interleaved_f32(dn, sn, ns, nrows, il_floats, mode == 4);
-        streamed = streamed || mode == 4;
+        copy_interleaved_f32(dn, sn, ns, nrows, kIlFloats);
         c += size_t(ns) - 1;
         continue;
       }
-      const double *sd[kMaxIl];
+      const double *sd[kIlStreams];
       ns = 0;
-      while (ns < il_streams && c + size_t(ns) < c1 && !cols[c + size_t(ns)].is_constant && cols[c + size_t(ns)].type == infera::INFERA_COL_DOUBLE) {
+      while (ns < kIlStreams && c + size_t(ns) < c1 && !cols[c + size_t(ns)].is_constant && cols[c + size_t(ns)].type == infera::INFERA_COL_DOUBLE) {
         dn[ns] = dst + (c + size_t(ns)) * nrows;
         sd[ns] = static_cast<const double *>(cols[c + size_t(ns)].data) + row0;
         ns++;
       }
       if (ns >= 2) {
-        convert_interleaved_f64(dn, sd, ns, nrows, il_floats / 2);  // (the same bytes of source per turn)
+        convert_interleaved_f64(dn, sd, ns, nrows, kIlFloats / 2);  // (the same bytes of source per turn)
         c += size_t(ns) - 1;
         continue;
       }
     }
     const infera::InferaColumn &col = cols[c];
     float *d = dst + c * nrows;
-    if (mode == 2 && c + 1 < c1 && !cols[c + 1].is_constant) {  // the next run's first lines: its page walk and DRAM row open overlap this run's copy
-      const size_t esz = cols[c + 1].type == infera::INFERA_COL_FLOAT || cols[c + 1].type == infera::INFERA_COL_INTEGER ? 4 : 8;
-      const char *nx = static_cast<const char *>(cols[c + 1].data) + row0 * esz;
-      for (int l = 0; l < 4; l++) _mm_prefetch(nx + 64 * l, _MM_HINT_T0);
-    }
-    if ((mode == 1 || mode == 2) && !col.is_constant && col.type == infera::INFERA_COL_FLOAT) {
-      (have_avx512 ? stream_copy_f32_avx512 : stream_copy_f32_avx2)(d, static_cast<const float *>(col.data) + row0, nrows);
-      streamed = true;
-      continue;
-    }
     if (col.is_constant) {
       const float v = cell(col, 0);
       for (size_t r = 0; r < nrows; r++) d[r] = v;
@@ -283,7 +240,6 @@ void gather_column_major(const infera::InferaColumn *cols, size_t c0, size_t c1,
         for (size_t r = 0; r < nrows; r++) d[r] = static_cast<float>(static_cast<const int64_t *>(col.data)[row0 + r]);
     }
   }
-  if (streamed) _mm_sfence();  // non-temporal stores are weakly ordered: globally visible before the copy engine is rung
 }
 
 void gather_columns(const infera::InferaColumn *cols, size_t ncols, size_t row0, size_t nrows, float *dst) {

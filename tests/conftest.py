@@ -45,3 +45,26 @@ def gpu_api(built):
 
     assert capi.device_count() >= 1, capi.get_devices()
     return capi
+
+
+def run_bench(args, env=None, launcher=None, timeout=1200):
+    """Runs bench.py (optionally under `launcher`, e.g. torch.distributed.run) and returns (compact stdout line, full detail object).
+    The driver's contract: exactly ONE JSON line on stdout, small enough for its 8 KB capture window; everything else in --detail."""
+    import json
+    import subprocess
+    import tempfile
+
+    detail = tempfile.NamedTemporaryFile(prefix="bench_detail_", suffix=".json", delete=False).name
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + list(args) + ["--detail", detail]
+    e = dict(os.environ if env is None else env)
+    p = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) <= 4096, len(lines[0])
+    try:
+        with open(detail) as fh:
+            full = json.load(fh)
+    finally:
+        os.unlink(detail)
+    return json.loads(lines[0]), full

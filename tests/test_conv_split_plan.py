@@ -1,6 +1,6 @@
-"""The split-fp16 convolution mode's HOST logic, without a GPU (the plan is made at infera_load_model): which steps INFERA_PRECISION=f16x3
-moves to the fp16 matrix cores, that the knob is read when a model is scheduled (models loaded without it are untouched), and which layers
-stay on the exact-fp32 kernels because the split kernels do not take their shape."""
+"""The convolution arithmetic's HOST logic, without a GPU (the plan is made at infera_load_model): which steps the default plan moves to the
+bf16 matrix cores (three exact parts per operand), which activation tensors it stores pre-split, that INFERA_PRECISION / INFERA_CONV_PRESPLIT
+are read when a model is scheduled, and which layers stay on the exact-fp32 kernels because the split kernels do not take their shape."""
 import os
 
 import numpy as np
@@ -23,24 +23,28 @@ def _plan(tmp_path, name, blob, precision=None):
         capi.unload_model("splitplan_" + name)
 
 
-def test_resnet18_plan_in_split_mode_and_without(built, tmp_path):
+def test_resnet18_plan_default_and_fp32(built, tmp_path):
     blob = W.resnet18()
-    split = _plan(tmp_path, "rn_split", blob, "f16x3")
     plain = _plan(tmp_path, "rn_plain", blob, "fp32")
     default = _plan(tmp_path, "rn_default", blob)
-    assert split["exec"][0] == "conv_patch_pool_f16x3" and split["exec"].count("conv_split_f16x3") == 19 and "f16x3" in split["conv_precision"]
     assert plain["exec"][0] == "conv_patch_pool" and plain["exec"].count("conv_tiled_cq") == 19 and "conv_precision" not in plain
-    # the default: the stem and the same 19 layers on the bf16 matrix cores with three exact parts per operand; no maxima, so no extra scratch
+    # the default: the stem and the same 19 layers on the bf16 matrix cores with three exact parts per operand
     assert default["exec"][0] == "conv_patch_pool_bf16x6" and default["exec"].count("conv_split_bf16x6") == 19 and "bf16x6" in default["conv_precision"]
-    assert default["scratch_floats_per_row"] == plain["scratch_floats_per_row"]
-    assert [{"conv_split_bf16x6": "conv_tiled_cq", "conv_patch_pool_bf16x6": "conv_patch_pool"}.get(e, e) for e in default["exec"]] == plain["exec"]
     # same steps, same fusions (residual adds in the epilogues, the head on the exact-fp32 tiled kernel): only the names of the moved steps differ
-    moved = {"conv_patch_pool_f16x3": "conv_patch_pool", "conv_split_f16x3": "conv_tiled_cq"}
-    assert [moved.get(e, e) for e in split["exec"]] == plain["exec"]
-    # one word of scratch per image and tracked tensor on top of the activations
-    assert 0 < split["scratch_floats_per_row"] - plain["scratch_floats_per_row"] <= 19
-    # bf16x3 is the fused MLP's mode: a convolutional plan keeps its default under it
-    assert _plan(tmp_path, "rn_bf", blob, "bf16x3")["exec"] == default["exec"]
+    assert [{"conv_split_bf16x6": "conv_tiled_cq", "conv_patch_pool_bf16x6": "conv_patch_pool"}.get(e, e) for e in default["exec"]] == plain["exec"]
+    # activations between split convolutions are stored pre-split (three bf16 planes = 1.5x the floats): every tensor that only split
+    # convolutions read -- all of ResNet-18's but the stem's output (produced by the stem kernel), the three downsample outputs (read only as
+    # residuals: they stay fp32, 4 bytes per value) and the last block's output (read by the global pool)
+    assert len(default["presplit_buffers"]) == 15 and plain.get("presplit_buffers", []) == []
+    assert default["scratch_floats_per_row"] > plain["scratch_floats_per_row"]
+    os.environ["INFERA_CONV_PRESPLIT"] = "0"
+    try:
+        fp32act = _plan(tmp_path, "rn_f32act", blob)
+    finally:
+        os.environ.pop("INFERA_CONV_PRESPLIT", None)
+    assert fp32act["exec"] == default["exec"] and fp32act.get("presplit_buffers", []) == [] and fp32act["scratch_floats_per_row"] == plain["scratch_floats_per_row"]
+    # a mode name this build does not know (a typo, a mode of an earlier round) must not silently pick an arithmetic: default + a warning
+    assert _plan(tmp_path, "rn_typo", blob, "f16x3")["exec"] == default["exec"]
 
 
 def test_layers_the_split_kernels_do_not_take_stay_exact(built, tmp_path):
@@ -58,12 +62,12 @@ def test_layers_the_split_kernels_do_not_take_stay_exact(built, tmp_path):
         return W.model("n", nodes, inits, [W.value_info("X", ["N", c_in, hw, hw])], [W.value_info("Y", ["N", c])])
 
     # 4 -> 24 (padded-channel kernel), 24 -> 48 (channels not multiples of 32: padded-channel kernel), depthwise 48, 48 -> 64 1x1 (C % 32 != 0)
-    p = _plan(tmp_path, "mobile", net(4, [(24, 3, 1), (48, 3, 1), (48, 3, 48), (64, 1, 1)]), "f16x3")
-    assert "conv_split_f16x3" not in p["exec"] and "conv_split_bf16x6" not in p["exec"] and "conv_precision" not in p
-    assert "conv_split_bf16x6" not in _plan(tmp_path, "mobile_d", net(4, [(24, 3, 1), (48, 3, 1), (48, 3, 48), (64, 1, 1)]))["exec"]
-    # 4 -> 64, then 64 -> 64 in two groups (generic kernel), then 64 -> 96 3x3 (split)
-    p = _plan(tmp_path, "grouped", net(4, [(64, 3, 1), (64, 3, 2), (96, 3, 1)]), "f16x3")
-    assert p["exec"][:3] == ["conv_patch", "normal", "conv_split_f16x3"] and p["exec"].count("conv_split_f16x3") == 1  # (activations ride in the conv steps)
+    p = _plan(tmp_path, "mobile", net(4, [(24, 3, 1), (48, 3, 1), (48, 3, 48), (64, 1, 1)]))
+    assert "conv_split_bf16x6" not in p["exec"] and "conv_precision" not in p and p.get("presplit_buffers", []) == []
+    # 4 -> 64, then 64 -> 64 in two groups (generic kernel), then 64 -> 128 3x3 (split), 128 -> 64 (split)
+    p = _plan(tmp_path, "grouped", net(4, [(64, 3, 1), (64, 3, 2), (128, 3, 1), (64, 3, 1)]))
+    assert p["exec"][:4] == ["conv_patch", "normal", "conv_split_bf16x6", "conv_split_bf16x6"]  # (activations ride in the conv steps)
+    assert len(p["presplit_buffers"]) == 1  # only the tensor between the two split convolutions
     # a model whose INPUT already has 32 channels: the caller's tensor is NCHW, its first convolution is not a channel-quad one
-    p = _plan(tmp_path, "wide_in", net(32, [(64, 3, 1), (64, 3, 1)]), "f16x3")
-    assert p["exec"][0] != "conv_split_f16x3" and p["exec"].count("conv_split_f16x3") == 1
+    p = _plan(tmp_path, "wide_in", net(32, [(64, 3, 1), (64, 3, 1)]))
+    assert p["exec"][0] != "conv_split_bf16x6" and p["exec"].count("conv_split_bf16x6") == 1 and p.get("presplit_buffers", []) == []

@@ -1,6 +1,6 @@
-"""Every host-path variant produces the same bits: the default chain (column-major chunk read by the fused kernel, results
-stored straight into pinned memory, blocking wait), the round-1 chain (GPU transpose + D2H copy + spinning wait), and the
-hipGraph replay of either -- for the fused MLP (C2) and for a plan without those shortcuts (Dense+Softmax, C4)."""
+"""Both launch mechanisms of the host path produce the same bits: direct stream enqueues and the hipGraph replay per (model, rows) --
+for the fused MLP (C2), for Dense+Softmax (C4), through the columnar and the row-major entry, and with the kernels that read
+column-major chunks themselves switched off (GPU transpose in front)."""
 import json
 import os
 import subprocess
@@ -33,9 +33,10 @@ print("RESULT " + json.dumps(out))
 
 VARIANTS = {
     "default": {},
-    "round1_chain": {"INFERA_HOST_WAIT": "spin", "INFERA_HOST_DIRECT_OUT": "0", "INFERA_HOST_FUSED_TRANSPOSE": "0"},
+    "direct": {"INFERA_HIPGRAPH": "0"},
     "hipgraph": {"INFERA_HIPGRAPH": "1"},
-    "hipgraph_round1_chain": {"INFERA_HIPGRAPH": "1", "INFERA_HOST_DIRECT_OUT": "0", "INFERA_HOST_FUSED_TRANSPOSE": "0"},
+    "direct_transposed": {"INFERA_HIPGRAPH": "0", "INFERA_DENSE_XCM": "0", "INFERA_CHAIN_XCM": "0"},
+    "hipgraph_transposed": {"INFERA_HIPGRAPH": "1", "INFERA_DENSE_XCM": "0", "INFERA_CHAIN_XCM": "0"},
 }
 
 

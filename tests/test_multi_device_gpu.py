@@ -97,31 +97,29 @@ def _free_port():
 @pytest.mark.gpu
 def test_bench_two_ranks_sharing_one_gpu(gpu_api):
     """bench.py's N>1 control path (gloo barrier, max over ranks, per-rank row ranges, concurrent host scans)."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--rows", str(2048 * 300), "--share-device", "0", "--e2e-threads", "4", "--e2e-reps", "3"]
+    from tests.conftest import run_bench
+
     env = dict(os.environ)
     env.pop("INFERA_DEVICES", None)
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    line, full = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", str(2048 * 300), "--share-device", "0", "--e2e-threads", "4", "--e2e-reps", "3"],
+                           env=env, launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                              "--master-port", str(_free_port())], timeout=900)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["rows_per_gpu"] == 2048 * 300 and line["config"]["parallelism"] == "row-range x2"
-    e = line["end_to_end"]
+    assert line["end_to_end"]["rows_per_s"] > 0 and line["end_to_end"]["threads"] == 4
+    e = full["end_to_end"]
     assert e["ranks"] == 2 and e["threads_per_rank"] == 4 and len(e["scan_seconds"]) == 3 and e["rows_per_s"] > 0
-    assert "cpu_baseline" not in line  # rank 0 at N=1 only
+    assert "cpu_baseline" not in line and "cpu_baseline" not in full  # rank 0 at N=1 only
 
 
 @pytest.mark.gpu
 def test_bench_host_path_single_process_two_slots(gpu_api):
     """DuckDB's shape: one process, worker threads dealt over two device slots (both on GPU 0 here)."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host-path", "--gpus", "2", "--share-device", "0", "--rows", str(2048 * 400),
-           "--e2e-threads", "8", "--e2e-reps", "3"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["INFERA_DEVICES"] == "0,0"
-    slots = line["end_to_end"]["device_slots"]
+    from tests.conftest import run_bench
+
+    line, full = run_bench(["--host-path", "--gpus", "2", "--share-device", "0", "--rows", str(2048 * 400), "--e2e-threads", "8", "--e2e-reps", "3"], timeout=900)
+    assert line["n_gpus"] == 2 and line["config"]["INFERA_DEVICES"] == "0,0" and line["value_is"] == "end_to_end"
+    slots = full["end_to_end"]["device_slots"]
     assert len(slots) == 2 and all(s["rows_this_run"] > 0 for s in slots)
     assert sum(s["rows_this_run"] for s in slots) == 3 * 2048 * 400
 
@@ -132,32 +130,13 @@ def test_two_slots_on_one_gpu_hold_the_single_slot_rate_at_32_threads(gpu_api):
     path as one slot does -- the 2-slot scan at 32 caller threads used to fall to 66 M rows/s where the 1-slot scan held 94-110.
     Asserted: within 15 % of the 1-slot scan (same process shape, same table size, medians of 5 scans; measured 0.99-1.01 -- the margin is for
     run-to-run noise between two processes, the regression it guards against was 0.6)."""
+    from tests.conftest import run_bench
+
     rates = {}
     for slots in (1, 2):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host-path", "--gpus", str(slots), "--share-device", "0", "--rows", "6000000",
-               "--e2e-threads", "32", "--e2e-reps", "5"]
         env = dict(os.environ)
         env.pop("INFERA_DEVICES", None)
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-        assert p.returncode == 0, p.stderr[-3000:]
-        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-        assert line["value_is"] == "end_to_end" and len(line["end_to_end"]["device_slots"]) == slots
-        rates[slots] = line["end_to_end"]["rows_per_s"]
+        line, full = run_bench(["--host-path", "--gpus", str(slots), "--share-device", "0", "--rows", "6000000", "--e2e-threads", "32", "--e2e-reps", "5"], env=env, timeout=900)
+        assert line["value_is"] == "end_to_end" and len(full["end_to_end"]["device_slots"]) == slots
+        rates[slots] = full["end_to_end"]["rows_per_s"]
     assert rates[2] >= 0.85 * rates[1], rates
-
-
-@pytest.mark.gpu
-def test_bench_host_ceiling_probe_mode(gpu_api):
-    """`bench.py --host-path --gpus 8 --share-device 0 --elide-h2d 2`: the link- and kernel-elided 8-slot probe runs, labels itself as a
-    probe, and serves rows on all 8 slots."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host-path", "--gpus", "8", "--share-device", "0", "--elide-h2d", "2", "--rows", "2000000",
-           "--e2e-threads", "16", "--e2e-reps", "2", "--e2e-numa", "off"]
-    env = dict(os.environ)
-    env.pop("INFERA_DEVICES", None)
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert "PROBE" in line["metric"] and line["value_is"].startswith("host_ceiling_probe") and line["config"]["elide_h2d"] == 2
-    slots = line["end_to_end"]["device_slots"]
-    assert len(slots) == 8 and all(s["rows_this_run"] > 0 for s in slots)
-    assert line["end_to_end"]["host_cpu_cost"]["cpu_us_per_chunk"] > 0

@@ -13,36 +13,10 @@ from infera_amd import synth
 
 
 def torch_resnet18(x, classes, width, dtype):
-    """Mirrors onnx_writer.resnet18 draw for draw (same _WeightStream order)."""
-    ws = W._WeightStream(1234)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    """onnx_writer.resnet18 rebuilt from the same weight stream (oracle/torch_ref.py), BatchNorm as its own operator."""
+    from oracle import torch_ref
 
-    def conv_bn(x, cin, cout, k, stride, pad, relu):
-        w = ws.take((cout, cin, k, k), cin * k * k)
-        scale = (1.0 + 0.1 * ws.take((cout,), 1)).astype(np.float32)
-        beta = (0.1 * ws.take((cout,), 1)).astype(np.float32)
-        mean = (0.1 * ws.take((cout,), 1)).astype(np.float32)
-        var = (1.0 + 0.5 * np.abs(ws.take((cout,), 1))).astype(np.float32)
-        y = F.conv2d(x, t(w), None, stride, pad)
-        y = F.batch_norm(y, t(mean), t(var), t(scale), t(beta), training=False, eps=1e-5)
-        return F.relu(y) if relu else y
-
-    x = conv_bn(x, 3, width, 7, 2, 3, True)
-    x = F.max_pool2d(x, 3, 2, 1)
-    cin = width
-    for stage, cout in enumerate([width, width * 2, width * 4, width * 8]):
-        for blk in range(2):
-            stride = 2 if (stage > 0 and blk == 0) else 1
-            y = conv_bn(x, cin, cout, 3, stride, 1, True)
-            y = conv_bn(y, cout, cout, 3, 1, 1, False)
-            sc = x
-            if stride != 1 or cin != cout:
-                sc = conv_bn(x, cin, cout, 1, stride, 0, False)
-            x, cin = F.relu(y + sc), cout
-    g = x.mean(dim=(2, 3))
-    w = ws.take((cin, classes), cin)
-    b = ws.take((classes,), cin)
-    return g @ t(w) + t(b)
+    return torch_ref.resnet18_forward(torch_ref.resnet18_params(classes, width, dtype), x)
 
 
 @pytest.mark.parametrize("hw,width", [(64, 16), (40, 8)])
