@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -24,9 +25,13 @@ namespace infera_hip {
 
 namespace {
 
-[[noreturn]] void hip_fail(hipError_t e, const char *what) {
-  throw InferaError::onnx(std::string("HIP: ") + what + ": " + hipGetErrorString(e));
-}
+// A failed HIP call.  The text is what a caller sees (error.rs:24-25 "ONNX error: ..."); the code lets the host path tell a device fault
+// (the slot is taken out of service and the call re-dealt to another GPU) from an allocation failure (the call fails, the GPU stays).
+struct HipFault : InferaError {
+  hipError_t code;
+  HipFault(hipError_t e, const char *what) : InferaError(InferaError::onnx(std::string("HIP: ") + what + ": " + hipGetErrorString(e))), code(e) {}
+};
+[[noreturn]] void hip_fail(hipError_t e, const char *what) { throw HipFault(e, what); }
 #define HIP_TRY(expr)                               \
   do {                                              \
     hipError_t _e = (expr);                         \
@@ -49,12 +54,19 @@ struct UnsafeOpGuard {
 constexpr size_t kHostPassBytes = 64ull << 20;     // pinned staging per direction per thread
 constexpr size_t kPipePassBytes = 16ull << 20;     // pass size of the two-slot pipeline used for larger host inputs
 constexpr size_t kScratchBudgetBytes = 8ull << 30; // activation scratch per thread for unfused plans
+// Pinned staging a GPU slot's contexts may hold for big-row (BLOB) batches, all of them together: contexts are pooled for the life of the
+// process and never shrink, so without a bound a host with many worker threads serving image batches locks RAM in proportion to its thread
+// count (24 contexts x 308 MB per GPU).  Each context gets an equal share (budget / INFERA_HOST_CONTEXTS); the pipeline pass
+// shrinks to fit it.  6 GiB / 24 = 256 MB = 221 ResNet-sized images per pass and direction (256 was the measured optimum: -1 %).
+constexpr size_t kPinnedBudgetPerSlot = 6ull << 30;
+std::atomic<uint64_t> g_pinned_bytes[64];  // per device slot: pinned staging held by its contexts right now (infera_hip_get_devices)
 
 // ---------------------------------------------------------------------------------------------
 // per-thread, per-device execution context (stream + staging + scratch)
 // ---------------------------------------------------------------------------------------------
 struct ThreadCtx {
   int device = -1;
+  int slot = 0;
   hipStream_t stream = nullptr;
   float *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr, *scratch = nullptr, *dev_cm = nullptr;
   size_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0, scratch_cap = 0, dev_cm_cap = 0;  // bytes
@@ -149,9 +161,11 @@ struct ThreadCtx {
     drop_graphs();
     if (p) HIP_TRY(hipHostFree(p));
     p = nullptr;
+    g_pinned_bytes[size_t(slot) % 64].fetch_sub(cap, std::memory_order_relaxed);
     cap = 0;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), bytes, hipHostMallocDefault));  // (host-coherent: kernels may store results into it)
     cap = bytes;
+    g_pinned_bytes[size_t(slot) % 64].fetch_add(bytes, std::memory_order_relaxed);
   }
   void ensure_dev(float *&p, size_t &cap, size_t bytes) {
     if (bytes <= cap) return;
@@ -212,6 +226,7 @@ ThreadCtx &ctx_for_slot(int slot) {
     if (!c) {
       auto *n = new ThreadCtx();
       n->device = ds.ids[size_t(slot)];
+      n->slot = slot;
       hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
       if (e != hipSuccess) {
         delete n;
@@ -268,6 +283,7 @@ struct HostLease {
     }
     auto *n = new ThreadCtx();
     n->device = ds.ids[size_t(slot)];
+    n->slot = slot;
     const hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
       delete n;
@@ -339,7 +355,46 @@ int current_numa_node() {
 // caller threads whose home is slot i right now (a thread leaves when it exits)
 std::atomic<int> g_slot_threads[64];
 
+// Device-fault handling (SURVEY 5 "failure detection"): a HIP error on the host path other than an allocation failure takes the slot out
+// of service -- its callers are re-dealt to the remaining slots and the failed chunk is run again there (the caller's buffers are only
+// read, so a chunk can be staged twice); infera_hip_get_devices reports the slot as unhealthy with the error text.  With no healthy slot
+// left the error goes to the caller as before (status -1 + last error, error.rs:13-61).
+std::atomic<bool> g_slot_unhealthy[64];
+std::mutex g_fault_mu;
+std::string g_slot_fault[64];
+int healthy_slots() {
+  int n = 0;
+  for (size_t i = 0; i < devices().ids.size() && i < 64; i++) n += !g_slot_unhealthy[i].load(std::memory_order_acquire);
+  return n;
+}
+void mark_slot_unhealthy(int slot, const std::string &why) {
+  {
+    std::lock_guard<std::mutex> lk(g_fault_mu);
+    if (g_slot_fault[size_t(slot) % 64].empty()) g_slot_fault[size_t(slot) % 64] = why;
+  }
+  if (!g_slot_unhealthy[size_t(slot) % 64].exchange(true, std::memory_order_acq_rel))
+    log_msg(0, "device slot " + std::to_string(slot) + " (HIP device " + std::to_string(devices().ids[size_t(slot)]) + ") taken out of service: " + why);
+}
+// TEST HOOK (tests/test_multi_device_gpu.py): INFERA_FAULT_INJECT=<slot>:<n> makes every host-ABI call on that slot after its n-th fail as a
+// launch failure would.  Read once; unset (always, outside that test) it costs one relaxed load per call.
+bool fault_injected(int slot) {
+  static const std::pair<int, long> inj = [] {
+    const char *e = getenv("INFERA_FAULT_INJECT");
+    int sl = -1;
+    long n = 0;
+    if (e && std::sscanf(e, "%d:%ld", &sl, &n) == 2) return std::make_pair(sl, n);
+    return std::make_pair(-1, 0L);
+  }();
+  if (inj.first != slot) return false;
+  static std::atomic<long> calls{0};
+  return calls.fetch_add(1, std::memory_order_relaxed) >= inj.second;
+}
+
 int home_slot() {
+  if (t_holder.home_slot >= 0 && g_slot_unhealthy[size_t(t_holder.home_slot) % 64].load(std::memory_order_acquire)) {  // re-deal
+    g_slot_threads[size_t(t_holder.home_slot) % 64].fetch_sub(1, std::memory_order_relaxed);
+    t_holder.home_slot = -1;
+  }
   if (t_holder.home_slot < 0) {
     const auto &ds = devices();
     const size_t n = ds.ids.size();
@@ -348,7 +403,8 @@ int home_slot() {
     // imbalance to one thread per slot; the knob switches the preference off altogether)
     const int node = n > 1 && Config::get().numa_slots ? current_numa_node() : -1;
     std::vector<int> load(n);
-    for (size_t i = 0; i < n; i++) load[i] = g_slot_threads[i % 64].load(std::memory_order_relaxed);
+    for (size_t i = 0; i < n; i++)  // (a slot that is out of service is never anybody's home while another one works)
+      load[i] = g_slot_unhealthy[i % 64].load(std::memory_order_acquire) ? (1 << 28) : g_slot_threads[i % 64].load(std::memory_order_relaxed);
     t_holder.home_slot = choose_slot_balanced(ds.numa, load, node);
     g_slot_threads[size_t(t_holder.home_slot) % 64].fetch_add(1, std::memory_order_relaxed);
   }
@@ -683,29 +739,6 @@ void schedule(LoadedModel &m) {
       if (gp.mvalid == 0 && kern::conv2d_stem_split6_supported(gp, kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)})) m.stem_split6[i] = 1;
     }
   }
-  // Activations stored PRE-SPLIT (round 4; conv_split.hip "S3"): a tensor written by a split convolution and read ONLY by split convolutions
-  // -- as their input, or as the residual their epilogue adds -- and by at least one of them as its input is stored as three bf16 planes per
-  // 16-channel group (1.5x the floats) by its producer's epilogue; its consumers load matrix-instruction operands instead of cutting every
-  // activation once per tap and feature slice.  Exact both ways, so the plan's results do not change by a bit.  Residual-only tensors (a
-  // downsample branch) stay fp32: 4 bytes per value instead of 6.  INFERA_CONV_PRESPLIT=0 (read when a model is scheduled): fp32 everywhere.
-  m.buf_s3.assign(m.plan.buf_per_row.size(), 0);
-  if (ScheduleKnobs::read().conv_presplit) {
-    const auto eff0 = effective_steps(m);
-    std::vector<int> writer(m.plan.buf_per_row.size(), -1), as_input(m.plan.buf_per_row.size(), 0), other(m.plan.buf_per_row.size(), 0);
-    for (const auto &e : eff0) {
-      if (writer[size_t(e.writes)] >= 0) other[size_t(e.writes)] = 1;  // (several writers: a Concat output)
-      writer[size_t(e.writes)] = e.idx;
-      const bool split = m.exec[size_t(e.idx)] == ExecKind::ConvTiled && m.conv_split6[size_t(e.idx)];
-      for (size_t k = 0; k < e.reads.size(); k++) {
-        if (!split) other[size_t(e.reads[k])] = 1;
-        else if (k == 0) as_input[size_t(e.reads[k])] = 1;
-      }
-    }
-    for (size_t b = 1; b < m.buf_s3.size(); b++)
-      m.buf_s3[b] = int(b) != m.plan.out_buf && writer[b] >= 0 && m.exec[size_t(writer[b])] == ExecKind::ConvTiled && m.conv_split6[size_t(writer[b])] &&
-                    as_input[b] && !other[b];
-  }
-
   // scratch slots by liveness: a slot is reused once its buffer has been read for the last time
   auto eff = effective_steps(m);
   {  // the served output: one writer (a fused streaming kernel that only stores it), no reader
@@ -779,7 +812,7 @@ void schedule(LoadedModel &m) {
       m.slot_per_row.push_back(0);
     }
     m.slot_of_buf[size_t(b)] = chosen;
-    m.slot_per_row[size_t(chosen)] = std::max(m.slot_per_row[size_t(chosen)], m.plan.buf_per_row[size_t(b)] / (m.buf_s3[size_t(b)] ? 2 : 1) * (m.buf_s3[size_t(b)] ? 3 : 1));
+    m.slot_per_row[size_t(chosen)] = std::max(m.slot_per_row[size_t(chosen)], m.plan.buf_per_row[size_t(b)]);
     slot_free_after[size_t(chosen)] = last_read[size_t(b)] < 0 ? int(e) : last_read[size_t(b)];
   }
   m.scratch_per_row = 0;
@@ -1004,9 +1037,8 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
           const int fj = m.conv_fused_add[i];
           const kern::ConvGeom gp = kern::conv2d_tiled_geom(g);
           if (m.conv_split6[i]) {
-            const int ob = fj >= 0 ? st[size_t(fj)].out : x.out, rb = fj >= 0 ? m.conv_residual_buf[i] : -1;
-            kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, rb >= 0 ? buf(rb) : nullptr, buf(ob), nr, gp, act_of(fj >= 0 ? st[size_t(fj)] : x),
-                                m.buf_s3[size_t(x.in0)], m.buf_s3[size_t(ob)], rb >= 0 && m.buf_s3[size_t(rb)]);
+            if (fj >= 0) kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]));
+            else kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, gp, act_of(x));
             continue;
           }
           if (fj >= 0) kern::conv2d_tiled(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]));
@@ -1173,6 +1205,8 @@ int choose_slot_balanced(const std::vector<int> &slot_numa, const std::vector<in
   return int(g);
 }
 
+uint64_t slot_pinned_bytes(int slot) { return g_pinned_bytes[size_t(slot) % 64].load(std::memory_order_relaxed); }
+
 void slot_counters(int slot, uint64_t *calls, uint64_t *rows) {
   *calls = g_slot_calls[size_t(slot) % 64].load(std::memory_order_relaxed);
   *rows = g_slot_rows[size_t(slot) % 64].load(std::memory_order_relaxed);
@@ -1325,12 +1359,31 @@ bool colmajor_direct_ok(const LoadedModel &m, int64_t rows) {
 
 namespace {
 bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn *dfill, float *h_out, int64_t rows, bool col_major);
+// the call on the thread's home slot; a device fault there takes the slot out of service and the call goes to the next healthy one
+bool run_host_redealt(const LoadedModel &m, const FillFn &fill, const DeviceFillFn *dfill, float *h_out, int64_t rows, bool col_major) {
+  for (;;) {
+    const int slot = home_slot();
+    try {
+      return run_host_impl(m, fill, dfill, h_out, rows, col_major);
+    } catch (const HipFault &f) {
+      (void)hipGetLastError();
+      if (f.code == hipErrorOutOfMemory || f.code == hipErrorMemoryAllocation) throw;  // the GPU is fine, this call was too big for what is free
+      mark_slot_unhealthy(slot, f.what());
+      if (healthy_slots() == 0) throw;
+    }
+  }
+}
 }
 void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major) {
-  (void)run_host_impl(m, fill, nullptr, h_out, rows, col_major);
+  (void)run_host_redealt(m, fill, nullptr, h_out, rows, col_major);
 }
 bool run_host_device_fill(const LoadedModel &m, const DeviceFillFn &dfill, float *h_out, int64_t rows) {
-  return run_host_impl(m, FillFn(), &dfill, h_out, rows, /*col_major=*/true);
+  return run_host_redealt(m, FillFn(), &dfill, h_out, rows, /*col_major=*/true);
+}
+bool slot_health(int slot, std::string *fault) {
+  std::lock_guard<std::mutex> lk(g_fault_mu);
+  if (fault) *fault = g_slot_fault[size_t(slot) % 64];
+  return !g_slot_unhealthy[size_t(slot) % 64].load(std::memory_order_acquire);
 }
 
 namespace {
@@ -1346,6 +1399,7 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
   HostLease lease(slot);
   const uint64_t t_leased = now_ns();
   ThreadCtx &ctx = *lease.c;
+  if (fault_injected(slot)) hip_fail(hipErrorLaunchFailure, "injected fault (INFERA_FAULT_INJECT)");
   const DeviceModel &dm = device_model(m, slot);
   g_slot_calls[size_t(slot) % 64].fetch_add(1, std::memory_order_relaxed);
   g_slot_rows[size_t(slot) % 64].fetch_add(uint64_t(rows), std::memory_order_relaxed);
@@ -1374,11 +1428,11 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
     // many more of them per pass, because a 27-image pass leaves the conv kernels half empty
     // (ResNet-18, 16 threads x 256-image calls: 18.5k img/s with 16 MB passes, 29.7k -- the resident rate -- with 64 MB).
     const int64_t by_bytes = std::max<int64_t>(1, int64_t(kPipePassBytes / widest));
-    // (round 3: 256 such rows per pass, up to 256 MB -- 96-image passes left C5 at 0.90 of its resident rate end to end, 256-image passes
-    // reach 0.96: 31.97k -> 34.0k img/s at 16 callers, 33.6k at 192, 34.1k at 384; INFERA_BLOB_PASS_ROWS for A/B.  Costs 2 x 154 MB of
-    // pinned staging per context that serves image batches.)
-    static const int64_t big_row_pass = [] { const char *e = getenv("INFERA_BLOB_PASS_ROWS"); const int v = e ? atoi(e) : 256; return int64_t(v < 1 ? 1 : v); }();
-    const int64_t by_rows = std::min<int64_t>(big_row_pass, std::max<int64_t>(1, int64_t(4 * kHostPassBytes / widest)));
+    // (round 3: up to 256 such rows per pass -- 96-image passes left C5 at 0.90 of its resident rate end to end, 256-image passes reach 0.96:
+    // 31.97k -> 34.0k img/s at 16 callers, 33.6k at 192, 34.1k at 384.  The pinned staging this costs -- two passes of inputs and two of
+    // results per context -- is bounded by the context's share of kPinnedBudgetPerSlot: 221 images of 602 KB per pass.)
+    const int64_t share_rows = int64_t(kPinnedBudgetPerSlot / size_t(std::max(1, Config::get().host_contexts)) / (2 * (in_row + out_row)));
+    const int64_t by_rows = std::min<int64_t>(std::min<int64_t>(256, std::max<int64_t>(16, share_rows)), std::max<int64_t>(1, int64_t(4 * kHostPassBytes / widest)));
     // equal passes, at least two when the call is worth cutting: the CPU copy of pass 2 must overlap the GPU's pass 1 also when ONE
     // caller brings one batch (256 images as 128 + 128, not as a single pass with nothing to overlap)
     const int64_t p0 = std::min<int64_t>(rows, std::max(by_bytes, by_rows));
@@ -1568,38 +1622,52 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
 }  // namespace
 
 // ---- registered host memory (zero-copy host path) -----------------------------------------------------------------------
-// The runtime pins whole pages, callers register byte ranges (numpy arrays, malloc'ed buffers: neighbours on the heap share pages).
-// So a registered RANGE (what lookups test against) points at a page BLOCK (what hipHostRegister was called on); ranges whose page
-// spans touch are served by ONE block: the blocks they overlap are replaced by a registration of their union (contiguous, because
-// they overlap), and a block lives until its last range is unregistered.  Replacing a block unmaps it for a moment, so calls that
-// read registered memory hold g_zc_inflight shared from their lookup to their completion and (un)registration takes it exclusively --
-// which also makes unregistering safe against calls that are still in flight.
+// The runtime pins whole pages, callers register byte ranges (numpy arrays, malloc'ed buffers, a database allocator's blocks: neighbours on
+// the heap share pages).  So a registered RANGE (what lookups test against) is covered by one or more page BLOCKS (what hipHostRegister
+// was called on): registering a range pins only the pages no earlier block covers -- a block is never replaced or re-registered once it
+// exists (round 3 merged neighbours into one new registration, which unmapped memory under running calls and forced every (un)registration
+// to drain ALL zero-copy calls in flight).  A block lives until the last range on its pages is unregistered; then it leaves the index at
+// once and is unmapped as soon as the calls that PINNED it (found it in a lookup and have not finished) are done -- only those calls are
+// waited for, every other call and every registration proceeds.  Lookups are O(log n) under a shared lock; the writers serialise among
+// themselves on a separate mutex and hold the index lock only for the map update, not for the hipHostRegister / hipHostUnregister calls.
 namespace {
 struct PageBlock {
-  uintptr_t pb, pe;    // page-aligned span handed to hipHostRegister
-  intptr_t dev_delta;  // device-visible address = host address + dev_delta
-  int refs;            // registered ranges inside
+  uintptr_t pb, pe;              // page-aligned span handed to hipHostRegister
+  intptr_t dev_delta;            // device-visible address = host address + dev_delta (the same on every selected GPU: checked)
+  int refs = 0;                  // registered ranges that touch these pages (under g_reg_mu)
+  std::atomic<int> readers{0};   // zero-copy calls in flight that resolved an address inside this block
 };
 struct HostRange {
-  uintptr_t base, end;  // as registered by the caller
-  PageBlock *block;
+  uintptr_t end;
+  bool usable;  // all covering blocks share one device delta (always, on the systems seen so far)
+  intptr_t dev_delta;
 };
-std::shared_mutex g_ranges_mu;      // g_ranges / g_blocks
-std::shared_mutex g_zc_inflight;    // shared: a call reading registered memory is in flight
-std::vector<HostRange> g_ranges;    // sorted by base, non-overlapping
-std::vector<std::unique_ptr<PageBlock>> g_blocks;
+std::mutex g_reg_mu;                                            // serialises register / unregister
+std::shared_mutex g_index_mu;                                   // g_ranges / g_blocks (readers: lookups)
+std::map<uintptr_t, HostRange> g_ranges;                        // by base; non-overlapping
+std::map<uintptr_t, std::shared_ptr<PageBlock>> g_blocks;       // by pb; non-overlapping
 std::atomic<size_t> g_nranges{0};
 
+// pins [pb, pe) and returns its device delta, the same on every selected GPU or an error
 intptr_t hip_register_span(uintptr_t pb, uintptr_t pe) {
+  const auto &ds = devices();
   // portable + mapped: visible to every selected GPU; the pages stay where they are (no copy), pinned until unregistered
+  HIP_TRY(hipSetDevice(ds.ids[0]));
   HIP_TRY(hipHostRegister(reinterpret_cast<void *>(pb), pe - pb, hipHostRegisterPortable | hipHostRegisterMapped));
-  void *dptr = nullptr;
-  const hipError_t ge = hipHostGetDevicePointer(&dptr, reinterpret_cast<void *>(pb), 0);
-  if (ge != hipSuccess) {
-    (void)hipHostUnregister(reinterpret_cast<void *>(pb));
-    hip_fail(ge, "hipHostGetDevicePointer");
+  intptr_t delta = 0;
+  for (size_t i = 0; i < ds.ids.size(); i++) {
+    void *dptr = nullptr;
+    hipError_t ge = hipSetDevice(ds.ids[i]);
+    if (ge == hipSuccess) ge = hipHostGetDevicePointer(&dptr, reinterpret_cast<void *>(pb), 0);
+    const intptr_t d = intptr_t(reinterpret_cast<uintptr_t>(dptr)) - intptr_t(pb);
+    if (ge != hipSuccess || (i > 0 && d != delta)) {
+      (void)hipHostUnregister(reinterpret_cast<void *>(pb));
+      if (ge != hipSuccess) hip_fail(ge, "hipHostGetDevicePointer");
+      throw InferaError::onnx("registered host memory has different device addresses on different GPUs");
+    }
+    delta = d;
   }
-  return intptr_t(reinterpret_cast<uintptr_t>(dptr)) - intptr_t(pb);
+  return delta;
 }
 }  // namespace
 
@@ -1608,105 +1676,143 @@ void register_host_memory(const void *base, size_t bytes) {
   const auto &ds = devices();
   if (ds.ids.empty()) throw InferaError::onnx("HIP backend unavailable: " + ds.why);
   const uintptr_t b = reinterpret_cast<uintptr_t>(base), e = b + bytes;
-  uintptr_t pb = b & ~uintptr_t(4095), pe = (e + 4095) & ~uintptr_t(4095);
-  std::unique_lock<std::shared_mutex> drained(g_zc_inflight);  // no call is reading registered memory while blocks may be replaced
-  std::unique_lock<std::shared_mutex> lk(g_ranges_mu);
-  for (const auto &r : g_ranges)
-    if (b < r.end && r.base < e) throw InferaError::onnx("host memory range overlaps a registered range");
-  UnsafeOpGuard guard;
-  HIP_TRY(hipSetDevice(ds.ids[0]));
-  std::vector<PageBlock *> hit;  // blocks whose pages the new span touches
-  for (auto &blk : g_blocks)
-    if (pb < blk->pe && blk->pb < pe) hit.push_back(blk.get());
-  PageBlock *target = nullptr;
-  if (hit.size() == 1 && hit[0]->pb <= pb && pe <= hit[0]->pe) {
-    target = hit[0];  // every page is already pinned by a neighbour's block
-    target->refs++;
-  } else {
-    int refs = 1;
-    for (PageBlock *h : hit) {
-      pb = std::min(pb, h->pb);
-      pe = std::max(pe, h->pe);
-      refs += h->refs;
-    }
-    for (PageBlock *h : hit) (void)hipHostUnregister(reinterpret_cast<void *>(h->pb));
-    intptr_t delta = 0;
-    try {
-      delta = hip_register_span(pb, pe);
-    } catch (...) {
-      // put the old blocks back (their pages were registrable a moment ago); ranges keep pointing at them
-      for (PageBlock *h : hit) {
-        try {
-          h->dev_delta = hip_register_span(h->pb, h->pe);
-        } catch (...) {
-        }
-      }
-      throw;
-    }
-    auto fresh = std::make_unique<PageBlock>(PageBlock{pb, pe, delta, refs});
-    target = fresh.get();
-    for (auto &r : g_ranges)
-      if (std::find(hit.begin(), hit.end(), r.block) != hit.end()) r.block = target;
-    g_blocks.erase(std::remove_if(g_blocks.begin(), g_blocks.end(), [&](const std::unique_ptr<PageBlock> &x) { return std::find(hit.begin(), hit.end(), x.get()) != hit.end(); }),
-                   g_blocks.end());
-    g_blocks.push_back(std::move(fresh));
+  const uintptr_t pb = b & ~uintptr_t(4095), pe = (e + 4095) & ~uintptr_t(4095);
+  std::lock_guard<std::mutex> writer(g_reg_mu);
+  {  // (nobody else mutates the index while g_reg_mu is held: reading it unlocked is safe here)
+    auto it = g_ranges.upper_bound(b);
+    if (it != g_ranges.end() && it->first < e) throw InferaError::onnx("host memory range overlaps a registered range");
+    if (it != g_ranges.begin() && std::prev(it)->second.end > b) throw InferaError::onnx("host memory range overlaps a registered range");
   }
-  HostRange r{b, e, target};
-  g_ranges.insert(std::upper_bound(g_ranges.begin(), g_ranges.end(), r, [](const HostRange &x, const HostRange &y) { return x.base < y.base; }), r);
-  g_nranges.store(g_ranges.size(), std::memory_order_release);
+  // pages of [pb, pe) that no block covers yet -> new blocks, pinned OUTSIDE the index lock
+  std::vector<std::shared_ptr<PageBlock>> fresh, covering;
+  UnsafeOpGuard guard;
+  try {
+    uintptr_t at = pb;
+    auto it = g_blocks.upper_bound(pb);
+    if (it != g_blocks.begin() && std::prev(it)->second->pe > pb) --it;
+    for (; at < pe; ++it) {
+      const uintptr_t gap_end = it == g_blocks.end() || it->second->pb >= pe ? pe : it->second->pb;
+      if (gap_end > at) {
+        auto blk = std::make_shared<PageBlock>();
+        blk->pb = at;
+        blk->pe = gap_end;
+        blk->dev_delta = hip_register_span(at, gap_end);
+        fresh.push_back(blk);
+        covering.push_back(blk);
+      }
+      if (it == g_blocks.end() || it->second->pb >= pe) break;
+      covering.push_back(it->second);
+      at = it->second->pe;
+    }
+  } catch (...) {
+    for (auto &blk : fresh) (void)hipHostUnregister(reinterpret_cast<void *>(blk->pb));  // nothing else changed: the index is as it was
+    throw;
+  }
+  HostRange r{e, true, covering.front()->dev_delta};
+  for (auto &blk : covering) r.usable = r.usable && blk->dev_delta == r.dev_delta;
+  {
+    std::unique_lock<std::shared_mutex> lk(g_index_mu);
+    for (auto &blk : fresh) g_blocks.emplace(blk->pb, blk);
+    for (auto &blk : covering) blk->refs++;
+    g_ranges.emplace(b, r);
+    g_nranges.store(g_ranges.size(), std::memory_order_release);
+  }
+  if (!r.usable) log_msg(1, "registered host range is covered by blocks with different device addresses: its chunks take the staged path");
 }
 
 bool unregister_host_memory(const void *base) {
   const uintptr_t b = reinterpret_cast<uintptr_t>(base);
-  std::unique_lock<std::shared_mutex> drained(g_zc_inflight);  // (waits for calls that still read the range)
-  std::unique_lock<std::shared_mutex> lk(g_ranges_mu);
-  for (size_t i = 0; i < g_ranges.size(); i++)
-    if (g_ranges[i].base == b) {
-      PageBlock *blk = g_ranges[i].block;
-      g_ranges.erase(g_ranges.begin() + long(i));
-      g_nranges.store(g_ranges.size(), std::memory_order_release);
-      if (--blk->refs == 0) {  // (a block shared with neighbours stays pinned until the last of them goes)
-        UnsafeOpGuard guard;
-        (void)hipHostUnregister(reinterpret_cast<void *>(blk->pb));
-        g_blocks.erase(std::remove_if(g_blocks.begin(), g_blocks.end(), [&](const std::unique_ptr<PageBlock> &x) { return x.get() == blk; }), g_blocks.end());
+  std::lock_guard<std::mutex> writer(g_reg_mu);
+  std::vector<std::shared_ptr<PageBlock>> dead;
+  {
+    std::unique_lock<std::shared_mutex> lk(g_index_mu);
+    auto rit = g_ranges.find(b);
+    if (rit == g_ranges.end()) return false;
+    const uintptr_t pb = b & ~uintptr_t(4095), pe = (rit->second.end + 4095) & ~uintptr_t(4095);
+    g_ranges.erase(rit);
+    g_nranges.store(g_ranges.size(), std::memory_order_release);
+    auto it = g_blocks.upper_bound(pb);
+    if (it != g_blocks.begin() && std::prev(it)->second->pe > pb) --it;
+    while (it != g_blocks.end() && it->second->pb < pe) {
+      if (--it->second->refs == 0) {  // (a block shared with neighbours stays pinned until the last of them goes)
+        dead.push_back(it->second);
+        it = g_blocks.erase(it);     // no later lookup can find it
+      } else {
+        ++it;
       }
-      return true;
     }
-  return false;
-}
-
-const void *lookup_host_memory(const void *p, size_t bytes) {
-  if (g_nranges.load(std::memory_order_acquire) == 0) return nullptr;
-  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-  std::shared_lock<std::shared_mutex> lk(g_ranges_mu);
-  auto it = std::upper_bound(g_ranges.begin(), g_ranges.end(), a, [](uintptr_t v, const HostRange &r) { return v < r.base; });
-  if (it == g_ranges.begin()) return nullptr;
-  --it;
-  if (a < it->base || a + bytes > it->end) return nullptr;
-  return reinterpret_cast<const void *>(intptr_t(a) + it->block->dev_delta);
-}
-
-bool lookup_host_memory_many(size_t n, const void *const *ptrs, const size_t *bytes, const void **out) {
-  if (g_nranges.load(std::memory_order_acquire) == 0) return false;
-  std::shared_lock<std::shared_mutex> lk(g_ranges_mu);  // one lock for the whole chunk's columns
-  const HostRange *hint = nullptr;                      // (columns of one table usually lie in one range)
-  for (size_t i = 0; i < n; i++) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(ptrs[i]);
-    if (!hint || a < hint->base || a + bytes[i] > hint->end) {
-      auto it = std::upper_bound(g_ranges.begin(), g_ranges.end(), a, [](uintptr_t v, const HostRange &r) { return v < r.base; });
-      if (it == g_ranges.begin()) return false;
-      --it;
-      if (a < it->base || a + bytes[i] > it->end) return false;
-      hint = &*it;
+  }
+  // unmap the dead blocks once the calls that pinned them have finished (a chunk's time, ~100 us); nobody else waits for anything
+  UnsafeOpGuard guard;
+  for (auto &blk : dead) {
+    for (int spin = 0; blk->readers.load(std::memory_order_acquire) > 0; spin++) {
+      if (spin < 64) std::this_thread::yield();
+      else std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
-    out[i] = reinterpret_cast<const void *>(intptr_t(a) + hint->block->dev_delta);
+    (void)hipHostUnregister(reinterpret_cast<void *>(blk->pb));
   }
   return true;
 }
 
+// Resolves n host runs to device-visible addresses; every run must lie inside ONE registered range.  The blocks under the runs are PINNED
+// (reader count) until the returned guard dies -- hold it until the GPU has finished reading.  O(log n) per run, one shared lock.
+ZeroCopyPins::~ZeroCopyPins() {
+  for (size_t i = 0; i < count; i++) static_cast<PageBlock *>(blocks[i].get())->readers.fetch_sub(1, std::memory_order_release);
+}
+
+bool lookup_host_memory_many(size_t n, const void *const *ptrs, const size_t *bytes, const void **out, ZeroCopyPins &pins) {
+  if (g_nranges.load(std::memory_order_acquire) == 0) return false;
+  std::shared_lock<std::shared_mutex> lk(g_index_mu);
+  uintptr_t hb = 0, he = 0;  // the range the previous run lay in (columns of one table usually share it)
+  intptr_t hd = 0;
+  PageBlock *last = nullptr;  // the block pinned last (consecutive runs usually share it too)
+  for (size_t i = 0; i < n; i++) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptrs[i]), ae = a + bytes[i];
+    if (!(a >= hb && ae <= he)) {
+      auto it = g_ranges.upper_bound(a);
+      if (it == g_ranges.begin()) return false;
+      --it;
+      if (ae > it->second.end || !it->second.usable) return false;
+      hb = it->first;
+      he = it->second.end;
+      hd = it->second.dev_delta;
+    }
+    out[i] = reinterpret_cast<const void *>(intptr_t(a) + hd);
+    // pin every block under [a, ae) (one, unless the run straddles a block border)
+    for (uintptr_t at = a; at < ae;) {
+      if (last && at >= last->pb && at < last->pe) {
+        at = last->pe;
+        continue;
+      }
+      auto bit = g_blocks.upper_bound(at);
+      if (bit == g_blocks.begin()) return false;
+      --bit;
+      if (at >= bit->second->pe) return false;  // (cannot happen for a registered range)
+      if (pins.count == ZeroCopyPins::kMax) return false;  // more blocks than a chunk is expected to touch: take the staged path
+      bit->second->readers.fetch_add(1, std::memory_order_acquire);
+      pins.blocks[pins.count++] = bit->second;
+      last = bit->second.get();
+      at = last->pe;
+    }
+  }
+  return true;
+}
+
+const void *lookup_host_memory(const void *p, size_t bytes) {
+  const void *out = nullptr;
+  ZeroCopyPins pins;
+  return lookup_host_memory_many(1, &p, &bytes, &out, pins) ? out : nullptr;  // (address only: the pin ends with this call)
+}
+
 size_t registered_host_ranges() { return g_nranges.load(std::memory_order_acquire); }
 
-std::shared_lock<std::shared_mutex> zero_copy_in_flight() { return std::shared_lock<std::shared_mutex>(g_zc_inflight); }
+void copy_rect_to_device(hipStream_t stream, float *dst, const void *src, size_t src_pitch, size_t width, size_t height) {
+  HIP_TRY(hipMemcpy2DAsync(dst, width, src, src_pitch, width, height, hipMemcpyHostToDevice, stream));
+}
+bool zero_copy_rect_enabled() {
+  static const bool on = [] { const char *e = getenv("INFERA_ZERO_COPY_RECT"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
 
 void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows) {
   const size_t in_per_row = size_t(m.plan.in_per_row());
@@ -1739,16 +1845,6 @@ std::string LoadedModel::describe_json() const {
   o << "]";
   if (std::find(conv_split6.begin(), conv_split6.end(), char(1)) != conv_split6.end())
     o << ",\"conv_precision\":\"bf16x6 (bf16 matrix cores, operands cut exactly into three parts, six partial products, fp32 accumulate)\"";
-  if (std::find(buf_s3.begin(), buf_s3.end(), char(1)) != buf_s3.end()) {
-    o << ",\"presplit_buffers\":[";
-    bool first = true;
-    for (size_t b = 0; b < buf_s3.size(); b++)
-      if (buf_s3[b]) {
-        o << (first ? "" : ",") << b;
-        first = false;
-      }
-    o << "]";
-  }
   for (size_t i = 0; i < exec.size(); i++)
     if (exec[i] == ExecKind::Mlp3Head)
       o << ",\"fused_kernel\":" << json_str(kern::mlp3_kernel_name(mlp3_shape)) << ",\"precision\":\"fp32\"";

@@ -37,8 +37,11 @@ int choose_slot(const std::vector<int> &slot_numa, int thread_node, uint64_t tic
 // the policy home_slot() applies: NUMA-local first, bounded by load (slot_threads[i] = caller threads homed on slot i)
 int choose_slot_balanced(const std::vector<int> &slot_numa, const std::vector<int> &slot_threads, int thread_node);
 const DeviceSet &devices();
+// false once a HIP error took the slot out of service (its callers were re-dealt to the other slots); *fault = the error text
+bool slot_health(int slot, std::string *fault);
 // host-ABI calls / table rows served so far by device slot `slot` (index into DeviceSet::ids)
 void slot_counters(int slot, uint64_t *calls, uint64_t *rows);
+uint64_t slot_pinned_bytes(int slot);  // pinned staging the slot's contexts hold right now
 // {"passes":n,"lease_ns":..,"gather_ns":..,"gate_ns":..,"enqueue_ns":..,"wait_ns":..,"copy_out_ns":..}: where the wall
 // time of the host-ABI calls went so far (single-pass path), summed over all caller threads
 std::string host_phase_json();
@@ -103,7 +106,6 @@ class LoadedModel {
   std::vector<int> conv_residual_buf;
   std::vector<char> conv_split6;  // ConvTiled steps on conv2d_split6 (default; INFERA_PRECISION=fp32 leaves them on the exact-fp32 kernels)
   std::vector<char> stem_split6;  // ConvPatch + fused MaxPool steps that run conv2d_stem_split6 (same arithmetic)
-  std::vector<char> buf_s3;       // per activation buffer: stored pre-split (three bf16 planes per 16-channel group, 1.5x the floats) -- schedule()
   std::vector<int> slot_of_buf;        // scratch slot per activation buffer (-1: external in/out)
   std::vector<int64_t> slot_per_row;   // floats per row of each scratch slot
   int64_t scratch_per_row = 0;         // sum over slots
@@ -133,17 +135,28 @@ void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64
 // false: the caller then stages through the CPU as usual).
 using DeviceFillFn = std::function<void(hipStream_t stream, float *dst, int64_t row0, int64_t nrows)>;
 bool run_host_device_fill(const LoadedModel &m, const DeviceFillFn &dfill, float *h_out, int64_t rows);
-// Registered host memory: [base, base + bytes) is pinned and mapped into every selected GPU (hipHostRegister, whole pages: ranges
-// that share a page share one registration); lookup() returns the device-visible address of `p` when [p, p + bytes) lies inside one
-// registered range, else nullptr.  Thread-safe; (un)registering waits for the zero-copy calls in flight.
+// Registered host memory: [base, base + bytes) is pinned and mapped into every selected GPU (hipHostRegister on whole pages; pages a
+// neighbouring range already pinned are shared, never re-registered).  Thread-safe; registering never waits for calls in flight, and
+// unregistering waits only for the calls that are reading the pages it unmaps.
 void register_host_memory(const void *base, size_t bytes);
 bool unregister_host_memory(const void *base);
-const void *lookup_host_memory(const void *p, size_t bytes);
-// the same for n runs under ONE lock: false unless every run lies inside a registered range
-bool lookup_host_memory_many(size_t n, const void *const *ptrs, const size_t *bytes, const void **out);
+// Pins (reader counts) on the page blocks a zero-copy call reads: hold until the GPU has finished with them.
+struct ZeroCopyPins {
+  static constexpr size_t kMax = 520;  // (kMaxZeroCopyCols runs, a few of them straddling a block border)
+  std::shared_ptr<void> blocks[kMax];
+  size_t count = 0;
+  ZeroCopyPins() = default;
+  ZeroCopyPins(const ZeroCopyPins &) = delete;
+  ZeroCopyPins &operator=(const ZeroCopyPins &) = delete;
+  ~ZeroCopyPins();
+};
+// device-visible addresses of n host runs, each inside ONE registered range (false otherwise), their blocks pinned in `pins`; O(log n) per run
+bool lookup_host_memory_many(size_t n, const void *const *ptrs, const size_t *bytes, const void **out, ZeroCopyPins &pins);
+const void *lookup_host_memory(const void *p, size_t bytes);  // (address only, no pin: tests / diagnostics)
 size_t registered_host_ranges();
-// held (shared) by a call from its lookup until the GPU has finished reading the registered memory: (un)registration waits for it
-std::shared_lock<std::shared_mutex> zero_copy_in_flight();
+// `height` runs of `width` bytes, `src_pitch` bytes apart in REGISTERED host memory -> one column-major chunk at dst, as ONE 2-D copy on `stream`
+void copy_rect_to_device(hipStream_t stream, float *dst, const void *src, size_t src_pitch, size_t width, size_t height);
+bool zero_copy_rect_enabled();  // INFERA_ZERO_COPY_RECT=0|1 (round-4 A/B; default set by it)
 // whether a host call of `rows` rows can be handed to the plan's first kernel as column-major chunks (one device pass per host pass)
 bool colmajor_direct_ok(const LoadedModel &m, int64_t rows);
 

@@ -34,44 +34,31 @@ __device__ __attribute__((aligned(256))) float g_split_zero_page[128];
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
 __device__ __forceinline__ bf16x8_t as_b(const u32x4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
-// two fp32 values -> the dwords {part(v0) | part(v1) << 16} of their hi, mid and lo bf16 parts.  An infinity keeps its place in the hi part
-// and has mid = lo = 0 (inf - inf would be NaN): its three parts still sum to it, which is what a residual read back from pre-split planes needs;
-// as a convolution INPUT an infinity still reaches its outputs as NaN wherever a weight part is zero.  NaN stays NaN in every part.
+// two fp32 values -> the dwords {part(v0) | part(v1) << 16} of their hi, mid and lo bf16 parts
+// An infinite input: hi = inf, mid = inf - inf = NaN -- every output it reaches is NaN, where fp32 arithmetic gives +-inf or NaN depending on
+// the weights' signs and zeros.  Passing the infinity through in hi with mid = lo = 0 (two v_cmp_class + two v_cndmask per pair, +36 % of the
+// cut's VALU work in the main loop) would not buy fidelity: inf x (a weight's zero mid or lo part) is NaN all the same.  Stated in DESIGN.md 3.3.
+// (Round 4 measured and dropped: activations stored PRE-SPLIT by the producing epilogue -- three bf16 planes per 16-channel group, consumers load
+// matrix operands and never cut.  Bit-identical results, and SLOWER: 20.97 against 19.59 ms per 1024 ResNet-18 images, every layer class
+// (profiles/r04_presplit_ab.txt) -- the cut was never the limiter, the nine-fold tap gathers out of L2 are, and pre-split tensors make them 1.5x
+// as many bytes.  The code is in the history: commit f180d80.)
 __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned &hi, unsigned &mid, unsigned &lo) {
   const unsigned x0 = __float_as_uint(v0), x1 = __float_as_uint(v1);
-  float r0 = v0 - __uint_as_float(x0 & 0xffff0000u), r1 = v1 - __uint_as_float(x1 & 0xffff0000u);  // exact: 16 bits left
-  r0 = __builtin_isinf(v0) ? 0.f : r0;
-  r1 = __builtin_isinf(v1) ? 0.f : r1;
+  const float r0 = v0 - __uint_as_float(x0 & 0xffff0000u), r1 = v1 - __uint_as_float(x1 & 0xffff0000u);  // exact: 16 bits left
   const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
   const float s0 = r0 - __uint_as_float(y0 & 0xffff0000u), s1 = r1 - __uint_as_float(y1 & 0xffff0000u);  // exact: 8 bits left
   hi = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
   mid = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
   lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
-// ... and back: the two fp32 values whose parts dword d of three plane words holds (exact: the parts are consecutive slices of the value)
-__device__ __forceinline__ void join3_pair(unsigned hi, unsigned mid, unsigned lo, float &v0, float &v1) {
-  v0 = (__uint_as_float(hi << 16) + __uint_as_float(mid << 16)) + __uint_as_float(lo << 16);
-  v1 = (__uint_as_float(hi & 0xffff0000u) + __uint_as_float(mid & 0xffff0000u)) + __uint_as_float(lo & 0xffff0000u);
-}
 
-// ---- activations stored PRE-SPLIT between split convolutions (round 4) ----------------------------------------------------------------
-// A tensor that only split convolutions read is written by its producer's epilogue as three bf16 planes per 16-channel group instead of fp32
-// channel quads ("S3", 6 bytes per value instead of 4): per image [G = C/16][h (2)][part (hi, mid, lo)][H][W][8 bf16], element e of (G, h) =
-// channel 16G + 8(e >> 2) + 4h + (e & 3) -- exactly the B fragment lane (pixel, h) feeds to k-block G of the matrix instruction, so a consumer
-// loads three 16-byte words per k-block and issues its six MFMAs: no v_and / v_sub / v_perm in the main loop (the round-3 kernel cut every
-// activation 9 taps x M/128 feature slices times; mfma_busy 0.59-0.62 at 1.9 GHz).  The cut is exact and so is the sum of the three parts
-// (join3_pair: the residual path), so a plan with pre-split tensors returns bit for bit what the fp32-activation plan returns
-// (tests/test_conv_split_gpu.py).  Plane stride = H*W*16 bytes = the channel-quad plane stride: S3 is the quad layout with 1.5x the planes.
-//
-// packed weights: [chunk (conv2d_tiled_pack's order)][mt][kb (2)][part (hi, mid, lo)][lane (64)][e (8 bf16)]
-template <int MT, bool IN_S3, bool OUT_S3, bool RES_S3>
+// packed: [chunk (conv2d_tiled_pack's order)][mt][kb (2)][part (hi, mid, lo)][lane (64)][e (8 bf16)]
+template <int MT>
 __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
-                                                                 float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
+                                                                 float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act, int SB) {
   static_assert(MT == 2 || MT == 4, "a stage's fragments (MT x 6 KB) are whole 4 KB pieces of the workgroup's copy");
-  // NB: 16-byte words a lane gathers per stage (one 32-channel chunk of one tap): four fp32 channel quads, or 2 k-blocks x 3 parts
-  constexpr int NB = IN_S3 ? 6 : 4, U = 2 * MT, P = 2, SLAB = MT * 1536;  // floats per stage
-  constexpr int CHUNK_PLANES = IN_S3 ? 12 : 8;                          // planes (of H*W*16 bytes) per 32 channels
+  constexpr int NB = 4, U = 2 * MT, P = 2, SLAB = MT * 1536;  // floats per stage
   __shared__ __attribute__((aligned(16))) float wbuf[2][SLAB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -79,7 +66,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
   const unsigned lb = blockIdx.x < nfull ? (blockIdx.x & 7u) * (nfull >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int OHW = g.OH * g.OW;
   const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
-  const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = ntaps * CC, SB = g.C % 64 == 0 ? 2 : 1;
+  const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = ntaps * CC;
   const int64_t pix = (int64_t(lb) * 4 + wave) * 32 + r;
   const bool pvalid = pix < total_pix;
   const unsigned pix32 = pvalid ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
@@ -88,8 +75,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
   const int oh = int(unsigned(prem) / unsigned(g.OW)), ow = prem - oh * g.OW;
   const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
   const int HW4 = g.H * g.W * 4;
-  // this lane's first plane of the image: quad h (fp32: then every second quad), or the hi plane of (G = 0, h) (S3: parts +1, +2; G at +6)
-  const float *xc = X + n * (int64_t(g.H) * g.W * g.C / 8 * CHUNK_PLANES) + int64_t(h) * (IN_S3 ? 3 : 1) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
+  const float *xc = X + n * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
   const float *zp = g_split_zero_page + 4 * h;
   uint64_t okmask = 0;
   if (pvalid) {
@@ -111,14 +97,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
   int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0, n_sl = 0;
   auto gather = [&](f32x4(&b)[NB]) {
     const bool ok = (okmask >> n_tap) & 1;
-    const float *p = ok ? xc + n_off + n_sl * (CHUNK_PLANES * HW4) : zp;
-    const int64_t pstride = ok ? int64_t(HW4) : 0;
+    const float *p = ok ? xc + n_off + n_sl * (2 * NB * HW4) : zp;
+    const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;
 #pragma unroll
-    for (int q = 0; q < NB; q++) {
-      // fp32: quads h, h + 2, h + 4, h + 6 of the chunk; S3: parts 0..2 of k-block 0, then of k-block 1 (six planes further on)
-      const int plane = IN_S3 ? (q / 3) * 6 + q % 3 : 2 * q;
-      b[q] = *reinterpret_cast<const f32x4 *>(p + plane * pstride);
-    }
+    for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
     if (++n_sl == SB) {  // next tap of this channel block
       n_sl = 0;
       n_tap++;
@@ -130,7 +112,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
       }
       if (n_tap == ntaps) {
         n_tap = 0;
-        n_base += SB * CHUNK_PLANES * HW4;
+        n_base += SB * 2 * NB * HW4;
         n_off = n_base;
       }
     }
@@ -146,22 +128,15 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-  // the three B fragments of k-block kb: cut here from two fp32 quads, or the three words the producer stored
   auto convert = [&](const f32x4(&bc)[NB], int kb, u32x4 &oh, u32x4 &om, u32x4 &ol) {
-    if constexpr (IN_S3) {
-      oh = __builtin_bit_cast(u32x4, bc[3 * kb]);
-      om = __builtin_bit_cast(u32x4, bc[3 * kb + 1]);
-      ol = __builtin_bit_cast(u32x4, bc[3 * kb + 2]);
-    } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const f32x4 &src = bc[2 * kb + (e >> 1)];
-        unsigned a, b, c;
-        split3_pair(src[2 * (e & 1)], src[2 * (e & 1) + 1], a, b, c);
-        oh[e] = a;
-        om[e] = b;
-        ol[e] = c;
-      }
+    for (int e = 0; e < 4; e++) {
+      const f32x4 &src = bc[2 * kb + (e >> 1)];
+      unsigned a, b, c;
+      split3_pair(src[2 * (e & 1)], src[2 * (e & 1) + 1], a, b, c);
+      oh[e] = a;
+      om[e] = b;
+      ol[e] = c;
     }
   };
   auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage, auto more_tag) {
@@ -216,16 +191,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
     step(b0, b1, stage, kLast);
   }
 
-  // epilogue: lane (r, h) holds pixel `pix`, channels 32 (mt0 + t) + 8q + 4h + j in acc[t][4q + j].  fp32 output: one 16-byte store per channel
-  // quad (plane 8 (mt0 + t) + 2q + h).  S3: quads q = 2p, 2p + 1 of a tile are the eight elements of group G = 2 (mt0 + t) + p, half h -- one
-  // 16-byte word per part, planes (2G + h) * 3 + part.  The residual is read the same way in whichever of the two formats it has.
   if (!pvalid) return;
   const int64_t OHW4 = int64_t(OHW) * 4;
-  const int64_t img = int64_t(OHW) * g.M;
-  const int64_t off32 = n * img + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;                    // fp32 channel-quad planes
-  const int64_t offs3 = n * (img / 2 * 3) + (12 * mt0 + 3 * h) * OHW4 + int64_t(prem) * 4;     // S3 planes: 12 per 32 features
-  const float *rp = residual ? residual + (RES_S3 ? offs3 : off32) : nullptr;
-  float *yp = Y + (OUT_S3 ? offs3 : off32);
+  const int64_t yoff = n * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+  float *yp = Y + yoff;
+  const float *rp = residual ? residual + yoff : nullptr;
   const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
   dispatch_act(act.kind, [&](auto kind_tag) {
     constexpr int KIND = decltype(kind_tag)::value;
@@ -233,55 +203,29 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
     for (int t = 0; t < MT; t++) {
       f32x4 bv[4], rv[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (RES_S3) {
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-          u32x4 w[3];
-#pragma unroll
-          for (int k = 0; k < 3; k++)
-            w[k] = rp ? *reinterpret_cast<const u32x4 *>(rp + (12 * t + 6 * p + k) * OHW4) : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-          for (int d = 0; d < 4; d++) {
-            float v0, v1;
-            join3_pair(w[0][d], w[1][d], w[2][d], v0, v1);
-            rv[2 * p + (d >> 1)][2 * (d & 1)] = v0;
-            rv[2 * p + (d >> 1)][2 * (d & 1) + 1] = v1;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 4; q++) {
+        bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      f32x4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++)
+      for (int q = 0; q < 4; q++) {
+        f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[q][j] = apply_act_c<KIND>((acc[t][4 * q + j] + bv[q][j]) + rv[q][j], act.a, act.b);
-      if constexpr (OUT_S3) {
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-          u32x4 w[3];
-#pragma unroll
-          for (int d = 0; d < 4; d++) {
-            unsigned a, b, c;
-            split3_pair(v[2 * p + (d >> 1)][2 * (d & 1)], v[2 * p + (d >> 1)][2 * (d & 1) + 1], a, b, c);
-            w[0][d] = a;
-            w[1][d] = b;
-            w[2][d] = c;
-          }
-#pragma unroll
-          for (int k = 0; k < 3; k++) *reinterpret_cast<u32x4 *>(yp + (12 * t + 6 * p + k) * OHW4) = w[k];
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v[q];
+        for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[t][4 * q + j] + bv[q][j]) + rv[q][j], act.a, act.b);
+        *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
       }
     }
   });
 }
 
 }  // namespace
+
+// chunks of 32 channels per channel block of the stage order (block outermost, then the tap, then the chunk inside the block)
+// (INFERA_SPLIT6_SB=1, read once: round-4 A/B of one-chunk blocks -- the taps of ONE chunk in consecutive stages)
+static int split6_block_chunks(const ConvGeom &g) {
+  static const int forced = getenv("INFERA_SPLIT6_SB") ? atoi(getenv("INFERA_SPLIT6_SB")) : 0;
+  return forced == 1 ? 1 : (g.C % 64 == 0 ? 2 : 1);
+}
 
 bool conv2d_split6_supported(const ConvGeom &g) {
   return conv2d_tiled_supported(g) && g.groups == 1 && g.C % 32 == 0 && g.M % 64 == 0 && g.kvalid == 0 && g.mvalid == 0 && !g.padc;
@@ -290,7 +234,7 @@ bool conv2d_split6_supported(const ConvGeom &g) {
 size_t conv2d_split6_packed_floats(const ConvGeom &g) { return size_t(g.kh) * g.kw * g.C * g.M * 3 / 2; }
 
 void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed) {
-  const int CC = g.C / 32, MTtot = g.M / 32, ntaps = g.kh * g.kw, S = g.C % 64 == 0 ? 2 : 1;
+  const int CC = g.C / 32, MTtot = g.M / 32, ntaps = g.kh * g.kw, S = split6_block_chunks(g);
   uint16_t *out = reinterpret_cast<uint16_t *>(packed);
   for (int tap = 0; tap < ntaps; tap++)
     for (int cc = 0; cc < CC; cc++)
@@ -321,31 +265,21 @@ void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed) {
 }
 
 void conv2d_split6(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y, int64_t rows,
-                   const ConvGeom &g, ActParam act, bool in_s3, bool out_s3, bool res_s3) {
+                   const ConvGeom &g, ActParam act) {
   const int64_t total_pix = rows * g.OH * g.OW;
   if (total_pix <= 0) return;
   if (total_pix >= (int64_t(1) << 31)) {
     const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(g.OH) * g.OW);
-    const int64_t in_row = int64_t(g.C) * g.H * g.W / 2 * (in_s3 ? 3 : 2), out32 = int64_t(g.M) * g.OH * g.OW;
+    const int64_t in_row = int64_t(g.C) * g.H * g.W, out_row = int64_t(g.M) * g.OH * g.OW;
     for (int64_t r0 = 0; r0 < rows; r0 += cap)
-      conv2d_split6(s, X + r0 * in_row, packed, bias, residual ? residual + r0 * (out32 / 2 * (res_s3 ? 3 : 2)) : nullptr,
-                    Y + r0 * (out32 / 2 * (out_s3 ? 3 : 2)), std::min(cap, rows - r0), g, act, in_s3, out_s3, res_s3);
+      conv2d_split6(s, X + r0 * in_row, packed, bias, residual ? residual + r0 * out_row : nullptr, Y + r0 * out_row, std::min(cap, rows - r0), g, act);
     return;
   }
   const unsigned bx = unsigned((total_pix + 127) / 128);
-  if (!residual) res_s3 = false;
-  auto launch = [&](auto mt_tag, auto in_tag, auto out_tag, auto res_tag) {
-    constexpr int MT = decltype(mt_tag)::value;
-    hipLaunchKernelGGL((conv2d_split6_kernel<MT, decltype(in_tag)::value, decltype(out_tag)::value, decltype(res_tag)::value>),
-                       dim3(bx, unsigned(g.M / (32 * MT))), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
-  };
-  auto by_res = [&](auto mt_tag, auto in_tag, auto out_tag) {
-    res_s3 ? launch(mt_tag, in_tag, out_tag, std::true_type{}) : launch(mt_tag, in_tag, out_tag, std::false_type{});
-  };
-  auto by_out = [&](auto mt_tag, auto in_tag) { out_s3 ? by_res(mt_tag, in_tag, std::true_type{}) : by_res(mt_tag, in_tag, std::false_type{}); };
-  auto by_in = [&](auto mt_tag) { in_s3 ? by_out(mt_tag, std::true_type{}) : by_out(mt_tag, std::false_type{}); };
-  if (g.M % 128 == 0) by_in(std::integral_constant<int, 4>{});
-  else by_in(std::integral_constant<int, 2>{});
+  if (g.M % 128 == 0)
+    hipLaunchKernelGGL((conv2d_split6_kernel<4>), dim3(bx, unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, split6_block_chunks(g));
+  else
+    hipLaunchKernelGGL((conv2d_split6_kernel<2>), dim3(bx, unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, split6_block_chunks(g));
 }
 
 }  // namespace infera_hip::kern

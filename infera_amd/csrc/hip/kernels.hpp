@@ -165,10 +165,8 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
 bool conv2d_split6_supported(const ConvGeom &g);
 size_t conv2d_split6_packed_floats(const ConvGeom &g);
 void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed);
-// in_s3 / out_s3 / res_s3: the tensor is stored PRE-SPLIT (three bf16 planes per 16-channel group, 1.5x the floats of the fp32 channel-quad
-// tensor; conv_split.hip) -- what a split convolution writes for readers that are all split convolutions.
 void conv2d_split6(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y, int64_t rows,
-                   const ConvGeom &g, ActParam act, bool in_s3 = false, bool out_s3 = false, bool res_s3 = false);
+                   const ConvGeom &g, ActParam act);
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
             int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq);
 // y[n,c,p] = x[n,c,p] / (bias + alpha/size * sum_{c' in window(c)} x[n,c',p]^2)^beta over [rows, C, S] (cq: channel-quad planes)

@@ -313,9 +313,12 @@ char *infera_hip_get_devices(void) {
     if (i) o += ",";
     uint64_t calls = 0, rows = 0;
     slot_counters(int(i), &calls, &rows);
-    o += "{\"arch\":" + json_str(ds.arch[i]) + ",\"cus\":" + std::to_string(ds.cus[i]) + ",\"host_calls\":" + std::to_string(calls) +
+    std::string fault;
+    const bool healthy = slot_health(int(i), &fault);
+    o += "{\"arch\":" + json_str(ds.arch[i]) + ",\"cus\":" + std::to_string(ds.cus[i]) + (healthy ? "" : ",\"fault\":" + json_str(fault)) +
+         ",\"healthy\":" + (healthy ? "true" : "false") + ",\"host_calls\":" + std::to_string(calls) +
          ",\"host_rows\":" + std::to_string(rows) + ",\"numa_node\":" + std::to_string(i < ds.numa.size() ? ds.numa[i] : -1) +
-         ",\"ordinal\":" + std::to_string(ds.ids[i]) + ",\"slot\":" + std::to_string(i) + "}";
+         ",\"ordinal\":" + std::to_string(ds.ids[i]) + ",\"pinned_staging_bytes\":" + std::to_string(slot_pinned_bytes(int(i))) + ",\"slot\":" + std::to_string(i) + "}";
   }
   o += "],\"host_phases\":" + host_phase_json() + ",\"reason\":" + json_str(ds.why) + "}";
   return dup_cstr(o);
@@ -525,10 +528,28 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
           run_bytes[c] = (col.is_constant ? 1 : size_t(rows)) * esz[c];
           tab.type[c] = static_cast<unsigned char>(int(col.type) | (col.is_constant ? 8 : 0));
         }
-        const auto reading = zero_copy_in_flight();  // (un)registration waits until this call has finished with the registered runs
-        const bool all = lookup_host_memory_many(ncols, host_ptr, run_bytes, tab.ptr);
+        ZeroCopyPins pins;  // the page blocks under the runs stay mapped until this call has finished with them (unregistering waits for it)
+        const bool all = lookup_host_memory_many(ncols, host_ptr, run_bytes, tab.ptr, pins);
+        // FLOAT runs at ONE stride (a [columns][rows] matrix: a numpy / Arrow table, a row group whose columns were allocated together): the
+        // chunk is a pitched rectangle, and ONE 2-D copy on the copy engines moves it -- they read pinned host memory at the link's DMA rate
+        // (~55 GB/s), where a kernel pulling the same runs reaches 42 (round 3).  Anything else (typed columns, constants, blocks of a
+        // database allocator scattered over the heap) keeps the pulling kernel.
+        int64_t pitch = 0;
+        bool rect = all && ncols >= 2 && zero_copy_rect_enabled();
+        for (uintptr_t c = 0; rect && c < ncols; c++) {
+          rect = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
+          if (rect && c > 0) {
+            const int64_t d = static_cast<const char *>(host_ptr[c]) - static_cast<const char *>(host_ptr[c - 1]);
+            rect = d >= int64_t(rows) * 4 && (c == 1 || d == pitch);
+            pitch = d;
+          }
+        }
         if (all)
           served = run_host_device_fill(*m, [&](hipStream_t stream, float *dst, int64_t r0, int64_t nr) {
+            if (rect) {
+              copy_rect_to_device(stream, dst, static_cast<const char *>(host_ptr[0]) + size_t(r0) * 4, size_t(pitch), size_t(nr) * 4, size_t(ncols));
+              return;
+            }
             // (Measured and dropped, round 3: ONE hipMemcpyBatchAsync of the 128 runs on the copy engines instead of this pulling kernel --
             // 292 us of CPU inside the call and 8.7 GB/s: the runtime issues 128 separate copies.)
             kern::ColumnTable t = tab;

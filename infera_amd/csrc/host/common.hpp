@@ -116,12 +116,11 @@ struct ScheduleKnobs {
   bool conv_bf16x6; // INFERA_PRECISION unset | bf16x6 (default): the tiled convolutions and the 7x7/2 stem on the bf16 matrix cores, every fp32 operand cut
                     //   EXACTLY into three bf16 parts, six partial products per product, fp32 accumulate (conv_split.hip) -- no scales, no precondition
                     //   on the data.  INFERA_PRECISION=fp32: the exact-fp32 matrix instruction instead (conv.hip's tiled / weight-stationary kernels)
-  bool conv_presplit; // INFERA_CONV_PRESPLIT=0|1 (default 1)  tensors that only split convolutions read are stored pre-split by their producer (tests: 0)
   static ScheduleKnobs read();
 };
 // Read per launch inside the kernel launchers, for the bit-identity TESTS only (no effect on results; defaults are the shipped paths):
 //   INFERA_CONV_WS (0 tiled kernel only | 1 default | 2 force the weight-stationary kernel), INFERA_CONV_TAIL_SPLIT, INFERA_STEM_POOL2,
-//   INFERA_STEM_SPLIT (0: the exact-fp32 stem kernels under a default plan), INFERA_CONV_PRESPLIT (0: fp32 activations between split convolutions).
+//   INFERA_STEM_SPLIT (0: the exact-fp32 stem kernels under a default plan).
 
 void log_msg(int level, const std::string &msg);  // config.rs:200-207 `log!`
 

@@ -1,6 +1,6 @@
 """The convolution arithmetic's HOST logic, without a GPU (the plan is made at infera_load_model): which steps the default plan moves to the
-bf16 matrix cores (three exact parts per operand), which activation tensors it stores pre-split, that INFERA_PRECISION / INFERA_CONV_PRESPLIT
-are read when a model is scheduled, and which layers stay on the exact-fp32 kernels because the split kernels do not take their shape."""
+bf16 matrix cores (three exact parts per operand), that INFERA_PRECISION is read when a model is scheduled, that an unknown mode name does not
+silently select an arithmetic, and which layers stay on the exact-fp32 kernels because the split kernels do not take their shape."""
 import os
 
 import numpy as np
@@ -28,23 +28,14 @@ def test_resnet18_plan_default_and_fp32(built, tmp_path):
     plain = _plan(tmp_path, "rn_plain", blob, "fp32")
     default = _plan(tmp_path, "rn_default", blob)
     assert plain["exec"][0] == "conv_patch_pool" and plain["exec"].count("conv_tiled_cq") == 19 and "conv_precision" not in plain
-    # the default: the stem and the same 19 layers on the bf16 matrix cores with three exact parts per operand
+    # the default: the stem and the same 19 layers on the bf16 matrix cores with three exact parts per operand; no maxima, so no extra scratch
     assert default["exec"][0] == "conv_patch_pool_bf16x6" and default["exec"].count("conv_split_bf16x6") == 19 and "bf16x6" in default["conv_precision"]
+    assert default["scratch_floats_per_row"] == plain["scratch_floats_per_row"]
     # same steps, same fusions (residual adds in the epilogues, the head on the exact-fp32 tiled kernel): only the names of the moved steps differ
     assert [{"conv_split_bf16x6": "conv_tiled_cq", "conv_patch_pool_bf16x6": "conv_patch_pool"}.get(e, e) for e in default["exec"]] == plain["exec"]
-    # activations between split convolutions are stored pre-split (three bf16 planes = 1.5x the floats): every tensor that only split
-    # convolutions read -- all of ResNet-18's but the stem's output (produced by the stem kernel), the three downsample outputs (read only as
-    # residuals: they stay fp32, 4 bytes per value) and the last block's output (read by the global pool)
-    assert len(default["presplit_buffers"]) == 15 and plain.get("presplit_buffers", []) == []
-    assert default["scratch_floats_per_row"] > plain["scratch_floats_per_row"]
-    os.environ["INFERA_CONV_PRESPLIT"] = "0"
-    try:
-        fp32act = _plan(tmp_path, "rn_f32act", blob)
-    finally:
-        os.environ.pop("INFERA_CONV_PRESPLIT", None)
-    assert fp32act["exec"] == default["exec"] and fp32act.get("presplit_buffers", []) == [] and fp32act["scratch_floats_per_row"] == plain["scratch_floats_per_row"]
     # a mode name this build does not know (a typo, a mode of an earlier round) must not silently pick an arithmetic: default + a warning
     assert _plan(tmp_path, "rn_typo", blob, "f16x3")["exec"] == default["exec"]
+    assert _plan(tmp_path, "rn_named", blob, "bf16x6")["exec"] == default["exec"]
 
 
 def test_layers_the_split_kernels_do_not_take_stay_exact(built, tmp_path):
@@ -63,11 +54,10 @@ def test_layers_the_split_kernels_do_not_take_stay_exact(built, tmp_path):
 
     # 4 -> 24 (padded-channel kernel), 24 -> 48 (channels not multiples of 32: padded-channel kernel), depthwise 48, 48 -> 64 1x1 (C % 32 != 0)
     p = _plan(tmp_path, "mobile", net(4, [(24, 3, 1), (48, 3, 1), (48, 3, 48), (64, 1, 1)]))
-    assert "conv_split_bf16x6" not in p["exec"] and "conv_precision" not in p and p.get("presplit_buffers", []) == []
-    # 4 -> 64, then 64 -> 64 in two groups (generic kernel), then 64 -> 128 3x3 (split), 128 -> 64 (split)
-    p = _plan(tmp_path, "grouped", net(4, [(64, 3, 1), (64, 3, 2), (128, 3, 1), (64, 3, 1)]))
-    assert p["exec"][:4] == ["conv_patch", "normal", "conv_split_bf16x6", "conv_split_bf16x6"]  # (activations ride in the conv steps)
-    assert len(p["presplit_buffers"]) == 1  # only the tensor between the two split convolutions
+    assert "conv_split_bf16x6" not in p["exec"] and "conv_precision" not in p
+    # 4 -> 64, then 64 -> 64 in two groups (generic kernel), then 64 -> 128 3x3 (split), 128 -> 96 (features no multiple of 64: exact-fp32 tiled kernel)
+    p = _plan(tmp_path, "grouped", net(4, [(64, 3, 1), (64, 3, 2), (128, 3, 1), (96, 3, 1)]))
+    assert p["exec"][:4] == ["conv_patch", "normal", "conv_split_bf16x6", "conv_tiled_cq"]  # (activations ride in the conv steps)
     # a model whose INPUT already has 32 channels: the caller's tensor is NCHW, its first convolution is not a channel-quad one
     p = _plan(tmp_path, "wide_in", net(32, [(64, 3, 1), (64, 3, 1)]))
-    assert p["exec"][0] != "conv_split_bf16x6" and p["exec"].count("conv_split_bf16x6") == 1 and p.get("presplit_buffers", []) == []
+    assert p["exec"][0] != "conv_split_bf16x6" and p["exec"].count("conv_split_bf16x6") == 1

@@ -140,3 +140,88 @@ def test_two_slots_on_one_gpu_hold_the_single_slot_rate_at_32_threads(gpu_api):
         assert line["value_is"] == "end_to_end" and len(full["end_to_end"]["device_slots"]) == slots
         rates[slots] = full["end_to_end"]["rows_per_s"]
     assert rates[2] >= 0.85 * rates[1], rates
+
+
+FAULT_CHILD = r"""
+import json, os, sys, threading
+sys.path.insert(0, %(root)r)
+import numpy as np
+from infera_amd import capi, onnx_writer as W, synth
+capi.load_model("m", W.write(os.path.join(%(tmp)r, "m.onnx"), W.mlp((128, 256, 64, 1))))
+x = synth.table(9, 0, 2048 * 24, 128)
+want = capi.predict("m", x)  # (one thread, before any fault: slot of this thread)
+bad, errors = [], []
+def work(t):
+    for i in range(t, 24 * 6, 8):
+        c = i %% 24
+        try:
+            got = capi.predict("m", x[c * 2048:(c + 1) * 2048])
+        except Exception as exc:
+            errors.append(str(exc))
+            continue
+        if not np.array_equal(got, want[c * 2048:(c + 1) * 2048]):
+            bad.append(i)
+th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+[t.start() for t in th]
+[t.join() for t in th]
+print("RESULT " + json.dumps({"bad": bad, "errors": errors, "devices": capi.get_devices()["devices"]}))
+"""
+
+
+@pytest.mark.gpu
+def test_a_faulting_slot_is_taken_out_of_service_and_its_callers_are_redealt(gpu_api, tmp_path):
+    """SURVEY 5 "failure detection": two device slots (INFERA_DEVICES=0,0), a launch failure injected on slot 1 from its 20th call on
+    (INFERA_FAULT_INJECT=1:20, the test hook).  No caller sees an error: the failing chunk and everything after it run on slot 0, bit for bit;
+    infera_hip_get_devices reports slot 1 as unhealthy with the error text."""
+    env = dict(os.environ, INFERA_DEVICES="0,0", INFERA_FAULT_INJECT="1:20", INFERA_LOG_LEVEL="ERROR")
+    p = subprocess.run([sys.executable, "-c", FAULT_CHILD % {"root": ROOT, "tmp": str(tmp_path)}], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert r["bad"] == [] and r["errors"] == [], r
+    d0, d1 = r["devices"]
+    assert d0["healthy"] and "fault" not in d0
+    assert not d1["healthy"] and "injected fault" in d1["fault"]
+    assert d0["host_rows"] > d1["host_rows"] and d0["host_rows"] + d1["host_rows"] >= 2048 * (24 + 24 * 6)
+    assert "out of service" in p.stderr  # logged once, at ERROR level
+    # ... and with the ONLY slot failing the error reaches the caller as a status, with the reference's "ONNX error: ..." shape
+    env = dict(os.environ, INFERA_DEVICES="0", INFERA_FAULT_INJECT="0:1", INFERA_LOG_LEVEL="ERROR")
+    p = subprocess.run([sys.executable, "-c", FAULT_CHILD % {"root": ROOT, "tmp": str(tmp_path)}], env=env, capture_output=True, text=True, timeout=600)
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert r["bad"] == [] and len(r["errors"]) == 24 * 6 and all(e.startswith("ONNX error: HIP: injected fault") for e in r["errors"]), r["errors"][:2]
+
+
+@pytest.mark.gpu
+def test_pinned_staging_of_image_batches_is_bounded_per_gpu(gpu_api, tmp_path):
+    """contexts that serve big-row (BLOB) batches keep two passes of pinned staging each, for the life of the process.  32 caller
+    threads x 300-image calls: at most INFERA_HOST_CONTEXTS (24) contexts exist per GPU and together they hold no more than the slot's budget
+    (6 GiB + the small-chunk staging), whatever the thread count; results are the same for every thread."""
+    import threading
+
+    import numpy as np
+
+    from infera_amd import onnx_writer as W
+    from infera_amd import synth
+
+    rng = np.random.default_rng(2)
+    w = (rng.standard_normal((8, 3, 3, 3)) * 0.2).astype(np.float32)
+    nodes = [W.node("Conv", ["X", "w"], ["c"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("strides", [2, 2]), W.attr_ints("pads", [1] * 4)]), W.node("Relu", ["c"], ["r"]),
+             W.node("GlobalAveragePool", ["r"], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
+    path = W.write(str(tmp_path / "img.onnx"), W.model("img", nodes, [W.tensor("w", w)], [W.value_info("X", ["N", 3, 224, 224])], [W.value_info("Y", ["N", 8])]))
+    x = synth.table(4, 0, 300, 3 * 224 * 224)
+    blob = x.tobytes()
+    gpu_api.load_model("img", path)
+    try:
+        want = gpu_api.predict_from_blob("img", blob)
+        outs = [None] * 32
+
+        def work(t):
+            outs[t] = gpu_api.predict_from_blob("img", blob)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(32)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert all(o is not None and np.array_equal(o, want) for o in outs)
+        pinned = sum(d["pinned_staging_bytes"] for d in gpu_api.get_devices()["devices"])
+        assert 0 < pinned <= (6 << 30) + 24 * (160 << 20), pinned
+    finally:
+        gpu_api.unload_model("img")
