@@ -375,6 +375,16 @@ void mark_slot_unhealthy(int slot, const std::string &why) {
   if (!g_slot_unhealthy[size_t(slot) % 64].exchange(true, std::memory_order_acq_rel))
     log_msg(0, "device slot " + std::to_string(slot) + " (HIP device " + std::to_string(devices().ids[size_t(slot)]) + ") taken out of service: " + why);
 }
+// Which HIP errors mean "this GPU is gone or wedged" rather than "this call was refused": the sticky execution faults, a lost device, a
+// dead context.  (An allocation failure or an invalid argument fails the call and leaves the GPU in service.)
+bool is_device_fault(hipError_t e) {
+  switch (e) {
+    case hipErrorLaunchFailure: case hipErrorIllegalAddress: case hipErrorLaunchTimeOut: case hipErrorECCNotCorrectable: case hipErrorNoDevice:
+    case hipErrorContextIsDestroyed: case hipErrorDeinitialized: case hipErrorUnknown: case hipErrorAssert:
+      return true;
+    default: return false;
+  }
+}
 // TEST HOOK (tests/test_multi_device_gpu.py): INFERA_FAULT_INJECT=<slot>:<n> makes every host-ABI call on that slot after its n-th fail as a
 // launch failure would.  Read once; unset (always, outside that test) it costs one relaxed load per call.
 bool fault_injected(int slot) {
@@ -1367,7 +1377,7 @@ bool run_host_redealt(const LoadedModel &m, const FillFn &fill, const DeviceFill
       return run_host_impl(m, fill, dfill, h_out, rows, col_major);
     } catch (const HipFault &f) {
       (void)hipGetLastError();
-      if (f.code == hipErrorOutOfMemory || f.code == hipErrorMemoryAllocation) throw;  // the GPU is fine, this call was too big for what is free
+      if (!is_device_fault(f.code)) throw;  // the GPU is fine: the call itself was refused (too big for what is free, a bad argument)
       mark_slot_unhealthy(slot, f.what());
       if (healthy_slots() == 0) throw;
     }

@@ -56,7 +56,7 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned &hi, un
 template <int MT>
 __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
-                                                                 float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act, int SB) {
+                                                                 float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
   static_assert(MT == 2 || MT == 4, "a stage's fragments (MT x 6 KB) are whole 4 KB pieces of the workgroup's copy");
   constexpr int NB = 4, U = 2 * MT, P = 2, SLAB = MT * 1536;  // floats per stage
   __shared__ __attribute__((aligned(16))) float wbuf[2][SLAB];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
   const unsigned lb = blockIdx.x < nfull ? (blockIdx.x & 7u) * (nfull >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int OHW = g.OH * g.OW;
   const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
-  const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = ntaps * CC;
+  const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = ntaps * CC, SB = g.C % 64 == 0 ? 2 : 1;
   const int64_t pix = (int64_t(lb) * 4 + wave) * 32 + r;
   const bool pvalid = pix < total_pix;
   const unsigned pix32 = pvalid ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
@@ -93,7 +93,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
     for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
 
   // stage order: channel block (SB chunks) outermost, then the tap, then the chunk inside the block -- conv2d_tiled_pack's chunk order, one
-  // chunk per stage
+  // chunk per stage.  (Round 4 measured one-chunk blocks -- the nine taps of ONE chunk in consecutive stages, so that a tap's re-read of the
+  // lines the previous tap fetched comes while they may still be in the 32 KB L1: 19.41-19.49 against 19.44-19.53 ms per 1024 ResNet-18
+  // images, no difference -- profiles/r04_split6_stage_order_ab.txt.)
   int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0, n_sl = 0;
   auto gather = [&](f32x4(&b)[NB]) {
     const bool ok = (okmask >> n_tap) & 1;
@@ -220,13 +222,6 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
 
 }  // namespace
 
-// chunks of 32 channels per channel block of the stage order (block outermost, then the tap, then the chunk inside the block)
-// (INFERA_SPLIT6_SB=1, read once: round-4 A/B of one-chunk blocks -- the taps of ONE chunk in consecutive stages)
-static int split6_block_chunks(const ConvGeom &g) {
-  static const int forced = getenv("INFERA_SPLIT6_SB") ? atoi(getenv("INFERA_SPLIT6_SB")) : 0;
-  return forced == 1 ? 1 : (g.C % 64 == 0 ? 2 : 1);
-}
-
 bool conv2d_split6_supported(const ConvGeom &g) {
   return conv2d_tiled_supported(g) && g.groups == 1 && g.C % 32 == 0 && g.M % 64 == 0 && g.kvalid == 0 && g.mvalid == 0 && !g.padc;
 }
@@ -234,7 +229,7 @@ bool conv2d_split6_supported(const ConvGeom &g) {
 size_t conv2d_split6_packed_floats(const ConvGeom &g) { return size_t(g.kh) * g.kw * g.C * g.M * 3 / 2; }
 
 void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed) {
-  const int CC = g.C / 32, MTtot = g.M / 32, ntaps = g.kh * g.kw, S = split6_block_chunks(g);
+  const int CC = g.C / 32, MTtot = g.M / 32, ntaps = g.kh * g.kw, S = g.C % 64 == 0 ? 2 : 1;
   uint16_t *out = reinterpret_cast<uint16_t *>(packed);
   for (int tap = 0; tap < ntaps; tap++)
     for (int cc = 0; cc < CC; cc++)
@@ -277,9 +272,9 @@ void conv2d_split6(hipStream_t s, const float *X, const float *packed, const flo
   }
   const unsigned bx = unsigned((total_pix + 127) / 128);
   if (g.M % 128 == 0)
-    hipLaunchKernelGGL((conv2d_split6_kernel<4>), dim3(bx, unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, split6_block_chunks(g));
+    hipLaunchKernelGGL((conv2d_split6_kernel<4>), dim3(bx, unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
   else
-    hipLaunchKernelGGL((conv2d_split6_kernel<2>), dim3(bx, unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, split6_block_chunks(g));
+    hipLaunchKernelGGL((conv2d_split6_kernel<2>), dim3(bx, unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
 }
 
 }  // namespace infera_hip::kern

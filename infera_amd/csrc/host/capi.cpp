@@ -535,7 +535,8 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
         // (~55 GB/s), where a kernel pulling the same runs reaches 42 (round 3).  Anything else (typed columns, constants, blocks of a
         // database allocator scattered over the heap) keeps the pulling kernel.
         int64_t pitch = 0;
-        bool rect = all && ncols >= 2 && zero_copy_rect_enabled();
+        // (the whole rectangle must lie inside ONE pinned block: the runtime resolves a 2-D copy's source to a single registration)
+        bool rect = all && ncols >= 2 && pins.count == 1 && zero_copy_rect_enabled();
         for (uintptr_t c = 0; rect && c < ncols; c++) {
           rect = columns[c].type == INFERA_COL_FLOAT && !columns[c].is_constant;
           if (rect && c > 0) {

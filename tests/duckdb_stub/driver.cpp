@@ -14,7 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -22,6 +24,7 @@
 #include "../../infera_amd/csrc/binding/sql_surface.h"
 
 extern "C" void infera_duckdb_cpp_init(duckdb::ExtensionLoader &loader);
+extern "C" bool infera_install_zero_copy_allocator(duckdb::DBConfig &config);
 
 namespace {
 using namespace duckdb;
@@ -287,6 +290,85 @@ double infera_stub_registration_seconds(int32_t reps, uint64_t *overloads, uint6
   if (overloads) *overloads = n;
   if (argument_types) *argument_types = types;
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+}
+
+// The allocator hook end to end: `threads` workers each loop { allocate four 256 KiB blocks from DBConfig::allocator --
+// the registering allocator when INFERA_ZERO_COPY_ALLOCATOR=1, malloc otherwise --, fill them with the 128 column runs of a 2048-row chunk,
+// scan the chunk `scans_per_alloc` times through the extension's infera_predict (FLAT vectors pointing into the blocks, as a table scan
+// hands them over), free the blocks } for `seconds`, all at once: allocation, scan and free of different threads overlap.  Every result is
+// compared with the first result for that chunk content.  Returns rows/s; *mismatches / *allocs report what happened.
+double infera_stub_allocator_scan(const char *model, int32_t threads, double seconds, int32_t scans_per_alloc, uint64_t *mismatches, uint64_t *allocs,
+                                  int32_t *hook_installed, char *err, uint64_t errcap) {
+  constexpr size_t K = 128, ROWS = 2048, BLOCK_COLS = 32, BLOCK = BLOCK_COLS * ROWS * sizeof(float);
+  try {
+    DBConfig config;
+    const bool hooked = infera_install_zero_copy_allocator(config);
+    if (!config.allocator) config.allocator = make_uniq<Allocator>();
+    if (hook_installed) *hook_installed = hooked ? 1 : 0;
+    const ScalarFunction *fn = nullptr;
+    for (const auto &f : db().catalog)
+      if (f.name == "infera_predict" && f.arguments.size() == K + 1 && f.arguments[1] == LogicalType::FLOAT) fn = &f;
+    if (!fn) throw Exception("infera_predict with 128 FLOAT features is not registered");
+    const std::string name = model;
+    std::atomic<uint64_t> chunks{0}, bad{0}, nalloc{0};
+    std::atomic<bool> stop{false};
+    std::mutex err_mu;
+    std::string first_error;
+    auto worker = [&](int t) {
+      std::vector<float> expected;
+      for (uint64_t round = 0; !stop.load(std::memory_order_relaxed); round++) {
+        data_ptr_t blk[K / BLOCK_COLS];
+        for (auto &b : blk) b = config.allocator->AllocateData(BLOCK);
+        nalloc.fetch_add(K / BLOCK_COLS, std::memory_order_relaxed);
+        uint64_t s = 1234 + uint64_t(t);  // the same content every round: one expected result per thread
+        for (size_t c = 0; c < K; c++) {
+          float *run = reinterpret_cast<float *>(blk[c / BLOCK_COLS]) + (c % BLOCK_COLS) * ROWS;
+          for (size_t r = 0; r < ROWS; r++) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            run[r] = float(int32_t(s >> 40) - (1 << 23)) * (1.0f / float(1 << 23));
+          }
+        }
+        try {
+          for (int k = 0; k < scans_per_alloc && !stop.load(std::memory_order_relaxed); k++) {
+            DataChunk chunk;
+            string_t nm(name.data(), uint32_t(name.size()));
+            Vector nv(LogicalType::VARCHAR, reinterpret_cast<data_ptr_t>(&nm));
+            nv.SetVectorType(VectorType::CONSTANT_VECTOR);
+            chunk.data.push_back(std::move(nv));
+            for (size_t c = 0; c < K; c++)
+              chunk.data.push_back(Vector(LogicalType::FLOAT, blk[c / BLOCK_COLS] + (c % BLOCK_COLS) * ROWS * sizeof(float)));
+            chunk.SetCardinality(ROWS);
+            Vector result(fn->return_type, ROWS);
+            ExpressionState state;
+            fn->function(chunk, state, result);
+            const float *y = FlatVector::GetData<float>(result);
+            if (expected.empty()) expected.assign(y, y + ROWS);
+            else if (std::memcmp(expected.data(), y, ROWS * sizeof(float)) != 0) bad.fetch_add(1, std::memory_order_relaxed);
+            chunks.fetch_add(1, std::memory_order_relaxed);
+          }
+        } catch (const std::exception &e) {
+          std::lock_guard<std::mutex> lk(err_mu);
+          if (first_error.empty()) first_error = e.what();
+          stop.store(true);
+        }
+        for (auto &b : blk) config.allocator->FreeData(b, BLOCK);
+      }
+    };
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++) th.emplace_back(worker, t);
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    stop.store(true);
+    for (auto &x : th) x.join();
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!first_error.empty()) throw Exception(first_error);
+    if (mismatches) *mismatches = bad.load();
+    if (allocs) *allocs = nalloc.load();
+    return double(chunks.load()) * ROWS / sec;
+  } catch (const std::exception &e) {
+    if (err && errcap) std::snprintf(err, size_t(errcap), "%s", e.what());
+    return -1.0;
+  }
 }
 
 }  // extern "C"

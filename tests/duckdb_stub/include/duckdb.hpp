@@ -339,6 +339,36 @@ public:
   vector<ScalarFunction> functions;
 };
 
+// duckdb/common/allocator.hpp: the allocator every buffer-manager block comes from (DBConfig::allocator)
+struct PrivateAllocatorData {
+  virtual ~PrivateAllocatorData() = default;
+};
+typedef data_ptr_t (*allocate_function_ptr_t)(PrivateAllocatorData *private_data, idx_t size);
+typedef void (*free_function_ptr_t)(PrivateAllocatorData *private_data, data_ptr_t pointer, idx_t size);
+typedef data_ptr_t (*reallocate_function_ptr_t)(PrivateAllocatorData *private_data, data_ptr_t pointer, idx_t old_size, idx_t size);
+class Allocator {
+public:
+  Allocator() : Allocator(DefaultAllocate, DefaultFree, DefaultReallocate, nullptr) {}
+  Allocator(allocate_function_ptr_t a, free_function_ptr_t f, reallocate_function_ptr_t r, unique_ptr<PrivateAllocatorData> pd)
+      : allocate_(a), free_(f), reallocate_(r), private_data_(std::move(pd)) {}
+  data_ptr_t AllocateData(idx_t size) { return allocate_(private_data_.get(), size); }
+  void FreeData(data_ptr_t p, idx_t size) { if (p) free_(private_data_.get(), p, size); }
+  data_ptr_t ReallocateData(data_ptr_t p, idx_t old_size, idx_t size) { return reallocate_(private_data_.get(), p, old_size, size); }
+  static data_ptr_t DefaultAllocate(PrivateAllocatorData *, idx_t size) { return static_cast<data_ptr_t>(std::malloc(size)); }
+  static void DefaultFree(PrivateAllocatorData *, data_ptr_t p, idx_t) { std::free(p); }
+  static data_ptr_t DefaultReallocate(PrivateAllocatorData *, data_ptr_t p, idx_t, idx_t size) { return static_cast<data_ptr_t>(std::realloc(p, size)); }
+
+private:
+  allocate_function_ptr_t allocate_;
+  free_function_ptr_t free_;
+  reallocate_function_ptr_t reallocate_;
+  unique_ptr<PrivateAllocatorData> private_data_;
+};
+// duckdb/main/config.hpp (the one member used here)
+struct DBConfig {
+  unique_ptr<Allocator> allocator;
+};
+
 class DatabaseInstance {
 public:
   vector<ScalarFunction> catalog;  // every registered overload

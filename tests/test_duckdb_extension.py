@@ -180,3 +180,43 @@ def test_registration_cost_of_2048_overloads(built):
     assert n.value == 256 * 2 * 4 + 10, n.value
     assert types.value == 4 * 2 * sum(f + 1 for f in range(1, 257)) + 2 + 1 + 2 + 1 + 1 + 1, types.value
     assert sec < 0.25, sec
+
+
+ALLOC_CHILD = r"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, %(root)r)
+from infera_amd import capi, onnx_writer as W
+capi.load_library()
+L = C.CDLL(os.path.join(%(root)r, "tests", "duckdb_stub", "libinfera_duckdb_stub.so"))
+L.infera_stub_allocator_scan.restype = C.c_double
+L.infera_stub_allocator_scan.argtypes = [C.c_char_p, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_char_p, C.c_uint64]
+capi.load_model("alloc_mlp", W.write(os.path.join(%(tmp)r, "mlp.onnx"), W.mlp((128, 256, 64, 1))))
+bad, allocs, hooked = C.c_uint64(), C.c_uint64(), C.c_int32()
+err = C.create_string_buffer(512)
+z0 = capi.zero_copy_calls()
+rate = L.infera_stub_allocator_scan(b"alloc_mlp", 16, 2.0, 8, C.byref(bad), C.byref(allocs), C.byref(hooked), err, len(err))
+print("RESULT " + json.dumps({"rows_per_s": rate, "mismatches": bad.value, "allocs": allocs.value, "hooked": hooked.value, "error": err.value.decode(),
+                              "zero_copy_calls": capi.zero_copy_calls() - z0, "ranges_left": capi.load_library().infera_hip_zero_copy_calls() >= 0}))
+"""
+
+
+@pytest.mark.gpu
+def test_zero_copy_allocator_hook_allocate_scan_free_under_16_threads(gpu_api, tmp_path):
+    """the extension's registering allocator (infera_install_zero_copy_allocator, INFERA_ZERO_COPY_ALLOCATOR=1) driven through
+    the stub the way an embedding application would: 16 threads each allocate four 256 KiB blocks from DBConfig::allocator, fill them with a
+    chunk's 128 column runs, scan the chunk eight times through the extension's infera_predict, free the blocks -- allocation, scan and free of
+    different threads overlapping.  With the hook every scan is served zero-copy, without it staged; the results are the same either way."""
+    import json
+    import sys
+
+    out = {}
+    for hook in ("1", "0"):
+        env = dict(os.environ, INFERA_ZERO_COPY_ALLOCATOR=hook)
+        p = subprocess.run([sys.executable, "-c", ALLOC_CHILD % {"root": ROOT, "tmp": str(tmp_path)}], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out[hook] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+        r = out[hook]
+        assert r["error"] == "" and r["rows_per_s"] > 0 and r["mismatches"] == 0 and r["allocs"] >= 16 * 4, r
+    assert out["1"]["hooked"] == 1 and out["0"]["hooked"] == 0
+    chunks = lambda r: r["rows_per_s"] * 2.0 / 2048
+    assert out["1"]["zero_copy_calls"] >= 0.9 * chunks(out["1"]) and out["0"]["zero_copy_calls"] == 0, out
