@@ -274,11 +274,33 @@ def bench_scan(function: str, model: str, rows: int, ncols: int, threads: int, p
 ROW_GROUP = 122880  # INFERA_SQL_ROW_GROUP
 
 
-def synth_table(rows: int, ncols: int, seed: int = 42, threads: int = 8, dtype=np.float32) -> np.ndarray:
+def aligned_empty(n: int, dtype, align: int = 4096, huge: bool = False) -> np.ndarray:
+    """n elements of dtype whose first byte sits on an `align` boundary (column stores align their buffers; a 2048-row chunk of a
+    page-aligned FLOAT column is exactly two 4 KiB pages, of an unaligned one three).  huge: ask for transparent huge pages (2 MiB)."""
+    item = np.dtype(dtype).itemsize
+    if huge:
+        import mmap
+
+        size = (n * item + (2 << 20) - 1) // (2 << 20) * (2 << 20) + (2 << 20)
+        m = mmap.mmap(-1, size)
+        try:
+            m.madvise(mmap.MADV_HUGEPAGE)
+        except (AttributeError, OSError):
+            pass
+        raw = np.frombuffer(m, np.uint8)
+        off = (-raw.ctypes.data) % (2 << 20)
+        return raw[off:off + n * item].view(dtype)
+    raw = np.empty(n * item + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n * item].view(dtype)
+
+
+def synth_table(rows: int, ncols: int, seed: int = 42, threads: int = 8, dtype=np.float32, align: int = 0, huge: bool = False) -> np.ndarray:
     """A materialised columnar table in host memory (row groups of 122,880 rows, one contiguous run per column inside a
     group), filled with the generator of SURVEY.md 8d.  Flat array of rows*ncols elements, float32 (FLOAT columns) or
-    float64 (DOUBLE columns, the same values widened)."""
-    t = np.empty(int(lib().infera_sql_table_floats(rows, ncols)), dtype)
+    float64 (DOUBLE columns, the same values widened).  align / huge: see aligned_empty (default: wherever numpy puts it)."""
+    n = int(lib().infera_sql_table_floats(rows, ncols))
+    t = aligned_empty(n, dtype, align or 4096, huge) if (align or huge) else np.empty(n, dtype)
     if t.dtype == np.float64:
         lib().infera_sql_synth_table_f64(t.ctypes.data, seed, rows, ncols, threads)
     else:

@@ -20,6 +20,8 @@ ap.add_argument("--pool", action="store_true", help="cache-resident per-thread c
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--double", action="store_true", help="DOUBLE columns (DuckDB's default floating type) instead of FLOAT")
 ap.add_argument("--register", action="store_true", help="register the host table (infera_hip_register_host_memory): the opt-in zero-copy path")
+ap.add_argument("--align", type=int, default=0, help="allocate the host table on this byte boundary (0: wherever numpy puts it)")
+ap.add_argument("--huge", action="store_true", help="back the host table with transparent huge pages (madvise)")
 ap.add_argument("--numa", default="off", choices=["auto", "off"], help="auto: bind the process to the CPUs of the (first) GPU's NUMA node before any thread exists")
 a = ap.parse_args()
 if a.numa == "auto":
@@ -43,7 +45,9 @@ sqlmock.bench_scan(fn, "m", 2048 * 64, cols, 4)  # warm
 print(f"devices={capi.get_devices()['devices']} workload={a.dims or a.workload} rows={a.rows} exec={capi.get_plan('m')['exec']} "
       f"env={ {k: v for k, v in os.environ.items() if k.startswith('INFERA_')} } source={'per-thread chunk pool' if a.pool else 'materialised columnar host table'}")
 import numpy as np  # noqa: E402
-table = None if a.pool else sqlmock.synth_table(a.rows, cols, 42, 16, np.float64 if a.double else np.float32)
+table = None if a.pool else sqlmock.synth_table(a.rows, cols, 42, 16, np.float64 if a.double else np.float32, align=a.align, huge=a.huge)
+if table is not None:
+    print(f"table at 0x{table.ctypes.data:x} (offset in its 4 KiB page: {table.ctypes.data % 4096}, in its 2 MiB page: {table.ctypes.data % (2 << 20)}) huge={a.huge}")
 print("column type:", "DOUBLE" if a.double else "FLOAT")
 if a.register and table is not None:
     import time
