@@ -1832,24 +1832,13 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
 }
 
 // ---- bf16 x three parts stem + max-pool (conv2d_stem_split6_kernel) ----
-// The pooled stem's patch geometry with the row pitch this kernel's 8-BYTE patch words want.  The k loop fetches them with ds_read2_b64, which is
-// served in 16-lane groups on 32 banks: consecutive convolution rows (15 pixels = 30 dwords each) must sit 28 dwords apart (mod 32) for the 16
-// pixels of a group that wraps onto the next row to keep to distinct banks -- row pitch = 7 (mod 8) words.  patch_pool_geom's rule (rows 16
-// banks apart) is for the 4-byte words of the exact-fp32 stems: with it rows of 8-byte words are 0 (mod 32) apart, and a group that wraps a row
-// reads the same banks twice -- the 43 % bank-conflict share of round 3's PMC pass.
-static PatchGeom stem_split6_geom(const ConvGeom &g, const PoolTail &pool) {
-  PatchGeom p = patch_pool_geom(g, pool);
-  static const bool old_pitch = getenv("INFERA_STEM_ROWS_PAD") && atoi(getenv("INFERA_STEM_ROWS_PAD")) == 0;  // (round-4 A/B, removed after it)
-  if (old_pitch) return p;
-  p.ROWS = g.sw * p.HALF;
-  while (p.ROWS % 8 != 7) p.ROWS++;
-  p.PLANE = p.PR * p.ROWS;
-  return p;
-}
-
+// (Round 4 measured and dropped: an own LDS row pitch for this kernel's 8-byte patch words -- its k loop fetches them with ds_read2_b64, served in
+// 16-lane groups on 32 banks, where patch_pool_geom's pitch (made for the 4-byte words of the exact-fp32 stems) puts consecutive convolution rows 0
+// banks apart (mod 32); a pitch of 7 (mod 8) words puts them 28 apart.  2145 against 2148 us per 1024 images: those reads are not what the 43 %
+// bank-conflict share of round 3's PMC pass costs the kernel -- profiles/r04_stem_pitch_ab.txt.)
 bool conv2d_stem_split6_supported(const ConvGeom &g, const PoolTail &pool) {
   if (!conv2d_patch_pool_supported(g, pool) || g.M != 64) return false;
-  const PatchGeom p = stem_split6_geom(g, pool);
+  const PatchGeom p = patch_pool_geom(g, pool);
   // (the k loop reads four consecutive words of each half of a de-interleaved patch row: 7 columns, stride 2)
   return g.kw == 7 && g.sw == 2 && g.dw == 1 && (g.C * g.kh + 1) / 2 == kStemKB && p.HALF >= kPoolCC + 3 &&
          (g.C * p.PR * p.PC + kPool2Block - 1) / kPool2Block <= kPatchMaxE && 2 * stem_split6_lds_bytes(g, p) <= 160 * 1024;
@@ -1887,7 +1876,7 @@ void conv2d_stem_split6_pack(const ConvGeom &g, const float *Wt, float *packed) 
 void conv2d_stem_split6(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
                         ActParam act, const PoolTail &pool, int num_cus) {
   if (rows <= 0) return;
-  const PatchGeom p = stem_split6_geom(g, pool);
+  const PatchGeom p = patch_pool_geom(g, pool);
   if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {
     for (int64_t r0 = 0; r0 < rows; r0 += cap)
       conv2d_stem_split6(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus);

@@ -53,7 +53,11 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned &hi, un
 }
 
 // packed: [chunk (conv2d_tiled_pack's order)][mt][kb (2)][part (hi, mid, lo)][lane (64)][e (8 bf16)]
-template <int MT>
+// MT feature tiles x PT pixel tiles per wave.  <4, 1>: 32 pixels x 128 features (M % 128 == 0); <2, 2>: 64 pixels x 64 features -- the same 48
+// matrix instructions per wave and stage, every weight fragment read from LDS once for both pixel tiles and one 12 KB slab per 256 pixels
+// instead of per 128 (round 4: the 64-feature layers ran <2, 1> at mfma_busy 0.59 where the 128-feature form reaches 0.74 -- half the matrix work
+// behind the same barrier, slab and gather latencies per stage); <2, 1> remains for launches too short to fill the chip with 256-pixel workgroups.
+template <int MT, int PT>
 __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
                                                                  float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
@@ -67,42 +71,56 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
   const int OHW = g.OH * g.OW;
   const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
   const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = ntaps * CC, SB = g.C % 64 == 0 ? 2 : 1;
-  const int64_t pix = (int64_t(lb) * 4 + wave) * 32 + r;
-  const bool pvalid = pix < total_pix;
-  const unsigned pix32 = pvalid ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
-  const int64_t n = n32;
-  const int prem = int(pix32 - n32 * unsigned(OHW));
-  const int oh = int(unsigned(prem) / unsigned(g.OW)), ow = prem - oh * g.OW;
-  const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
   const int HW4 = g.H * g.W * 4;
-  const float *xc = X + n * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
   const float *zp = g_split_zero_page + 4 * h;
-  uint64_t okmask = 0;
-  if (pvalid) {
-    int tap = 0;
-    for (int ky = 0; ky < g.kh; ky++)
-      for (int kx = 0; kx < g.kw; kx++, tap++) {
-        const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
-        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) okmask |= uint64_t(1) << tap;
-      }
+  // per pixel tile of this wave: the lane's pixel, where its receptive field starts, which taps lie inside the image
+  bool pvalid[PT];
+  int64_t nimg[PT];
+  int prem[PT];
+  const float *xc[PT];
+  uint64_t okmask[PT];
+#pragma unroll
+  for (int p = 0; p < PT; p++) {
+    const int64_t pix = ((int64_t(lb) * 4 + wave) * PT + p) * 32 + r;
+    pvalid[p] = pix < total_pix;
+    const unsigned pix32 = pvalid[p] ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
+    nimg[p] = n32;
+    prem[p] = int(pix32 - n32 * unsigned(OHW));
+    const int oh = int(unsigned(prem[p]) / unsigned(g.OW)), ow = prem[p] - oh * g.OW;
+    const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
+    xc[p] = X + nimg[p] * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
+    okmask[p] = 0;
+    if (pvalid[p]) {
+      int tap = 0;
+      for (int ky = 0; ky < g.kh; ky++)
+        for (int kx = 0; kx < g.kw; kx++, tap++) {
+          const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
+          if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) okmask[p] |= uint64_t(1) << tap;
+        }
+    }
   }
-  f32x16 acc[MT];
+  f32x16 acc[PT][MT];
 #pragma unroll
-  for (int t = 0; t < MT; t++)
+  for (int p = 0; p < PT; p++)
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[p][t][i] = 0.f;
 
   // stage order: channel block (SB chunks) outermost, then the tap, then the chunk inside the block -- conv2d_tiled_pack's chunk order, one
   // chunk per stage.  (Round 4 measured one-chunk blocks -- the nine taps of ONE chunk in consecutive stages, so that a tap's re-read of the
   // lines the previous tap fetched comes while they may still be in the 32 KB L1: 19.41-19.49 against 19.44-19.53 ms per 1024 ResNet-18
   // images, no difference -- profiles/r04_split6_stage_order_ab.txt.)
   int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0, n_sl = 0;
-  auto gather = [&](f32x4(&b)[NB]) {
-    const bool ok = (okmask >> n_tap) & 1;
-    const float *p = ok ? xc + n_off + n_sl * (2 * NB * HW4) : zp;
-    const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;
+  auto gather = [&](f32x4(&b)[PT][NB]) {
 #pragma unroll
-    for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
+    for (int p = 0; p < PT; p++) {
+      const bool ok = (okmask[p] >> n_tap) & 1;
+      const float *src = ok ? xc[p] + n_off + n_sl * (2 * NB * HW4) : zp;
+      const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;
+#pragma unroll
+      for (int q = 0; q < NB; q++) b[p][q] = *reinterpret_cast<const f32x4 *>(src + q * pstride);
+    }
     if (++n_sl == SB) {  // next tap of this channel block
       n_sl = 0;
       n_tap++;
@@ -141,16 +159,17 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
       ol[e] = c;
     }
   };
-  auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage, auto more_tag) {
+  auto step = [&](const f32x4(&bc)[PT][NB], f32x4(&bn)[PT][NB], int stage, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;
     const u32x4 *wl = reinterpret_cast<const u32x4 *>(wbuf[stage & 1]) + lane;
     auto fidx = [](int u) { return (((u % MT) * 2 + u / MT) * 3) * 64; };  // unit u: k-block u / MT, feature tile u % MT; hi, mid = +64, lo = +128
-    u32x4 ra[P][3], bb[2][3];
+    u32x4 ra[P][3], bb[PT][2][3];
 #pragma unroll
     for (int u = 0; u < P && u < U; u++)
 #pragma unroll
       for (int k = 0; k < 3; k++) ra[u][k] = wl[fidx(u) + 64 * k];
-    convert(bc, 0, bb[0][0], bb[0][1], bb[0][2]);
+#pragma unroll
+    for (int p = 0; p < PT; p++) convert(bc[p], 0, bb[p][0][0], bb[p][0][1], bb[p][0][2]);
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int kb = u / MT, t = u % MT;
@@ -163,19 +182,23 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
         if (u == 0) gather(bn);
         if (u == 1) stage_issue(stage + 1, (stage + 1) & 1);
       }
-      const u32x4 &bh = bb[kb][0], &bm = bb[kb][1], &bl = bb[kb][2];
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(al), as_b(bh), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bl), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bm), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bh), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bm), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bh), acc[t], 0, 0, 0);
-      if (t == 0 && kb == 0) convert(bc, 1, bb[1][0], bb[1][1], bb[1][2]);
+#pragma unroll
+      for (int p = 0; p < PT; p++) {
+        const u32x4 &bh = bb[p][kb][0], &bm = bb[p][kb][1], &bl = bb[p][kb][2];
+        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(al), as_b(bh), acc[p][t], 0, 0, 0);
+        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bl), acc[p][t], 0, 0, 0);
+        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bm), acc[p][t], 0, 0, 0);
+        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bh), acc[p][t], 0, 0, 0);
+        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bm), acc[p][t], 0, 0, 0);
+        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bh), acc[p][t], 0, 0, 0);
+        // the second k-block's fragments are cut while the first one's matrix instructions run (tile p's behind tile p's first unit)
+        if (t == 0 && kb == 0) convert(bc[p], 1, bb[p][1][0], bb[p][1][1], bb[p][1][2]);
+      }
     }
     if constexpr (more) stage_commit();
   };
 
-  f32x4 b0[NB], b1[NB];
+  f32x4 b0[PT][NB], b1[PT][NB];
   gather(b0);
   stage_issue(0, 0);
   stage_commit();
@@ -193,28 +216,32 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
     step(b0, b1, stage, kLast);
   }
 
-  if (!pvalid) return;
+  // epilogue: lane (r, h) holds, per pixel tile, its pixel's channels 32 (mt0 + t) + 8q + 4h + j -> one 16-byte store per channel quad
   const int64_t OHW4 = int64_t(OHW) * 4;
-  const int64_t yoff = n * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
-  float *yp = Y + yoff;
-  const float *rp = residual ? residual + yoff : nullptr;
   const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
   dispatch_act(act.kind, [&](auto kind_tag) {
     constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-      f32x4 bv[4], rv[4];
+    for (int p = 0; p < PT; p++) {
+      if (!pvalid[p]) continue;
+      const int64_t yoff = nimg[p] * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem[p]) * 4;
+      float *yp = Y + yoff;
+      const float *rp = residual ? residual + yoff : nullptr;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
-        rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int t = 0; t < MT; t++) {
+        f32x4 bv[4], rv[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        f32x4 v;
+        for (int q = 0; q < 4; q++) {
+          bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+          rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[t][4 * q + j] + bv[q][j]) + rv[q][j], act.a, act.b);
-        *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
+        for (int q = 0; q < 4; q++) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[p][t][4 * q + j] + bv[q][j]) + rv[q][j], act.a, act.b);
+          *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
+        }
       }
     }
   });
@@ -270,11 +297,22 @@ void conv2d_split6(hipStream_t s, const float *X, const float *packed, const flo
       conv2d_split6(s, X + r0 * in_row, packed, bias, residual ? residual + r0 * out_row : nullptr, Y + r0 * out_row, std::min(cap, rows - r0), g, act);
     return;
   }
-  const unsigned bx = unsigned((total_pix + 127) / 128);
-  if (g.M % 128 == 0)
-    hipLaunchKernelGGL((conv2d_split6_kernel<4>), dim3(bx, unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+  if (g.M % 128 == 0) {
+    hipLaunchKernelGGL((conv2d_split6_kernel<4, 1>), dim3(unsigned((total_pix + 127) / 128), unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y,
+                       total_pix, g, act);
+    return;
+  }
+  // 64-feature slices: 64 pixels per wave (256 per workgroup) once the launch fills the chip that way -- at least ~4 rounds of two workgroups
+  // per CU; shorter launches keep 128-pixel workgroups (INFERA_SPLIT6_PT=1|2 forces either: tests, A/B)
+  const char *pt_env = getenv("INFERA_SPLIT6_PT");  // (read per launch: one process runs both forms in the bit-identity test)
+  const int forced_pt = pt_env ? atoi(pt_env) : 0;
+  const int64_t wg256 = (total_pix + 255) / 256 * (g.M / 64);
+  if (forced_pt == 2 || (forced_pt != 1 && wg256 >= 2048))
+    hipLaunchKernelGGL((conv2d_split6_kernel<2, 2>), dim3(unsigned((total_pix + 255) / 256), unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y,
+                       total_pix, g, act);
   else
-    hipLaunchKernelGGL((conv2d_split6_kernel<2>), dim3(bx, unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+    hipLaunchKernelGGL((conv2d_split6_kernel<2, 1>), dim3(unsigned((total_pix + 127) / 128), unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y,
+                       total_pix, g, act);
 }
 
 }  // namespace infera_hip::kern

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-4 end-of-work evidence: rocprofv3 kernel trace + PMC passes of the C5 / C2 / C4 benches, summaries as text.
+set -u
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r04_lines
+bash tools/profile_bench.sh r04_final_resnet18 --workload resnet18 --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end > gpurun_out/r04_lines/prof_resnet.log 2>&1
+bash tools/profile_bench.sh r04_final_mlp --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads > gpurun_out/r04_lines/prof_mlp.log 2>&1
+bash tools/profile_bench.sh r04_final_logreg --workload logreg --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end > gpurun_out/r04_lines/prof_logreg.log 2>&1
+for w in resnet18 mlp logreg; do
+  d=gpurun_out/r04_final_$w
+  python tools/rocpd_summary.py $(find $d/trace -name "*.db") 2>/dev/null | head -60 > gpurun_out/r04_final_${w}_bench.txt
+  cp $d/bench_line.json gpurun_out/r04_final_${w}_bench_line.json
+  python tools/pmc_table.py $(find $d/pmc_sq $d/pmc_grbm -name "*.db") > gpurun_out/r04_final_${w}_pmc_table.txt 2>&1
+done
+python tools/traffic_json.py gpurun_out/r04_final_mlp mlp3_split 10000000 mlp "r04 final" > gpurun_out/traffic_mlp.json
+python tools/traffic_json.py gpurun_out/r04_final_logreg dense_narrow16 50000000 logreg "r04 final" > gpurun_out/traffic_logreg.json
+python tools/traffic_pass_json.py gpurun_out/r04_final_resnet18 global_avgpool 1024 "r04 final" > gpurun_out/traffic_resnet18.json
+ls -la gpurun_out/ | tail -20
+find gpurun_out/r04_final_mlp -name "*.db" | head
