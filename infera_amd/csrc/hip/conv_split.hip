@@ -53,16 +53,21 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned &hi, un
 }
 
 // packed: [chunk (conv2d_tiled_pack's order)][mt][kb (2)][part (hi, mid, lo)][lane (64)][e (8 bf16)]
-// MT feature tiles x PT pixel tiles per wave.  <4, 1>: 32 pixels x 128 features (M % 128 == 0); <2, 2>: 64 pixels x 64 features -- the same 48
-// matrix instructions per wave and stage, every weight fragment read from LDS once for both pixel tiles and one 12 KB slab per 256 pixels
-// instead of per 128 (round 4: the 64-feature layers ran <2, 1> at mfma_busy 0.59 where the 128-feature form reaches 0.74 -- half the matrix work
-// behind the same barrier, slab and gather latencies per stage); <2, 1> remains for launches too short to fill the chip with 256-pixel workgroups.
-template <int MT, int PT>
-__global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+// Two stage forms:
+//   TT = false: a stage = ONE tap x a 32-channel chunk (two k-blocks); stage order: channel block (one or two chunks) outermost, then the tap, then the
+//               chunk inside the block -- conv2d_tiled_pack's chunk order.  Serves every geometry.
+//   TT = true (round 4, three-column filters): a stage = the THREE kx taps of one filter row x a 16-channel group (three k-blocks, one per tap); order:
+//               channel group outermost, then ky.  The three taps' gathers of a lane are the same cache lines shifted by one pixel (16 bytes) and
+//               are issued back to back, so two of the three are served by the L1 instead of coming out of L2 again a stage later -- the tap
+//               gathers are what bounds these kernels (profiles/r04_presplit_ab.txt, r04_split6_pixel_tiles_ab.txt).  packed (conv2d_split6_pack):
+//               [stage = group * kh + ky][mt][kx (3)][part (hi, mid, lo)][lane (64)][e (8 bf16)].
+template <int MT, bool TT>
+__global__ __launch_bounds__(kBlock, MT == 2 ? 3 : 2) void conv2d_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
                                                                  float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
-  static_assert(MT == 2 || MT == 4, "a stage's fragments (MT x 6 KB) are whole 4 KB pieces of the workgroup's copy");
-  constexpr int NB = 4, U = 2 * MT, P = 2, SLAB = MT * 1536;  // floats per stage
+  static_assert(MT == 2 || MT == 4, "feature tiles per workgroup");
+  constexpr int KB = TT ? 3 : 2;  // k-blocks (16 channels of one tap) per stage
+  constexpr int NB = 2 * KB, U = KB * MT, P = 2, SLAB = MT * KB * 768;  // gathered quads per lane and stage; units; A ring depth; floats of weights per stage
   __shared__ __attribute__((aligned(16))) float wbuf[2][SLAB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -70,57 +75,59 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
   const unsigned lb = blockIdx.x < nfull ? (blockIdx.x & 7u) * (nfull >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int OHW = g.OH * g.OW;
   const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
-  const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = ntaps * CC, SB = g.C % 64 == 0 ? 2 : 1;
+  const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = TT ? (g.C / 16) * g.kh : ntaps * CC, SB = g.C % 64 == 0 ? 2 : 1;
+  const int64_t pix = (int64_t(lb) * 4 + wave) * 32 + r;
+  const bool pvalid = pix < total_pix;
+  const unsigned pix32 = pvalid ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
+  const int64_t n = n32;
+  const int prem = int(pix32 - n32 * unsigned(OHW));
+  const int oh = int(unsigned(prem) / unsigned(g.OW)), ow = prem - oh * g.OW;
+  const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
   const int HW4 = g.H * g.W * 4;
+  const float *xc = X + n * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
   const float *zp = g_split_zero_page + 4 * h;
-  // per pixel tile of this wave: the lane's pixel, where its receptive field starts, which taps lie inside the image
-  bool pvalid[PT];
-  int64_t nimg[PT];
-  int prem[PT];
-  const float *xc[PT];
-  uint64_t okmask[PT];
-#pragma unroll
-  for (int p = 0; p < PT; p++) {
-    const int64_t pix = ((int64_t(lb) * 4 + wave) * PT + p) * 32 + r;
-    pvalid[p] = pix < total_pix;
-    const unsigned pix32 = pvalid[p] ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
-    nimg[p] = n32;
-    prem[p] = int(pix32 - n32 * unsigned(OHW));
-    const int oh = int(unsigned(prem[p]) / unsigned(g.OW)), ow = prem[p] - oh * g.OW;
-    const int ih0 = oh * g.sh - g.pt, iw0 = ow * g.sw - g.pl;
-    xc[p] = X + nimg[p] * g.H * g.W * g.C + int64_t(h) * HW4 + (int64_t(ih0) * g.W + iw0) * 4;
-    okmask[p] = 0;
-    if (pvalid[p]) {
-      int tap = 0;
-      for (int ky = 0; ky < g.kh; ky++)
-        for (int kx = 0; kx < g.kw; kx++, tap++) {
-          const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
-          if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) okmask[p] |= uint64_t(1) << tap;
-        }
-    }
+  uint64_t okmask = 0;
+  if (pvalid) {
+    int tap = 0;
+    for (int ky = 0; ky < g.kh; ky++)
+      for (int kx = 0; kx < g.kw; kx++, tap++) {
+        const int iy = ih0 + ky * g.dh, ix = iw0 + kx * g.dw;
+        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) okmask |= uint64_t(1) << tap;
+      }
   }
-  f32x16 acc[PT][MT];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int p = 0; p < PT; p++)
+  for (int t = 0; t < MT; t++)
 #pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) acc[p][t][i] = 0.f;
+    for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
 
-  // stage order: channel block (SB chunks) outermost, then the tap, then the chunk inside the block -- conv2d_tiled_pack's chunk order, one
-  // chunk per stage.  (Round 4 measured one-chunk blocks -- the nine taps of ONE chunk in consecutive stages, so that a tap's re-read of the
-  // lines the previous tap fetched comes while they may still be in the 32 KB L1: 19.41-19.49 against 19.44-19.53 ms per 1024 ResNet-18
-  // images, no difference -- profiles/r04_split6_stage_order_ab.txt.)
+  // (Round 4 measured one-chunk blocks for the TT = false order -- the nine taps of ONE chunk in consecutive stages: no difference,
+  // profiles/r04_split6_stage_order_ab.txt.)
   int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0, n_sl = 0;
-  auto gather = [&](f32x4(&b)[PT][NB]) {
+  auto gather = [&](f32x4(&b)[NB]) {
+    if constexpr (TT) {
+      // the three taps of filter row n_tap (= ky) for channel group n_sl: quads h and h + 2 of the group at each tap
 #pragma unroll
-    for (int p = 0; p < PT; p++) {
-      const bool ok = (okmask[p] >> n_tap) & 1;
-      const float *src = ok ? xc[p] + n_off + n_sl * (2 * NB * HW4) : zp;
-      const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;
-#pragma unroll
-      for (int q = 0; q < NB; q++) b[p][q] = *reinterpret_cast<const f32x4 *>(src + q * pstride);
+      for (int kx = 0; kx < 3; kx++) {
+        const bool ok = (okmask >> (n_tap * 3 + kx)) & 1;
+        const float *p = ok ? xc + n_off + kx * (g.dw * 4) : zp;
+        const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;
+        b[2 * kx] = *reinterpret_cast<const f32x4 *>(p);
+        b[2 * kx + 1] = *reinterpret_cast<const f32x4 *>(p + pstride);
+      }
+      n_off += g.dh * g.W * 4;
+      if (++n_tap == g.kh) {  // next 16-channel group: four quad planes further on
+        n_tap = 0;
+        n_base += 4 * HW4;
+        n_off = n_base;
+      }
+      return;
     }
+    const bool ok = (okmask >> n_tap) & 1;
+    const float *p = ok ? xc + n_off + n_sl * (2 * NB * HW4) : zp;
+    const int64_t pstride = ok ? 2 * int64_t(HW4) : 0;
+#pragma unroll
+    for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
     if (++n_sl == SB) {  // next tap of this channel block
       n_sl = 0;
       n_tap++;
@@ -138,11 +145,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
     }
   };
   auto stage_issue = [&](int stage, int buf) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(Wp + (int64_t(stage) * MTtot + mt0) * 1536) + threadIdx.x;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(Wp + (int64_t(stage) * MTtot + mt0) * (KB * 768)) + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < SLAB / 1024; i++)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 256),
                                        (__attribute__((address_space(3))) void *)(wbuf[buf] + i * 1024 + wave * 256), 16, 0, 0);
+    if constexpr (SLAB % 1024 != 0) {  // (MT = 2, TT: 18 KB = four whole rounds of the workgroup and half a round -- waves 0 and 1)
+      if (wave < (SLAB % 1024) / 256)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (SLAB / 1024) * 256),
+                                         (__attribute__((address_space(3))) void *)(wbuf[buf] + (SLAB / 1024) * 1024 + wave * 256), 16, 0, 0);
+    }
   };
   auto stage_commit = [] {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -159,17 +171,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
       ol[e] = c;
     }
   };
-  auto step = [&](const f32x4(&bc)[PT][NB], f32x4(&bn)[PT][NB], int stage, auto more_tag) {
+  auto step = [&](const f32x4(&bc)[NB], f32x4(&bn)[NB], int stage, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;
     const u32x4 *wl = reinterpret_cast<const u32x4 *>(wbuf[stage & 1]) + lane;
-    auto fidx = [](int u) { return (((u % MT) * 2 + u / MT) * 3) * 64; };  // unit u: k-block u / MT, feature tile u % MT; hi, mid = +64, lo = +128
-    u32x4 ra[P][3], bb[PT][2][3];
+    auto fidx = [](int u) { return (((u % MT) * KB + u / MT) * 3) * 64; };  // unit u: k-block u / MT, feature tile u % MT; hi, mid = +64, lo = +128
+    u32x4 ra[P][3], bb[2][3];
 #pragma unroll
     for (int u = 0; u < P && u < U; u++)
 #pragma unroll
       for (int k = 0; k < 3; k++) ra[u][k] = wl[fidx(u) + 64 * k];
-#pragma unroll
-    for (int p = 0; p < PT; p++) convert(bc[p], 0, bb[p][0][0], bb[p][0][1], bb[p][0][2]);
+    convert(bc, 0, bb[0][0], bb[0][1], bb[0][2]);
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int kb = u / MT, t = u % MT;
@@ -182,23 +193,20 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
         if (u == 0) gather(bn);
         if (u == 1) stage_issue(stage + 1, (stage + 1) & 1);
       }
-#pragma unroll
-      for (int p = 0; p < PT; p++) {
-        const u32x4 &bh = bb[p][kb][0], &bm = bb[p][kb][1], &bl = bb[p][kb][2];
-        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(al), as_b(bh), acc[p][t], 0, 0, 0);
-        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bl), acc[p][t], 0, 0, 0);
-        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bm), acc[p][t], 0, 0, 0);
-        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bh), acc[p][t], 0, 0, 0);
-        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bm), acc[p][t], 0, 0, 0);
-        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bh), acc[p][t], 0, 0, 0);
-        // the second k-block's fragments are cut while the first one's matrix instructions run (tile p's behind tile p's first unit)
-        if (t == 0 && kb == 0) convert(bc[p], 1, bb[p][1][0], bb[p][1][1], bb[p][1][2]);
-      }
+      const u32x4 &bh = bb[kb & 1][0], &bm = bb[kb & 1][1], &bl = bb[kb & 1][2];
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(al), as_b(bh), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bl), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bm), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(am), as_b(bh), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bm), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(ah), as_b(bh), acc[t], 0, 0, 0);
+      // the next k-block's fragments are cut while this one's matrix instructions run
+      if (t == 0 && kb + 1 < KB) convert(bc, kb + 1, bb[(kb + 1) & 1][0], bb[(kb + 1) & 1][1], bb[(kb + 1) & 1][2]);
     }
     if constexpr (more) stage_commit();
   };
 
-  f32x4 b0[PT][NB], b1[PT][NB];
+  f32x4 b0[NB], b1[NB];
   gather(b0);
   stage_issue(0, 0);
   stage_commit();
@@ -216,32 +224,28 @@ __global__ __launch_bounds__(kBlock, 2) void conv2d_split6_kernel(const float *_
     step(b0, b1, stage, kLast);
   }
 
-  // epilogue: lane (r, h) holds, per pixel tile, its pixel's channels 32 (mt0 + t) + 8q + 4h + j -> one 16-byte store per channel quad
+  if (!pvalid) return;
   const int64_t OHW4 = int64_t(OHW) * 4;
+  const int64_t yoff = n * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem) * 4;
+  float *yp = Y + yoff;
+  const float *rp = residual ? residual + yoff : nullptr;
   const f32x4 *bq = bias ? reinterpret_cast<const f32x4 *>(bias + 32 * mt0 + 4 * h) : nullptr;
   dispatch_act(act.kind, [&](auto kind_tag) {
     constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
-    for (int p = 0; p < PT; p++) {
-      if (!pvalid[p]) continue;
-      const int64_t yoff = nimg[p] * OHW * g.M + (8 * mt0 + h) * OHW4 + int64_t(prem[p]) * 4;
-      float *yp = Y + yoff;
-      const float *rp = residual ? residual + yoff : nullptr;
+    for (int t = 0; t < MT; t++) {
+      f32x4 bv[4], rv[4];
 #pragma unroll
-      for (int t = 0; t < MT; t++) {
-        f32x4 bv[4], rv[4];
+      for (int q = 0; q < 4; q++) {
+        bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          bv[q] = bq ? bq[8 * t + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
-          rv[q] = rp ? *reinterpret_cast<const f32x4 *>(rp + (8 * t + 2 * q) * OHW4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+      for (int q = 0; q < 4; q++) {
+        f32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[p][t][4 * q + j] + bv[q][j]) + rv[q][j], act.a, act.b);
-          *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
-        }
+        for (int j = 0; j < 4; j++) v[j] = apply_act_c<KIND>((acc[t][4 * q + j] + bv[q][j]) + rv[q][j], act.a, act.b);
+        *reinterpret_cast<f32x4 *>(yp + (8 * t + 2 * q) * OHW4) = v;
       }
     }
   });
@@ -255,9 +259,35 @@ bool conv2d_split6_supported(const ConvGeom &g) {
 
 size_t conv2d_split6_packed_floats(const ConvGeom &g) { return size_t(g.kh) * g.kw * g.C * g.M * 3 / 2; }
 
+// three-column filters take the tap-triple stage form (conv2d_split6_kernel<MT, true>); INFERA_SPLIT6_TT=0, read when a model is loaded AND per
+// launch (tests: set it around both), keeps them on the one-tap form
+static bool split6_tt(const ConvGeom &g) {
+  const char *e = getenv("INFERA_SPLIT6_TT");
+  return g.kw == 3 && !(e && atoi(e) == 0);
+}
+
+// exact truncation cut of one weight: v = hi + mid + lo, each a bf16
+static void cut3(float v, uint16_t &hi, uint16_t &mid, uint16_t &lo) {
+  uint32_t x, y, z;
+  std::memcpy(&x, &v, 4);
+  const uint32_t xh = x & 0xffff0000u;
+  float fh, fm;
+  std::memcpy(&fh, &xh, 4);
+  const float r1 = v - fh;
+  std::memcpy(&y, &r1, 4);
+  const uint32_t yh = y & 0xffff0000u;
+  std::memcpy(&fm, &yh, 4);
+  const float r2 = r1 - fm;
+  std::memcpy(&z, &r2, 4);
+  hi = uint16_t(x >> 16);
+  mid = uint16_t(y >> 16);
+  lo = uint16_t(z >> 16);
+}
+
 void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed) {
   const int CC = g.C / 32, MTtot = g.M / 32, ntaps = g.kh * g.kw, S = g.C % 64 == 0 ? 2 : 1;
   uint16_t *out = reinterpret_cast<uint16_t *>(packed);
+  const bool tt = split6_tt(g);
   for (int tap = 0; tap < ntaps; tap++)
     for (int cc = 0; cc < CC; cc++)
       for (int mt = 0; mt < MTtot; mt++)
@@ -265,24 +295,20 @@ void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed) {
           for (int lane = 0; lane < 64; lane++)
             for (int e = 0; e < 8; e++) {
               const int m = 32 * mt + (lane & 31), c = 32 * cc + 16 * kb + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-              const size_t chunk = (size_t(cc / S) * ntaps + tap) * S + cc % S;
-              const float v = Wt[(size_t(m) * g.C + c) * ntaps + tap];
-              uint32_t x, y, z;  // exact truncation split: v = hi + mid + lo
-              std::memcpy(&x, &v, 4);
-              const uint32_t xh = x & 0xffff0000u;
-              float fh;
-              std::memcpy(&fh, &xh, 4);
-              const float r1 = v - fh;
-              std::memcpy(&y, &r1, 4);
-              const uint32_t yh = y & 0xffff0000u;
-              float fm;
-              std::memcpy(&fm, &yh, 4);
-              const float r2 = r1 - fm;
-              std::memcpy(&z, &r2, 4);
-              const size_t base = ((chunk * MTtot + mt) * 2 + kb) * 3;  // fragments of 64 lanes x 8 bf16
-              out[(base + 0) * 512 + size_t(lane) * 8 + e] = uint16_t(x >> 16);
-              out[(base + 1) * 512 + size_t(lane) * 8 + e] = uint16_t(y >> 16);
-              out[(base + 2) * 512 + size_t(lane) * 8 + e] = uint16_t(z >> 16);
+              // fragment group of (tap, 16-channel group 2cc + kb, feature tile mt): three fragments (hi, mid, lo) of 64 lanes x 8 bf16
+              size_t base;
+              if (tt) {  // [stage = group * kh + ky][mt][kx]
+                const int ky = tap / 3, kx = tap % 3;
+                base = ((size_t(2 * cc + kb) * g.kh + ky) * MTtot + mt) * 3 + kx;
+              } else {  // [chunk (conv2d_tiled_pack's order)][mt][kb]
+                const size_t chunk = (size_t(cc / S) * ntaps + tap) * S + cc % S;
+                base = (chunk * MTtot + mt) * 2 + kb;
+              }
+              uint16_t hi, mid, lo;
+              cut3(Wt[(size_t(m) * g.C + c) * ntaps + tap], hi, mid, lo);
+              out[(base * 3 + 0) * 512 + size_t(lane) * 8 + e] = hi;
+              out[(base * 3 + 1) * 512 + size_t(lane) * 8 + e] = mid;
+              out[(base * 3 + 2) * 512 + size_t(lane) * 8 + e] = lo;
             }
 }
 
@@ -297,22 +323,12 @@ void conv2d_split6(hipStream_t s, const float *X, const float *packed, const flo
       conv2d_split6(s, X + r0 * in_row, packed, bias, residual ? residual + r0 * out_row : nullptr, Y + r0 * out_row, std::min(cap, rows - r0), g, act);
     return;
   }
-  if (g.M % 128 == 0) {
-    hipLaunchKernelGGL((conv2d_split6_kernel<4, 1>), dim3(unsigned((total_pix + 127) / 128), unsigned(g.M / 128)), dim3(kBlock), 0, s, X, packed, bias, residual, Y,
-                       total_pix, g, act);
-    return;
-  }
-  // 64-feature slices: 64 pixels per wave (256 per workgroup) once the launch fills the chip that way -- at least ~4 rounds of two workgroups
-  // per CU; shorter launches keep 128-pixel workgroups (INFERA_SPLIT6_PT=1|2 forces either: tests, A/B)
-  const char *pt_env = getenv("INFERA_SPLIT6_PT");  // (read per launch: one process runs both forms in the bit-identity test)
-  const int forced_pt = pt_env ? atoi(pt_env) : 0;
-  const int64_t wg256 = (total_pix + 255) / 256 * (g.M / 64);
-  if (forced_pt == 2 || (forced_pt != 1 && wg256 >= 2048))
-    hipLaunchKernelGGL((conv2d_split6_kernel<2, 2>), dim3(unsigned((total_pix + 255) / 256), unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y,
-                       total_pix, g, act);
-  else
-    hipLaunchKernelGGL((conv2d_split6_kernel<2, 1>), dim3(unsigned((total_pix + 127) / 128), unsigned(g.M / 64)), dim3(kBlock), 0, s, X, packed, bias, residual, Y,
-                       total_pix, g, act);
+  const unsigned bx = unsigned((total_pix + 127) / 128);
+  auto launch = [&](auto kernel, int features) {
+    hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / features)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+  };
+  if (split6_tt(g)) g.M % 128 == 0 ? launch(conv2d_split6_kernel<4, true>, 128) : launch(conv2d_split6_kernel<2, true>, 64);
+  else g.M % 128 == 0 ? launch(conv2d_split6_kernel<4, false>, 128) : launch(conv2d_split6_kernel<2, false>, 64);
 }
 
 }  // namespace infera_hip::kern

@@ -88,30 +88,6 @@ def test_gpu_bf16x6_conv_chains_match_oracle(gpu_api, tmp_path, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["resnet_like", "many_tiles"])
-def test_gpu_bf16x6_two_pixel_tiles_per_wave_is_bit_identical(gpu_api, tmp_path, case):
-    """Round 4: 64-feature layers run 64 pixels x 64 features per wave (conv2d_split6_kernel<2, 2>) once a launch is long enough, 32 x 64
-    (<2, 1>) otherwise.  Same k order per output element -> INFERA_SPLIT6_PT=1 / 2 (read per launch) must agree bit for bit, ragged last
-    workgroups included (22 x 22 and 40 x 40 images: pixel counts that are no multiples of 256)."""
-    c = CASES[case]
-    path = W.write(str(tmp_path / "net.onnx"), _net(c["chain"], c["cin"], c["hw"], c["residual_at"]))
-    x = synth.table(31, 0, c["rows"], c["cin"] * c["hw"] * c["hw"])
-    gpu_api.load_model("conv_bf6", path)
-    try:
-        out = {}
-        for pt in ("1", "2"):
-            os.environ["INFERA_SPLIT6_PT"] = pt
-            try:
-                out[pt] = gpu_api.predict_from_blob("conv_bf6", x.tobytes())
-            finally:
-                os.environ.pop("INFERA_SPLIT6_PT", None)
-        default = gpu_api.predict_from_blob("conv_bf6", x.tobytes())
-    finally:
-        gpu_api.unload_model("conv_bf6")
-    assert np.array_equal(out["1"], out["2"]) and np.array_equal(default, out["1"])
-
-
-@pytest.mark.gpu
 def test_gpu_bf16x6_non_finite_rows_stay_in_their_rows(gpu_api, tmp_path):
     """ResNet-18 (64 x 64 images, full width) over a batch that mixes magnitudes: a NaN or an infinity in one image leaves every OTHER image of
     the batch bit for bit what it is without the poisoned neighbour (no scales: nothing of one row reaches another).  What the poisoned rows
