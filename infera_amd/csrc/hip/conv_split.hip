@@ -56,7 +56,7 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned &hi, un
 // Two stage forms:
 //   TT = false: a stage = ONE tap x a 32-channel chunk (two k-blocks); stage order: channel block (one or two chunks) outermost, then the tap, then the
 //               chunk inside the block -- conv2d_tiled_pack's chunk order.  Serves every geometry.
-//   TT = true (round 4, three-column filters): a stage = the THREE kx taps of one filter row x a 16-channel group (three k-blocks, one per tap); order:
+//   TT = true (round 4; three-column filters with 64-feature slices, split6_tt()): a stage = the THREE kx taps of one filter row x a 16-channel group (three k-blocks, one per tap); order:
 //               channel group outermost, then ky.  The three taps' gathers of a lane are the same cache lines shifted by one pixel (16 bytes) and
 //               are issued back to back, so two of the three are served by the L1 instead of coming out of L2 again a stage later -- the tap
 //               gathers are what bounds these kernels (profiles/r04_presplit_ab.txt, r04_split6_pixel_tiles_ab.txt).  packed (conv2d_split6_pack):
@@ -259,12 +259,10 @@ bool conv2d_split6_supported(const ConvGeom &g) {
 
 size_t conv2d_split6_packed_floats(const ConvGeom &g) { return size_t(g.kh) * g.kw * g.C * g.M * 3 / 2; }
 
-// three-column filters take the tap-triple stage form (conv2d_split6_kernel<MT, true>); INFERA_SPLIT6_TT=0, read when a model is loaded AND per
-// launch (tests: set it around both), keeps them on the one-tap form
-static bool split6_tt(const ConvGeom &g) {
-  const char *e = getenv("INFERA_SPLIT6_TT");
-  return g.kw == 3 && !(e && atoi(e) == 0);
-}
+// Three-column filters whose features come in 64-wide slices take the tap-triple stage form (conv2d_split6_kernel<2, true>): ResNet-18's four
+// 64-channel layers 1275 -> 1195 us each (-6 %).  With 128-feature slices a gathered pixel already feeds four feature tiles and the form is 1 %
+// SLOWER (36 KB slabs, 232 registers): those stay on the one-tap form (profiles/r04_split6_tap_triple_ab.txt).
+static bool split6_tt(const ConvGeom &g) { return g.kw == 3 && g.M % 128 != 0; }
 
 // exact truncation cut of one weight: v = hi + mid + lo, each a bf16
 static void cut3(float v, uint16_t &hi, uint16_t &mid, uint16_t &lo) {
@@ -327,8 +325,9 @@ void conv2d_split6(hipStream_t s, const float *X, const float *packed, const flo
   auto launch = [&](auto kernel, int features) {
     hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / features)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
   };
-  if (split6_tt(g)) g.M % 128 == 0 ? launch(conv2d_split6_kernel<4, true>, 128) : launch(conv2d_split6_kernel<2, true>, 64);
-  else g.M % 128 == 0 ? launch(conv2d_split6_kernel<4, false>, 128) : launch(conv2d_split6_kernel<2, false>, 64);
+  if (g.M % 128 == 0) launch(conv2d_split6_kernel<4, false>, 128);
+  else if (split6_tt(g)) launch(conv2d_split6_kernel<2, true>, 64);
+  else launch(conv2d_split6_kernel<2, false>, 64);
 }
 
 }  // namespace infera_hip::kern

@@ -17,3 +17,9 @@ python tools/traffic_json.py gpurun_out/r04_final_logreg dense_narrow16 50000000
 python tools/traffic_pass_json.py gpurun_out/r04_final_resnet18 global_avgpool 1024 "r04 final" > gpurun_out/traffic_resnet18.json
 ls -la gpurun_out/ | tail -20
 find gpurun_out/r04_final_mlp -name "*.db" | head
+# the driver-shaped default run (compact line + detail) and the full GPU suite on the final tree
+( timeout 900 python bench.py --steps 20 --warmup 5 --detail gpurun_out/r04_line_mlp_detail.json > gpurun_out/r04_line_mlp.json 2> /dev/null; echo "rc=$? bytes=$(wc -c < gpurun_out/r04_line_mlp.json)" ) > gpurun_out/r04_lines/bench_rc.txt 2>&1
+( timeout 600 python bench.py --workload resnet18 --steps 10 --warmup 3 --detail gpurun_out/r04_line_resnet18_detail.json > gpurun_out/r04_line_resnet18.json 2> /dev/null )
+( timeout 600 python bench.py --workload logreg --steps 20 --warmup 3 --detail gpurun_out/r04_line_logreg_detail.json > gpurun_out/r04_line_logreg.json 2> /dev/null )
+python tools/trace_last_step.py $(find gpurun_out/r04_final_resnet18/trace -name "*.db") > gpurun_out/r04_final_resnet18_last_pass.txt 2>&1
+( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 ) > gpurun_out/r04_lines/pytest.txt
