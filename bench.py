@@ -562,7 +562,7 @@ def compact_line(full: dict) -> dict:
     line["dtype"] = full["dtype"].split(" ")[0]
     line["data"] = "synthetic"
     c = full["config"]
-    line["config"] = {"workload": c["workload"].split(":")[0] + ":" + c["workload"].split(":", 1)[1][:70] if ":" in c["workload"] else c["workload"][:72],
+    line["config"] = {"workload": c["workload"][:120],
                       **_pick(c, ("rows_per_gpu", "rows", "features", "parallelism", "precision", "INFERA_DEVICES")), "kernel": str(c.get("kernel", ""))[:64]}
     line["value_is"] = full["value_is"].split(" ")[0]
     if "roofline" in full:

@@ -88,6 +88,6 @@ th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
 [x.join(timeout=secs + 120) for x in th]
 stuck = sum(x.is_alive() for x in th)
 print(f"calls={sum(counts)} threads={nthreads} stuck={stuck} errors={errors[:3]} zero_copy_calls={capi.zero_copy_calls()} "
-      f"wait={os.environ.get('INFERA_HOST_WAIT', 'poll')}")
+      f"hipgraph={os.environ.get('INFERA_HIPGRAPH', '0')}")
 print("host RSS (s, MB):", samples)
 sys.exit(1 if (errors or stuck) else 0)
