@@ -1819,10 +1819,7 @@ size_t registered_host_ranges() { return g_nranges.load(std::memory_order_acquir
 void copy_rect_to_device(hipStream_t stream, float *dst, const void *src, size_t src_pitch, size_t width, size_t height) {
   HIP_TRY(hipMemcpy2DAsync(dst, width, src, src_pitch, width, height, hipMemcpyHostToDevice, stream));
 }
-bool zero_copy_rect_enabled() {
-  static const bool on = [] { const char *e = getenv("INFERA_ZERO_COPY_RECT"); return e ? atoi(e) != 0 : true; }();
-  return on;
-}
+bool zero_copy_rect_enabled() { return Config::get().zero_copy_rect; }
 
 void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows) {
   const size_t in_per_row = size_t(m.plan.in_per_row());

@@ -156,7 +156,7 @@ const void *lookup_host_memory(const void *p, size_t bytes);  // (address only, 
 size_t registered_host_ranges();
 // `height` runs of `width` bytes, `src_pitch` bytes apart in REGISTERED host memory -> one column-major chunk at dst, as ONE 2-D copy on `stream`
 void copy_rect_to_device(hipStream_t stream, float *dst, const void *src, size_t src_pitch, size_t width, size_t height);
-bool zero_copy_rect_enabled();  // INFERA_ZERO_COPY_RECT=0|1 (round-4 A/B; default set by it)
+bool zero_copy_rect_enabled();  // Config::zero_copy_rect
 // whether a host call of `rows` rows can be handed to the plan's first kernel as column-major chunks (one device pass per host pass)
 bool colmajor_direct_ok(const LoadedModel &m, int64_t rows);
 

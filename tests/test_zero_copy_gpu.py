@@ -201,3 +201,43 @@ def test_gpu_zero_copy_ranges_that_share_pages(gpu_api, tmp_path):
         assert np.array_equal(gpu_api.predict_columns("zp", cols), staged) and gpu_api.zero_copy_calls() == before + 3
     finally:
         gpu_api.unload_model("zp")
+
+
+RECT_CHILD = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from infera_amd import capi, onnx_writer as W, synth
+capi.load_model("zr", W.write(os.path.join(%(tmp)r, "m.onnx"), W.mlp((128, 256, 64, 1))))
+rows, k = 2048 * 6 + 77, 128
+raw = np.zeros(k * rows * 4 + 8192, np.uint8)
+off = (-raw.ctypes.data) %% 4096
+big = raw[off:off + k * rows * 4].view(np.float32).reshape(k, rows)
+big[...] = synth.table(3, 0, rows, k).T
+capi.register_host_memory(big)
+h = hashlib.sha256()
+z0 = capi.zero_copy_calls()
+for r0, n in ((0, 2048), (2048, 2048), (4099, 1000), (rows - 77, 77), (5, 1)):
+    h.update(capi.predict_columns("zr", [big[c, r0:r0 + n] for c in range(k)]).tobytes())
+print("RESULT " + json.dumps({"sha": h.hexdigest(), "zero_copy_calls": capi.zero_copy_calls() - z0}))
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_zero_copy_rect_copy_equals_pulling_kernel(gpu_api, tmp_path):
+    """Round 4: chunks of a pitched FLOAT table are fetched by ONE 2-D copy (INFERA_ZERO_COPY_RECT=1, default); =0 keeps the pulling kernel.
+    Same bytes in HBM either way, so the results must be identical -- aligned and unaligned row offsets, ragged tails, a single row."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for rect in ("1", "0"):
+        env = dict(os.environ, INFERA_ZERO_COPY_RECT=rect)
+        p = subprocess.run([sys.executable, "-c", RECT_CHILD % {"root": root, "tmp": str(tmp_path)}], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out[rect] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+        assert out[rect]["zero_copy_calls"] == 5
+    assert out["1"]["sha"] == out["0"]["sha"]

@@ -1,6 +1,7 @@
 #!/bin/bash
-# ThreadSanitizer run of the host path on a GPU box (profiles/r04_tsan.txt).  Build first, HERE or on the box: make -C tests/native tsan
-# (libinfera_tsan.so = the library's host objects under -fsanitize=thread + the normal gfx950 kernel objects; both harnesses instrumented).
+# ThreadSanitizer and AddressSanitizer runs of the host path on a GPU box (profiles/r04_tsan.txt, r04_asan.txt).  Build first, HERE or on the
+# box: make -C tests/native tsan asan   (libinfera_{tsan,asan}.so = the library's host objects under the sanitizer + the normal gfx950 kernel
+# objects; both harnesses instrumented).
 # ASLR is switched off for the run: gcc 11's TSan runtime cannot map its shadow under large mmap_rnd_bits ("unexpected memory mapping").
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -15,3 +16,7 @@ export TSAN_OPTIONS="halt_on_error=0 suppressions=/tmp/tsan.supp history_size=4 
 ( setarch $(uname -m) -R timeout 900 tests/native/scan_stress_tsan /tmp/mlp128.onnx tests/golden/linear.onnx 3 16 2>&1 | grep -v "^\[WARN\]" | tail -250 ) > $O/scan_stress.txt
 ( tests/native/scan_stress /tmp/mlp128.onnx tests/golden/linear.onnx 3 16 2>&1 | tail -1 ) > $O/scan_stress_plain.txt
 grep -c "WARNING: ThreadSanitizer" $O/concurrency.txt $O/scan_stress.txt; tail -1 $O/scan_stress.txt
+export ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0:halt_on_error=0"
+( timeout 600 tests/native/concurrency_harness_asan tests/golden/linear.onnx 2>&1 | grep -v "^\[WARN\]" | tail -60 ) > $O/asan_concurrency.txt
+( timeout 900 tests/native/scan_stress_asan /tmp/mlp128.onnx tests/golden/linear.onnx 3 16 2>&1 | grep -v "^\[WARN\]" | tail -120 ) > $O/asan_scan_stress.txt
+grep -c "ERROR: AddressSanitizer" $O/asan_concurrency.txt $O/asan_scan_stress.txt; tail -1 $O/asan_scan_stress.txt
