@@ -1387,7 +1387,24 @@ bool run_host_redealt(const LoadedModel &m, const FillFn &fill, const DeviceFill
 void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major) {
   (void)run_host_redealt(m, fill, nullptr, h_out, rows, col_major);
 }
+// Zero-copy fetches a GPU has in flight right now.  GPU-initiated reads of host memory top out at ~42 GB/s on this link whoever issues them, and
+// two to four fetches in flight already reach that; the copy engines, which the STAGED path uses, read host memory at 56.  So with more callers
+// than INFERA_ZERO_COPY_MAX_INFLIGHT (per GPU) the surplus chunks take the staged path -- the two mechanisms share the link instead of queueing
+// on the slower one (false = "stage it", exactly as for a chunk outside the registered ranges).
+std::atomic<int> g_zc_fetches[64];
 bool run_host_device_fill(const LoadedModel &m, const DeviceFillFn &dfill, float *h_out, int64_t rows) {
+  const int limit = Config::get().zero_copy_max_inflight;
+  std::atomic<int> &n = g_zc_fetches[size_t(home_slot()) % 64];
+  if (limit > 0 && n.fetch_add(1, std::memory_order_relaxed) >= limit) {
+    n.fetch_sub(1, std::memory_order_relaxed);
+    return false;
+  }
+  struct Leave {
+    std::atomic<int> *n;
+    ~Leave() {
+      if (n) n->fetch_sub(1, std::memory_order_relaxed);
+    }
+  } leave{limit > 0 ? &n : nullptr};
   return run_host_redealt(m, FillFn(), &dfill, h_out, rows, /*col_major=*/true);
 }
 bool slot_health(int slot, std::string *fault) {
