@@ -205,13 +205,15 @@ def test_zero_copy_allocator_hook_allocate_scan_free_under_16_threads(gpu_api, t
     """the extension's registering allocator (infera_install_zero_copy_allocator, INFERA_ZERO_COPY_ALLOCATOR=1) driven through
     the stub the way an embedding application would: 16 threads each allocate four 256 KiB blocks from DBConfig::allocator, fill them with a
     chunk's 128 column runs, scan the chunk eight times through the extension's infera_predict, free the blocks -- allocation, scan and free of
-    different threads overlapping.  With the hook every scan is served zero-copy, without it staged; the results are the same either way."""
+    different threads overlapping.  With the hook every scan is served zero-copy (the cap on concurrent fetches lifted for the test), without it
+    staged; the results are the same either way."""
     import json
     import sys
 
     out = {}
     for hook in ("1", "0"):
-        env = dict(os.environ, INFERA_ZERO_COPY_ALLOCATOR=hook)
+        # (INFERA_ZERO_COPY_MAX_INFLIGHT=0: no cap on concurrent in-place fetches, so that EVERY scan of a registered chunk must be served zero-copy)
+        env = dict(os.environ, INFERA_ZERO_COPY_ALLOCATOR=hook, INFERA_ZERO_COPY_MAX_INFLIGHT="0")
         p = subprocess.run([sys.executable, "-c", ALLOC_CHILD % {"root": ROOT, "tmp": str(tmp_path)}], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-3000:]
         out[hook] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])

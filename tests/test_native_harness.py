@@ -46,8 +46,9 @@ def test_native_scan_stress_registration_churn_and_model_churn_under_a_16_thread
 
     subprocess.run(["make", "-C", NATIVE, "scan_stress"], check=True, capture_output=True)
     mlp = W.write(str(tmp_path / "mlp128.onnx"), W.mlp((128, 256, 64, 1)))
+    # (INFERA_ZERO_COPY_MAX_INFLIGHT=0: every chunk whose blocks are registered is fetched in place -- the registry under maximum pressure)
     p = subprocess.run([os.path.join(NATIVE, "scan_stress"), mlp, os.path.join(ROOT, "tests", "golden", "linear.onnx"), "2", "16"],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, INFERA_ZERO_COPY_MAX_INFLIGHT="0"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["gpu"] and r["failures"] == 0 and r["scanners"] == 16

@@ -132,7 +132,8 @@ def test_gpu_zero_copy_long_call_and_registration_errors(gpu_api, tmp_path):
 
 @pytest.mark.gpu
 def test_gpu_zero_copy_concurrent_callers(gpu_api, tmp_path):
-    """8 threads x 40 chunks each over one registered table: every chunk equals its slice of one big staged call."""
+    """8 threads x 40 chunks each over one registered table: every chunk equals its slice of one big staged call, whether it was fetched in
+    place or -- the GPU already running its four zero-copy fetches -- staged."""
     k, chunk, nchunks = 128, 2048, 40
     path = W.write(str(tmp_path / "m.onnx"), W.mlp((128, 256, 64, 1)))
     big, x = _table(k, chunk * nchunks, seed=11)
@@ -155,7 +156,8 @@ def test_gpu_zero_copy_concurrent_callers(gpu_api, tmp_path):
             [t.start() for t in th]
             [t.join() for t in th]
             assert not bad, bad
-            assert gpu_api.zero_copy_calls() == before + nchunks
+            # (with more callers than INFERA_ZERO_COPY_MAX_INFLIGHT = 4 the surplus chunks are staged: same results, fewer in-place fetches)
+            assert before + nchunks // 4 <= gpu_api.zero_copy_calls() <= before + nchunks
         finally:
             gpu_api.unregister_host_memory(big)
     finally:
