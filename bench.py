@@ -407,7 +407,6 @@ def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_
                   "kernels -> result vector; beyond INFERA_ZERO_COPY_MAX_INFLIGHT fetches in flight the surplus chunks are staged")
     e["register_seconds"] = reg_s
     e["zero_copy_calls"] = served
-    e["zero_copy_share"] = served / max(1, (len(e["thread_sweep_rows_per_s"]) + 1 + reps) * ((rows + 2047) // 2048))
     fh = f["host_cpu_cost"]
     e["few_callers"] = {"threads_per_rank": few, "rows_per_s": f["rows_per_s"], "cpu_us_per_chunk": fh["cpu_us_per_chunk"],
                         "frac_of_pcie": f["frac_of_pcie"], **{k: fh[k] for k in ("predicted_rows_per_s_at_8_gpus", "predicted_scaling_at_8_gpus", "cpus_needed_for_6x") if k in fh}}

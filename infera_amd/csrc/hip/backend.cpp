@@ -1676,8 +1676,20 @@ std::map<uintptr_t, std::shared_ptr<PageBlock>> g_blocks;       // by pb; non-ov
 std::atomic<size_t> g_nranges{0};
 
 // pins [pb, pe) and returns its device delta, the same on every selected GPU or an error
+// (un)registration is called from the APPLICATION's threads (an allocator hook): their current HIP device is put back afterwards
+struct DeviceRestore {
+  int dev = -1;
+  DeviceRestore() {
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  }
+  ~DeviceRestore() {
+    if (dev >= 0) (void)hipSetDevice(dev);
+  }
+};
+
 intptr_t hip_register_span(uintptr_t pb, uintptr_t pe) {
   const auto &ds = devices();
+  DeviceRestore restore;
   // portable + mapped: visible to every selected GPU; the pages stay where they are (no copy), pinned until unregistered
   HIP_TRY(hipSetDevice(ds.ids[0]));
   HIP_TRY(hipHostRegister(reinterpret_cast<void *>(pb), pe - pb, hipHostRegisterPortable | hipHostRegisterMapped));
