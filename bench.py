@@ -377,7 +377,7 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
 
 
 def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_cols: int, reps: int, budget: dict, world: int, barrier,
-                          max_over_ranks, threads_arg: str = "") -> dict:
+                          max_over_ranks, threads_arg: str = "", all_ok=lambda ok: ok) -> dict:
     """The same scan with the host table REGISTERED once (infera_hip_register_host_memory -- an opt-in for an application that owns
     long-lived column storage or opens DuckDB with the extension's registering allocator; NOT the drop-in path and never the headline).
     Two regimes in one block: `rows_per_s` = the best of the caller sweep -- with many callers the GPU fetches up to
@@ -387,8 +387,16 @@ def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_
     from infera_amd import capi
 
     t0 = time.perf_counter()
-    capi.register_host_memory(table)
+    try:
+        capi.register_host_memory(table)  # (pins the whole table: may hit the box's locked-memory limit -- then NO rank runs this phase)
+        registered, why = True, ""
+    except Exception as exc:
+        registered, why = False, f"{type(exc).__name__}: {exc}"
     reg_s = time.perf_counter() - t0
+    if not all_ok(registered):
+        if registered:
+            capi.unregister_host_memory(table)
+        return {"error": why or "a peer rank could not register its table"}
     try:
         before = capi.zero_copy_calls()
         top = budget["usable"]
@@ -646,7 +654,10 @@ def main():
         os.environ["INFERA_PRECISION"] = args.precision  # (the convolution mode is read when a model is scheduled)
     if world > 1:
         # control plane only (barrier + max-reduce of one float); the data path has no collective
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (a rank that dies inside a collective phase must cost the others minutes, not the default half hour: the contract line is still printed)
+        from datetime import timedelta
+
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=600))
     torch.cuda.set_device(dev)
     torch.cuda.init()
 
@@ -769,26 +780,45 @@ def main():
             e2e["resident_rows_per_s"] = rows * args.steps / elapsed
         except Exception as exc:
             e2e_error = f"{type(exc).__name__}: {exc}"
+    # With N ranks every host-path phase is collective (barriers, max over ranks).  A phase starts only when EVERY rank is ready for it
+    # (all_ok), and an exception inside one -- a peer died: the barrier times out -- ends the collective phases on this rank; the contract
+    # fields above are reported either way.
+    dist_broken = False
+
+    def all_ok(local_ok: bool) -> bool:
+        nonlocal dist_broken
+        if world == 1 or dist_broken:
+            return local_ok and not dist_broken
+        try:
+            return shard.max_over_ranks(0.0 if local_ok else 1.0) == 0.0
+        except Exception:
+            dist_broken = True
+            return False
+
     if sql_fn and not args.no_end_to_end:
         e2e_rows = min(rows, 10_000_000) if args.workload != "mlp" else rows
         try:
             table = sqlmock.synth_table(e2e_rows, cols, 42 + rank, min(32, max(1, budget["usable"] // world)))
-            e2e = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, args.e2e_reps, budget, world, barrier,
-                             shard.max_over_ranks)
-        except Exception as exc:  # the contract fields above must still be reported (single rank; N > 1 would have hung in a barrier)
-            if world > 1:
-                raise
-            e2e_error = f"{type(exc).__name__}: {exc}"
+        except Exception as exc:
+            table, e2e_error = None, f"host table: {type(exc).__name__}: {exc}"
+        if not all_ok(table is not None):
+            table, e2e_error = None, e2e_error or "a peer rank could not materialise its host table"
+        else:
+            try:
+                e2e = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, args.e2e_reps, budget, world, barrier,
+                                 shard.max_over_ranks)
+            except Exception as exc:
+                dist_broken = world > 1
+                e2e_error = f"{type(exc).__name__}: {exc}"
 
     # ---- the same scan over a REGISTERED table (zero-copy path): what the host side costs without the gather ----
     e2e_reg = None
-    if sql_fn and e2e and table is not None and not args.no_end_to_end and not args.no_registered:
+    if sql_fn and table is not None and not args.no_end_to_end and not args.no_registered and all_ok(e2e is not None):
         try:
             e2e_reg = end_to_end_registered(sql_fn, "bench", table, min(rows, 10_000_000) if args.workload != "mlp" else rows, cols, out_cols,
-                                            max(2, min(args.e2e_reps, 3)), budget, world, barrier, shard.max_over_ranks)
+                                            max(2, min(args.e2e_reps, 3)), budget, world, barrier, shard.max_over_ranks, all_ok=all_ok)
         except Exception as exc:
-            if world > 1:
-                raise
+            dist_broken = world > 1
             e2e_reg = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- C4 / C5 end to end + their CPU baselines, short (default single-GPU run) ----
@@ -860,7 +890,7 @@ def main():
                 e2e["vs_cpu_reference_shaped"] = e2e["rows_per_s"] / cb["value"]
                 e2e["pcie_cap_on_ratio"] = e2e["pcie_bound_rows_per_s_per_gpu"]["raw"] / best
         emit(full, args.detail)
-    if world > 1:
+    if world > 1 and not dist_broken:
         dist.destroy_process_group()
 
 

@@ -55,5 +55,6 @@ def test_native_scan_stress_registration_churn_and_model_churn_under_a_16_thread
     assert r["quiet_zero_copy_share"] > 0.99                          # nothing unregistered: every chunk read in place
     assert r["register_unregister_ops"] > 200 and r["load_predict_unload_ops"] > 20
     assert 0.5 < r["disturbed_zero_copy_share"] < 1.0                 # some chunks met an unregistered block and were staged -- and still matched
-    # the churn must not stall the scan (measured 0.95-1.0; the bound leaves room for the two disturber pairs' own CPU and GPU time)
-    assert r["disturbed_rows_per_s"] >= 0.85 * r["quiet_rows_per_s"], r
+    # the churn must not stall the scan: measured 0.975-0.987 of the quiet rate over five boxes (profiles/r04_tsan.txt); VERDICT r3 asked for <= 5 % loss,
+    # the bound leaves three more points for run-to-run noise of two 2-second phases
+    assert r["disturbed_rows_per_s"] >= 0.92 * r["quiet_rows_per_s"], r
