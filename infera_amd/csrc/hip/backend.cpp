@@ -466,7 +466,9 @@ std::vector<EffStep> effective_steps(const LoadedModel &m) {
         out.push_back({int(i), {st[i].in0}, i < m.conv_fused_pool.size() && m.conv_fused_pool[i] >= 0 ? st[size_t(m.conv_fused_pool[i])].out : st[i].out});
         break;
       case ExecKind::ConvTiled:
-        if (i < m.conv_fused_add.size() && m.conv_fused_add[i] >= 0)
+        if (i < m.conv_fold.size() && m.conv_fold[i] >= 0)  // the block's projection shortcut rides in this convolution: it reads that layer's input too
+          out.push_back({int(i), {st[i].in0, st[size_t(m.conv_fold[i])].in0}, st[size_t(m.conv_fused_add[i])].out});
+        else if (i < m.conv_fused_add.size() && m.conv_fused_add[i] >= 0)
           out.push_back({int(i), {st[i].in0, m.conv_residual_buf[i]}, st[size_t(m.conv_fused_add[i])].out});
         else
           out.push_back({int(i), {st[i].in0}, st[i].out});
@@ -749,6 +751,40 @@ void schedule(LoadedModel &m) {
       if (gp.mvalid == 0 && kern::conv2d_stem_split6_supported(gp, kern::PoolTail{int(q.OH), int(q.OW), int(q.pt), int(q.pl)})) m.stem_split6[i] = 1;
     }
   }
+  // A ResNet block's PROJECTION SHORTCUT folded into the block's second convolution (round 4): out = act(conv_kxk(A) + conv_1x1/s(P)) where the
+  // 1x1 layer runs last and carries the fused Add today -- its result tensor is written, and the other operand read back, only to be added.  As
+  // x2.C / 32 more K stages of the second convolution's kernel (conv_split.hip SecondInput) the sum forms in one accumulator: one launch and two
+  // tensor passes less per block.  Conditions: both layers on the split form, the 1x1 layer unpadded and undilated, the other one a
+  // 128-feature launch with no activation and no residual of its own, its output read by the Add alone.  INFERA_CONV_FOLD_SHORTCUT=0 (read when
+  // a model is scheduled): two launches (tests, A/B).
+  m.conv_fold.assign(n, -1);
+  if (m.cq_mode && ScheduleKnobs::read().conv_fold_shortcut) {
+    std::vector<int> prod(m.plan.buf_per_row.size(), -1);
+    for (size_t i = 0; i < n; i++)
+      if (m.exec[i] != ExecKind::Skipped) prod[size_t(st[i].out)] = int(i);
+    for (size_t late = 0; late < n; late++) {
+      const int j = m.conv_fused_add[late];
+      if (j < 0 || !m.conv_split6[late]) continue;
+      const Step &d = st[late];
+      if (d.kh != 1 || d.kw != 1 || d.pt != 0 || d.pl != 0 || d.groups != 1 || d.C % 32 != 0 || d.act != Act::None) continue;
+      const int skip = m.conv_residual_buf[late], early = skip >= 0 ? prod[size_t(skip)] : -1;
+      if (early < 0 || size_t(early) >= late || !m.conv_split6[size_t(early)] || m.conv_fused_add[size_t(early)] >= 0) continue;
+      const Step &c = st[size_t(early)];
+      const kern::ConvGeom gc{int(c.C), int(c.H), int(c.Wd), int(c.Mo), int(c.OH), int(c.OW), int(c.kh), int(c.kw),
+                              int(c.sh), int(c.sw), int(c.pt), int(c.pl), int(c.dh), int(c.dw), int(c.groups)};
+      if (!kern::conv2d_split6_takes_second_input(kern::conv2d_tiled_geom(gc)) || c.act != Act::None || uses[size_t(c.out)] != 1) continue;
+      if (c.Mo != d.Mo || c.OH != d.OH || c.OW != d.OW || c.bias.empty() != d.bias.empty()) continue;
+      if ((d.OH - 1) * d.sh >= d.H || (d.OW - 1) * d.sw >= d.Wd) continue;  // (every output pixel's source pixel lies inside the shortcut's input)
+      if (m.nchw_buf[size_t(d.in0)] || prod[size_t(d.in0)] >= early) continue;  // the shortcut's input exists before the second convolution runs
+      m.conv_fold[size_t(early)] = int(late);
+      m.conv_fused_add[size_t(early)] = j;   // the Add's activation and output now belong to the second convolution ...
+      m.conv_residual_buf[size_t(early)] = -1;  // ... which has no residual to read
+      m.conv_fused_add[late] = -1;
+      m.conv_residual_buf[late] = -1;
+      m.exec[late] = ExecKind::Skipped;
+    }
+  }
+
   // scratch slots by liveness: a slot is reused once its buffer has been read for the last time
   auto eff = effective_steps(m);
   {  // the served output: one writer (a fused streaming kernel that only stores it), no reader
@@ -881,8 +917,20 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
         continue;
       }
       if (m.conv_split6[i]) {
-        packed.resize(kern::conv2d_split6_packed_floats(g));
+        const size_t main_floats = kern::conv2d_split6_packed_floats(g);
+        packed.resize(main_floats);
         kern::conv2d_split6_pack(g, s.W.data(), packed.data());
+        if (const int fl = m.conv_fold[i]; fl >= 0) {  // the folded 1x1 shortcut: its chunks behind the main filter's, its bias added to this layer's
+          const Step &q = st[size_t(fl)];
+          const kern::ConvGeom gq{int(q.C), int(q.H), int(q.Wd), int(q.Mo), int(q.OH), int(q.OW), 1, 1, int(q.sh), int(q.sw), 0, 0, 1, 1, 1};
+          packed.resize(main_floats + kern::conv2d_split6_packed_floats(gq));
+          kern::conv2d_split6_pack(gq, q.W.data(), packed.data() + main_floats);
+          d.W = upload(packed, us);
+          std::vector<float> b(s.bias);
+          for (size_t k = 0; k < b.size() && k < q.bias.size(); k++) b[k] += q.bias[k];
+          d.bias = upload(b, us);
+          continue;
+        }
       } else {
         kern::conv2d_tiled_pack(g, s.W.data(), packed.data());
       }
@@ -1046,6 +1094,12 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
                            int(x.sh), int(x.sw), int(x.pt), int(x.pl), int(x.dh), int(x.dw), int(x.groups)};
           const int fj = m.conv_fused_add[i];
           const kern::ConvGeom gp = kern::conv2d_tiled_geom(g);
+          if (m.conv_split6[i] && m.conv_fold[i] >= 0) {
+            const Step &q = st[size_t(m.conv_fold[i])];
+            const kern::SecondInput x2{buf(q.in0), int(q.C), int(q.H), int(q.Wd), int(q.sh), int(q.sw)};
+            kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, nullptr, buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]), x2);
+            continue;
+          }
           if (m.conv_split6[i]) {
             if (fj >= 0) kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, buf(m.conv_residual_buf[i]), buf(st[size_t(fj)].out), nr, gp, act_of(st[size_t(fj)]));
             else kern::conv2d_split6(s, buf(x.in0), d.W, d.bias, nullptr, buf(x.out), nr, gp, act_of(x));
@@ -1875,12 +1929,18 @@ std::string LoadedModel::describe_json() const {
   std::ostringstream o;
   o << "{\"name\":" << json_str(name) << ",\"plan\":" << plan.describe_json() << ",\"exec\":[";
   for (size_t i = 0; i < exec.size(); i++)
-    o << (i ? "," : "") << "\"" << (i < stem_split6.size() && stem_split6[i] ? "conv_patch_pool_bf16x6" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split6.size() && conv_split6[i] ? "conv_split_bf16x6" : ek[int(exec[i])]) << "\"";
+    o << (i ? "," : "") << "\"" << (exec[i] == ExecKind::Skipped ? "skipped" : i < stem_split6.size() && stem_split6[i] ? "conv_patch_pool_bf16x6" : i < conv_fused_pool.size() && conv_fused_pool[i] >= 0 ? "conv_patch_pool" : i < conv_split6.size() && conv_split6[i] ? "conv_split_bf16x6" : ek[int(exec[i])]) << "\"";
   o << "],\"activation_layout\":\"" << (cq_mode ? "NC/4HW4" : "NCHW") << "\",\"scratch_floats_per_row\":" << scratch_per_row << ",\"devices\":[";
   for (size_t i = 0; i < dev.size(); i++) o << (i ? "," : "") << dev[i]->device;
   o << "]";
   if (std::find(conv_split6.begin(), conv_split6.end(), char(1)) != conv_split6.end())
     o << ",\"conv_precision\":\"bf16x6 (bf16 matrix cores, operands cut exactly into three parts, six partial products, fp32 accumulate)\"";
+  {
+    std::string folded;
+    for (size_t i = 0; i < conv_fold.size(); i++)
+      if (conv_fold[i] >= 0) folded += std::string(folded.empty() ? "" : ",") + std::to_string(conv_fold[i]);
+    if (!folded.empty()) o << ",\"folded_shortcuts\":[" << folded << "]";
+  }
   for (size_t i = 0; i < exec.size(); i++)
     if (exec[i] == ExecKind::Mlp3Head)
       o << ",\"fused_kernel\":" << json_str(kern::mlp3_kernel_name(mlp3_shape)) << ",\"precision\":\"fp32\"";

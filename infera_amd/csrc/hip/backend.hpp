@@ -104,6 +104,7 @@ class LoadedModel {
   std::vector<int> conv_fused_pool;  // per step: the MaxPool 3x3/2 step a ConvPatch stem computes in its own kernel, or -1
   std::vector<int> conv_fused_add;
   std::vector<int> conv_residual_buf;
+  std::vector<int> conv_fold;  // per ConvTiled step: the 1x1 projection-shortcut step computed inside it as extra K stages (conv_split.hip SecondInput), or -1
   std::vector<char> conv_split6;  // ConvTiled steps on conv2d_split6 (default; INFERA_PRECISION=fp32 leaves them on the exact-fp32 kernels)
   std::vector<char> stem_split6;  // ConvPatch + fused MaxPool steps that run conv2d_stem_split6 (same arithmetic)
   std::vector<int> slot_of_buf;        // scratch slot per activation buffer (-1: external in/out)

@@ -61,10 +61,15 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned &hi, un
 //               are issued back to back, so two of the three are served by the L1 instead of coming out of L2 again a stage later -- the tap
 //               gathers are what bounds these kernels (profiles/r04_presplit_ab.txt, r04_split6_pixel_tiles_ab.txt).  packed (conv2d_split6_pack):
 //               [stage = group * kh + ky][mt][kx (3)][part (hi, mid, lo)][lane (64)][e (8 bf16)].
+//
+// A SECOND INPUT (round 4; TT = false only): `x2` -- a tensor of x2.C channels on an H2 x W2 grid, read at (oh * x2.sh, ow * x2.sw) -- supplies
+// x2.C / 32 more stages of a 1x1 filter behind the main filter's stages, their weight chunks appended to the blob.  That is a ResNet block's
+// projection shortcut computed inside the block's second convolution: out = act(conv3x3(A) + conv1x1/s(P) + (b2 + bd)) in ONE accumulator,
+// instead of a separate launch that writes its result and a residual read that fetches it back (x2.X == nullptr: no second input).
 template <int MT, bool TT>
 __global__ __launch_bounds__(kBlock, MT == 2 ? 3 : 2) void conv2d_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
-                                                                 float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act) {
+                                                                 float *__restrict__ Y, int64_t total_pix, ConvGeom g, ActParam act, SecondInput x2) {
   static_assert(MT == 2 || MT == 4, "feature tiles per workgroup");
   constexpr int KB = TT ? 3 : 2;  // k-blocks (16 channels of one tap) per stage
   constexpr int NB = 2 * KB, U = KB * MT, P = 2, SLAB = MT * KB * 768;  // gathered quads per lane and stage; units; A ring depth; floats of weights per stage
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(kBlock, MT == 2 ? 3 : 2) void conv2d_split6_kernel(
   const unsigned lb = blockIdx.x < nfull ? (blockIdx.x & 7u) * (nfull >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int OHW = g.OH * g.OW;
   const int MTtot = g.M / 32, mt0 = blockIdx.y * MT;
-  const int CC = g.C / 32, ntaps = g.kh * g.kw, nstages = TT ? (g.C / 16) * g.kh : ntaps * CC, SB = g.C % 64 == 0 ? 2 : 1;
+  const int CC = g.C / 32, ntaps = g.kh * g.kw, SB = g.C % 64 == 0 ? 2 : 1;
+  const int nmain = TT ? (g.C / 16) * g.kh : ntaps * CC, nstages = nmain + (TT || !x2.X ? 0 : x2.C / 32);
   const int64_t pix = (int64_t(lb) * 4 + wave) * 32 + r;
   const bool pvalid = pix < total_pix;
   const unsigned pix32 = pvalid ? unsigned(pix) : 0u, n32 = pix32 / unsigned(OHW);
@@ -103,8 +109,22 @@ __global__ __launch_bounds__(kBlock, MT == 2 ? 3 : 2) void conv2d_split6_kernel(
 
   // (Round 4 measured one-chunk blocks for the TT = false order -- the nine taps of ONE chunk in consecutive stages: no difference,
   // profiles/r04_split6_stage_order_ab.txt.)
-  int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0, n_sl = 0;
+  int n_tap = 0, n_kx = 0, n_off = 0, n_base = 0, n_sl = 0, n_issued = 0;
+  // this lane's pixel in the second input (a 1x1 filter, no padding: always inside)
+  const int HW4b = x2.H * x2.W * 4;
+  const float *xc2 = (!TT && x2.X && pvalid) ? x2.X + n * int64_t(x2.H) * x2.W * x2.C + int64_t(h) * HW4b + (int64_t(oh * x2.sh) * x2.W + ow * x2.sw) * 4 : nullptr;
   auto gather = [&](f32x4(&b)[NB]) {
+    if constexpr (!TT) {
+      if (n_issued >= nmain) {  // (uniform) a 32-channel chunk of the second input
+        const float *p = xc2 ? xc2 + (n_issued - nmain) * (2 * NB * HW4b) : zp;
+        const int64_t pstride = xc2 ? 2 * int64_t(HW4b) : 0;
+#pragma unroll
+        for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const f32x4 *>(p + q * pstride);
+        n_issued++;
+        return;
+      }
+      n_issued++;
+    }
     if constexpr (TT) {
       // the three taps of filter row n_tap (= ky) for channel group n_sl: quads h and h + 2 of the group at each tap
 #pragma unroll
@@ -253,6 +273,9 @@ __global__ __launch_bounds__(kBlock, MT == 2 ? 3 : 2) void conv2d_split6_kernel(
 
 }  // namespace
 
+// a second input can ride in the one-tap stage form only, which every 128-feature launch takes (conv2d_split6)
+bool conv2d_split6_takes_second_input(const ConvGeom &g) { return g.M % 128 == 0; }
+
 bool conv2d_split6_supported(const ConvGeom &g) {
   return conv2d_tiled_supported(g) && g.groups == 1 && g.C % 32 == 0 && g.M % 64 == 0 && g.kvalid == 0 && g.mvalid == 0 && !g.padc;
 }
@@ -311,22 +334,26 @@ void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed) {
 }
 
 void conv2d_split6(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y, int64_t rows,
-                   const ConvGeom &g, ActParam act) {
+                   const ConvGeom &g, ActParam act, const SecondInput &x2) {
   const int64_t total_pix = rows * g.OH * g.OW;
   if (total_pix <= 0) return;
   if (total_pix >= (int64_t(1) << 31)) {
     const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(g.OH) * g.OW);
     const int64_t in_row = int64_t(g.C) * g.H * g.W, out_row = int64_t(g.M) * g.OH * g.OW;
     for (int64_t r0 = 0; r0 < rows; r0 += cap)
-      conv2d_split6(s, X + r0 * in_row, packed, bias, residual ? residual + r0 * out_row : nullptr, Y + r0 * out_row, std::min(cap, rows - r0), g, act);
+    {
+      SecondInput part = x2;
+      if (part.X) part.X += r0 * int64_t(x2.C) * x2.H * x2.W;
+      conv2d_split6(s, X + r0 * in_row, packed, bias, residual ? residual + r0 * out_row : nullptr, Y + r0 * out_row, std::min(cap, rows - r0), g, act, part);
+    }
     return;
   }
   const unsigned bx = unsigned((total_pix + 127) / 128);
   auto launch = [&](auto kernel, int features) {
-    hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / features)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act);
+    hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / features)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, x2);
   };
   if (g.M % 128 == 0) launch(conv2d_split6_kernel<4, false>, 128);
-  else if (split6_tt(g)) launch(conv2d_split6_kernel<2, true>, 64);
+  else if (split6_tt(g) && !x2.X) launch(conv2d_split6_kernel<2, true>, 64);
   else launch(conv2d_split6_kernel<2, false>, 64);
 }
 

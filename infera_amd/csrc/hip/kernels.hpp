@@ -165,8 +165,16 @@ void conv2d_tiled(hipStream_t s, const float *X, const float *packed, const floa
 bool conv2d_split6_supported(const ConvGeom &g);
 size_t conv2d_split6_packed_floats(const ConvGeom &g);
 void conv2d_split6_pack(const ConvGeom &g, const float *Wt, float *packed);
+// Second input of a split convolution (a ResNet block's projection shortcut folded into the block's second convolution): a channel-quad tensor of C
+// channels on an H x W grid, read at (oh * sh, ow * sw) through a 1x1 filter whose C / 32 weight chunks (conv2d_split6_pack of the 1x1 layer) follow
+// the main filter's in `packed`; X == nullptr: none.  Only where conv2d_split6_takes_second_input(g).
+struct SecondInput {
+  const float *X = nullptr;
+  int C = 0, H = 0, W = 0, sh = 1, sw = 1;
+};
+bool conv2d_split6_takes_second_input(const ConvGeom &g);
 void conv2d_split6(hipStream_t s, const float *X, const float *packed, const float *bias, const float *residual, float *Y, int64_t rows,
-                   const ConvGeom &g, ActParam act);
+                   const ConvGeom &g, ActParam act, const SecondInput &x2 = SecondInput());
 void pool2d(hipStream_t s, const float *X, float *Y, int64_t rows, int C, int H, int W, int OH, int OW, int kh, int kw,
             int sh, int sw, int pt, int pl, int dh, int dw, bool is_max, bool count_pad, bool cq);
 // y[n,c,p] = x[n,c,p] / (bias + alpha/size * sum_{c' in window(c)} x[n,c',p]^2)^beta over [rows, C, S] (cq: channel-quad planes)

@@ -107,7 +107,8 @@ ScheduleKnobs ScheduleKnobs::read() {
   // typo (or a mode of an earlier round) and must not silently select one or the other: warn and keep the default
   const std::string prec = env_or("INFERA_PRECISION", "bf16x6");
   if (prec != "bf16x6" && prec != "fp32") log_msg(1, "INFERA_PRECISION='" + prec + "' is not one of bf16x6 | fp32: using the default (bf16x6)");
-  return ScheduleKnobs{env_flag("INFERA_STEM_POOL", true), env_flag("INFERA_CHAIN_XCM", true), env_flag("INFERA_DENSE_XCM", true), prec != "fp32"};
+  return ScheduleKnobs{env_flag("INFERA_STEM_POOL", true), env_flag("INFERA_CHAIN_XCM", true), env_flag("INFERA_DENSE_XCM", true), prec != "fp32",
+                       env_flag("INFERA_CONV_FOLD_SHORTCUT", true)};
 }
 
 void log_msg(int level, const std::string &msg) {

@@ -121,6 +121,7 @@ struct ScheduleKnobs {
   bool conv_bf16x6; // INFERA_PRECISION unset | bf16x6 (default): the tiled convolutions and the 7x7/2 stem on the bf16 matrix cores, every fp32 operand cut
                     //   EXACTLY into three bf16 parts, six partial products per product, fp32 accumulate (conv_split.hip) -- no scales, no precondition
                     //   on the data.  INFERA_PRECISION=fp32: the exact-fp32 matrix instruction instead (conv.hip's tiled / weight-stationary kernels)
+  bool conv_fold_shortcut;  // INFERA_CONV_FOLD_SHORTCUT=0|1 (default 1)  a ResNet block's 1x1 projection shortcut as extra K stages of the block's second convolution
   static ScheduleKnobs read();
 };
 // Read per launch inside the kernel launchers, for the bit-identity TESTS only (no effect on results; defaults are the shipped paths):

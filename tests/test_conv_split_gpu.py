@@ -88,6 +88,39 @@ def test_gpu_bf16x6_conv_chains_match_oracle(gpu_api, tmp_path, case):
 
 
 @pytest.mark.gpu
+def test_gpu_bf16x6_folded_projection_shortcuts_match_the_two_launch_plan_and_the_oracle(gpu_api, tmp_path):
+    """Round 4: a ResNet block's 1x1 projection shortcut computed as extra K stages of the block's second convolution (one accumulator, one
+    launch) against INFERA_CONV_FOLD_SHORTCUT=0 (the shortcut as its own launch, its result added in an epilogue): the same sums in another
+    order -- equal to a few fp32 roundings of the output scale -- and both within the parity bar of the oracle; a row alone == the row in its
+    batch; odd image sizes (stride-2 shortcuts over 33 x 33 and 17 x 17 maps)."""
+    from oracle import oracle
+
+    for hw in (64, 66):
+        path = W.write(str(tmp_path / f"rn{hw}.onnx"), W.resnet18(classes=10, in_hw=hw, width=64))
+        x = synth.table(13, 0, 5, 3 * hw * hw)
+        gpu_api.load_model("folded", path)
+        os.environ["INFERA_CONV_FOLD_SHORTCUT"] = "0"
+        try:
+            gpu_api.load_model("unfolded", path)
+        finally:
+            os.environ.pop("INFERA_CONV_FOLD_SHORTCUT", None)
+        try:
+            assert len(gpu_api.get_plan("folded")["folded_shortcuts"]) == 3 and "folded_shortcuts" not in gpu_api.get_plan("unfolded")
+            a = gpu_api.predict_from_blob("folded", x.tobytes())
+            b = gpu_api.predict_from_blob("unfolded", x.tobytes())
+            assert np.array_equal(a, gpu_api.predict_from_blob("folded", x.tobytes()))
+            assert np.array_equal(a[3], gpu_api.predict_from_blob("folded", x[3].tobytes()).reshape(-1))
+        finally:
+            gpu_api.unload_model("folded")
+            gpu_api.unload_model("unfolded")
+        want = oracle.Model(path).predict_blob(x.tobytes())
+        scale = np.abs(want).max()
+        assert np.abs(a - b).max() <= 2e-6 * scale, np.abs(a - b).max() / scale
+        for got in (a, b):
+            assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-6), np.abs(got - want).max()
+
+
+@pytest.mark.gpu
 def test_gpu_bf16x6_non_finite_rows_stay_in_their_rows(gpu_api, tmp_path):
     """ResNet-18 (64 x 64 images, full width) over a batch that mixes magnitudes: a NaN or an infinity in one image leaves every OTHER image of
     the batch bit for bit what it is without the poisoned neighbour (no scales: nothing of one row reaches another).  What the poisoned rows
@@ -101,7 +134,8 @@ def test_gpu_bf16x6_non_finite_rows_stay_in_their_rows(gpu_api, tmp_path):
     bad[4, 77] = np.inf
     gpu_api.load_model("conv_bf6", path)
     try:
-        assert gpu_api.get_plan("conv_bf6")["exec"].count("conv_split_bf16x6") == 19
+        plan = gpu_api.get_plan("conv_bf6")  # (sixteen launches: the three 1x1 projection shortcuts ride in their blocks' second convolutions)
+        assert plan["exec"].count("conv_split_bf16x6") == 16 and len(plan["folded_shortcuts"]) == 3
         y = gpu_api.predict_from_blob("conv_bf6", clean.tobytes())
         y_bad = gpu_api.predict_from_blob("conv_bf6", bad.tobytes())
     finally:
@@ -155,7 +189,7 @@ def test_gpu_bf16x6_c5_full_width_error_against_float64(gpu_api, tmp_path):
     gpu_api.load_model("conv_bf6", path)  # the default
     try:
         plan = gpu_api.get_plan("conv_bf6")
-        assert plan["exec"].count("conv_split_bf16x6") == 19 and plan["exec"][0] == "conv_patch_pool_bf16x6"
+        assert plan["exec"].count("conv_split_bf16x6") == 16 and len(plan["folded_shortcuts"]) == 3 and plan["exec"][0] == "conv_patch_pool_bf16x6"
         y6 = gpu_api.predict_from_blob("conv_bf6", x.tobytes())
         y32 = gpu_api.predict_from_blob("conv_fp32", x.tobytes())
         assert np.array_equal(y6[2], gpu_api.predict_from_blob("conv_bf6", x[2].tobytes()).reshape(-1))

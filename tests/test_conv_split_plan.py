@@ -29,10 +29,19 @@ def test_resnet18_plan_default_and_fp32(built, tmp_path):
     default = _plan(tmp_path, "rn_default", blob)
     assert plain["exec"][0] == "conv_patch_pool" and plain["exec"].count("conv_tiled_cq") == 19 and "conv_precision" not in plain
     # the default: the stem and the same 19 layers on the bf16 matrix cores with three exact parts per operand; no maxima, so no extra scratch
-    assert default["exec"][0] == "conv_patch_pool_bf16x6" and default["exec"].count("conv_split_bf16x6") == 19 and "bf16x6" in default["conv_precision"]
-    assert default["scratch_floats_per_row"] == plain["scratch_floats_per_row"]
+    # ... and each block's 1x1 projection shortcut (three of them) folded into the block's second convolution as extra K stages: sixteen launches
+    assert default["exec"][0] == "conv_patch_pool_bf16x6" and default["exec"].count("conv_split_bf16x6") == 16 and "bf16x6" in default["conv_precision"]
+    assert len(default["folded_shortcuts"]) == 3 and all(default["exec"][i] == "skipped" for i in default["folded_shortcuts"])
+    assert default["scratch_floats_per_row"] <= plain["scratch_floats_per_row"]
+    os.environ["INFERA_CONV_FOLD_SHORTCUT"] = "0"
+    try:
+        unfolded = _plan(tmp_path, "rn_unfolded", blob)
+    finally:
+        os.environ.pop("INFERA_CONV_FOLD_SHORTCUT", None)
+    assert unfolded["exec"].count("conv_split_bf16x6") == 19 and "folded_shortcuts" not in unfolded
     # same steps, same fusions (residual adds in the epilogues, the head on the exact-fp32 tiled kernel): only the names of the moved steps differ
-    assert [{"conv_split_bf16x6": "conv_tiled_cq", "conv_patch_pool_bf16x6": "conv_patch_pool"}.get(e, e) for e in default["exec"]] == plain["exec"]
+    assert [{"conv_split_bf16x6": "conv_tiled_cq", "conv_patch_pool_bf16x6": "conv_patch_pool"}.get(e, e) for e in unfolded["exec"]] == plain["exec"]
+    assert "folded_shortcuts" not in plain  # (the exact-fp32 kernels keep the shortcut as its own launch)
     # a mode name this build does not know (a typo, a mode of an earlier round) must not silently pick an arithmetic: default + a warning
     assert _plan(tmp_path, "rn_typo", blob, "f16x3")["exec"] == default["exec"]
     assert _plan(tmp_path, "rn_named", blob, "bf16x6")["exec"] == default["exec"]
