@@ -401,7 +401,7 @@ def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_
         before = capi.zero_copy_calls()
         top = budget["usable"]
         share = max(2, top // world)
-        th = threads_arg or ",".join(str(t) for t in sorted({max(2, share // 4), max(2, share // 2), share, 2 * share}))
+        th = threads_arg or ",".join(str(t) for t in sorted({max(2, share // 4), max(2, share // 2), share}))
         e = end_to_end(fn, model, table, rows, cols, out_cols, th, reps, budget, world, barrier, max_over_ranks)
         served = capi.zero_copy_calls() - before
         few = min(4, max(2, share))
