@@ -660,6 +660,7 @@ struct PatchGeom {
   int K8;           // 8-wide k groups (C*kh*kw rounded up)
   int tiles_x, tiles_y;
   int NE;           // patch words each thread moves per tile
+  int PP, RO;       // conv2d_stem_split6_kernel only (stem_split6_geom): words per PAIR of patch rows, offset of the pair's odd row
 };
 constexpr int kPatchMaxE = 16;
 
@@ -1310,6 +1311,21 @@ constexpr int kStemKB = 11;
 // workgroups per CU the exchange tile ALIASES the patch (37 KB each): the pooling runs
 // between the k loops (four barriers per tile instead of two: out of the k loop -> exchange tile written -> pooled and stored -> next patch parked)
 // rather than in the next tile's shadow.  Same tile flow otherwise (two half-channel workgroups per CU, the odd half half a tile late).
+// The patch layout of this kernel (8-byte words).  A lane group of a patch-word read (ds_read_b64: 32 lanes = 32 consecutive pixels of the 15-wide
+// pixel tile, two to four convolution rows) is conflict-free when pixel i sits on 8-byte slot i mod 32, i.e. when consecutive convolution rows are
+// 15 slots apart (mod 32).  A convolution row is TWO patch rows down (stride 2), so no single row pitch can do that (twice a pitch is even -- the
+// 16-slot pitch of the exact-fp32 stems left two lanes of every group on a taken slot: every read took twice its cycles, 0.63 M of the 0.87 M
+// conflict cycles per CU of the round-4 PMC pass): patch rows are laid out in PAIRS, PP = 15 (mod 32) words per pair, the odd row RO words in.
+static PatchGeom stem_split6_geom(const ConvGeom &g, const PoolTail &pool) {
+  PatchGeom p = patch_pool_geom(g, pool);
+  const int row_words = g.sw * p.HALF;
+  p.RO = row_words;
+  p.PP = 2 * row_words;
+  while (p.PP % 32 != 15) p.PP++;
+  p.ROWS = 0;  // (no uniform row pitch here)
+  p.PLANE = (p.PR + 1) / 2 * p.PP;
+  return p;
+}
 static size_t stem_split6_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
   const size_t patch_b = (size_t(g.C) * p.PLANE + 8) * 8, exch_b = 256 * size_t(32 + 4) * 4;
   return size_t(kStemKB) * 3072 + std::max(patch_b, exch_b) + 64;
@@ -1328,6 +1344,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
   const int r = lane & 31, h = lane >> 5;
   const int psz = g.C * pg.PLANE;
   const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, half = wg & 1, pair = wg >> 1;
+  auto rowoff = [&](int row) { return (row >> 1) * pg.PP + (row & 1) * pg.RO; };  // (stem_split6_geom)
 
   // blob: [KBC][half][part][64][4 dwords]
   for (int i = threadIdx.x; i < KBC * 192; i += BS)
@@ -1336,7 +1353,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
 #pragma unroll
   for (int rr = 0; rr < 2 * KBC; rr++) {
     const int c = rr / g.kh, ky = rr - c * g.kh;
-    soff[rr] = rr < g.C * g.kh ? c * pg.PLANE + ky * g.dh * pg.ROWS : 0;
+    soff[rr] = rr < g.C * g.kh ? c * pg.PLANE + rowoff(ky) : 0;
   }
   int e_rel[kPatchMaxE], e_rc[kPatchMaxE], e_lds[kPatchMaxE];
 #pragma unroll
@@ -1346,7 +1363,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
     const bool live = c < g.C;
     e_rel[i] = (c * g.H + row) * g.W + col;
     e_rc[i] = live ? (row << 16) | col : -1;
-    e_lds[i] = live ? c * pg.PLANE + row * pg.ROWS + (col % g.sw) * pg.HALF + col / g.sw : -1;
+    e_lds[i] = live ? c * pg.PLANE + rowoff(row) + (col % g.sw) * pg.HALF + col / g.sw : -1;
   }
   const int tiles_per_img = pg.tiles_x * pg.tiles_y;
   auto tile_origin = [&](int64_t t, int &img, int &oy0, int &ox0) {
@@ -1367,7 +1384,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
   auto park_patch = [&](const float(&v)[kPatchMaxE]) {
     // (one word per patch row is read but never parked -- the odd half's word HALF - 1 = column 2 HALF - 1 past the patch, kx = 7 of the last
     //  pixels, weight zero: it must be finite, and the exchange tile has been there)
-    for (int i = threadIdx.x; i < g.C * pg.PR; i += BS) patch[(i / pg.PR) * pg.PLANE + (i % pg.PR) * pg.ROWS + 2 * pg.HALF - 1] = uint2{0u, 0u};
+    for (int i = threadIdx.x; i < g.C * pg.PR; i += BS) patch[(i / pg.PR) * pg.PLANE + rowoff(i % pg.PR) + 2 * pg.HALF - 1] = uint2{0u, 0u};
 #pragma unroll
     for (int i = 0; i < kPatchMaxE; i++) {  // exact cut: hi = top 16 bits, mid = top 16 bits of the rest, lo = what is left (8 bits: exact in bf16)
       const unsigned x = __float_as_uint(v[i]);
@@ -1384,7 +1401,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
     const int pix = min((wave + 4 * p) * 32 + r, kPoolCR * kPoolCC - 1);
     py[p] = pix / kPoolCC;
     px[p] = pix % kPoolCC;
-    lbase[p] = py[p] * g.sh * pg.ROWS + px[p];
+    lbase[p] = py[p] * pg.PP + px[p];  // (stride 2: convolution row py starts at patch row 2 py)
   }
   const u32x4_t *wfrag = wl + lane;
   f32x4 bres[4];
@@ -1434,48 +1451,82 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
     const uint2 *pb[PW] = {patch + lbase[0], patch + lbase[1]};
-    // a step = (k-block, pixel tile): eight cut patch words (even half: kx 0 2 4 6, odd half: kx 1 3 5 7), fetched one step ahead; the
-    // k-block's three weight fragments one k-block ahead
-    uint2 w[2][8];
+    // a step = one k-block for BOTH pixel tiles: eight cut patch words per tile (even half: kx 0 2 4 6, odd half: kx 1 3 5 7) and the k-block's
+    // three weight fragments, all fetched one k-block ahead.  The order is PINNED with sched_barriers: fragments of this k-block assembled ->
+    // the next k-block's LDS reads issued -> twelve matrix instructions (the two tiles' accumulators alternate, so consecutive ones are
+    // independent).  Left to itself the scheduler sinks the reads below the matrix instructions and waits for them at once.
+    // The patch words are read with ds_read_b64 (two LDS cycles per wave instruction, 64 banks), written as inline assembly: the compiler fuses
+    // the two adjacent words of a lane into ds_read2_b64, which the LDS serves at a quarter of that rate (eight cycles per instruction: 32 banks,
+    // 16-lane groups) -- sixteen of them per k-block and wave kept the LDS, not the matrix cores, busy (MI355X_MICROARCH.md, LDS table;
+    // profiles/r04_stem_lds_ab.txt).  The counter wait is written by hand as well (wait_words), with the words as operands so that no use moves
+    // above it.
+    using u64w = unsigned long long;
+    u64w w[PW][8];
     u32x4_t a3[2][3];
-    auto fetch_words = [&](int step, int buf) {
-      const int kb = step / PW, p = step % PW;
-      const uint2 *row = pb[p] + (h ? soff[2 * kb + 1] : soff[2 * kb]), *rowh = row + pg.HALF;
+    auto fetch_words = [&](int kb, int p) {
+      const uint2 *row = pb[p] + (h ? soff[2 * kb + 1] : soff[2 * kb]);
+      const unsigned a0 = unsigned(size_t((const __attribute__((address_space(3))) void *)row)), a1 = a0 + unsigned(pg.HALF) * 8u;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        w[buf][e] = row[e];
-        w[buf][4 + e] = rowh[e];
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w[p][e]) : "v"(a0), "n"(8 * e));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w[p][4 + e]) : "v"(a1), "n"(8 * e));
       }
     };
-    fetch_words(0, 0);
+    // (the weight fragments the same way: a read the compiler counts would make it wait for "all but the last three" LDS reads before the matrix
+    //  instructions -- that is, for every patch word just issued)
+    const unsigned wfrag_a = unsigned(size_t((const __attribute__((address_space(3))) void *)wfrag));
+    auto fetch_weights = [&](int kb, int buf) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) a3[0][k] = wfrag[k * 64];
+      for (int k = 0; k < 3; k++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a3[buf][k]) : "v"(wfrag_a), "n"((kb * 3 + k) * 1024));
+    };
+    auto wait_words = [&](int buf) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[0][4]), "+v"(w[0][5]), "+v"(w[0][6]), "+v"(w[0][7]),
+                     "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]), "+v"(w[1][4]), "+v"(w[1][5]), "+v"(w[1][6]), "+v"(w[1][7]),
+                     "+v"(a3[buf][0]), "+v"(a3[buf][1]), "+v"(a3[buf][2]));
+    };
 #pragma unroll
-    for (int step = 0; step < KBC * PW; step++) {
-      const int kb = step / PW, p = step % PW, cur = step & 1, kc = kb & 1;
-      if (step + 1 < KBC * PW) fetch_words(step + 1, cur ^ 1);
-      if (p == 0 && kb + 1 < KBC) {
+    for (int p = 0; p < PW; p++) fetch_words(0, p);
+    fetch_weights(0, 0);
 #pragma unroll
-        for (int k = 0; k < 3; k++) a3[kc ^ 1][k] = wfrag[((kb + 1) * 3 + k) * 64];
+    for (int kb = 0; kb < KBC; kb++) {
+      const int kc = kb & 1;
+      u32x4_t bh[PW], bm[PW], bl[PW];
+      wait_words(kc);
+#pragma unroll
+      for (int p = 0; p < PW; p++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {  // elements 2i, 2i + 1 of the fragment: hi halves, mid halves, lo halves of two cut words
+          const unsigned x0 = unsigned(w[p][2 * i]), y0 = unsigned(w[p][2 * i] >> 32), x1 = unsigned(w[p][2 * i + 1]), y1 = unsigned(w[p][2 * i + 1] >> 32);
+          bh[p][i] = __builtin_amdgcn_perm(x1, x0, 0x05040100u);
+          bm[p][i] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+          bl[p][i] = __builtin_amdgcn_perm(y1, y0, 0x05040100u);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb + 1 < KBC) {
+#pragma unroll
+        for (int p = 0; p < PW; p++) fetch_words(kb + 1, p);
+        fetch_weights(kb + 1, kc ^ 1);
       }
-      u32x4_t bh, bm, bl;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {  // elements 2i, 2i + 1 of the fragment: hi halves, mid halves, lo halves of two cut words
-        bh[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1].x, w[cur][2 * i].x, 0x05040100u);
-        bm[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1].x, w[cur][2 * i].x, 0x07060302u);
-        bl[i] = __builtin_amdgcn_perm(w[cur][2 * i + 1].y, w[cur][2 * i].y, 0x05040100u);
-      }
-      // the next tile's patch words ride along: sixteen fetches over the 22 steps
+      // the next tile's patch words ride along: sixteen fetches over the eleven k-blocks
 #pragma unroll
       for (int sl = 0; sl < kPatchMaxE; sl++)
-        if (sl * (KBC * PW) / kPatchMaxE == step) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
+        if (sl * KBC / kPatchMaxE == kb) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
+      __builtin_amdgcn_sched_barrier(0);
       auto B = [](const u32x4_t &v) { return __builtin_bit_cast(bf16x8_s, v); };
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][2]), B(bh), acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bl), acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][1]), B(bm), acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][1]), B(bh), acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bm), acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bh), acc[p], 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PW; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][2]), B(bh[p]), acc[p], 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PW; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bl[p]), acc[p], 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PW; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][1]), B(bm[p]), acc[p], 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PW; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][1]), B(bh[p]), acc[p], 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PW; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bm[p]), acc[p], 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PW; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B(a3[kc][0]), B(bh[p]), acc[p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     __syncthreads();  // everybody is out of the k loop: the patch region becomes the exchange tile
@@ -1838,9 +1889,9 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
 // bank-conflict share of round 3's PMC pass costs the kernel -- profiles/r04_stem_pitch_ab.txt.)
 bool conv2d_stem_split6_supported(const ConvGeom &g, const PoolTail &pool) {
   if (!conv2d_patch_pool_supported(g, pool) || g.M != 64) return false;
-  const PatchGeom p = patch_pool_geom(g, pool);
+  const PatchGeom p = stem_split6_geom(g, pool);
   // (the k loop reads four consecutive words of each half of a de-interleaved patch row: 7 columns, stride 2)
-  return g.kw == 7 && g.sw == 2 && g.dw == 1 && (g.C * g.kh + 1) / 2 == kStemKB && p.HALF >= kPoolCC + 3 &&
+  return g.kw == 7 && g.sw == 2 && g.dw == 1 && g.sh == 2 && g.dh == 1 && (g.C * g.kh + 1) / 2 == kStemKB && p.HALF >= kPoolCC + 3 &&
          (g.C * p.PR * p.PC + kPool2Block - 1) / kPool2Block <= kPatchMaxE && 2 * stem_split6_lds_bytes(g, p) <= 160 * 1024;
 }
 
@@ -1876,7 +1927,7 @@ void conv2d_stem_split6_pack(const ConvGeom &g, const float *Wt, float *packed) 
 void conv2d_stem_split6(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows, const ConvGeom &g,
                         ActParam act, const PoolTail &pool, int num_cus) {
   if (rows <= 0) return;
-  const PatchGeom p = patch_pool_geom(g, pool);
+  const PatchGeom p = stem_split6_geom(g, pool);
   if (const int64_t cap = ((int64_t(1) << 31) - 1) / (int64_t(p.tiles_x) * p.tiles_y); rows > cap) {
     for (int64_t r0 = 0; r0 < rows; r0 += cap)
       conv2d_stem_split6(s, X + r0 * g.C * g.H * g.W, packed, bias, Y + r0 * g.M * pool.OH * pool.OW, std::min(cap, rows - r0), g, act, pool, num_cus);
