@@ -1331,6 +1331,17 @@ static size_t stem_split6_lds_bytes(const ConvGeom &g, const PatchGeom &p) {
   return size_t(kStemKB) * 3072 + std::max(patch_b, exch_b) + 64;
 }
 using bf16x8_s = __attribute__((ext_vector_type(8))) __bf16;
+#ifdef INFERA_STEM_TIMING  // tools/ubench/stem_phases.hip: cycle sums per phase of the first workgroup pair (wave 0 of each half)
+__device__ unsigned long long g_stem_phase[2][10];
+#define STEM_T(i)                                                   \
+  if (timing) {                                                     \
+    const unsigned long long t_now = __builtin_readcyclecounter();  \
+    tsum[i] += t_now - tlast;                                       \
+    tlast = t_now;                                                  \
+  }
+#else
+#define STEM_T(i)
+#endif
 
 __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                            const float *__restrict__ bias, float *__restrict__ Y, int64_t ntiles,
@@ -1438,7 +1449,12 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
   }
   const unsigned pooled_img_bytes = unsigned(g.M / 4) * unsigned(pool.OH) * unsigned(pool.OW) * 16u;
 
+#ifdef INFERA_STEM_TIMING
+  const bool timing = __builtin_amdgcn_readfirstlane(wave) == 0 && pair == 0 && xcd == 0;
+  unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
   for (; tile < t_end; tile += tstep) {
+    STEM_T(8)
     const int64_t next = tile + tstep;
     const int oy0 = oy0_n, ox0 = ox0_n, img = img_n;
     tile_origin(next < t_end ? next : tile, img_n, oy0_n, ox0_n);
@@ -1488,6 +1504,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
 #pragma unroll
     for (int p = 0; p < PW; p++) fetch_words(0, p);
     fetch_weights(0, 0);
+    STEM_T(9)
 #pragma unroll
     for (int kb = 0; kb < KBC; kb++) {
       const int kc = kb & 1;
@@ -1529,7 +1546,9 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    STEM_T(0)
     __syncthreads();  // everybody is out of the k loop: the patch region becomes the exchange tile
+    STEM_T(1)
     dispatch_act(act.kind, [&](auto kind_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
@@ -1545,7 +1564,9 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
         }
       }
     });
+    STEM_T(2)
     __syncthreads();
+    STEM_T(3)
     {  // pooling: every thread its (at most two) pooled (pixel, channel quad) items
       const char *base = reinterpret_cast<const char *>(Y) + int64_t(__builtin_amdgcn_readfirstlane(img)) * pooled_img_bytes;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, int(pooled_img_bytes), 0x00020000);
@@ -1566,10 +1587,18 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), rs, voff, 0, 0);
       }
     }
+    STEM_T(4)
     __syncthreads();  // the exchange tile has been read: the region is the patch again
+    STEM_T(5)
     park_patch(pv);   // (unconditional: the last tile parks its own re-fetched patch)
+    STEM_T(6)
     __syncthreads();
+    STEM_T(7)
   }
+#ifdef INFERA_STEM_TIMING
+  if (timing && lane == 0)
+    for (int i = 0; i < 10; i++) g_stem_phase[half][i] = tsum[i];
+#endif
 }
 
 // Depthwise convolution (groups == C == M) in channel-quad planes: HBM-bound, no matrix cores.  One thread per
@@ -1883,10 +1912,9 @@ void conv2d_patch_pool(hipStream_t s, const float *X, const float *packed, const
 }
 
 // ---- bf16 x three parts stem + max-pool (conv2d_stem_split6_kernel) ----
-// (Round 4 measured and dropped: an own LDS row pitch for this kernel's 8-byte patch words -- its k loop fetches them with ds_read2_b64, served in
-// 16-lane groups on 32 banks, where patch_pool_geom's pitch (made for the 4-byte words of the exact-fp32 stems) puts consecutive convolution rows 0
-// banks apart (mod 32); a pitch of 7 (mod 8) words puts them 28 apart.  2145 against 2148 us per 1024 images: those reads are not what the 43 %
-// bank-conflict share of round 3's PMC pass costs the kernel -- profiles/r04_stem_pitch_ab.txt.)
+// (Round 4, first try: a different ROW pitch for the 8-byte patch words while the k loop still fetched them with the compiler's ds_read2_b64 --
+// no change, profiles/r04_stem_pitch_ab.txt.  What the LDS share was really made of -- the instruction, then the banks -- is in
+// stem_split6_geom's and the k loop's comments: profiles/r04_stem_lds_ab.txt, 2186 -> 1895 us.)
 bool conv2d_stem_split6_supported(const ConvGeom &g, const PoolTail &pool) {
   if (!conv2d_patch_pool_supported(g, pool) || g.M != 64) return false;
   const PatchGeom p = stem_split6_geom(g, pool);
