@@ -82,6 +82,10 @@ struct ThreadCtx {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // completion of the pass that last used staging slot 0 / 1
+  // second lane of a long convolutional pass (exec_plan): its own stream, forked from / joined into `stream` by events
+  static constexpr int kMaxLanes = 2;  // (three and four lanes: no better than one, profiles/r04_conv_lanes_ab.txt)
+  hipStream_t lane_stream[kMaxLanes - 1] = {nullptr};
+  hipEvent_t lane_ev[kMaxLanes] = {nullptr, nullptr};  // [0]: fork; [i]: lane i done
   hipEvent_t poll_ev = nullptr;                // completion marker of a host-ABI call, queried between naps
   // How a host-ABI call waits for its chunk: it NAPS.  ROCm 7.2's "blocking" event wait (hipEventSynchronize on a hipEventBlockingSync event)
   // burns the core for the whole wait, and so does hipStreamSynchronize: 277 us of CPU per chunk at 16 callers against 85 with naps at the same
@@ -1023,8 +1027,25 @@ int64_t rows_per_pass(const LoadedModel &m, int64_t rows) {
 // ... and grows the scratch for it (never inside a stream capture: callers that capture call this first).
 int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
   const int64_t rows_pass = rows_per_pass(m, rows);
-  if (m.scratch_per_row > 0 && m.plan.out_buf != 0) ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass) * size_t(m.scratch_per_row) * 4);
+  // (+ 1 row: a pass cut into two lanes of ceil(n / 2) rows each)
+  if (m.scratch_per_row > 0 && m.plan.out_buf != 0)
+    ctx.ensure_dev(ctx.scratch, ctx.scratch_cap, size_t(rows_pass + ThreadCtx::kMaxLanes) * size_t(m.scratch_per_row) * 4);
   return rows_pass;
+}
+
+// A long pass of a convolutional plan runs as TWO LANES: its rows in two halves, each through all the plan's kernels on its own stream, with
+// its own half of the scratch.  Every launch of such a plan ends in a partial round of workgroups (ResNet-18 at 1024 images: 12.25 / 6.125 /
+// 3.06 rounds for its 128 / 256 / 512-channel layers -- 3.2 % of the pass, profiles/r04_tail_rounds.txt); with two independent kernel
+// sequences in flight the other lane's workgroups fill those rounds (and the stem of one lane runs beside the matrix-bound layers of the
+// other).  Same kernels, same per-row arithmetic: results are bit-identical (tests/test_conv_split_gpu.py).  ResNet-18, 1024 images: 18.42 ->
+// 17.94 ms (-2.6 %); three or four lanes: no gain (profiles/r04_conv_lanes_ab.txt).  Not under a stream capture (INFERA_HIPGRAPH=1), not
+// for the short passes of the host path (many contexts already overlap there).
+constexpr int64_t kLaneMinRows = 512;
+int lanes_of(const LoadedModel &m, int64_t nr) {
+  if (nr < kLaneMinRows || Config::get().use_hipgraph || m.scratch_per_row <= 0) return 1;
+  for (const ExecKind k : m.exec)
+    if (k == ExecKind::ConvTiled) return ThreadCtx::kMaxLanes;
+  return 1;
 }
 
 // in_colmajor: d_in is one column-major chunk [in_per_row][rows] (only with m.in_colmajor_ok, which implies a single pass)
@@ -1042,16 +1063,16 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
   // callers check single_pass() first and stage such calls row-major instead; this guards every kernel family at once
   if (in_colmajor && rows_pass != rows) throw InferaError::onnx("internal: column-major input needs a single pass");
   std::vector<int64_t> slot_base(m.slot_per_row.size(), 0);
-  {
-    int64_t off = 0;
-    for (size_t i = 0; i < m.slot_per_row.size(); i++) {
-      slot_base[i] = off;
-      off += m.slot_per_row[i] * rows_pass;
-    }
-  }
   const auto &st = p.steps;
-  for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
-    const int64_t nr = std::min(rows_pass, rows - r0);
+  // rows r0 .. r0 + nr - 1 through every step on stream s; scratch slots sized for slot_rows rows, from scratch_off floats into the scratch
+  auto run_rows = [&](hipStream_t s, int64_t r0, int64_t nr, int64_t slot_rows, int64_t scratch_off) {
+    {
+      int64_t off = scratch_off;
+      for (size_t i = 0; i < m.slot_per_row.size(); i++) {
+        slot_base[i] = off;
+        off += m.slot_per_row[i] * slot_rows;
+      }
+    }
     auto buf = [&](int b) -> float * {
       if (b == 0) return const_cast<float *>(d_in) + r0 * p.in_per_row();
       if (b == p.out_buf) return d_out + r0 * p.out_per_row();
@@ -1185,6 +1206,31 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
       }
     }
     HIP_TRY(hipGetLastError());
+  };
+  for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
+    const int64_t nr = std::min(rows_pass, rows - r0);
+    const int nl = in_colmajor ? 1 : lanes_of(m, nr);
+    if (nl == 1) {
+      run_rows(ctx.stream, r0, nr, rows_pass, 0);
+      continue;
+    }
+    if (!ctx.lane_ev[0]) {
+      for (hipStream_t &ls : ctx.lane_stream) HIP_TRY(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+      for (hipEvent_t &e : ctx.lane_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int64_t nlane = (nr + nl - 1) / nl;  // rows per lane (the last lane: what is left)
+    HIP_TRY(hipEventRecord(ctx.lane_ev[0], ctx.stream));  // (the input is on the device, the previous pass has left the scratch)
+    for (int l = 0; l < nl; l++) {
+      const int64_t l0 = l * nlane, ln = std::min(nlane, nr - l0);
+      if (ln <= 0) break;
+      hipStream_t ls = l == 0 ? ctx.stream : ctx.lane_stream[l - 1];
+      if (l > 0) HIP_TRY(hipStreamWaitEvent(ls, ctx.lane_ev[0], 0));
+      run_rows(ls, r0 + l0, ln, nlane, int64_t(m.scratch_per_row) * nlane * l);
+      if (l > 0) {
+        HIP_TRY(hipEventRecord(ctx.lane_ev[l], ls));
+        HIP_TRY(hipStreamWaitEvent(ctx.stream, ctx.lane_ev[l], 0));
+      }
+    }
   }
 }
 

@@ -275,3 +275,25 @@ def test_gpu_bf16x6_stem_alone_and_ranges(gpu_api, tmp_path):
         for r in range(len(mags)):
             scale = np.abs(want[r]).max()
             assert np.abs(got[r] - want[r]).max() <= max(1.5e-6 * scale, 1.5 * np.abs(ref32[r] - want[r]).max()) + 1e-37, (hw, r, np.abs(got[r] - want[r]).max() / scale)
+
+
+@pytest.mark.gpu
+def test_gpu_long_conv_passes_run_as_two_lanes_bit_identical_to_short_calls(gpu_api, tmp_path):
+    """backend.cpp exec_plan: a pass of >= 512 rows of a convolutional plan runs as two lanes (two halves, two streams, two halves of the
+    scratch).  Same kernels, same per-row arithmetic: the long call must equal the same rows served 100 at a time (single lane), bit for
+    bit, for an odd row count, and twice in a row (the lanes share nothing but the weights)."""
+    hw, rows = 9, 1037
+    path = W.write(str(tmp_path / "net.onnx"), _net([(64, 3, 1), (64, 3, 1), (128, 3, 2), (128, 3, 1)], 4, hw, residual_at=(1, 3)))
+    x = synth.table(31, 0, rows, 4 * hw * hw).astype(np.float32)
+    gpu_api.load_model("lanes", path)
+    try:
+        plan = gpu_api.get_plan("lanes")
+        assert plan["exec"].count("conv_split_bf16x6") >= 3, plan["exec"]
+        long_call = gpu_api.predict_from_blob("lanes", x.tobytes())
+        again = gpu_api.predict_from_blob("lanes", x.tobytes())
+        short = np.concatenate([gpu_api.predict_from_blob("lanes", x[r0:r0 + 100].tobytes()).reshape(-1, long_call.shape[1]) for r0 in range(0, rows, 100)])
+    finally:
+        gpu_api.unload_model("lanes")
+    assert long_call.shape == (rows, 128) and np.all(np.isfinite(long_call))
+    assert np.array_equal(long_call, again)
+    assert np.array_equal(long_call, short)
