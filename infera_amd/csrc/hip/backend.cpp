@@ -1220,16 +1220,23 @@ void exec_plan(const LoadedModel &m, const DeviceModel &dm, ThreadCtx &ctx, cons
     }
     const int64_t nlane = (nr + nl - 1) / nl;  // rows per lane (the last lane: what is left)
     HIP_TRY(hipEventRecord(ctx.lane_ev[0], ctx.stream));  // (the input is on the device, the previous pass has left the scratch)
-    for (int l = 0; l < nl; l++) {
-      const int64_t l0 = l * nlane, ln = std::min(nlane, nr - l0);
-      if (ln <= 0) break;
-      hipStream_t ls = l == 0 ? ctx.stream : ctx.lane_stream[l - 1];
-      if (l > 0) HIP_TRY(hipStreamWaitEvent(ls, ctx.lane_ev[0], 0));
-      run_rows(ls, r0 + l0, ln, nlane, int64_t(m.scratch_per_row) * nlane * l);
-      if (l > 0) {
-        HIP_TRY(hipEventRecord(ctx.lane_ev[l], ls));
-        HIP_TRY(hipStreamWaitEvent(ctx.stream, ctx.lane_ev[l], 0));
+    try {
+      for (int l = 0; l < nl; l++) {
+        const int64_t l0 = l * nlane, ln = std::min(nlane, nr - l0);
+        if (ln <= 0) break;
+        hipStream_t ls = l == 0 ? ctx.stream : ctx.lane_stream[l - 1];
+        if (l > 0) HIP_TRY(hipStreamWaitEvent(ls, ctx.lane_ev[0], 0));
+        run_rows(ls, r0 + l0, ln, nlane, int64_t(m.scratch_per_row) * nlane * l);
+        if (l > 0) {
+          HIP_TRY(hipEventRecord(ctx.lane_ev[l], ls));
+          HIP_TRY(hipStreamWaitEvent(ctx.stream, ctx.lane_ev[l], 0));
+        }
       }
+    } catch (...) {
+      // a lane that was not joined must not still be writing the scratch / the result when the caller unwinds and the context is reused
+      for (hipStream_t ls : ctx.lane_stream)
+        if (ls) (void)hipStreamSynchronize(ls);
+      throw;
     }
   }
 }
