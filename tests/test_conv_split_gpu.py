@@ -21,6 +21,8 @@ VARIANTS = {
     "mt4_s1_3x3": [(32, 3, 1), (128, 3, 1)], "mt4_s2_3x3": [(64, 3, 1), (128, 3, 2)],
     "mt2_s1_1x1": [(32, 3, 1), (64, 1, 1)], "mt4_s2_1x1_s2": [(64, 3, 1), (128, 1, 2)], "mt2_s2_1x1": [(64, 3, 1), (64, 1, 1)],
     "mt4_s2_2stages": [(128, 3, 1), (128, 1, 1)],
+    # the software-pipelined 128-feature kernel at its shortest: ONE stage (it issues two stages ahead: everything past the end must be harmless), three stages
+    "mt4_one_stage": [(32, 3, 1), (128, 1, 1)], "mt4_three_stages": [(96, 3, 1), (128, 1, 1)],
 }
 
 
@@ -148,7 +150,7 @@ def test_gpu_bf16x6_non_finite_rows_stay_in_their_rows(gpu_api, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["mt2_s1_3x3", "mt2_s1_3blocks", "mt2_s2_3x3", "mt4_s1_3x3", "mt4_s2_3x3", "mt2_s1_1x1", "mt4_s2_1x1_s2", "mt2_s2_1x1",
-                                     "mt4_s2_2stages"])
+                                     "mt4_s2_2stages", "mt4_one_stage", "mt4_three_stages"])
 def test_gpu_bf16x6_conv_every_instantiation_is_accurate(gpu_api, tmp_path, variant):
     from oracle import oracle
 
