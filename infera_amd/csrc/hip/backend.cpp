@@ -1042,7 +1042,9 @@ int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
 // for the short passes of the host path (many contexts already overlap there).
 constexpr int64_t kLaneMinRows = 512;
 int lanes_of(const LoadedModel &m, int64_t nr) {
-  if (nr < kLaneMinRows || Config::get().use_hipgraph || m.scratch_per_row <= 0) return 1;
+  // (INFERA_CONV_LANES=1: one lane -- for counter passes, which serialise kernels: per-kernel figures of full-size launches; tools/profile_bench.sh)
+  static const bool one = getenv("INFERA_CONV_LANES") && atoi(getenv("INFERA_CONV_LANES")) == 1;
+  if (one || nr < kLaneMinRows || Config::get().use_hipgraph || m.scratch_per_row <= 0) return 1;
   for (const ExecKind k : m.exec)
     if (k == ExecKind::ConvTiled) return ThreadCtx::kMaxLanes;
   return 1;
