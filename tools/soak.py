@@ -19,6 +19,7 @@ for k, p in paths.items():
 capi.load_model("zoo", blob_path)
 capi.load_model("r18s", W.write(f"{d}/r18s.onnx", W.resnet18(in_hw=64)))  # fused stem + pool, weight-stationary and tiled convolutions
 imgs64 = synth.table(9, 0, 6, 3 * 64 * 64)
+imgs64_long = synth.table(10, 0, 531, 3 * 64 * 64)  # >= 512 rows: the pass runs as two lanes on two streams (backend.cpp exec_plan)
 tables = {k: synth.table(7, 0, 4096, c) for k, c in cols.items()}
 imgs = synth.table(8, 0, 24, 3 * 16 * 16)
 # the same tables column-major in REGISTERED memory: predict_columns over their runs is served zero-copy (the GPU reads them in place)
@@ -56,9 +57,11 @@ def worker(t):
             elif r < 0.88:
                 n = rng.choice([1, 5, 24])
                 check(("zoo", n), capi.predict_from_blob("zoo", imgs[:n].tobytes()))
-            elif r < 0.92:
+            elif r < 0.915:
                 n = rng.choice([1, 3, 6])
                 check(("r18s", n), capi.predict_from_blob("r18s", imgs64[:n].tobytes()))
+            elif r < 0.92:
+                check(("r18s_long", 531), capi.predict_from_blob("r18s", imgs64_long.tobytes()))
             else:
                 name = f"tmp{t}"
                 capi.load_model(name, paths[rng.choice(["skl", "tiny", "wide"])])
