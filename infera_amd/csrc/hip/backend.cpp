@@ -82,6 +82,8 @@ struct ThreadCtx {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // completion of the pass that last used staging slot 0 / 1
+  // the big-row pipeline's H2D copies run on the slot's shared copy stream (big_copy_stream); these mark a pass's copy on it
+  hipEvent_t h2d_ev[2] = {nullptr, nullptr};
   // second lane of a long convolutional pass (exec_plan): its own stream, forked from / joined into `stream` by events
   static constexpr int kMaxLanes = 2;  // (three and four lanes: no better than one, profiles/r04_conv_lanes_ab.txt)
   hipStream_t lane_stream[kMaxLanes - 1] = {nullptr};
@@ -1009,6 +1011,18 @@ void upload_to_device(const LoadedModel &m, DeviceModel &dm) {
   }
 }
 
+// One copy stream per device slot for the big-row pipeline's H2D copies (run_host: why), created on first use; `mu` serialises
+// {copy, event record} pairs of different callers.
+hipStream_t big_copy_stream(int slot, std::mutex *&mu) {
+  static std::mutex create_mu, pair_mu[64];
+  static hipStream_t streams[64] = {};
+  const size_t i = size_t(slot) % 64;
+  mu = &pair_mu[i];
+  std::lock_guard<std::mutex> lk(create_mu);
+  if (!streams[i]) HIP_TRY(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));  // (the caller has made the slot's device current)
+  return streams[i];
+}
+
 // Rows per device pass for plans that need activation scratch (pure: no allocation).
 int64_t rows_per_pass(const LoadedModel &m, int64_t rows) {
   if (m.scratch_per_row <= 0 || m.plan.out_buf == 0) return rows;
@@ -1580,6 +1594,19 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
     ctx.ensure_dev(ctx.dev_out, ctx.dev_out_cap, 2 * size_t(P) * out_row);
     for (auto &e : ctx.pipe_ev)
       if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // Row-major passes are copied to the device on ONE copy stream per GPU slot, shared by all its contexts, and a pass's kernels wait for
+    // the copy's event.  (1) On the context's own stream the copy of pass i + 1 queues behind the kernels of pass i.  (2) Copies of
+    // several callers on several streams SHARE the link: sixteen 133 MB copies issued together all arrive after 38 ms, where one at a time
+    // the first arrives after 2.4 ms and its kernels start -- a kernel + copy trace of the C5 scan at 16 callers showed the matrix cores
+    // idle 8 % of the time, always with copies running (profiles/r04_e2e_timeline.txt).  One stream is first-come-first-served at full
+    // link speed.  (A column-major pass lands in the single dev_cm buffer first: it stays on the context's stream.)
+    hipStream_t copy_stream = nullptr;
+    std::mutex *copy_mu = nullptr;
+    if (!col_major) {
+      copy_stream = big_copy_stream(ctx.slot, copy_mu);
+      for (auto &e : ctx.h2d_ev)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     int64_t pend_r0[2] = {0, 0}, pend_nr[2] = {0, 0};
     auto slot_ptr = [&](float *base, int k, size_t row_bytes) { return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + size_t(k) * size_t(P) * row_bytes); };
     auto drain = [&](int k) {
@@ -1602,7 +1629,16 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
         const uint64_t t_f0 = now_ns();
         fill(pin, r0, nr);
         const uint64_t t_f1 = now_ns();
-        upload_pass(pin, din, nr);
+        if (col_major) {
+          upload_pass(pin, din, nr);
+        } else {  // (slot k's device buffer is free: drain(k) waited for the pass that used it last)
+          {
+            std::lock_guard<std::mutex> lk(*copy_mu);  // (copy + its event as one unit: the event must not cover a later caller's copy)
+            HIP_TRY(hipMemcpyAsync(din, pin, h2d_bytes(nr), hipMemcpyHostToDevice, copy_stream));
+            HIP_TRY(hipEventRecord(ctx.h2d_ev[k], copy_stream));
+          }
+          HIP_TRY(hipStreamWaitEvent(ctx.stream, ctx.h2d_ev[k], 0));
+        }
         exec_plan(m, dm, ctx, din, dout, nr);
         HIP_TRY(hipMemcpyAsync(slot_ptr(ctx.pin_out, k, out_row), dout, size_t(nr) * out_row, hipMemcpyDeviceToHost, ctx.stream));
         HIP_TRY(hipEventRecord(ctx.pipe_ev[k], ctx.stream));
@@ -1615,6 +1651,7 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
       drain(k);
       drain(k ^ 1);
     } catch (...) {
+      if (copy_stream) (void)hipStreamSynchronize(copy_stream);
       (void)hipStreamSynchronize(ctx.stream);  // nothing may still be reading the staging slots when we unwind
       throw;
     }
