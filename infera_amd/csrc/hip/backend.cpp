@@ -768,6 +768,15 @@ void schedule(LoadedModel &m) {
     std::vector<int> prod(m.plan.buf_per_row.size(), -1);
     for (size_t i = 0; i < n; i++)
       if (m.exec[i] != ExecKind::Skipped) prod[size_t(st[i].out)] = int(i);
+    // which EXECUTED step writes each buffer once the fusions so far are applied: the output of a fused epilogue (conv + Add, stem + pool, a
+    // fused head) belongs to the kernel that carries it, not to its Skipped Add / Pool step -- `prod` above knows nothing of those buffers
+    // (the ordering check below was vacuous for them).  Rebuilt after every fold: a folded block's output moves to its second conv.
+    std::vector<int> writer;
+    auto rebuild_writers = [&] {
+      writer.assign(m.plan.buf_per_row.size(), -1);
+      for (const auto &e : effective_steps(m)) writer[size_t(e.writes)] = e.idx;
+    };
+    rebuild_writers();
     for (size_t late = 0; late < n; late++) {
       const int j = m.conv_fused_add[late];
       if (j < 0 || !m.conv_split6[late]) continue;
@@ -781,13 +790,17 @@ void schedule(LoadedModel &m) {
       if (!kern::conv2d_split6_takes_second_input(kern::conv2d_tiled_geom(gc)) || c.act != Act::None || uses[size_t(c.out)] != 1) continue;
       if (c.Mo != d.Mo || c.OH != d.OH || c.OW != d.OW || c.bias.empty() != d.bias.empty()) continue;
       if ((d.OH - 1) * d.sh >= d.H || (d.OW - 1) * d.sw >= d.Wd) continue;  // (every output pixel's source pixel lies inside the shortcut's input)
-      if (m.nchw_buf[size_t(d.in0)] || prod[size_t(d.in0)] >= early) continue;  // the shortcut's input exists before the second convolution runs
+      // the shortcut's input must EXIST when the second convolution runs in its place: written by a step executed before `early` (the caller's
+      // tensor, buffer 0, is excluded above as NCHW).  y = Conv3x3(A); P = Relu(Conv(B) + C); out = Relu(y + Conv1x1(P)) is a valid ONNX order
+      // in which P is produced BETWEEN the two convolutions: no fold.
+      if (m.nchw_buf[size_t(d.in0)] || writer[size_t(d.in0)] < 0 || writer[size_t(d.in0)] >= early) continue;
       m.conv_fold[size_t(early)] = int(late);
       m.conv_fused_add[size_t(early)] = j;   // the Add's activation and output now belong to the second convolution ...
       m.conv_residual_buf[size_t(early)] = -1;  // ... which has no residual to read
       m.conv_fused_add[late] = -1;
       m.conv_residual_buf[late] = -1;
       m.exec[late] = ExecKind::Skipped;
+      rebuild_writers();
     }
   }
 

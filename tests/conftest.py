@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: asserts a timing RATIO or rate threshold (always also `gpu`); collected LAST, so that under `-x` a noisy "
+                                       "box can stop the run only after every parity / functional test has been reached")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Timing assertions run after everything else: `-m gpu -x` stops at the first failure, and a rate that dips on one noisy
+    box must not leave test_parity_gpu.py, test_sql_surface.py, ... unreached.  Stable sort: the order inside each group stays pytest's."""
+    items.sort(key=lambda it: 1 if it.get_closest_marker("perf") else 0)
 
 
 @pytest.fixture(scope="session")
@@ -45,6 +53,33 @@ def gpu_api(built):
 
     assert capi.device_count() >= 1, capi.get_devices()
     return capi
+
+
+@pytest.fixture(scope="session")
+def default_bench_run():
+    """bench.py's default invocation, run ONCE per session: the contract test reads its fields, the perf test (collected last) its ratios."""
+    env = dict(os.environ)
+    env.pop("INFERA_DEVICES", None)
+    return run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "3", "--e2e-reps", "2"], env=env)  # (asserts ONE line, <= 4096 bytes)
+
+
+@pytest.fixture(scope="session")
+def scan_stress_run(tmp_path_factory, built):
+    """tests/native/scan_stress (16 scanners + registration churn + model churn), run ONCE per session: functional asserts in
+    test_native_harness.py, the rate-under-churn ratio in its perf test."""
+    import json
+    import subprocess
+
+    from infera_amd import onnx_writer as W
+
+    native = os.path.join(ROOT, "tests", "native")
+    subprocess.run(["make", "-C", native, "scan_stress"], check=True, capture_output=True)
+    mlp = W.write(str(tmp_path_factory.mktemp("stress") / "mlp128.onnx"), W.mlp((128, 256, 64, 1)))
+    # (INFERA_ZERO_COPY_MAX_INFLIGHT=0: every chunk whose blocks are registered is fetched in place -- the registry under maximum pressure)
+    p = subprocess.run([os.path.join(native, "scan_stress"), mlp, os.path.join(ROOT, "tests", "golden", "linear.onnx"), "2", "16"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, INFERA_ZERO_COPY_MAX_INFLIGHT="0"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
 
 
 def run_bench(args, env=None, launcher=None, timeout=1200):

@@ -6,14 +6,8 @@ import pytest
 
 
 @pytest.mark.gpu
-def test_default_bench_line_is_small_and_has_contract_fields_and_other_workloads():
-    import os
-
-    from tests.conftest import run_bench
-
-    env = dict(os.environ)
-    env.pop("INFERA_DEVICES", None)
-    d, full = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "3", "--e2e-reps", "2"], env=env)  # (asserts ONE line, <= 4096 bytes)
+def test_default_bench_line_is_small_and_has_contract_fields_and_other_workloads(default_bench_run):
+    d, full = default_bench_run  # (conftest: ONE line, <= 4096 bytes, asserted there)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["unit"] == "rows/s" and d["dtype"] == "f32" and d["vs_baseline"] is None

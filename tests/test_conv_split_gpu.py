@@ -123,6 +123,28 @@ def test_gpu_bf16x6_folded_projection_shortcuts_match_the_two_launch_plan_and_th
 
 
 @pytest.mark.gpu
+def test_gpu_shortcut_input_produced_between_the_two_convolutions(gpu_api, tmp_path):
+    """out = Relu(Conv3x3(A) + Conv1x1(P)) with P's producer (a convolution carrying a fused Add) standing between the two layers in
+    the graph -- not folded (tests/test_conv_split_plan.py); with P first it is.  Both orders against the oracle, and against each other."""
+    from oracle import oracle
+    from tests.test_conv_split_plan import shortcut_block
+
+    x = synth.table(17, 0, 6, 4 * 12 * 12)
+    got = {}
+    for between in (True, False):
+        path = W.write(str(tmp_path / f"blk{int(between)}.onnx"), shortcut_block(between))
+        gpu_api.load_model("blk", path)
+        try:
+            assert ("folded_shortcuts" in gpu_api.get_plan("blk")) == (not between)
+            got[between] = gpu_api.predict_from_blob("blk", x.tobytes())
+        finally:
+            gpu_api.unload_model("blk")
+        want = oracle.Model(path).predict_blob(x.tobytes())
+        assert np.all(np.abs(got[between] - want) <= 1e-4 * np.abs(want) + 1e-6), (between, np.abs(got[between] - want).max())
+    assert np.abs(got[True] - got[False]).max() <= 2e-6 * np.abs(got[False]).max()
+
+
+@pytest.mark.gpu
 def test_gpu_bf16x6_non_finite_rows_stay_in_their_rows(gpu_api, tmp_path):
     """ResNet-18 (64 x 64 images, full width) over a batch that mixes magnitudes: a NaN or an infinity in one image leaves every OTHER image of
     the batch bit for bit what it is without the poisoned neighbour (no scales: nothing of one row reaches another).  What the poisoned rows

@@ -70,3 +70,31 @@ def test_layers_the_split_kernels_do_not_take_stay_exact(built, tmp_path):
     # a model whose INPUT already has 32 channels: the caller's tensor is NCHW, its first convolution is not a channel-quad one
     p = _plan(tmp_path, "wide_in", net(32, [(64, 3, 1), (64, 3, 1)]))
     assert p["exec"][0] != "conv_split_bf16x6" and p["exec"].count("conv_split_bf16x6") == 1
+
+
+def shortcut_block(p_between: bool, hw: int = 12, seed: int = 5) -> bytes:
+    """out = Relu(Conv3x3(A) + Conv1x1(P)) with P = Relu(Conv3x3(A) + A).  `p_between`: P's nodes stand BETWEEN the block's 3x3 convolution and
+    its 1x1 shortcut in the graph -- a valid ONNX order in which the shortcut's input does not exist yet when the 3x3 layer runs."""
+    rng = np.random.default_rng(seed)
+    t = lambda name, *shape: W.tensor(name, (rng.standard_normal(shape) / np.sqrt(max(1, int(np.prod(shape[1:]))))).astype(np.float32))
+    conv = lambda x, w, b, y, k: W.node("Conv", [x, w, b], [y], [W.attr_ints("kernel_shape", [k, k]), W.attr_ints("pads", [k // 2] * 4)])
+    head = [conv("X", "w0", "b0", "c0", 3), W.node("Relu", ["c0"], ["A"])]
+    y_path = [conv("A", "wy", "by", "y", 3)]
+    p_path = [conv("A", "wt", "bt", "t", 3), W.node("Add", ["t", "A"], ["ta"]), W.node("Relu", ["ta"], ["P"])]
+    tail = [conv("P", "ws", "bs", "s", 1), W.node("Add", ["y", "s"], ["ys"]), W.node("Relu", ["ys"], ["o"]),
+            W.node("GlobalAveragePool", ["o"], ["g"]), W.node("Flatten", ["g"], ["Y"], [W.attr_i("axis", 1)])]
+    nodes = head + (y_path + p_path if p_between else p_path + y_path) + tail
+    inits = [t("w0", 128, 4, 3, 3), t("b0", 128), t("wy", 128, 128, 3, 3), t("by", 128), t("wt", 128, 128, 3, 3), t("bt", 128), t("ws", 128, 128, 1, 1), t("bs", 128)]
+    return W.model("blk", nodes, inits, [W.value_info("X", ["N", 4, hw, hw])], [W.value_info("Y", ["N", 128])])
+
+
+def test_a_shortcut_whose_input_is_produced_after_the_second_convolution_is_not_folded(built, tmp_path):
+    """the fold moves the read of the shortcut's input up into the block's 3x3 convolution.  That input may be the output of
+    a FUSED epilogue (conv + Add + Relu) that stands between the two layers; the old check asked the per-step producer table, which knows no
+    such buffer, and folded -- reading P before it was written.  Same arithmetic with P's nodes first: folds as before."""
+    late = _plan(tmp_path, "p_between", shortcut_block(True))
+    early = _plan(tmp_path, "p_first", shortcut_block(False))
+    assert "folded_shortcuts" not in late, late["exec"]
+    assert len(early["folded_shortcuts"]) == 1 and early["exec"][early["folded_shortcuts"][0]] == "skipped"
+    # both plans run the split kernels; the unfolded one has one more launch (the 1x1 layer with the Add in its epilogue)
+    assert late["exec"].count("conv_split_bf16x6") == early["exec"].count("conv_split_bf16x6") + 1 == 3

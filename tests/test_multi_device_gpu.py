@@ -125,6 +125,7 @@ def test_bench_host_path_single_process_two_slots(gpu_api):
 
 
 @pytest.mark.gpu
+@pytest.mark.perf
 def test_two_slots_on_one_gpu_hold_the_single_slot_rate_at_32_threads(gpu_api):
     """admission is per PHYSICAL GPU, so two device slots on one GPU admit as many calls onto its submission
     path as one slot does -- the 2-slot scan at 32 caller threads used to fall to 66 M rows/s where the 1-slot scan held 94-110.
