@@ -458,7 +458,7 @@ void LoadInternal(ExtensionLoader &loader) {
 // REGISTERS the blocks it hands out (infera_hip_register_host_memory: pinned where they lie, mapped into every GPU, nothing copied) makes a
 // chunk whose column vectors all point into such blocks readable in place by the GPU: infera_predict_columns then costs the CPU no gather
 // and no H2D enqueue (16-28 us per 2048 x 128 chunk instead of 70).  Registration never stalls running scans and freeing a
-// block waits only for the calls that are reading THAT block (backend.cpp registry; tests/native/scan_stress.cpp).  Blocks smaller than
+// block waits only for the calls that are reading THAT block (hip/zero_copy.cpp registry; tests/native/scan_stress.cpp).  Blocks smaller than
 // `min_bytes` (default 128 KiB: a column segment is 256 KiB) are not worth a registration and stay ordinary memory.
 // The allocator has to be in place BEFORE the database is opened -- an extension cannot swap it afterwards -- so this is for the embedding
 // application:   DBConfig config;  infera_install_zero_copy_allocator(config);  DuckDB db(path, &config);

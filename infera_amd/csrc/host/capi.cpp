@@ -435,7 +435,7 @@ int32_t infera_hip_free(int32_t device, void *ptr) {
 int32_t infera_hip_memcpy_h2d(int32_t device, void *dst, const void *src, uint64_t bytes) {
   return guarded([&] {
            if (!dst || !src) throw InferaError::null_pointer();
-           hipStream_t st = thread_stream(device);  // explicit stream: never the legacy stream (see backend.cpp upload)
+           hipStream_t st = thread_stream(device);  // explicit stream: never the legacy stream (see hip/model.cpp upload)
            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
            if (e == hipSuccess) e = hipStreamSynchronize(st);
            if (e != hipSuccess) throw InferaError::onnx(std::string("HIP: hipMemcpy H2D: ") + hipGetErrorString(e));

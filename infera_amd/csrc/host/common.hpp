@@ -126,7 +126,7 @@ struct ScheduleKnobs {
 };
 // Read per launch inside the kernel launchers, for the bit-identity TESTS only (no effect on results; defaults are the shipped paths):
 //   INFERA_CONV_WS (0 tiled kernel only | 1 default | 2 force the weight-stationary kernel), INFERA_CONV_TAIL_SPLIT, INFERA_STEM_POOL2,
-//   INFERA_STEM_SPLIT (0: the exact-fp32 stem kernels under a default plan); INFERA_CONV_LANES=1 (backend.cpp: long convolutional passes
+//   INFERA_STEM_SPLIT (0: the exact-fp32 stem kernels under a default plan); INFERA_CONV_LANES=1 (hip/exec.cpp: long convolutional passes
 //   as ONE lane -- counter passes serialise kernels, so tools/profile_bench.sh takes its PMC passes this way; read once).
 
 void log_msg(int level, const std::string &msg);  // config.rs:200-207 `log!`

@@ -303,7 +303,7 @@ def test_gpu_bf16x6_stem_alone_and_ranges(gpu_api, tmp_path):
 
 @pytest.mark.gpu
 def test_gpu_long_conv_passes_run_as_two_lanes_bit_identical_to_short_calls(gpu_api, tmp_path):
-    """backend.cpp exec_plan: a pass of >= 512 rows of a convolutional plan runs as two lanes (two halves, two streams, two halves of the
+    """hip/exec.cpp exec_plan: a pass of >= 512 rows of a convolutional plan runs as two lanes (two halves, two streams, two halves of the
     scratch).  Same kernels, same per-row arithmetic: the long call must equal the same rows served 100 at a time (single lane), bit for
     bit, for an odd row count, and twice in a row (the lanes share nothing but the weights)."""
     hw, rows = 9, 1037

@@ -19,7 +19,7 @@ for k, p in paths.items():
 capi.load_model("zoo", blob_path)
 capi.load_model("r18s", W.write(f"{d}/r18s.onnx", W.resnet18(in_hw=64)))  # fused stem + pool, weight-stationary and tiled convolutions
 imgs64 = synth.table(9, 0, 6, 3 * 64 * 64)
-imgs64_long = synth.table(10, 0, 531, 3 * 64 * 64)  # >= 512 rows: the pass runs as two lanes on two streams (backend.cpp exec_plan)
+imgs64_long = synth.table(10, 0, 531, 3 * 64 * 64)  # >= 512 rows: the pass runs as two lanes on two streams (hip/exec.cpp exec_plan)
 tables = {k: synth.table(7, 0, 4096, c) for k, c in cols.items()}
 imgs = synth.table(8, 0, 24, 3 * 16 * 16)
 # the same tables column-major in REGISTERED memory: predict_columns over their runs is served zero-copy (the GPU reads them in place)
