@@ -120,10 +120,10 @@ def torch_cpu_leg(table, rows: int, cols: int, budget: dict, dims, softmax: bool
     """The CPU leg this repository did NOT write: PyTorch's CPU operators (oneDNN / MKL) on the same 2048-row
     chunks of the same host table -- T worker threads with ONE intra-op thread each, the shape the reference gets from DuckDB's
     workers around a single-threaded Tract run.  oracle/torch_ref.py; never part of the product."""
-    from infera_amd import sqlmock
+    from infera_amd import sqlharness
     from oracle import torch_ref
 
-    rg, top = sqlmock.ROW_GROUP, budget["usable"]
+    rg, top = sqlharness.ROW_GROUP, budget["usable"]
     try:
         n0 = min(rows, max(rg, 2048 * top * 4 // rg * rg))
         sec0, _ = torch_ref.scan_table(table, n0, cols, rg, top, dims, softmax)
@@ -144,13 +144,13 @@ def cpu_baseline(model_path: str, table, rows: int, cols: int, target_s: float, 
     quota slows the scan down).  Two legs: `value` = reference-shaped (per-cell boxed gather + plain GEMM
     loop) and `best_cpu` = tiled gather + register-blocked AVX-512 / AVX2 micro-kernel GEMM (bit-identical results: what a
     packed SIMD matmul such as Tract's does with the same arithmetic)."""
-    from infera_amd import sqlmock
+    from infera_amd import sqlharness
     from oracle import oracle
 
     m = oracle.Model(model_path)
     top = budget["usable"]
     cands = sorted({max(1, top // d) for d in (8, 4, 2, 1)} | ({min(budget["affinity"], top * 2)} if budget["cgroup_quota_cpus"] else set()))
-    rg = sqlmock.ROW_GROUP
+    rg = sqlharness.ROW_GROUP
 
     def sample_rows(want):  # whole row groups (or the whole table) so the sample's layout is the table's layout
         return rows if want >= rows else max(rg, int(want) // rg * rg)
@@ -248,20 +248,20 @@ def end_to_end_blobs(model: str, images, blob_bytes: int, out_cols: int, threads
     """The BLOB path end to end (config C5): T threads x 2048-row chunks of an image table in host memory through
     infera_sql_call('infera_predict_from_blob') -- one batched engine call per chunk, pipelined pinned staging, H2D, the
     conv net, D2H, LIST result.  Rows cycle over the images held in `images` (a 1M-row x 602 KB table does not fit)."""
-    from infera_amd import capi, sqlmock
+    from infera_amd import capi, sqlharness
 
     nimg = images.nbytes // blob_bytes
     cands = [int(x) for x in threads_arg.split(",")] if threads_arg else [4, 8, 16]
     cands = [t for t in cands if t <= max(4, 2 * budget["usable"])] or [4]
-    sqlmock.bench_blob_scan(model, images, blob_bytes, 2048, 1, 1)  # contexts, pinned staging, scratch
+    sqlharness.bench_blob_scan(model, images, blob_bytes, 2048, 1, 1)  # contexts, pinned staging, scratch
     sweep = {}
     for t in cands:
         rows = 2048 * max(t, 4)
-        secs, _ = sqlmock.bench_blob_scan(model, images, blob_bytes, rows, t, 1)
+        secs, _ = sqlharness.bench_blob_scan(model, images, blob_bytes, rows, t, 1)
         sweep[str(t)] = rows / secs[0]
     best_t = int(max(sweep, key=sweep.get))
     rows = 2048 * max(best_t, 4) * 2
-    secs, checksum = sqlmock.bench_blob_scan(model, images, blob_bytes, rows, best_t, reps)
+    secs, checksum = sqlharness.bench_blob_scan(model, images, blob_bytes, rows, best_t, reps)
     med = sorted(secs)[len(secs) // 2]
     rate = rows / med
     h2d = rate * blob_bytes / 1e9
@@ -299,7 +299,7 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
     the CPU budget: callers SLEEP while their chunk is in flight (INFERA_HOST_WAIT=poll), so more threads than CPUs is how a
     CPU quota is used up.  Reports CPU time per chunk (getrusage over the whole process), which -- not wall time per thread --
     is what bounds N GPUs fed from one CPU quota."""
-    from infera_amd import capi, sqlmock
+    from infera_amd import capi, sqlharness
 
     top = budget["usable"]
     if threads_arg:
@@ -311,13 +311,13 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
         cands = sorted({t for t in (4, 8, 12, 16, 24, 32, 48) if t <= max(8, 3 * top)})
     else:
         cands = [min(24, max(8, top))]
-    sqlmock.bench_scan_table(fn, model, table, min(rows, 60 * 2048 * 4), cols, cands[0], 1)  # contexts, pinned buffers, code objects
+    sqlharness.bench_scan_table(fn, model, table, min(rows, 60 * 2048 * 4), cols, cands[0], 1)  # contexts, pinned buffers, code objects
     sweep = {}
     if len(cands) > 1:
         sweep_rows = rows if world == 1 else min(rows, 6_000_000)
         for t in cands:
             barrier()
-            secs, _ = sqlmock.bench_scan_table(fn, model, table, sweep_rows, cols, t, 1)
+            secs, _ = sqlharness.bench_scan_table(fn, model, table, sweep_rows, cols, t, 1)
             sweep[str(t)] = sweep_rows * world / max_over_ranks(secs[0])
         top_rate = max(sweep.values())  # (identical on every rank: the rates are max-reduced)
         best_t = min(int(t) for t, v in sweep.items() if v >= 0.98 * top_rate)  # fewest threads within 2 % of the best: less CPU per chunk
@@ -334,7 +334,7 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
     before = {d["slot"]: d["host_rows"] for d in capi.get_devices()["devices"]}
     barrier()
     t0 = time.perf_counter()
-    (secs, checksum), phases = sqlmock.phase_breakdown(sqlmock.bench_scan_table, fn, model, table, rows, cols, best_t, reps)
+    (secs, checksum), phases = sqlharness.phase_breakdown(sqlharness.bench_scan_table, fn, model, table, rows, cols, best_t, reps)
     barrier()
     wall = max_over_ranks(time.perf_counter() - t0)
     secs_sorted = sorted(secs)
@@ -348,7 +348,7 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
     cost_rate = None
     if cost_t < best_t:
         barrier()
-        (secs_c, _), phases_c = sqlmock.phase_breakdown(sqlmock.bench_scan_table, fn, model, table, rows, cols, cost_t, max(2, reps // 2))
+        (secs_c, _), phases_c = sqlharness.phase_breakdown(sqlharness.bench_scan_table, fn, model, table, rows, cols, cost_t, max(2, reps // 2))
         cost_rate = rows * world / max_over_ranks(sorted(secs_c)[len(secs_c) // 2])
         phases = dict(phases, **{k: phases_c[k] for k in ("cpu_us_per_chunk", "sys_us_per_chunk", "cpus_busy", "gather") if k in phases_c})
     cpu_us = max_over_ranks(phases.get("cpu_us_per_chunk", 0.0))
@@ -670,7 +670,7 @@ def main():
     torch.cuda.set_device(dev)
     torch.cuda.init()
 
-    from infera_amd import capi, onnx_writer, shard, sqlmock
+    from infera_amd import capi, onnx_writer, shard, sqlharness
 
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: " + capi.get_devices()["reason"])
@@ -706,7 +706,7 @@ def main():
 
     if args.host_path:
         e2e_rows = args.rows or 10_000_000 * args.gpus  # one table, scanned by one process over N slots
-        table = sqlmock.synth_table(e2e_rows, cols, 42, min(32, budget["usable"]))
+        table = sqlharness.synth_table(e2e_rows, cols, 42, min(32, budget["usable"]))
         e2e = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, args.e2e_reps, budget, 1, barrier, shard.max_over_ranks)
         full = {"metric": "rows/sec through infera_predict (host path: one process, worker threads dealt over the device slots)",
                 "value": e2e["rows_per_s"], "unit": "rows/s", "n_gpus": args.gpus, "steps": args.e2e_reps, "warmup": 1,
@@ -807,7 +807,7 @@ def main():
     if sql_fn and not args.no_end_to_end:
         e2e_rows = min(rows, 10_000_000) if args.workload != "mlp" else rows
         try:
-            table = sqlmock.synth_table(e2e_rows, cols, 42 + rank, min(32, max(1, budget["usable"] // world)))
+            table = sqlharness.synth_table(e2e_rows, cols, 42 + rank, min(32, max(1, budget["usable"] // world)))
         except Exception as exc:
             table, e2e_error = None, f"host table: {type(exc).__name__}: {exc}"
         if not all_ok(table is not None):
@@ -889,7 +889,7 @@ def main():
                 e2e["vs_cpu_reference_shaped"] = e2e["rows_per_s"] / cb["value"]
         elif world == 1 and not args.no_cpu_baseline:
             if table is None:
-                table = sqlmock.synth_table(min(rows, 10_000_000), cols, 42, min(32, budget["usable"]))
+                table = sqlharness.synth_table(min(rows, 10_000_000), cols, 42, min(32, budget["usable"]))
             trows = table.size // cols
             cb = cpu_baseline(path, table, trows, cols, args.cpu_seconds, budget, flops_row, torch_dims=torch_dims, torch_softmax=torch_softmax)
             full["cpu_baseline"] = cb

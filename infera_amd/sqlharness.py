@@ -1,6 +1,9 @@
-"""ctypes driver for libinfera_sqlmock.so -- the SQL scalar-function layer over a mock DataChunk
-(infera_amd/csrc/binding/sql_surface.{h,cpp}).  Lets the tests read like the reference's
-sqllogictests (/root/reference test/sql/*.test): `sql("infera_predict", "linear", 1.0, 2.0, 3.0)`.
+"""ctypes driver of the chunk harness: tests/duckdb_stub/libinfera_duckdb_stub.so = the REAL DuckDB extension source
+(infera_amd/csrc/binding/infera_extension_hip.cpp) compiled against the test-only stand-in for duckdb.hpp, the one-chunk driver
+(`infera_sql_call`, tests/duckdb_stub/driver.cpp) and the table-scan drivers bench.py times (csrc/binding/scan_driver.cpp); C ABI in
+csrc/binding/sql_surface.h.  Lets the tests read like the reference's sqllogictests (/root/reference test/sql/*.test):
+`sql("infera_predict", "linear", 1.0, 2.0, 3.0)`.  Test / bench infrastructure only.  (Until round 4 a second, mock implementation
+of the SQL functions stood beside the extension source and carried the benchmarks; it is gone: one SQL layer.)
 
 Argument conventions (one call = one DataChunk of <= 2048 rows):
   * Python str / bytes / float / int / None  -> CONSTANT_VECTOR (None = SQL NULL)
@@ -19,13 +22,9 @@ import numpy as np
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinfera_sqlmock.so")
-# Two implementations of the same C ABI (csrc/binding/sql_surface.h):
-#   "mock"        libinfera_sqlmock.so -- the SQL layer written over a mock chunk (also holds the scan benchmarks)
-#   "duckdb_stub" tests/duckdb_stub/libinfera_duckdb_stub.so -- the REAL DuckDB extension source
-#                 (csrc/binding/infera_extension_hip.cpp) compiled against a test-only stand-in for duckdb.hpp
-BACKENDS = {"mock": LIB_PATH,
-            "duckdb_stub": os.path.join(os.path.dirname(_HERE), "tests", "duckdb_stub", "libinfera_duckdb_stub.so")}
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "tests", "duckdb_stub", "libinfera_duckdb_stub.so")
+
+
 class SqlError(RuntimeError):
     """Carries the message exactly as DuckDB would print it ("Invalid Input Error: ...")."""
 
@@ -42,34 +41,6 @@ class _Result(C.Structure):
                 ("list_values", C.POINTER(C.c_float)), ("validity", C.POINTER(C.c_uint64))]
 
 
-_backend = "mock"
-_libs: dict = {}
-
-
-def set_backend(name: str) -> None:
-    """Selects which library `sql()` / `list_functions()` talk to (the benchmarks always use the mock)."""
-    global _backend
-    if name not in BACKENDS:
-        raise ValueError(name)
-    _backend = name
-
-
-def _sql_lib() -> C.CDLL:
-    if _backend == "mock":
-        return lib()
-    if _backend not in _libs:
-        capi.load_library()
-        path = BACKENDS[_backend]
-        if not os.path.exists(path):
-            raise capi.InferaError(f"{path} is missing: run __graft_entry__.build()")
-        L = C.CDLL(path)
-        L.infera_sql_call.argtypes = [C.c_char_p, C.POINTER(_Vector), C.c_size_t, C.c_size_t, C.POINTER(_Result)]
-        L.infera_sql_call.restype = C.c_int32
-        L.infera_sql_free_result.argtypes = [C.POINTER(_Result)]
-        L.infera_sql_list_functions.restype = C.c_void_p
-        _libs[_backend] = L
-    return _libs[_backend]
-
 VARCHAR, FLOAT, DOUBLE, INTEGER, BIGINT, BLOB, BOOLEAN, LIST_FLOAT = range(8)
 _NP = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE, np.dtype(np.int32): INTEGER, np.dtype(np.int64): BIGINT}
 
@@ -81,7 +52,7 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        capi.load_library()  # libinfera.so first (same instance the mock links against)
+        capi.load_library()  # libinfera.so first (the instance the harness library links against)
         if not os.path.exists(LIB_PATH):
             raise capi.InferaError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
         L = C.CDLL(LIB_PATH)
@@ -116,7 +87,7 @@ def lib() -> C.CDLL:
 
 
 def list_functions() -> list[dict]:
-    p = _sql_lib().infera_sql_list_functions()
+    p = lib().infera_sql_list_functions()
     s = C.string_at(p).decode()
     C.CDLL(None).free(C.c_void_p(p))
     return json.loads(s)
@@ -227,7 +198,7 @@ def sql(function: str, *args: Any, rows: int | None = None):
         rows = counts[0] if counts else 1
     assert all(c == rows for c in counts), "all flat vectors of a chunk must have the same row count"
     res = _Result()
-    rc = _sql_lib().infera_sql_call(function.encode(), vecs, len(args), rows, C.byref(res))
+    rc = lib().infera_sql_call(function.encode(), vecs, len(args), rows, C.byref(res))
     try:
         if rc != 0:
             raise SqlError(res.error.decode() if res.error else "unknown error")
@@ -257,7 +228,7 @@ def sql(function: str, *args: Any, rows: int | None = None):
                        np.ctypeslib.as_array(res.list_values, shape=(res.list_offsets[rows],))[a:b].copy())
         return out
     finally:
-        _sql_lib().infera_sql_free_result(C.byref(res))
+        lib().infera_sql_free_result(C.byref(res))
 
 
 def bench_scan(function: str, model: str, rows: int, ncols: int, threads: int, pool_chunks: int = 8, seed: int = 42):

@@ -122,7 +122,7 @@ def _run_threads(threads: int, body) -> float:
 
 
 def scan_table(table: np.ndarray, rows: int, cols: int, row_group: int, threads: int, dims, final_softmax: bool = False, chunk: int = 2048):
-    """Scans the first `rows` rows of the columnar host table (sqlmock.synth_table layout: row groups of `row_group` rows, one
+    """Scans the first `rows` rows of the columnar host table (sqlharness.synth_table layout: row groups of `row_group` rows, one
     contiguous run per column inside a group) in `chunk`-row chunks: gather to a row-major [n, cols] tensor, Linear/ReLU chain.
     Returns (seconds, checksum)."""
     layers = mlp_layers(dims)

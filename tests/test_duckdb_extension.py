@@ -1,5 +1,5 @@
 """The real DuckDB extension source (infera_amd/csrc/binding/infera_extension_hip.cpp), compiled against
-the test-only stand-in for duckdb.hpp (tests/duckdb_stub/) and driven through the same C ABI as the mock SQL layer.
+the test-only stand-in for duckdb.hpp (tests/duckdb_stub/) and driven through the chunk ABI of csrc/binding/sql_surface.h.
 tests/test_sql_surface.py already replays the reference's sqllogictests against it; this file covers what only the real
 binding has: registration metadata, overload counts, dictionary / constant / DECIMAL argument vectors, >127 features.
 Replaces /root/reference infera/bindings/infera_extension.cpp:199-227, :297-328, :430-462, :546-592."""
@@ -19,13 +19,11 @@ EXT_SRC = os.path.join(ROOT, "infera_amd", "csrc", "binding", "infera_extension_
 
 @pytest.fixture(scope="module")
 def X(built):
-    from infera_amd import sqlmock
+    from infera_amd import sqlharness
 
-    sqlmock.lib()
-    sqlmock.set_backend("duckdb_stub")
-    yield sqlmock
+    sqlharness.lib()
+    yield sqlharness
     os.environ.pop("INFERA_STUB_DICTIONARY", None)
-    sqlmock.set_backend("mock")
 
 
 def test_extension_source_compiles_warning_free_and_exports_entry_points(built):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from infera_amd import onnx_writer as W
-from infera_amd import sqlmock, synth
+from infera_amd import sqlharness, synth
 from oracle import oracle
 
 
@@ -28,7 +28,7 @@ def test_best_cpu_scan_same_checksum(tmp_path):
     """bench_scan_table's three gather / GEMM variants scan the same table to the same checksum."""
     path = W.write(str(tmp_path / "m.onnx"), W.mlp((128, 256, 64, 1)))
     m = oracle.Model(path)
-    rows = sqlmock.ROW_GROUP + 4096  # one full row group + a ragged one
-    table = sqlmock.synth_table(rows, 128, 42, 2)
+    rows = sqlharness.ROW_GROUP + 4096  # one full row group + a ragged one
+    table = sqlharness.synth_table(rows, 128, 42, 2)
     sums = [oracle.bench_scan_table(m, table, rows, 128, threads=2, boxed=b)[1] for b in (1, 0, 2)]
     assert sums[0] == sums[1] == sums[2], sums

@@ -371,7 +371,7 @@ def test_full_size_c2_host_scan_equals_device_scan(api, models):
     scan of the same table: every chunk is bit-identical to its slice (asserted on samples elsewhere), so the f64 sum of all
     10M outputs -- a checksum over every chunk, thread and staging context -- agrees to summation-order rounding; the
     per-slot row counter accounts for every row exactly once."""
-    from infera_amd import sqlmock
+    from infera_amd import sqlharness
 
     rows, cols = 10_000_000, 128
     api.load_model("mlp", models["mlp"])
@@ -382,10 +382,10 @@ def test_full_size_c2_host_scan_equals_device_scan(api, models):
     api.predict_device("mlp", d_in, rows, cols, d_out)
     want = d_out.download((rows,)).astype(np.float64).sum()
     del d_in, d_out
-    table = sqlmock.synth_table(rows, cols, 42, 16)
+    table = sqlharness.synth_table(rows, cols, 42, 16)
     before = sum(d["host_rows"] for d in api.get_devices()["devices"])
     for threads in (16, 3):
-        secs, checksum = sqlmock.bench_scan_table("infera_predict", "mlp", table, rows, cols, threads, 1)
+        secs, checksum = sqlharness.bench_scan_table("infera_predict", "mlp", table, rows, cols, threads, 1)
         assert abs(checksum - want) <= 1e-9 * abs(want) + 1e-6, (threads, checksum, want)
     assert sum(d["host_rows"] for d in api.get_devices()["devices"]) - before == 2 * rows
 

@@ -1,5 +1,6 @@
-"""The SQL scalar-function layer over the mock DataChunk (csrc/binding/sql_surface.cpp), driven the
-way the reference's sqllogictests drive the DuckDB extension (/root/reference test/sql/*.test).
+"""The SQL scalar-function layer -- the REAL DuckDB extension source (csrc/binding/infera_extension_hip.cpp) compiled against the
+test-only stand-in for duckdb.hpp (tests/duckdb_stub/) -- driven the way the reference's sqllogictests drive the DuckDB extension
+(/root/reference test/sql/*.test).
 The CPU half covers everything that does not reach a kernel; the GPU half (marked) replays the
 value-producing statements of those test files."""
 import os
@@ -12,16 +13,12 @@ LINEAR = os.path.join(ROOT, "tests", "golden", "linear.onnx")
 MULTI = os.path.join(ROOT, "tests", "golden", "multi_output.onnx")
 
 
-# Every test below runs twice: against the SQL layer written over the mock chunk (csrc/binding/sql_surface.cpp) and against
-# the REAL DuckDB extension source (csrc/binding/infera_extension_hip.cpp) compiled against tests/duckdb_stub/.
-@pytest.fixture(scope="module", params=["mock", "duckdb_stub"])
-def S(built, request):
-    from infera_amd import sqlmock
+@pytest.fixture(scope="module")
+def S(built):
+    from infera_amd import sqlharness
 
-    sqlmock.lib()
-    sqlmock.set_backend(request.param)
-    yield sqlmock
-    sqlmock.set_backend("mock")
+    sqlharness.lib()
+    return sqlharness
 
 
 # ---------------------------------------------------------------- CPU: registration / management / errors

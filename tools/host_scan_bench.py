@@ -8,7 +8,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from infera_amd import capi, onnx_writer, sqlmock  # noqa: E402
+from infera_amd import capi, onnx_writer, sqlharness  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=4_000_000)
@@ -41,11 +41,11 @@ else:
     blob = onnx_writer.mlp() if a.workload == "mlp" else onnx_writer.logreg_softmax()
     cols, fn = 128, "infera_predict" if a.workload == "mlp" else "infera_predict_array"
 capi.load_model("m", onnx_writer.write(os.path.join(tmp, "m.onnx"), blob))
-sqlmock.bench_scan(fn, "m", 2048 * 64, cols, 4)  # warm
+sqlharness.bench_scan(fn, "m", 2048 * 64, cols, 4)  # warm
 print(f"devices={capi.get_devices()['devices']} workload={a.dims or a.workload} rows={a.rows} exec={capi.get_plan('m')['exec']} "
       f"env={ {k: v for k, v in os.environ.items() if k.startswith('INFERA_')} } source={'per-thread chunk pool' if a.pool else 'materialised columnar host table'}")
 import numpy as np  # noqa: E402
-table = None if a.pool else sqlmock.synth_table(a.rows, cols, 42, 16, np.float64 if a.double else np.float32, align=a.align, huge=a.huge)
+table = None if a.pool else sqlharness.synth_table(a.rows, cols, 42, 16, np.float64 if a.double else np.float32, align=a.align, huge=a.huge)
 if table is not None:
     print(f"table at 0x{table.ctypes.data:x} (offset in its 4 KiB page: {table.ctypes.data % 4096}, in its 2 MiB page: {table.ctypes.data % (2 << 20)}) huge={a.huge}")
 print("column type:", "DOUBLE" if a.double else "FLOAT")
@@ -56,10 +56,10 @@ if a.register and table is not None:
     print(f"host table registered in {time.perf_counter() - t0:.3f} s ({table.nbytes / 1e9:.2f} GB): chunks are read in place by the GPU")
 for t in [int(x) for x in a.threads.split(",")]:
     if a.pool:
-        sec, cs = sqlmock.bench_scan(fn, "m", a.rows, cols, t)
+        sec, cs = sqlharness.bench_scan(fn, "m", a.rows, cols, t)
         secs = [sec]
     else:
-        (secs, cs), phases = sqlmock.phase_breakdown(sqlmock.bench_scan_table, fn, "m", table, a.rows, cols, t, a.reps)
+        (secs, cs), phases = sqlharness.phase_breakdown(sqlharness.bench_scan_table, fn, "m", table, a.rows, cols, t, a.reps)
     sec = sorted(secs)[len(secs) // 2]
     print(f"threads={t:>3}  {a.rows / sec / 1e6:>9.2f} M rows/s  ({a.rows * cols * 4 / sec / 1e9:.2f} GB/s of features)  "
           f"scans={[round(x, 4) for x in secs]}  checksum={cs:.4f}" + ("" if a.pool else f"\n             us/chunk/thread: {phases}"))
