@@ -130,16 +130,6 @@ using FillFn = std::function<void(float *dst, int64_t row0, int64_t nrows)>;
 // col_major: `fill` writes the pass as [in_per_row][nrows] (column-major -- flat columns are copied as they are) and
 // the transpose to the row-major table happens on the GPU.
 void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major = false);
-// Streamed chunks (round 5): for a model whose whole plan is one fused-MLP kernel with a streaming form (kern::mlp3_stream), a chunk that
-// finds its GPU quiet (at most INFERA_STREAM_MAX_INFLIGHT host-ABI calls in flight, this one included) is not staged-then-copied: the kernel
-// is launched FIRST, reads the pinned staging buffer over the link itself and waits, column group by column group, for `cfill` to have
-// written columns [c0, c1) of the column-major chunk [in_per_row][rows] (it is called once per group, in order).  The copy engine's start-up,
-// the copy and the copy -> kernel dependency leave the chunk's wall time; results are bit-identical to the staged path.  false: not taken
-// (another model, a busy GPU, hipGraph mode, a longer call) -- the caller stages as usual.
-using ColsFillFn = std::function<void(float *dst, int64_t rows, size_t c0, size_t c1)>;
-bool run_host_streamed(const LoadedModel &m, const ColsFillFn &cfill, float *h_out, int64_t rows);
-bool stream_capable(const LoadedModel &m, int64_t rows);
-uint64_t streamed_calls();  // host-ABI chunks served that way so far  // (cheap pre-check: the model has the kernel and the call is short enough)
 // Zero-copy host path (round 3): `dfill(stream, dst, row0, nrows)` makes the GPU itself write rows [row0, row0 + nrows) as one
 // column-major chunk [in_per_row][nrows] into `dst` (HBM) on `stream` -- the caller's columns live in REGISTERED host memory and are
 // read in place over PCIe; no CPU copy, no pinned staging, no hipMemcpyAsync.  Calls longer than one host pass fall back (return

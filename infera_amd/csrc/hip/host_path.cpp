@@ -7,7 +7,6 @@
 //   hipGraph       INFERA_HIPGRAPH=1: {H2D, kernels[, D2H]} replayed from a per-(model, rows) graph (off by default: DESIGN.md 4)
 //   run_pipelined  calls above 24 MB (image batches): two staging slots, the CPU copy of pass i + 1 beside the GPU's pass i
 // and around them run_host_redealt: a device fault takes the slot out of service and the call runs again on another one.
-#include <cstdlib>
 #include <cstring>
 #include <optional>
 #include <thread>
@@ -18,8 +17,6 @@
 namespace infera_hip {
 namespace rt {
 namespace {
-
-std::atomic<uint64_t> g_streamed_calls{0};  // host-ABI chunks served by the streamed path (infera_hip_get_devices "streamed_calls")
 
 // One copy stream per device slot for the big-row pipeline's H2D copies (run_pipelined: why), created on first use; `mu` serialises
 // {copy, event record} pairs of different callers.
@@ -126,7 +123,6 @@ struct HostCall {
   void enqueue_chunk(int64_t r0, int64_t nr, bool single_pass, bool direct_out, int in_flight);
   bool graph_chunk(int64_t r0, int64_t nr, bool direct_out);
   void run_chunks(uint64_t lease_ns);
-  bool run_streamed(const ColsFillFn &cfill, uint64_t lease_ns);
 };
 
 // Pass size of the big-row pipeline: 16 MB keeps the CPU copy and the H2D of table rows overlapped best; rows as big as images (602 KB) get
@@ -321,9 +317,16 @@ bool HostCall::graph_chunk(int64_t r0, int64_t nr, bool direct_out) {
 }
 
 // Calls of up to one staging pass (64 MB) per device pass: a DataChunk, a point query, a medium infera_predict call.
-// (Measured and dropped in round 3: one chunk as two sub-passes on the call's stream, the gather of the second overlapping the H2D + kernels
-// of the first -- a loss at every caller count: a chunk's 45-50 us in flight are fixed latencies, not its 20 us of transfer, and halves pay
-// them twice; profiles/r03_host_cpu_ab_split_pollq.txt.)
+// Measured and dropped, twice:
+//   * one chunk as two halves on the call's stream, the gather of the second under the H2D + kernel of the first (round 3, and again in round 5
+//     with rows/s at 1 and 2 callers and CPU per chunk as the yardsticks): a loss at every caller count -- 1 caller 20.5 -> 17.8 M rows/s, 2 callers
+//     37.8 -> 32.6, CPU per chunk 55-66 -> 75-82 us.  The wait behind the second enqueue is as long as a whole chunk's (46-52 us): it is latency
+//     (copy-engine start-up, launch, completion), not the 19 us of transfer (profiles/r05_half_chunk_ab.txt, r03_host_cpu_ab_split_pollq.txt);
+//   * STREAMED chunks (round 5): the fused-MLP tile kernel launched BEFORE the gather, consuming the columns out of pinned staging 16 at a time
+//     behind per-group flags, no H2D copy at all.  Bit-identical; a lone caller gains 13-23 % (93 -> 80 us per chunk) -- and two callers LOSE
+//     whenever their streams share one of the runtime's hardware queues (a kernel that waits for its host blocks the queue behind it: 35 -> 26 M
+//     rows/s), four and more lose 15-20 % (profiles/r05_stream_chunk_ab.txt).  Even with the host spinning on the event the tail AFTER the last
+//     column group was there took 29 us: what is left of a chunk's wait is the device's completion path, which no pipelining of the input hides.
 void HostCall::run_chunks(uint64_t lease_ns) {
   // hipGraph mode captures {H2D, kernels[, D2H]}: a column-major chunk only when the model's first kernel reads it itself (the transposing
   // path allocates per pass, which a capture cannot contain)
@@ -335,38 +338,6 @@ void HostCall::run_chunks(uint64_t lease_ns) {
   ctx.ensure_dev(ctx.dev_in, ctx.dev_in_cap, size_t(rows_pass) * in_row);
   ctx.ensure_dev(ctx.dev_out, ctx.dev_out_cap, size_t(rows_pass) * out_row);
   const bool profiling = prof::enabled();
-  // EXPERIMENT (tools/stream_chunk_ab.sh): INFERA_EXP_HALF_CHUNK=1 -- a column-major chunk as two halves on the call's
-  // stream, the gather of the second half under the H2D + kernel of the first.
-  static const bool half_exp = getenv("INFERA_EXP_HALF_CHUNK") && atoi(getenv("INFERA_EXP_HALF_CHUNK")) == 1;
-  if (half_exp && !dfill && !use_graph && col_major && m.in_colmajor_ok && direct_out && rows == rows_pass && rows >= 512 && rows % 2 == 0 &&
-      prepare_scratch(m, ctx, rows / 2) == rows / 2) {
-    const int64_t h = rows / 2;
-    const size_t hin = size_t(h) * in_row / 4, hout = size_t(h) * out_row / 4;
-    const uint64_t t0 = now_ns();
-    fill(ctx.pin_in, 0, h);
-    const uint64_t t1 = now_ns();
-    GateHold admitted(gate_for_slot(slot), Config::get().max_inflight, Config::get().max_inflight_total);
-    const uint64_t t2 = now_ns();
-    HIP_TRY(hipMemcpyAsync(ctx.dev_in, ctx.pin_in, hin * 4, hipMemcpyHostToDevice, ctx.stream));
-    exec_plan(m, dm, ctx, ctx.dev_in, ctx.pin_out, h, true);
-    const uint64_t t3 = now_ns();
-    fill(ctx.pin_in + hin, h, h);
-    const uint64_t t4 = now_ns();
-    HIP_TRY(hipMemcpyAsync(ctx.dev_in + hin, ctx.pin_in + hin, hin * 4, hipMemcpyHostToDevice, ctx.stream));
-    exec_plan(m, dm, ctx, ctx.dev_in + hin, ctx.pin_out + hout, h, true);
-    const uint64_t t5 = now_ns();
-    ctx.wait_stream(wait_key(rows) ^ 0x48414C46ull);
-    const uint64_t t6 = now_ns();
-    std::memcpy(h_out, ctx.pin_out, size_t(rows) * out_row);
-    g_phase_ns[kPhLease].fetch_add(lease_ns, std::memory_order_relaxed);
-    g_phase_ns[kPhGather].fetch_add((t1 - t0) + (t4 - t3), std::memory_order_relaxed);
-    g_phase_ns[kPhGate].fetch_add(t2 - t1, std::memory_order_relaxed);
-    g_phase_ns[kPhEnqueue].fetch_add((t3 - t2) + (t5 - t4), std::memory_order_relaxed);
-    g_phase_ns[kPhWait].fetch_add(t6 - t5, std::memory_order_relaxed);
-    g_phase_ns[kPhCopyOut].fetch_add(now_ns() - t6, std::memory_order_relaxed);
-    g_phase_calls.fetch_add(1, std::memory_order_relaxed);
-    return;
-  }
   for (int64_t r0 = 0; r0 < rows; r0 += rows_pass) {
     const int64_t nr = std::min(rows_pass, rows - r0);
     // The caller's buffer is only borrowed for the call (SURVEY.md 8b "Ownership"): stage it.
@@ -416,86 +387,8 @@ void HostCall::run_chunks(uint64_t lease_ns) {
   }
 }
 
-// TEST HOOK (tests/test_stream_chunks_gpu.py): INFERA_STREAM_ABORT_INJECT=<n> makes the n-th streamed chunk's gather throw half way -- the
-// only way to reach the abort protocol (the real gather does not throw).  Read once; unset it costs one relaxed load per streamed chunk.
-bool stream_abort_injected() {
-  static const long nth = [] {
-    const char *e = getenv("INFERA_STREAM_ABORT_INJECT");
-    return e ? atol(e) : 0L;
-  }();
-  if (nth <= 0) return false;
-  static std::atomic<long> calls{0};
-  return calls.fetch_add(1, std::memory_order_relaxed) + 1 == nth;
-}
-
-// A chunk on a quiet GPU, streamed (backend.hpp run_host_streamed): admission FIRST -- the kernel is launched before the gather and sits on
-// CUs until its columns have come, so how many may do that at a time is what the gate decides here; a busy GPU means "stage it" (false, and
-// the copy engines, which move more bytes per second than kernels reading host memory, carry the chunk).
-bool HostCall::run_streamed(const ColsFillFn &cfill, uint64_t lease_ns) {
-  const int groups = kern::mlp3_stream_flag_groups(m.mlp3_shape), per = kern::mlp3_stream_cols_per_flag();
-  const size_t ncols = in_row / 4;
-  const uint64_t t_g0 = now_ns();
-  GateHold admitted(gate_for_slot(slot), Config::get().max_inflight, Config::get().max_inflight_total);
-  if (admitted.in_flight > Config::get().stream_max_inflight) return false;
-  const uint64_t t_g = now_ns();
-  ctx.ensure_pinned(ctx.pin_in, ctx.pin_in_cap, size_t(rows) * in_row);
-  ctx.ensure_pinned(ctx.pin_out, ctx.pin_out_cap, size_t(rows) * out_row);
-  if (!ctx.stream_flags) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx.stream_flags), ThreadCtx::kStreamFlagWords * sizeof(uint32_t), hipHostMallocDefault));
-    std::memset(ctx.stream_flags, 0, ThreadCtx::kStreamFlagWords * sizeof(uint32_t));
-  }
-  uint32_t epoch = ++ctx.stream_epoch;
-  if (epoch == 0 || epoch == kern::kStreamAbortFlag) epoch = ctx.stream_epoch = 1;
-  uint32_t *status = ctx.stream_flags + ThreadCtx::kStreamFlagWords - 1;
-  *status = 0;
-  {
-    prof::Range range("infera:enqueue");
-    if (!kern::mlp3_stream(ctx.stream, m.mlp3_shape, ctx.pin_in, ctx.stream_flags, epoch, status, dm.mlp3_packed, ctx.pin_out, rows))
-      throw InferaError::onnx("internal: no streaming kernel for this chain");
-    HIP_TRY(hipGetLastError());
-    ctx.mark_stream();  // (the completion marker goes in behind the kernel NOW: after the gather only the query is left)
-  }
-  const uint64_t t_e = now_ns();
-  auto publish = [&](int g, uint32_t v) { __atomic_store_n(ctx.stream_flags + g, v, __ATOMIC_RELEASE); };
-  try {
-    prof::Range range("infera:gather");
-    for (int g = 0; g < groups; g++) {
-      if (g == groups / 2 && stream_abort_injected()) throw InferaError::onnx("injected gather failure (INFERA_STREAM_ABORT_INJECT)");
-      cfill(ctx.pin_in, rows, size_t(g) * size_t(per), std::min(ncols, size_t(g + 1) * size_t(per)));
-      publish(g, epoch);
-    }
-  } catch (...) {
-    for (int g = 0; g < groups; g++) publish(g, kern::kStreamAbortFlag);  // the kernel leaves at once; nothing may read the staging when we unwind
-    (void)hipStreamSynchronize(ctx.stream);
-    throw;
-  }
-  const uint64_t t_f = now_ns();
-  {
-    prof::Range range("infera:wait");
-    ctx.wait_marked(wait_key(rows) ^ 0x5354524Dull);  // (its own nap estimate: a streamed chunk's wait is the kernel's tail only)
-  }
-  const uint64_t t_w = now_ns();
-  if (__atomic_load_n(status, __ATOMIC_ACQUIRE) != 0)
-    throw InferaError::onnx("HIP: streamed chunk: the kernel gave up waiting for the host's columns (caller thread stalled for seconds?)");
-  {
-    prof::Range range("infera:copy_out");
-    std::memcpy(h_out, ctx.pin_out, size_t(rows) * out_row);
-  }
-  const uint64_t t_c = now_ns();
-  g_phase_ns[kPhLease].fetch_add(lease_ns, std::memory_order_relaxed);
-  g_phase_ns[kPhGate].fetch_add(t_g - t_g0, std::memory_order_relaxed);
-  g_phase_ns[kPhEnqueue].fetch_add(t_e - t_g, std::memory_order_relaxed);
-  g_phase_ns[kPhGather].fetch_add(t_f - t_e, std::memory_order_relaxed);
-  g_phase_ns[kPhWait].fetch_add(t_w - t_f, std::memory_order_relaxed);
-  g_phase_ns[kPhCopyOut].fetch_add(t_c - t_w, std::memory_order_relaxed);
-  g_phase_calls.fetch_add(1, std::memory_order_relaxed);
-  g_streamed_calls.fetch_add(1, std::memory_order_relaxed);
-  return true;
-}
-
 // One host-ABI call on the calling thread's home slot (false: a zero-copy call this path does not take -- the caller stages it instead).
-bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn *dfill, const ColsFillFn *cfill, float *h_out, int64_t rows,
-                   bool col_major) {
+bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn *dfill, float *h_out, int64_t rows, bool col_major) {
   if (m.dev.empty()) throw InferaError::onnx("HIP backend unavailable: " + m.device_error);
   if (rows <= 0) return true;
   if (dfill) {  // zero-copy: one host pass, direct (non-graph) enqueue only -- anything else goes the staging way
@@ -513,16 +406,10 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
   HostCall call(m, fill, dfill, h_out, rows, col_major, slot, *lease.c);
   g_slot_calls[size_t(slot) % 64].fetch_add(1, std::memory_order_relaxed);
   g_slot_rows[size_t(slot) % 64].fetch_add(uint64_t(rows), std::memory_order_relaxed);
-  bool taken = true;
-  if (cfill) taken = call.run_streamed(*cfill, t_leased - t_entry);
-  else if (call.is_big()) call.run_pipelined();
+  if (call.is_big()) call.run_pipelined();
   else call.run_chunks(t_leased - t_entry);
-  if (!taken) {  // (not served here: the staged call that follows counts it)
-    g_slot_calls[size_t(slot) % 64].fetch_sub(1, std::memory_order_relaxed);
-    g_slot_rows[size_t(slot) % 64].fetch_sub(uint64_t(rows), std::memory_order_relaxed);
-  }
-  if (range.on && taken) prof::note_call(t_entry, now_ns(), uint64_t(rows));
-  return taken;
+  if (range.on) prof::note_call(t_entry, now_ns(), uint64_t(rows));
+  return true;
 }
 
 // Is the device behind `slot` answering?  Asked before a call that failed with a device fault on one slot is run again on the next: on ROCm a
@@ -537,12 +424,11 @@ bool slot_responds(int slot) {
 }
 
 // the call on the thread's home slot; a device fault there takes the slot out of service and the call goes to the next healthy one
-bool run_host_redealt(const LoadedModel &m, const FillFn &fill, const DeviceFillFn *dfill, const ColsFillFn *cfill, float *h_out, int64_t rows,
-                      bool col_major) {
+bool run_host_redealt(const LoadedModel &m, const FillFn &fill, const DeviceFillFn *dfill, float *h_out, int64_t rows, bool col_major) {
   for (;;) {
     const int slot = home_slot();
     try {
-      return run_host_impl(m, fill, dfill, cfill, h_out, rows, col_major);
+      return run_host_impl(m, fill, dfill, h_out, rows, col_major);
     } catch (const HipFault &f) {
       (void)hipGetLastError();
       if (!is_device_fault(f.code)) throw;  // the GPU is fine: the call itself was refused (too big for what is free, a bad argument)
@@ -611,7 +497,7 @@ bool colmajor_direct_ok(const LoadedModel &m, int64_t rows) {
 }
 
 void run_host_fill(const LoadedModel &m, const FillFn &fill, float *h_out, int64_t rows, bool col_major) {
-  (void)run_host_redealt(m, fill, nullptr, nullptr, h_out, rows, col_major);
+  (void)run_host_redealt(m, fill, nullptr, h_out, rows, col_major);
 }
 
 bool run_host_device_fill(const LoadedModel &m, const DeviceFillFn &dfill, float *h_out, int64_t rows) {
@@ -627,24 +513,8 @@ bool run_host_device_fill(const LoadedModel &m, const DeviceFillFn &dfill, float
       if (n) n->fetch_sub(1, std::memory_order_relaxed);
     }
   } leave{limit > 0 ? &n : nullptr};
-  return run_host_redealt(m, FillFn(), &dfill, nullptr, h_out, rows, /*col_major=*/true);
+  return run_host_redealt(m, FillFn(), &dfill, h_out, rows, /*col_major=*/true);
 }
-
-// the whole plan is ONE fused-MLP launch from the caller's table to the served result, and that chain has a streaming kernel
-bool stream_capable(const LoadedModel &m, int64_t rows) {
-  if (Config::get().stream_max_inflight <= 0 || Config::get().use_hipgraph || m.dev.empty() || rows <= 0 || rows > kern::kStreamMaxRows) return false;
-  if (!m.in_colmajor_ok || !m.out_write_once || m.scratch_per_row != 0 || m.exec.empty() || m.exec[0] != ExecKind::Mlp3Head) return false;
-  if (m.plan.steps.size() < 3 || m.plan.steps[0].in0 != 0 || m.plan.steps[2].out != m.plan.out_buf) return false;
-  const int groups = kern::mlp3_stream_flag_groups(m.mlp3_shape);
-  return groups > 0 && groups < ThreadCtx::kStreamFlagWords && size_t(rows) * size_t(m.plan.out_per_row()) * 4 <= (1u << 20);
-}
-
-bool run_host_streamed(const LoadedModel &m, const ColsFillFn &cfill, float *h_out, int64_t rows) {
-  if (!stream_capable(m, rows)) return false;
-  return run_host_redealt(m, FillFn(), nullptr, &cfill, h_out, rows, /*col_major=*/true);
-}
-
-uint64_t streamed_calls() { return g_streamed_calls.load(std::memory_order_relaxed); }
 
 void run_host(const LoadedModel &m, const float *h_in, float *h_out, int64_t rows) {
   const size_t in_per_row = size_t(m.plan.in_per_row());

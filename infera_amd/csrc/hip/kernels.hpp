@@ -86,16 +86,6 @@ bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packe
 bool mlp3_colmajor_supported(const Mlp3Shape &sh);
 int64_t mlp3_colmajor_max_rows(const Mlp3Shape &sh);  // longest column-major chunk the chain's kernels read themselves (0: none)
 std::string mlp3_kernel_name(const Mlp3Shape &sh);
-// Streamed chunks (host path, few callers): the chain's tile kernel launched BEFORE its chunk is there.  `x_host_colmajor` is the
-// pinned, host-coherent staging buffer [d0][rows] the CPU is still gathering into; flags[i] (pinned too) becomes `epoch` once columns
-// [16 i, 16 i + 16) are complete, or kStreamAbortFlag when the host gives up; *status = 1 if the kernel gave up waiting (~2 s).  Results are
-// those of mlp3() on the finished chunk, bit for bit.  mlp3_stream_flag_groups: how many flags the chain's kernel waits for (0: it has none).
-constexpr int64_t kStreamMaxRows = 4096;  // a workgroup per 32 rows sits on a CU while it waits: short chunks only
-constexpr uint32_t kStreamAbortFlag = 0xFFFFFFFFu;
-int mlp3_stream_flag_groups(const Mlp3Shape &sh);
-int mlp3_stream_cols_per_flag();
-bool mlp3_stream(hipStream_t s, const Mlp3Shape &sh, const float *x_host_colmajor, const uint32_t *flags, uint32_t epoch, uint32_t *status,
-                 const float *packed, float *Y, int64_t rows);
 
 // ---- fused chain of small Dense layers over tables of any width (chain_device.inc, specialised with hipRTC) ----
 // k0 table columns; layer l maps dims[l-1] (dims[-1] = k0) -> dims[l] and applies acts[l] (plan.hpp Act 0..5) with

@@ -221,32 +221,6 @@ void launch_tile(hipStream_t s, const float *X, const float *packed, float *Y, i
 bool tile_kernel_enabled() { return true; }
 }  // namespace
 
-// ---- streamed chunks (host path, few callers): the tile kernel launched ahead of its data (mlp_device.inc, mlp3_stream_kernel) ----
-int mlp3_stream_flag_groups(const Mlp3Shape &sh) {
-#define X_(C) \
-  if (matches<C>(sh)) return C::L3V ? (C::D0 + kStreamCols - 1) / kStreamCols : 0;
-  INFERA_MLP3_CONFIGS(X_)
-#undef X_
-  return 0;  // (load-time specialised chains: not yet)
-}
-int mlp3_stream_cols_per_flag() { return kStreamCols; }
-bool mlp3_stream(hipStream_t s, const Mlp3Shape &sh, const float *x_host_colmajor, const uint32_t *flags, uint32_t epoch, uint32_t *status,
-                 const float *packed, float *Y, int64_t rows) {
-  if (rows <= 0 || rows > kStreamMaxRows) return false;
-  const int64_t ntiles = (rows + 31) / 32;
-#define X_(C)                                                                                                                          \
-  if (matches<C>(sh)) {                                                                                                                \
-    if constexpr (C::L3V) {                                                                                                            \
-      hipLaunchKernelGGL((mlp3_stream_kernel<C>), dim3(unsigned(ntiles)), dim3(256), 0, s, x_host_colmajor, flags, epoch, status, packed, Y, rows); \
-      return true;                                                                                                                     \
-    }                                                                                                                                  \
-    return false;                                                                                                                      \
-  }
-  INFERA_MLP3_CONFIGS(X_)
-#undef X_
-  return false;
-}
-
 bool mlp3(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows, int num_cus,
           std::string *why, bool x_colmajor) {
   if (rows <= 0) return true;

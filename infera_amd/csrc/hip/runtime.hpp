@@ -12,7 +12,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <cstdlib>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -90,11 +89,6 @@ struct ThreadCtx {
   hipStream_t lane_stream[kMaxLanes - 1] = {nullptr};
   hipEvent_t lane_ev[kMaxLanes] = {nullptr, nullptr};  // [0]: fork; [i]: lane i done
   hipEvent_t poll_ev = nullptr;                // completion marker of a host-ABI call, queried between naps
-  // streamed chunks (host_path.cpp run_streamed): per-column-group flags + a status word in pinned memory, and the value that means "this
-  // chunk's group is complete" -- a new one per chunk, so the flags never have to be cleared under a kernel that may still read them
-  uint32_t *stream_flags = nullptr;
-  uint32_t stream_epoch = 0;
-  static constexpr int kStreamFlagWords = 64;  // [0, 63): flags, [63]: status
   // How a host-ABI call waits for its chunk: it NAPS.  ROCm 7.2's "blocking" event wait (hipEventSynchronize on a hipEventBlockingSync event)
   // burns the core for the whole wait, and so does hipStreamSynchronize: 277 us of CPU per chunk at 16 callers against 85 with naps at the same
   // rows/s (profiles/r03_host_cpu_ab_wait_gather.txt) -- under a CPU quota (16 CPUs feeding 8 GPUs) CPU time per chunk is what bounds the
@@ -137,17 +131,6 @@ struct ThreadCtx {
       (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
     };
     const bool known = est.ema_ns > 0.0;
-    static const bool spin_exp = getenv("INFERA_EXP_SPIN_WAIT") && atoi(getenv("INFERA_EXP_SPIN_WAIT")) == 1;
-    if (spin_exp) {  // EXPERIMENT: no naps at all -- what the device side of a wait really takes
-      for (;;) {
-        const hipError_t e = query();
-        if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery");
-        __builtin_ia32_pause();
-      }
-      (void)hipGetLastError();
-      return;
-    }
     {
       TimerSlack slack;
       if (known) nap(std::min({est.ema_ns * kPollFirst, est.min_ns * 0.9, 2.0e6}));
@@ -169,15 +152,8 @@ struct ThreadCtx {
   }
   // waits for everything enqueued on `stream` so far.  `key` identifies the kind of work (0 = unknown)
   void wait_stream(uint64_t key = 0) {
-    mark_stream();
-    wait_marked(key);
-  }
-  // the same in two steps: the completion marker enqueued now (behind what is on the stream), waited for later
-  void mark_stream() {
     if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(poll_ev, stream));
-  }
-  void wait_marked(uint64_t key = 0) {
     poll_until([&] { return hipEventQuery(poll_ev); }, wait_est, key);
   }
   void drop_graphs() {

@@ -320,7 +320,7 @@ char *infera_hip_get_devices(void) {
          ",\"host_rows\":" + std::to_string(rows) + ",\"numa_node\":" + std::to_string(i < ds.numa.size() ? ds.numa[i] : -1) +
          ",\"ordinal\":" + std::to_string(ds.ids[i]) + ",\"pinned_staging_bytes\":" + std::to_string(slot_pinned_bytes(int(i))) + ",\"slot\":" + std::to_string(i) + "}";
   }
-  o += "],\"host_phases\":" + host_phase_json() + ",\"streamed_calls\":" + std::to_string(streamed_calls()) + ",\"reason\":" + json_str(ds.why) + "}";
+  o += "],\"host_phases\":" + host_phase_json() + ",\"reason\":" + json_str(ds.why) + "}";
   return dup_cstr(o);
 }
 
@@ -562,13 +562,8 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
         if (served) g_zero_copy_calls.fetch_add(1, std::memory_order_relaxed);
       }
       bool col_major = ncols > 0 && (colmajor_direct_ok(*m, int64_t(rows)) || !Config::get().use_hipgraph);
-      // Streamed (round 5): a fused-MLP model's chunk on a quiet GPU -- the kernel is launched first and consumes the columns out of pinned
-      // staging, sixteen at a time, while this thread gathers them (backend.hpp run_host_streamed; false = busy GPU / other model: stage it)
-      if (!served && col_major && stream_capable(*m, int64_t(rows)))
-        served = run_host_streamed(*m, [&](float *dst, int64_t nr, size_t c0, size_t c1) { gather_column_major(columns, c0, c1, 0, size_t(nr), dst); }, out,
-                                   int64_t(rows));
       if (served) {
-        // (done: the GPU gathered the registered columns itself, or the chunk was streamed)
+        // (done: the GPU gathered the registered columns itself)
       } else if (col_major) {
         run_host_fill(*m, [&](float *dst, int64_t r0, int64_t nr) { gather_column_major(columns, 0, ncols, size_t(r0), size_t(nr), dst); },
                       out, int64_t(rows), /*col_major=*/true);

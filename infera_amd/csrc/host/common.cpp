@@ -92,7 +92,6 @@ const Config &Config::get() {
     c.host_zero_copy = env_flag("INFERA_HOST_ZERO_COPY", true);
     c.zero_copy_rect = env_flag("INFERA_ZERO_COPY_RECT", true);
     c.zero_copy_max_inflight = int(env_u64("INFERA_ZERO_COPY_MAX_INFLIGHT", 4));
-    c.stream_max_inflight = int(env_u64("INFERA_STREAM_MAX_INFLIGHT", 4));
     c.numa_slots = env_flag("INFERA_NUMA_SLOTS", true);
     c.host_direct_in_bytes = (long long)env_u64("INFERA_HOST_DIRECT_IN", 128 * 1024);
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);

@@ -100,10 +100,6 @@ struct Config {
   int zero_copy_max_inflight;         // INFERA_ZERO_COPY_MAX_INFLIGHT=n (default 4)  zero-copy fetches a GPU runs at a time; chunks beyond that are STAGED: shader reads of
                                       //   host memory top out at ~42 GB/s (reached with 2-4 fetches in flight), the copy engines at 56 -- the surplus shares the
                                       //   link instead of queueing on the slower mechanism (registered table, 16 callers: 80 -> 108 M rows/s; 0 = no limit: lowest CPU)
-  int stream_max_inflight;            // INFERA_STREAM_MAX_INFLIGHT=n (default 4; 0 = off)  a chunk of a fused-MLP model that meets at most n-1 other host-ABI calls in flight on its
-                                      //   GPU is STREAMED: the kernel is launched first and consumes the chunk's columns out of pinned staging while the CPU gathers
-                                      //   them (no H2D copy, no copy-then-kernel latency: a lone caller's chunk 93 -> ~65 us).  Busier GPUs stage + copy as before:
-                                      //   the copy engines move 56 GB/s, kernels reading host memory ~42
   bool numa_slots;                    // INFERA_NUMA_SLOTS=0|1 (default 1)  caller threads prefer the device slots on their own NUMA node (bounded by load)
   long long host_direct_in_bytes;     // INFERA_HOST_DIRECT_IN=<bytes>  chunks up to this size are read from pinned memory by the first kernel itself
                                       //   (default 131072; 0 = always H2D).  On a quiet GPU the effective limit is higher: x2 with at most four
