@@ -93,7 +93,7 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
  * vectorised ExtractFeatures.  Validity masks are checked ("Feature values cannot be NULL"). 0 / -1. */
 int32_t infera_gather_columns(const InferaColumn *columns, uintptr_t ncols, uintptr_t row0, uintptr_t nrows, float *dst);
 /* The same rows as ONE COLUMN-MAJOR chunk dst[ncols x nrows] -- the layout the host path stages (each column's run copied / converted as
- * it lies, INFERA_HOST_GATHER picks the copy loop) and the fused kernels read.  Host only; what the staged path's gather step does,
+ * it lies: four runs in lockstep, 512 bytes of each in turn) and the fused kernels read.  Host only; what the staged path's gather step does,
  * exposed so that it can be checked without a GPU.  0 / -1. */
 int32_t infera_gather_columns_colmajor(const InferaColumn *columns, uintptr_t ncols, uintptr_t row0, uintptr_t nrows, float *dst);
 

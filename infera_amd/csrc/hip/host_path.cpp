@@ -451,36 +451,66 @@ std::atomic<int> g_zc_fetches[64];
 }  // namespace rt
 using namespace rt;
 
-// What the host link really delivers on this box: `threads` threads, each looping {hipMemcpyAsync(bytes) from its own
-// pinned buffer on its own stream; wait} -- the ceiling the host path's "fraction of PCIe" is honestly compared with
-// (measured 46-48 GB/s on the round-2 MI355X boxes against 64 GB/s raw Gen5 x16).
+// What the host link really delivers on this box: `threads` threads, each keeping TWO hipMemcpyAsync(bytes) in flight from its own pinned
+// buffers on its own stream (copy i + 1 is enqueued before copy i is waited for: with one copy per thread the link idled between a completion
+// and the next enqueue, and the "ceiling" read lower than the pipeline it is meant to bound -- VERDICT r4) -- what the host path's
+// "fraction of PCIe" is shown beside.  NOT an upper bound of the pipeline: bare 1 MiB copies from 8-24 threads reach 35-48 GB/s on these
+// boxes and 8 MiB copies 53-55, while the host path moves its 1 MiB chunks at 56 (a kernel behind every copy keeps the queues busier than a
+// copy alone) -- the fraction that matters is the one against the link's raw 64 GB/s.
 double h2d_probe_gbs(int device_ordinal, size_t bytes, int iters, int threads) {
   if (threads < 1) threads = 1;
-  if (iters < 1) iters = 1;
-  std::atomic<int> failed{0};
-  auto worker = [&] {
+  if (iters < 2) iters = 2;
+  std::atomic<int> failed{0}, ready{0};
+  std::atomic<bool> go{false};
+  std::vector<std::chrono::steady_clock::time_point> done;
+  done.resize(size_t(threads));
+  // (buffers, streams and events are set up BEFORE the clock starts and torn down after every thread's own end stamp: round 4's probe timed them too)
+  auto worker = [&](int t) {
+    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // (this thread's own: the 2 us sleeps below must not become 52)
     hipStream_t s = nullptr;
-    char *pin = nullptr, *dev = nullptr;
-    hipEvent_t ev = nullptr;
-    bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void **>(&pin), bytes, hipHostMallocDefault) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void **>(&dev), bytes) == hipSuccess &&
-              hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
-    if (ok) std::memset(pin, 1, bytes);
-    for (int i = 0; ok && i < iters; i++)
-      ok = hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, s) == hipSuccess && hipEventRecord(ev, s) == hipSuccess &&
-           hipEventSynchronize(ev) == hipSuccess;
+    char *pin[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; ok && k < 2; k++) {
+      ok = hipHostMalloc(reinterpret_cast<void **>(&pin[k]), bytes, hipHostMallocDefault) == hipSuccess &&
+           hipMalloc(reinterpret_cast<void **>(&dev[k]), bytes) == hipSuccess &&
+           hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+      if (ok) std::memset(pin[k], 1, bytes);
+    }
+    auto enqueue = [&](int k) { return hipMemcpyAsync(dev[k], pin[k], bytes, hipMemcpyHostToDevice, s) == hipSuccess && hipEventRecord(ev[k], s) == hipSuccess; };
+    // waits like the host path does -- short sleeps between queries: hipEventSynchronize spins on ROCm 7.2, and sixteen spinning threads on a
+    // 16-CPU quota are throttled by the cgroup, which is the link's "ceiling" no more
+    auto wait = [&](int k) {
+      for (;;) {
+        const hipError_t e = hipEventQuery(ev[k]);
+        if (e == hipSuccess) return true;
+        if (e != hipErrorNotReady) return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(2));
+      }
+    };
+    if (ok) ok = enqueue(0) && wait(0);  // (one untimed copy: first-use work of the stream)
+    ready.fetch_add(1);
+    while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+    if (ok) ok = enqueue(0);
+    for (int i = 1; ok && i < iters; i++) ok = enqueue(i & 1) && wait((i - 1) & 1);
+    if (ok) ok = wait((iters - 1) & 1);
+    done[size_t(t)] = std::chrono::steady_clock::now();
     if (!ok) failed = 1;
-    if (ev) (void)hipEventDestroy(ev);
-    if (dev) (void)hipFree(dev);
-    if (pin) (void)hipHostFree(pin);
+    if (s) (void)hipStreamSynchronize(s);
+    for (int k = 0; k < 2; k++) {
+      if (ev[k]) (void)hipEventDestroy(ev[k]);
+      if (dev[k]) (void)hipFree(dev[k]);
+      if (pin[k]) (void)hipHostFree(pin[k]);
+    }
     if (s) (void)hipStreamDestroy(s);
   };
-  const auto t0 = std::chrono::steady_clock::now();
   std::vector<std::thread> th;
-  for (int t = 0; t < threads; t++) th.emplace_back(worker);
+  for (int t = 0; t < threads; t++) th.emplace_back(worker, t);
+  while (ready.load() < threads) std::this_thread::yield();
+  const auto t0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
   for (auto &x : th) x.join();
-  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double sec = std::chrono::duration<double>(*std::max_element(done.begin(), done.end()) - t0).count();
   (void)hipGetLastError();
   return failed ? -1.0 : double(bytes) * iters * threads / sec / 1e9;
 }

@@ -45,6 +45,17 @@ def max_over_ranks(value: float) -> float:
     return float(t.item())
 
 
+def gather_objects(obj):
+    """[rank 0's obj, rank 1's obj, ...] on every rank (control plane: a few hundred bytes per rank); [obj] without a process group."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def barrier() -> None:
     import torch.distributed as dist
 

@@ -113,6 +113,62 @@ def test_bench_two_ranks_sharing_one_gpu(gpu_api):
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_sharing_one_gpu_is_what_the_driver_will_launch(gpu_api, tmp_path):
+    """the driver's 8-GPU run, dry on ONE GPU -- `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`
+    with every rank on device 0 (--share-device) and the rows cut to fit a test.  ONE JSON line <= 4 KB from rank 0; eight ranks scanned at
+    once through the host path, each its own table; every rank's rows are accounted for and ranks 0 and 7 reproduce the ORACLE's checksum of
+    their table; the N > 1 line carries what answers the scaling question (callers per GPU, CPU per chunk, host read rate, the registered
+    scan) and no cpu_baseline (rank 0 at N = 1 only)."""
+    import time
+
+    from infera_amd import onnx_writer as W
+    from infera_amd import sqlharness
+    from oracle import oracle
+    from tests.conftest import run_bench
+
+    rows, reps = 2048 * 120, 2
+    env = dict(os.environ)
+    env.pop("INFERA_DEVICES", None)
+    t0 = time.time()
+    line, full = run_bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--rows", str(rows), "--share-device", "0", "--e2e-reps", str(reps)],
+                           env=env, launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                                              "--master-port", str(_free_port())], timeout=1500)
+    wall = time.time() - t0
+    assert wall < 900, wall  # (the driver's own limit per bench run is well above this; 8 ranks on one GPU take ~2 minutes)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["parallelism"] == "row-range x8"
+    assert "cpu_baseline" not in line and line["value_is"] == "device_resident" and line["value_end_to_end"] > 0
+    e = full["end_to_end"]
+    assert e["ranks"] == 8 and len(e["per_rank"]) == 8 and sorted(r["rank"] for r in e["per_rank"]) == list(range(8))
+    assert all(r["ordinal"] == 0 and r["rows_this_run"] == rows * reps for r in e["per_rank"]), e["per_rank"]
+    assert e["callers_per_gpu"] == e["threads_per_rank"] >= 2 and e["host_cpu_cost"]["cpu_us_per_chunk"] > 0
+    assert e["rows_per_s"] == pytest.approx(8 * rows / e["median_scan_seconds"], rel=1e-6) and e["host_read_gbs"] == pytest.approx(e["rows_per_s"] * 512 / 1e9)
+    le = line["end_to_end"]
+    assert le["callers_per_gpu"] >= 2 and le["cpu_us_per_chunk"] > 0 and le["host_read_gbs"] > 0 and le["rows_per_s_per_gpu"] == pytest.approx(le["rows_per_s"] / 8, rel=1e-3)
+    g = line["end_to_end_registered"]
+    assert "error" not in g and g["rows_per_s"] > 0 and g["zero_copy_calls"] > 0 and g["few_callers"]["rows_per_s"] > 0
+    # each rank scanned ITS table (seed 42 + rank): the oracle's scan of the same table gives the same sum of outputs (fp32 results summed in
+    # double: equal to the 1e-4 parity bar, scaled by the rows)
+    model = oracle.Model(W.write(str(tmp_path / "mlp.onnx"), W.mlp((128, 256, 64, 1))))
+    for r in (0, 7):
+        table = sqlharness.synth_table(rows, 128, 42 + r, 8)
+        _, want = oracle.bench_scan_table(model, table, rows, 128, threads=8, boxed=2)
+        got = [x for x in e["per_rank"] if x["rank"] == r][0]["checksum"]
+        assert abs(got - want) <= 1e-4 * rows * 0.05 + 1e-3, (r, got, want)
+
+
+@pytest.mark.gpu
+def test_bench_host_path_single_process_eight_slots(gpu_api):
+    """... and DuckDB's shape at 8 GPUs: ONE process, 16 worker threads dealt over eight device slots (all on GPU 0 here)."""
+    from tests.conftest import run_bench
+
+    line, full = run_bench(["--host-path", "--gpus", "8", "--share-device", "0", "--rows", str(2048 * 480), "--e2e-threads", "16", "--e2e-reps", "3"], timeout=900)
+    assert line["n_gpus"] == 8 and line["config"]["INFERA_DEVICES"] == ",".join(["0"] * 8) and line["value_is"] == "end_to_end"
+    slots = full["end_to_end"]["device_slots"]
+    assert len(slots) == 8 and all(s["rows_this_run"] > 0 for s in slots), slots  # 16 threads: two per slot
+    assert sum(s["rows_this_run"] for s in slots) == 3 * 2048 * 480
+
+
+@pytest.mark.gpu
 def test_bench_host_path_single_process_two_slots(gpu_api):
     """DuckDB's shape: one process, worker threads dealt over two device slots (both on GPU 0 here)."""
     from tests.conftest import run_bench
