@@ -402,10 +402,9 @@ def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_
                           max_over_ranks, threads_arg: str = "", all_ok=lambda ok: ok) -> dict:
     """The same scan with the host table REGISTERED once (infera_hip_register_host_memory -- an opt-in for an application that owns
     long-lived column storage or opens DuckDB with the extension's registering allocator; NOT the drop-in path and never the headline).
-    Two regimes in one block: `rows_per_s` = the best of the caller sweep -- with many callers the GPU fetches up to
-    INFERA_ZERO_COPY_MAX_INFLIGHT (4) chunks in place at a time and the surplus chunks are staged, so both the shader-read path (~42 GB/s)
-    and the copy engines share the link -- and `few_callers` = 4 callers per rank, every chunk fetched in place: the CPU neither gathers
-    nor enqueues a copy, which is what 8 GPUs fed from one small CPU quota run like."""
+    Every chunk is fetched in place (round 5: at most three 2-D copies in flight per GPU -- the runtime runs them one at a time -- and the
+    pulling kernel for the other chunks; the CPU neither gathers nor enqueues a linear copy).  `rows_per_s` = the best of the caller sweep,
+    `few_callers` = 4 callers per rank, which is what 8 GPUs fed from one small CPU quota run like."""
     from infera_amd import capi
 
     t0 = time.perf_counter()
@@ -433,15 +432,15 @@ def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_
     for k in ("bare_h2d_copy_gbs", "bare_h2d_copy_note", "pcie_achievable_gbs", "frac_of_pcie_achievable", "all_reps_wall_seconds"):
         e.pop(k, None)
     e["entry"] = (f"infera_sql_call('{fn}') per 2048-row chunk over a host table registered with infera_hip_register_host_memory: "
-                  "infera_predict_columns -> ONE 2-D copy of the chunk's 128 column runs out of the table (pulling kernel for typed / scattered columns) -> model "
-                  "kernels -> result vector; beyond INFERA_ZERO_COPY_MAX_INFLIGHT fetches in flight the surplus chunks are staged")
+                  "infera_predict_columns -> the GPU fetches the chunk's 128 column runs out of the table itself (up to 3 chunks per GPU at a time by ONE 2-D copy each, "
+                  "the others -- and typed / scattered columns -- by the pulling kernel) -> model kernels -> result vector")
     e["register_seconds"] = reg_s
     e["zero_copy_calls"] = served
     fh = f["host_cpu_cost"]
     e["few_callers"] = {"threads_per_rank": few, "rows_per_s": f["rows_per_s"], "cpu_us_per_chunk": fh["cpu_us_per_chunk"],
                         "frac_of_pcie": f["frac_of_pcie"], **{k: fh[k] for k in ("predicted_rows_per_s_at_8_gpus", "predicted_scaling_at_8_gpus", "cpus_needed_for_6x") if k in fh}}
-    e["what"] = ("OPT-IN zero-copy path (include/infera_hip.h), not the drop-in path.  GPU-initiated reads of host memory top out at ~42 GB/s on this link, "
-                 "the copy engines (staged path) at 56: few_callers shows the pure in-place regime (lowest CPU per chunk), rows_per_s the shared-link regime")
+    e["what"] = ("OPT-IN zero-copy path (include/infera_hip.h), not the drop-in path: no CPU gather, no pinned staging, no linear H2D copy -- "
+                 "a third of the staged path's CPU time per chunk, which is what bounds 8 GPUs on one CPU quota")
     return e
 
 

@@ -158,6 +158,8 @@ size_t registered_host_ranges();
 // `height` runs of `width` bytes, `src_pitch` bytes apart in REGISTERED host memory -> one column-major chunk at dst, as ONE 2-D copy on `stream`
 void copy_rect_to_device(hipStream_t stream, float *dst, const void *src, size_t src_pitch, size_t width, size_t height);
 bool zero_copy_rect_enabled();  // Config::zero_copy_rect
+int rect_copy_acquire();             // a 2-D copy ticket of the calling thread's GPU (-1: enough of them in flight, use the pulling kernel)
+void rect_copy_release(int ticket);
 // whether a host call of `rows` rows can be handed to the plan's first kernel as column-major chunks (one device pass per host pass)
 bool colmajor_direct_ok(const LoadedModel &m, int64_t rows);
 

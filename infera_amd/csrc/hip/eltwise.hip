@@ -463,55 +463,84 @@ void pad_cols(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t
   hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for(rows * Kp)), dim3(kBlock), 0, s, src, dst, rows, K, Kp);
 }
 
-// ---- zero-copy column gather (round 3) ---------------------------------------------------------------------------------
+// ---- zero-copy column gather (round 3; launch shape round 5) ----------------------------------------------------------------------
 // The caller's column runs live in host memory that the application REGISTERED with the runtime (infera_hip_register_host_memory):
 // the GPU reads them in place over PCIe and writes the column-major f32 chunk [ncols][rows] into HBM -- the CPU never touches the
-// data.  One workgroup per (column, 4096-row block): a wave instruction reads 1 KB of one column run (16 B per lane, contiguous),
-// every load of the workgroup is in flight at once.  Casts as the reference's ExtractFeatures (static_cast<float>,
-// infera_extension.cpp:211-222): f64 -> f32 and i64 -> f32 round to nearest even (v_cvt_f32_f64; __ll2float_rn), i32 -> f32 exact
-// rounding; a constant vector broadcasts its one value.  Runs whose address is not 16-byte aligned are read element-wise.
-__global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, int64_t rows, float *__restrict__ dst, int rowblock) {
-  const int c = blockIdx.x;
+// data.  ONE WAVE per (column, 2048-row block): a wave instruction reads 1 KB of one column run (16 B per lane, contiguous) and all
+// eight of a FLOAT run's are issued before the first store -- the whole 8 KB run of a DataChunk column is in flight from one wave.
+// Casts as the reference's ExtractFeatures (static_cast<float>, infera_extension.cpp:211-222): f64 -> f32 and i64 -> f32 round to
+// nearest even (v_cvt_f32_f64; __ll2float_rn), i32 -> f32 exact rounding; a constant vector broadcasts its one value.  Runs whose
+// address is not 16-byte aligned are read element-wise.
+// Launch shape, measured with nothing else in the queues (tools/ubench/chunk_pull_probe.hip, 1 MiB fetches back to back on 1 / 4
+// streams): this shape 49.7 / 54.3 GB/s; round 3's one 256-lane workgroup per column with two loads per lane 48.1 / 51.0; one-wave
+// workgroups with two loads 43.1 / 47.5; hipMemcpy2DAsync 36.7 / 36.7 -- a 2-D copy runs ALONE however many streams issue them.
+constexpr int kGatherRowBlock = 2048;
+template <class T, class Cvt>
+__device__ __forceinline__ void gather_run(const T *__restrict__ s, float *__restrict__ d, int n, int lane, Cvt cvt) {
+  for (int base = 0; base < n; base += 64 * 8) {
+    T v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int idx = base + lane + 64 * i;
+      if (idx < n) v[i] = s[idx];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int idx = base + lane + 64 * i;
+      if (idx < n) d[idx] = cvt(v[i]);
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, int ncols, int64_t rows, float *__restrict__ dst) {
+  const int c = int(blockIdx.x) * (kBlock / 64) + int(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= ncols) return;
   const int type = tab.type[c] & 7;
   const bool constant = tab.type[c] & 8;
   const char *src = static_cast<const char *>(tab.ptr[c]);
-  float *d = dst + int64_t(c) * rows;
-  const int64_t r0 = int64_t(blockIdx.y) * rowblock, r1 = min(rows, r0 + rowblock);
+  const int64_t r0 = int64_t(blockIdx.y) * kGatherRowBlock;
+  const int n = int(min<int64_t>(rows - r0, kGatherRowBlock));
+  float *d = dst + int64_t(c) * rows + r0;
   if (constant) {
     float v;
     if (type == 0) v = *reinterpret_cast<const float *>(src);
     else if (type == 1) v = float(*reinterpret_cast<const double *>(src));
     else if (type == 2) v = float(*reinterpret_cast<const int *>(src));
     else v = __ll2float_rn(*reinterpret_cast<const long long *>(src));
-    for (int64_t r = r0 + threadIdx.x; r < r1; r += kBlock) d[r] = v;
+    for (int r = lane; r < n; r += 64) d[r] = v;
     return;
   }
-  if (type == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(d)) & 15) == 0 && (rows & 3) == 0) {
-    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
-    f32x4 *d4 = reinterpret_cast<f32x4 *>(d);
-    for (int64_t i = r0 / 4 + threadIdx.x; i < r1 / 4; i += kBlock) d4[i] = s4[i];
-    return;
-  }
-  for (int64_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
-    float v;
-    if (type == 0) v = reinterpret_cast<const float *>(src)[r];
-    else if (type == 1) v = float(reinterpret_cast<const double *>(src)[r]);
-    else if (type == 2) v = float(reinterpret_cast<const int *>(src)[r]);
-    else v = __ll2float_rn(reinterpret_cast<const long long *>(src)[r]);
-    d[r] = v;
+  if (type == 0) {
+    const float *s = reinterpret_cast<const float *>(src) + r0;
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0 && (n & 3) == 0) {
+      const f32x4 *s4 = reinterpret_cast<const f32x4 *>(s);
+      f32x4 *d4 = reinterpret_cast<f32x4 *>(d);
+      const int n4 = n >> 2;  // (<= 512: one round of eight loads per lane)
+      f32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (lane + 64 * i < n4) v[i] = s4[lane + 64 * i];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (lane + 64 * i < n4) d4[lane + 64 * i] = v[i];
+      return;
+    }
+    gather_run(s, d, n, lane, [](float x) { return x; });
+  } else if (type == 1) {
+    gather_run(reinterpret_cast<const double *>(src) + r0, d, n, lane, [](double x) { return float(x); });
+  } else if (type == 2) {
+    gather_run(reinterpret_cast<const int *>(src) + r0, d, n, lane, [](int x) { return float(x); });
+  } else {
+    gather_run(reinterpret_cast<const long long *>(src) + r0, d, n, lane, [](long long x) { return __ll2float_rn(x); });
   }
 }
 
 void gather_columns_device(hipStream_t s, const ColumnTable &tab, int ncols, int64_t rows, float *dst) {
   if (rows <= 0 || ncols <= 0) return;
-  // (4096-row blocks = one workgroup per column of a DataChunk, two 16-byte loads per lane: 82-83 M rows/s on C2 at 8+ callers; 1024- /
-  // 512-row blocks -- more, thinner workgroups -- 73-75 M; more hardware queues (GPU_MAX_HW_QUEUES=8 / 16) 66-74 M.  One kernel streaming
-  // 1 GiB of registered memory reaches the copy engines' 57 GB/s (tools/ubench/pull_probe.hip): the gap is the per-chunk launch structure.
-  // Also measured and dropped: the fused MLP's tile kernel reading the column runs ITSELF (each workgroup pulling its own 32 rows of
+  // (Also measured and dropped: the fused MLP's tile kernel reading the column runs ITSELF (each workgroup pulling its own 32 rows of
   // every column into LDS: one launch per chunk, bit-identical) -- 46 M rows/s against 82: 128-byte pieces per (column, tile) use the
-  // link far worse than this kernel's 1 KB wave instructions.)
-  constexpr int rowblock = 4096;
-  hipLaunchKernelGGL(gather_cols_kernel, dim3(unsigned(ncols), unsigned((rows + rowblock - 1) / rowblock)), dim3(kBlock), 0, s, tab, rows, dst, rowblock);
+  // link far worse than this kernel's 1 KB wave instructions; more hardware queues (GPU_MAX_HW_QUEUES=8 / 16): worse.)
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(unsigned((ncols + kBlock / 64 - 1) / (kBlock / 64)), unsigned((rows + kGatherRowBlock - 1) / kGatherRowBlock)),
+                     dim3(kBlock), 0, s, tab, ncols, rows, dst);
 }
 
 void transpose_cm(hipStream_t s, const float *src, float *dst, int64_t rows, int64_t ncols) {

@@ -326,7 +326,19 @@ bool HostCall::graph_chunk(int64_t r0, int64_t nr, bool direct_out) {
 //     behind per-group flags, no H2D copy at all.  Bit-identical; a lone caller gains 13-23 % (93 -> 80 us per chunk) -- and two callers LOSE
 //     whenever their streams share one of the runtime's hardware queues (a kernel that waits for its host blocks the queue behind it: 35 -> 26 M
 //     rows/s), four and more lose 15-20 % (profiles/r05_stream_chunk_ab.txt).  Even with the host spinning on the event the tail AFTER the last
-//     column group was there took 29 us: what is left of a chunk's wait is the device's completion path, which no pipelining of the input hides.
+//     column group was there took 29 us: what is left of a chunk's wait is the device's completion path, which no pipelining of the input hides;
+//   * waiting by READING the results (round 5): pinned result buffer filled with a sentinel before the enqueue, the words copied out as they
+//     change -- one nap until shortly before they are due, then a short spin -- instead of an event behind the kernel: no gain at 1-2 callers
+//     (wait 46.6-48 vs 45-47 us: the results are there when the event says so, the 7 us "tail" of a rocprofv3 timeline is the profiler's own),
+//     a loss at 4+ (profiles/r05_result_poll_ab.txt).  What a lone caller waits for is the device's pipeline: ~5 us until the copy starts,
+//     24 us of copy (18.4 at link speed), 8 us between the copy engine's completion and the kernel's start, 12 us of tile kernel
+//     (profiles/r05_e2e_ranges.txt);
+//   * staging contexts dealt so that concurrent callers never share a hardware queue (round 5; the runtime maps streams onto four queues in
+//     creation order 1 2 3 4 | 4 3 2 1 | ..., and two callers on one queue run strictly one behind the other): no gain, staged 3-4 callers lose
+//     4-7 % -- on one queue two callers ALTERNATE (one's copy under the other's kernel), on two they fall into lockstep and share the link
+//     (profiles/r05_ctx_queue_groups_ab.txt, r05_stream_queue_probe.txt); likewise ONE high-priority fetch stream per GPU for all zero-copy
+//     pulls with the kernels waiting for its events: the cross-queue dependency costs a lone caller 6 us per chunk and four callers collapse
+//     to 36 M rows/s.
 void HostCall::run_chunks(uint64_t lease_ns) {
   // hipGraph mode captures {H2D, kernels[, D2H]}: a column-major chunk only when the model's first kernel reads it itself (the transposing
   // path allocates per pass, which a capture cannot contain)
@@ -441,10 +453,13 @@ bool run_host_redealt(const LoadedModel &m, const FillFn &fill, const DeviceFill
   }
 }
 
-// Zero-copy fetches a GPU has in flight right now.  GPU-initiated reads of host memory top out at ~42 GB/s on this link whoever issues them, and
-// two to four fetches in flight already reach that; the copy engines, which the STAGED path uses, read host memory at 56.  So with more callers
-// than INFERA_ZERO_COPY_MAX_INFLIGHT (per GPU) the surplus chunks take the staged path -- the two mechanisms share the link instead of queueing
-// on the slower one (false = "stage it", exactly as for a chunk outside the registered ranges).
+// Zero-copy fetches a GPU has in flight right now, for INFERA_ZERO_COPY_MAX_INFLIGHT (default 0 = no limit): with a limit, the chunks beyond it
+// take the staged path (false = "stage it", exactly as for a chunk outside the registered ranges).  Round 4 shipped a limit of four because
+// in-place fetches stopped at 80 M rows/s per GPU whatever mechanism issued them and only the copy engines' linear copies filled the rest of
+// the link -- at 46-63 us of CPU per chunk at 8-16 callers.  Round 5 found what the 80 were: a 2-D copy takes 24-28 us and the runtime runs
+// them one at a time; the pulling kernel's launch shape cost it 10 %.  With at most three 2-D copies in flight per GPU and the (re-shaped)
+// pulling kernel for every other chunk (zero_copy.cpp, rect_copy_acquire) every chunk is fetched in place: 89.5 / 97.8 / 101.8 M rows/s at
+// 4 / 6 / 8 callers at 22-24 us of CPU per chunk (profiles/r05_zero_copy_ab.txt).
 std::atomic<int> g_zc_fetches[64];
 
 }  // namespace

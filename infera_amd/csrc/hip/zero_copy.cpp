@@ -291,4 +291,25 @@ void copy_rect_to_device(hipStream_t stream, float *dst, const void *src, size_t
 }
 bool zero_copy_rect_enabled() { return Config::get().zero_copy_rect; }
 
+// 2-D copies a GPU has in flight (between a call's enqueue and its return).  The runtime executes them ONE AT A TIME however many streams
+// issue them (tools/ubench/chunk_pull_probe.hip: 28.6 us per MiB from 1 to 16 streams), which is what makes two or three callers alternate
+// nicely -- and what stops a GPU at 80 M rows/s.  The pulling kernel runs beside it on the shader cores.  So a chunk takes the 2-D copy while
+// fewer than INFERA_ZERO_COPY_RECT_INFLIGHT (default 2) are in flight on its GPU and the pulling kernel otherwise.
+namespace {
+std::atomic<int> g_rect_inflight[64];
+}
+int rect_copy_acquire() {
+  const int limit = Config::get().zero_copy_rect_inflight;
+  const int slot = rt::home_slot();
+  std::atomic<int> &n = g_rect_inflight[size_t(slot) % 64];
+  if (limit > 0 && n.fetch_add(1, std::memory_order_relaxed) >= limit) {
+    n.fetch_sub(1, std::memory_order_relaxed);
+    return -1;
+  }
+  return limit > 0 ? slot : 64;  // (64: no limit, nothing to give back)
+}
+void rect_copy_release(int ticket) {
+  if (ticket >= 0 && ticket < 64) g_rect_inflight[size_t(ticket)].fetch_sub(1, std::memory_order_relaxed);
+}
+
 }  // namespace infera_hip

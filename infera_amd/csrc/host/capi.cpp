@@ -545,6 +545,11 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
             pitch = d;
           }
         }
+        struct RectTicket {  // (held until the call returns: the copy is "in flight" until its chunk has been waited for)
+          int t = -1;
+          ~RectTicket() { rect_copy_release(t); }
+        } ticket;
+        if (rect) rect = (ticket.t = rect_copy_acquire()) >= 0;
         if (all)
           served = run_host_device_fill(*m, [&](hipStream_t stream, float *dst, int64_t r0, int64_t nr) {
             if (rect) {

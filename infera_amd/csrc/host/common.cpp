@@ -91,7 +91,8 @@ const Config &Config::get() {
     c.max_inflight_total = int(env_u64("INFERA_MAX_INFLIGHT_TOTAL", 0));
     c.host_zero_copy = env_flag("INFERA_HOST_ZERO_COPY", true);
     c.zero_copy_rect = env_flag("INFERA_ZERO_COPY_RECT", true);
-    c.zero_copy_max_inflight = int(env_u64("INFERA_ZERO_COPY_MAX_INFLIGHT", 4));
+    c.zero_copy_rect_inflight = int(env_u64("INFERA_ZERO_COPY_RECT_INFLIGHT", 3));
+    c.zero_copy_max_inflight = int(env_u64("INFERA_ZERO_COPY_MAX_INFLIGHT", 0));
     c.numa_slots = env_flag("INFERA_NUMA_SLOTS", true);
     c.host_direct_in_bytes = (long long)env_u64("INFERA_HOST_DIRECT_IN", 128 * 1024);
     c.fused_mlp = env_flag("INFERA_FUSED_MLP", true);

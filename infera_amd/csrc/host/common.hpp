@@ -96,10 +96,10 @@ struct Config {
   bool host_zero_copy;                // INFERA_HOST_ZERO_COPY=0|1 (default 1)  infera_predict_columns chunks whose column runs all lie in host memory
                                       //   registered with infera_hip_register_host_memory are read in place by the GPU (no CPU gather, no H2D copy)
   bool zero_copy_rect;                // INFERA_ZERO_COPY_RECT=0|1 (default 1)  a zero-copy chunk whose runs are FLOAT at one stride inside one pinned block is fetched by ONE
-                                      //   2-D copy (reaches the path's plateau with 2-4 callers instead of 8, 20 % less CPU); 0: always the pulling kernel
-  int zero_copy_max_inflight;         // INFERA_ZERO_COPY_MAX_INFLIGHT=n (default 4)  zero-copy fetches a GPU runs at a time; chunks beyond that are STAGED: shader reads of
-                                      //   host memory top out at ~42 GB/s (reached with 2-4 fetches in flight), the copy engines at 56 -- the surplus shares the
-                                      //   link instead of queueing on the slower mechanism (registered table, 16 callers: 80 -> 108 M rows/s; 0 = no limit: lowest CPU)
+                                      //   2-D copy (two or three callers alternate on the one-at-a-time 2-D copy engine path: 64 / 80 M rows/s against the pulling kernel's 52 / 65); 0: always the pulling kernel
+  int zero_copy_rect_inflight;        // INFERA_ZERO_COPY_RECT_INFLIGHT=n (default 3; 0 = no limit)  2-D copies a GPU runs at a time; chunks beyond that take the pulling kernel
+  int zero_copy_max_inflight;         // INFERA_ZERO_COPY_MAX_INFLIGHT=n (default 0 = no limit)  zero-copy fetches a GPU runs at a time; chunks beyond that are STAGED
+                                      //   (round 4 shipped 4: in-place fetches stopped at 80 M rows/s per GPU then -- host_path.cpp, g_zc_fetches)
   bool numa_slots;                    // INFERA_NUMA_SLOTS=0|1 (default 1)  caller threads prefer the device slots on their own NUMA node (bounded by load)
   long long host_direct_in_bytes;     // INFERA_HOST_DIRECT_IN=<bytes>  chunks up to this size are read from pinned memory by the first kernel itself
                                       //   (default 131072; 0 = always H2D).  On a quiet GPU the effective limit is higher: x2 with at most four

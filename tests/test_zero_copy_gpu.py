@@ -156,7 +156,7 @@ def test_gpu_zero_copy_concurrent_callers(gpu_api, tmp_path):
             [t.start() for t in th]
             [t.join() for t in th]
             assert not bad, bad
-            # (with more callers than INFERA_ZERO_COPY_MAX_INFLIGHT = 4 the surplus chunks are staged: same results, fewer in-place fetches)
+            # (under an INFERA_ZERO_COPY_MAX_INFLIGHT limit -- round 4's default was 4, round 5's is none -- surplus chunks are staged: same results, fewer in-place fetches)
             assert before + nchunks // 4 <= gpu_api.zero_copy_calls() <= before + nchunks
         finally:
             gpu_api.unregister_host_memory(big)
