@@ -422,10 +422,12 @@ def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_
         before = capi.zero_copy_calls()
         top = budget["usable"]
         share = max(2, top // world)
-        th = threads_arg or ",".join(str(t) for t in sorted({max(2, share // 4), max(2, share // 2), share}))
+        # (a caller of this path costs ~20-29 us of CPU per ~60-80 us chunk -- it sleeps most of the time -- so callers, not CPUs, are what a rank needs:
+        #  with N ranks on one quota the sweep oversubscribes the rank's CPU share up to 8 callers per GPU, where one GPU's link is full)
+        th = threads_arg or ",".join(str(t) for t in (sorted({min(8, 2 * share), min(8, 4 * share)}) if world > 1 else sorted({max(2, share // 4), max(2, share // 2), share})))
         e = end_to_end(fn, model, table, rows, cols, out_cols, th, reps, budget, world, barrier, max_over_ranks)
         served = capi.zero_copy_calls() - before
-        few = min(4, max(2, share))
+        few = 4
         f = end_to_end(fn, model, table, rows, cols, out_cols, str(few), max(2, reps - 1), budget, world, barrier, max_over_ranks)
     finally:
         capi.unregister_host_memory(table)
