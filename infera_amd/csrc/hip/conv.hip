@@ -1343,10 +1343,13 @@ __device__ unsigned long long g_stem_phase[2][10];
 #define STEM_T(i)
 #endif
 
-__global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
+template <int NW>  // waves per workgroup: 4 (two pixel tiles per wave) or 8 (one: four waves per SIMD with two workgroups per CU)
+__global__ __launch_bounds__(NW * 64, 2) void conv2d_stem_split6_kernel(const float *__restrict__ X, const float *__restrict__ Wp,
                                                                            const float *__restrict__ bias, float *__restrict__ Y, int64_t ntiles,
                                                                            ConvGeom g, PatchGeom pg, ActParam act, PoolTail pool, int desync) {
-  constexpr int BS = kPool2Block, PW = 2, KBC = kStemKB;
+  constexpr int BS = NW * 64, PW = 8 / NW, KBC = kStemKB;
+  constexpr int PE = kPatchMaxE * kPool2Block / BS;  // patch words a thread fetches and parks per tile
+  constexpr int NI = 2 * kPool2Block / BS;           // pooled (pixel, channel quad) items per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   u32x4_t *wl = reinterpret_cast<u32x4_t *>(smem);           // [KBC][hi, mid, lo][64 lanes]: this half's 32 features
   uint2 *patch = reinterpret_cast<uint2 *>(smem + KBC * 768);  // [C * PLANE] cut words {hi | mid << 16, lo} (+ 8 spare) ...
@@ -1366,9 +1369,9 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
     const int c = rr / g.kh, ky = rr - c * g.kh;
     soff[rr] = rr < g.C * g.kh ? c * pg.PLANE + rowoff(ky) : 0;
   }
-  int e_rel[kPatchMaxE], e_rc[kPatchMaxE], e_lds[kPatchMaxE];
+  int e_rel[PE], e_rc[PE], e_lds[PE];
 #pragma unroll
-  for (int i = 0; i < kPatchMaxE; i++) {
+  for (int i = 0; i < PE; i++) {
     const int e = threadIdx.x + i * BS;
     const int c = e / (pg.PR * pg.PC), rem = e - c * (pg.PR * pg.PC), row = rem / pg.PC, col = rem - row * pg.PC;
     const bool live = c < g.C;
@@ -1392,12 +1395,12 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
   };
   // park a patch: first every word of the region nobody parks (the odd half's fourth word of the last pixels: kx = 7, weight zero -- and what
   // the exchange tile left there) is made finite again, then the fetched words
-  auto park_patch = [&](const float(&v)[kPatchMaxE]) {
+  auto park_patch = [&](const float(&v)[PE]) {
     // (one word per patch row is read but never parked -- the odd half's word HALF - 1 = column 2 HALF - 1 past the patch, kx = 7 of the last
     //  pixels, weight zero: it must be finite, and the exchange tile has been there)
     for (int i = threadIdx.x; i < g.C * pg.PR; i += BS) patch[(i / pg.PR) * pg.PLANE + rowoff(i % pg.PR) + 2 * pg.HALF - 1] = uint2{0u, 0u};
 #pragma unroll
-    for (int i = 0; i < kPatchMaxE; i++) {  // exact cut: hi = top 16 bits, mid = top 16 bits of the rest, lo = what is left (8 bits: exact in bf16)
+    for (int i = 0; i < PE; i++) {  // exact cut: hi = top 16 bits, mid = top 16 bits of the rest, lo = what is left (8 bits: exact in bf16)
       const unsigned x = __float_as_uint(v[i]);
       const float r1 = v[i] - __uint_as_float(x & 0xffff0000u);
       const unsigned y = __float_as_uint(r1);
@@ -1409,7 +1412,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
   int lbase[PW], py[PW], px[PW];
 #pragma unroll
   for (int p = 0; p < PW; p++) {
-    const int pix = min((wave + 4 * p) * 32 + r, kPoolCR * kPoolCC - 1);
+    const int pix = min((wave + NW * p) * 32 + r, kPoolCR * kPoolCC - 1);
     py[p] = pix / kPoolCC;
     px[p] = pix % kPoolCC;
     lbase[p] = py[p] * pg.PP + px[p];  // (stride 2: convolution row py starts at patch row 2 py)
@@ -1418,7 +1421,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
   f32x4 bres[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) bres[q] = bias ? reinterpret_cast<const f32x4 *>(bias)[h + 8 * half + 2 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
-  float pv[kPatchMaxE];
+  float pv[PE];
   const int64_t chunk = (ntiles + 7) >> 3, t_end = min(ntiles, (int64_t(xcd) + 1) * chunk);
   const int64_t tstep = ((gridDim.x + 7 - xcd) >> 3) >> 1;
   int64_t tile = int64_t(xcd) * chunk + pair;
@@ -1428,7 +1431,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
     const int iy0 = oy0_n * g.sh - g.pt, ix0 = ox0_n * g.sw - g.pl;
     const float *image = X + int64_t(img_n) * g.C * g.H * g.W;
 #pragma unroll
-    for (int i = 0; i < kPatchMaxE; i++) pv[i] = load_slot(i, image, iy0, ix0);
+    for (int i = 0; i < PE; i++) pv[i] = load_slot(i, image, iy0, ix0);
   }
   __syncthreads();  // (the weights)
   if (tile < t_end) park_patch(pv);
@@ -1436,9 +1439,9 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
   if (half)
     for (int i = 0; i < desync; i++) __builtin_amdgcn_s_sleep(127);
   constexpr int XQ = 9, NQ = 8, PT = kPoolTR * kPoolTC;
-  int pwin[2] = {0, 0}, poff[2] = {-1, -1}, ppr[2] = {0, 0}, ppc[2] = {0, 0};
+  int pwin[NI], poff[NI], ppr[NI], ppc[NI];
 #pragma unroll
-  for (int n = 0; n < 2; n++) {
+  for (int n = 0; n < NI; n++) {
     const int it = threadIdx.x + n * BS;
     const bool ok = it < NQ * PT;
     const int cq = ok ? it / PT : 0, pp = ok ? it % PT : 0, pr = pp / kPoolTC, pc = pp % kPoolTC;
@@ -1466,7 +1469,9 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
     for (int p = 0; p < PW; p++)
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
-    const uint2 *pb[PW] = {patch + lbase[0], patch + lbase[1]};
+    const uint2 *pb[PW];
+#pragma unroll
+    for (int p = 0; p < PW; p++) pb[p] = patch + lbase[p];
     // a step = one k-block for BOTH pixel tiles: eight cut patch words per tile (even half: kx 0 2 4 6, odd half: kx 1 3 5 7) and the k-block's
     // three weight fragments, all fetched one k-block ahead.  The order is PINNED with sched_barriers: fragments of this k-block assembled ->
     // the next k-block's LDS reads issued -> twelve matrix instructions (the two tiles' accumulators alternate, so consecutive ones are
@@ -1496,10 +1501,15 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
       for (int k = 0; k < 3; k++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a3[buf][k]) : "v"(wfrag_a), "n"((kb * 3 + k) * 1024));
     };
     auto wait_words = [&](int buf) {
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[0][4]), "+v"(w[0][5]), "+v"(w[0][6]), "+v"(w[0][7]),
-                     "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]), "+v"(w[1][4]), "+v"(w[1][5]), "+v"(w[1][6]), "+v"(w[1][7]),
-                     "+v"(a3[buf][0]), "+v"(a3[buf][1]), "+v"(a3[buf][2]));
+      if constexpr (PW == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[0][4]), "+v"(w[0][5]), "+v"(w[0][6]), "+v"(w[0][7]),
+                       "+v"(w[PW - 1][0]), "+v"(w[PW - 1][1]), "+v"(w[PW - 1][2]), "+v"(w[PW - 1][3]), "+v"(w[PW - 1][4]), "+v"(w[PW - 1][5]),
+                       "+v"(w[PW - 1][6]), "+v"(w[PW - 1][7]), "+v"(a3[buf][0]), "+v"(a3[buf][1]), "+v"(a3[buf][2]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[0][4]), "+v"(w[0][5]), "+v"(w[0][6]), "+v"(w[0][7]),
+                       "+v"(a3[buf][0]), "+v"(a3[buf][1]), "+v"(a3[buf][2]));
     };
 #pragma unroll
     for (int p = 0; p < PW; p++) fetch_words(0, p);
@@ -1525,10 +1535,10 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
         for (int p = 0; p < PW; p++) fetch_words(kb + 1, p);
         fetch_weights(kb + 1, kc ^ 1);
       }
-      // the next tile's patch words ride along: sixteen fetches over the eleven k-blocks
+      // the next tile's patch words ride along: sixteen (eight) fetches over the eleven k-blocks
 #pragma unroll
-      for (int sl = 0; sl < kPatchMaxE; sl++)
-        if (sl * KBC / kPatchMaxE == kb) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
+      for (int sl = 0; sl < PE; sl++)
+        if (sl * KBC / PE == kb) pv[sl] = load_slot(sl, image_n, iy0_n, ix0_n);
       __builtin_amdgcn_sched_barrier(0);
       auto B = [](const u32x4_t &v) { return __builtin_bit_cast(bf16x8_s, v); };
 #pragma unroll
@@ -1560,7 +1570,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; j++) v[j] = inside ? apply_act_c<KIND>(acc[p][4 * q + j] + bres[q][j], act.a, act.b) : -INFINITY;
-          exch[((wave + 4 * p) * 32 + r) * XQ + 2 * q + h] = v;
+          exch[((wave + NW * p) * 32 + r) * XQ + 2 * q + h] = v;
         }
       }
     });
@@ -1572,7 +1582,7 @@ __global__ __launch_bounds__(kPool2Block, 2) void conv2d_stem_split6_kernel(cons
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, int(pooled_img_bytes), 0x00020000);
       const int pr0 = (oy0 + pool.pt) >> 1, pc0 = (ox0 + pool.pl) >> 1;
 #pragma unroll
-      for (int n = 0; n < 2; n++) {
+      for (int n = 0; n < NI; n++) {
         const f32x4 *win = exch + pwin[n];
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -1964,15 +1974,22 @@ void conv2d_stem_split6(hipStream_t s, const float *X, const float *packed, cons
   const int64_t ntiles = rows * p.tiles_x * p.tiles_y;
   const int desync = getenv("INFERA_STEM_POOL2_DESYNC") ? atoi(getenv("INFERA_STEM_POOL2_DESYNC")) : 1;
   const int cus = std::max(8, (num_cus > 0 ? num_cus : 256) / 8 * 8);  // whole workgroup pairs on each of 8 XCD queues; runs for every batch size
+  // INFERA_STEM_WAVES=4|8 (measurement knob): workgroups of four waves with two pixel tiles each, or of eight with one
+  static const int waves = getenv("INFERA_STEM_WAVES") && atoi(getenv("INFERA_STEM_WAVES")) == 8 ? 8 : 4;
   static std::atomic<uint64_t> attr_done{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_stem_split6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_stem_split6_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_stem_split6_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
   }
-  hipLaunchKernelGGL(conv2d_stem_split6_kernel, dim3(unsigned(2 * cus)), dim3(kPool2Block), stem_split6_lds_bytes(g, p), s, X, packed, bias, Y, ntiles, g,
-                     p, act, pool, desync);
+  if (waves == 8)
+    hipLaunchKernelGGL(conv2d_stem_split6_kernel<8>, dim3(unsigned(2 * cus)), dim3(512), stem_split6_lds_bytes(g, p), s, X, packed, bias, Y, ntiles, g, p, act,
+                       pool, desync);
+  else
+    hipLaunchKernelGGL(conv2d_stem_split6_kernel<4>, dim3(unsigned(2 * cus)), dim3(256), stem_split6_lds_bytes(g, p), s, X, packed, bias, Y, ntiles, g, p, act,
+                       pool, desync);
 }
 
 void conv2d_patch(hipStream_t s, const float *X, const float *packed, const float *bias, float *Y, int64_t rows,
