@@ -588,7 +588,8 @@ def compact_cpu(cb: dict) -> dict:
 
 
 def compact_e2e(e: dict) -> dict:
-    out = _pick(e, ("rows_per_s", "rows_per_s_per_gpu", "frac_of_pcie", "bare_h2d_copy_gbs", "host_read_gbs", "vs_cpu_baseline", "vs_cpu_reference_shaped", "zero_copy_calls", "error"))
+    out = _pick(e, ("rows_per_s", "rows_per_s_per_gpu", "frac_of_pcie", "bare_h2d_copy_gbs", "host_read_gbs", "vs_cpu_baseline", "vs_cpu_reference_shaped", "zero_copy_calls",
+                    "vs_staged", "predicted_8_gpus_vs_staged_1_gpu", "error"))
     if "threads_per_rank" in e or "threads" in e:
         out["threads"] = out["callers_per_gpu"] = e.get("threads_per_rank", e.get("threads"))
     h = e.get("host_cpu_cost") or {}
@@ -901,6 +902,13 @@ def main():
             e2e["numa_binding"] = numa
             full["end_to_end"] = e2e
             if e2e_reg:
+                if "rows_per_s" in e2e_reg and e2e.get("rows_per_s"):
+                    # the registered scan beside the headline: this run's rate, and (1 GPU) what its CPU cost predicts for 8 GPUs on this quota,
+                    # both as multiples of the STAGED 1-GPU rate -- the >= 6x of north_star is asked of the drop-in path's 1-GPU number
+                    e2e_reg["vs_staged"] = e2e_reg["rows_per_s"] / e2e["rows_per_s"]
+                    p8 = (e2e_reg.get("host_cpu_cost") or {}).get("predicted_rows_per_s_at_8_gpus")
+                    if p8 and world == 1:
+                        e2e_reg["predicted_8_gpus_vs_staged_1_gpu"] = p8 / e2e["rows_per_s"]
                 full["end_to_end_registered"] = e2e_reg
         elif e2e_error:
             full["end_to_end"] = {"error": e2e_error}
