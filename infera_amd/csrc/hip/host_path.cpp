@@ -338,7 +338,7 @@ bool HostCall::graph_chunk(int64_t r0, int64_t nr, bool direct_out) {
 //     4-7 % -- on one queue two callers ALTERNATE (one's copy under the other's kernel), on two they fall into lockstep and share the link
 //     (profiles/r05_ctx_queue_groups_ab.txt, r05_stream_queue_probe.txt); likewise ONE high-priority fetch stream per GPU for all zero-copy
 //     pulls with the kernels waiting for its events: the cross-queue dependency costs a lone caller 6 us per chunk and four callers collapse
-//     to 36 M rows/s;
+//     to 36 M rows/s (profiles/r05_fetch_stream_ab.txt);
 //   * a staged chunk PULLED out of pinned staging by a kernel instead of copied by a copy engine while few calls are in flight (round 5): a lone
 //     caller +4-6 %, two and more lose 5-15 % and pay 5-15 us more CPU per chunk (profiles/r05_staged_pull_ab.txt).
 void HostCall::run_chunks(uint64_t lease_ns) {
