@@ -197,6 +197,7 @@ struct Compiled {
   int threads = 256, lds_bytes = 0;
   std::map<int, hipFunction_t> fn_by_device;
   Variant tile, tile_xcm;
+  Variant tile16, tile16_xcm;  // mlp3_tile16_kernel (chunks up to kTile16MaxRows rows: 16-row tiles on the 16x16x4 instruction)
 };
 
 std::mutex g_mu;  // the map only
@@ -275,6 +276,15 @@ Compiled &compile_locked(const Mlp3Shape &s, std::unique_lock<std::mutex> &held)
       if (!v->ok) log_msg(1, "fused MLP " + c.expr + ": no tile kernel (" + v->why.substr(0, 300) + ")");
     }
   }
+  // ... and the 16-row form for the shortest launches (mlp_device.inc, mlp3_tile16_kernel: VALU head, D1 in 64s, D2 <= 128, its
+  // 16 x (D1+4) activation tile in static LDS)
+  if (c.ok && c.tile.ok && c.tile_xcm.ok && L.l3v && s.d1 % 64 == 0 && s.d2 <= 128 && 16 * (s.d1 + 4 + s.d2 + 4) * 4 <= 60 * 1024) {
+    for (Variant *v : {&c.tile16, &c.tile16_xcm}) {
+      v->expr = "infera_hip::kern::mlpdev::mlp3_tile16_kernel<" + c.cfg + "," + (v == &c.tile16_xcm ? "true" : "false") + ">";
+      v->ok = jit_compile(kMlpDeviceSrc, "infera_mlp_jit.hip", v->expr, v->code, v->lowered, v->why);
+      if (!v->ok) log_msg(1, "fused MLP " + c.expr + ": no 16-row tile kernel (" + v->why.substr(0, 300) + ")");
+    }
+  }
   return c;
 }
 
@@ -309,6 +319,7 @@ bool mlp3_jit_prepare(const Mlp3Shape &sh, std::string *why) {
 }
 
 constexpr int64_t kTileKernelMaxRows = 32768;  // (as for the ahead-of-time configurations, mlp_fused.hip)
+constexpr int64_t kTile16MaxRows = 4096;
 
 int64_t mlp3_jit_colmajor_max_rows(const Mlp3Shape &sh) {
   std::unique_lock<std::mutex> lk;
@@ -320,7 +331,7 @@ bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const f
                      int num_cus, std::string *why, bool x_colmajor) {
   hipFunction_t fn = nullptr;
   int threads = 256, lds = 0;
-  bool tile = false;
+  bool tile = false, tile16 = false;
   {
     std::unique_lock<std::mutex> lk;
     Compiled &c = compile_locked(sh, lk);
@@ -329,7 +340,11 @@ bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const f
       return false;
     }
     Variant &v = x_colmajor ? c.tile_xcm : c.tile;
-    if (rows <= kTileKernelMaxRows && v.ok) {
+    Variant &v16 = x_colmajor ? c.tile16_xcm : c.tile16;
+    if (rows <= kTile16MaxRows && v16.ok) {
+      tile = tile16 = true;
+      fn = function_on_device(v16.code, v16.lowered, v16.fn_by_device, 0, why);
+    } else if (rows <= kTileKernelMaxRows && v.ok) {
       tile = true;
       fn = function_on_device(v.code, v.lowered, v.fn_by_device, 0, why);
     } else if (x_colmajor) {
@@ -343,7 +358,7 @@ bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const f
     if (!fn) return false;
   }
   const int64_t ntiles = (rows + 31) / 32;
-  int64_t blocks = ntiles;  // tile kernel: one workgroup per 32-row tile
+  int64_t blocks = tile16 ? (rows + 15) / 16 : ntiles;  // tile kernels: one workgroup per 32-row (16-row) tile
   if (!tile) {
     const int waves = threads / 64;
     blocks = (ntiles + waves - 1) / waves;
