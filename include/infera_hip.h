@@ -123,14 +123,15 @@ int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32
  * An application that OWNS long-lived column storage (an in-memory table, Arrow buffers, a DuckDB build with an allocator hook)
  * registers it once: [base, base + bytes) is pinned where it lies and mapped into every selected GPU (hipHostRegister; ~15 us per
  * 480 KB, nothing is copied).  From then on an infera_predict_columns call whose column runs ALL lie inside registered ranges is
- * served without the CPU touching the data: one GPU kernel reads the runs in place over PCIe (FLOAT as they are; DOUBLE / INTEGER /
- * BIGINT converted with the reference's static_cast<float> roundings; constant vectors broadcast) into the column-major chunk the
- * model's first kernel reads.  Results are bit-identical to the staged path.  Chunks with any column outside a registered range, and
+ * served without the CPU touching the data: the GPU fetches the runs in place over PCIe -- one 2-D copy when they are FLOAT at one
+ * stride inside one registered block (at most three such copies in flight per GPU: the runtime runs them one at a time), else one
+ * kernel (FLOAT as they are; DOUBLE / INTEGER / BIGINT converted with the reference's static_cast<float> roundings; constant vectors
+ * broadcast) -- into the column-major chunk the model's first kernel reads.  Results are bit-identical to the staged path.  Chunks with any column outside a registered range, and
  * calls longer than one staging pass (> 24 MB of features), take the staged path as before.
  * CONTRACT: a registered range must stay mapped until it is unregistered.  The library never registers memory on its own -- a buffer
  * the caller frees behind a stale registration would fault the GPU.  Ranges must not overlap each other; they MAY share memory pages
  * (neighbours on the heap): the runtime pins whole pages, so ranges whose page spans touch share one registration, which lives until
- * the last of them is unregistered.  Both calls wait for zero-copy calls that are in flight.  0 / -1 (+ infera_last_error). */
+ * the last of them is unregistered.  Unregistering waits for the zero-copy calls that are reading the pages it unmaps (a chunk's time).  0 / -1 (+ infera_last_error). */
 int32_t infera_hip_register_host_memory(const void *base, uint64_t bytes);
 int32_t infera_hip_unregister_host_memory(const void *base);
 /* infera_predict_columns calls served zero-copy so far (tests, bench) */
