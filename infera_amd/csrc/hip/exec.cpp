@@ -37,7 +37,8 @@ int64_t prepare_scratch(const LoadedModel &m, ThreadCtx &ctx, int64_t rows) {
 // 3.06 rounds for its 128 / 256 / 512-channel layers -- 3.2 % of the pass, profiles/r04_tail_rounds.txt); with two independent kernel
 // sequences in flight the other lane's workgroups fill those rounds (and the stem of one lane runs beside the matrix-bound layers of the
 // other).  Same kernels, same per-row arithmetic: results are bit-identical (tests/test_conv_split_gpu.py).  ResNet-18, 1024 images: 18.42 ->
-// 17.94 ms (-2.6 %); three or four lanes: no gain (profiles/r04_conv_lanes_ab.txt).  Not under a stream capture (INFERA_HIPGRAPH=1), not
+// 17.94 ms (-2.6 %); three or four lanes: no gain (profiles/r04_conv_lanes_ab.txt).  With the lanes a 1024-image pass is within 0.2 % of the per-image
+// time of a 1003-image one (whole rounds everywhere), and splitting the last round finer only costs (round 5, profiles/r05_tail_split_ab.txt).  Not under a stream capture (INFERA_HIPGRAPH=1), not
 // for the short passes of the host path (many contexts already overlap there).
 constexpr int64_t kLaneMinRows = 512;
 int lanes_of(const LoadedModel &m, int64_t nr) {
