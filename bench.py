@@ -589,7 +589,7 @@ def compact_cpu(cb: dict) -> dict:
 
 def compact_e2e(e: dict) -> dict:
     out = _pick(e, ("rows_per_s", "rows_per_s_per_gpu", "frac_of_pcie", "bare_h2d_copy_gbs", "host_read_gbs", "vs_cpu_baseline", "vs_cpu_reference_shaped", "zero_copy_calls",
-                    "vs_staged", "predicted_8_gpus_vs_staged_1_gpu", "error"))
+                    "vs_staged", "predicted_8_gpus_vs_staged_1_gpu", "alone_rows_per_s", "scaling_vs_alone", "vs_staged_alone", "error"))
     if "threads_per_rank" in e or "threads" in e:
         out["threads"] = out["callers_per_gpu"] = e.get("threads_per_rank", e.get("threads"))
     h = e.get("host_cpu_cost") or {}
@@ -612,6 +612,9 @@ def compact_line(full: dict) -> dict:
         # BASELINE.json's metric as SURVEY 8(d) defines it (host table in, result vector out), whole job, all ranks scanning at once -- beside
         # `value` at EVERY N: the scaling question (north_star: >= 6x at 8 GPUs) is answered by this field of the N = 1 and N = 8 lines
         line["value_end_to_end"] = _r(full["end_to_end"]["rows_per_s"], 7)
+        if full.get("scaling_vs_alone"):
+            line["value_end_to_end_alone"] = _r(full["value_end_to_end_alone"], 7)
+            line["scaling_vs_alone"] = _r(full["scaling_vs_alone"], 4)
     if "roofline" in full:
         line["roofline"] = _pick(full["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "kernel_ms", "vs_fp32_mfma_peak"), 6)
         line["roofline"].setdefault("traffic", None)
@@ -665,12 +668,32 @@ def emit(full: dict, detail_path: str) -> None:
     print(line, flush=True)
 
 
+def relaunch_command(gpus: int, host_path: bool, argv: list, env: dict):
+    """`python bench.py --gpus N` with N > 1 and NO launcher around it (the shape the driver uses at N = 1) is one process
+    with no WORLD_SIZE: it used to scan one shard on GPU 0 and print "n_gpus": 1.  Returns the `torch.distributed.run` command that runs the
+    N ranks the flag asks for (one per GPU, rendezvous on 127.0.0.1 at a free port) -- or None when this process is already a rank, when
+    N = 1, or for --host-path (ONE process over N device slots by definition)."""
+    if gpus <= 1 or host_path or "WORLD_SIZE" in env or "RANK" in env:
+        return None
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse_args()
+    cmd = relaunch_command(args.gpus, args.host_path, sys.argv[1:], os.environ)
+    if cmd:
+        print(f"bench.py: --gpus {args.gpus} without a launcher: re-executing as {args.gpus} ranks under torch.distributed.run", file=sys.stderr, flush=True)
+        os.execv(cmd[0], cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus and not args.host_path:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.host_path and world > 1:
         raise SystemExit("--host-path is the single-process shape: run it without torch.distributed.run")
@@ -799,6 +822,7 @@ def main():
     # ---- the metric as SURVEY 8(d) defines it: the host path, PCIe included (all ranks scan concurrently) ----
     e2e, table = None, None
     e2e_error = None
+    alone, alone_reg = None, None  # (N > 1: rank 0's scan with every other rank idle)
     numa = {"bound": False, "why": "--e2e-numa off"}
     if args.e2e_numa == "auto" and (sql_fn and not args.no_end_to_end or not args.no_cpu_baseline):
         node = capi.get_devices()["devices"][0].get("numa_node", -1)
@@ -837,12 +861,29 @@ def main():
         if not all_ok(table is not None):
             table, e2e_error = None, e2e_error or "a peer rank could not materialise its host table"
         else:
-            try:
-                e2e = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, args.e2e_reps, budget, world, barrier,
-                                 shard.max_over_ranks)
-            except Exception as exc:
-                dist_broken = world > 1
-                e2e_error = f"{type(exc).__name__}: {exc}"
+            if world > 1:
+                # Rank 0 ALONE first, every other rank waiting at the barrier: the 1-GPU reference of `scaling_vs_alone` is
+                # measured on THIS box in THIS run, with the whole CPU budget behind one GPU -- what a plain N = 1 run of this file measures.
+                if rank == 0:
+                    try:
+                        alone = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, max(2, min(args.e2e_reps, 3)), budget, 1,
+                                           lambda: None, lambda v: v, sweep_full=False)
+                        if not args.no_registered:
+                            alone_reg = end_to_end_registered(sql_fn, "bench", table, e2e_rows, cols, out_cols, 2, budget, 1, lambda: None, lambda v: v)
+                    except Exception as exc:  # (the alone phase must never cost the collective one: the barrier below is reached either way)
+                        alone_reg = {"error": f"{type(exc).__name__}: {exc}"}
+                try:
+                    barrier()
+                except Exception as exc:
+                    dist_broken = True
+                    e2e_error = f"alone phase: {type(exc).__name__}: {exc}"
+            if all_ok(not dist_broken):
+                try:
+                    e2e = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, args.e2e_reps, budget, world, barrier,
+                                     shard.max_over_ranks)
+                except Exception as exc:
+                    dist_broken = world > 1
+                    e2e_error = f"{type(exc).__name__}: {exc}"
 
     # ---- the same scan over a REGISTERED table (zero-copy path): what the host side costs without the gather ----
     e2e_reg = None
@@ -901,6 +942,16 @@ def main():
         if e2e:
             e2e["numa_binding"] = numa
             full["end_to_end"] = e2e
+            if alone and alone.get("rows_per_s"):
+                # N > 1: `value` is N independent resident scans (N x by construction); THIS is the scaling figure -- all ranks' end-to-end rate over
+                # rank 0's own end-to-end rate with the node to itself, same box, same run
+                e2e["alone"] = {k: alone[k] for k in ("rows_per_s", "threads_per_rank", "median_scan_seconds", "frac_of_pcie", "thread_sweep_rows_per_s") if k in alone}
+                e2e["alone"]["cpu_us_per_chunk"] = (alone.get("host_cpu_cost") or {}).get("cpu_us_per_chunk")
+                e2e["alone"]["predicted_scaling_at_8_gpus"] = (alone.get("host_cpu_cost") or {}).get("predicted_scaling_at_8_gpus")
+                e2e["alone_rows_per_s"] = alone["rows_per_s"]
+                e2e["scaling_vs_alone"] = e2e["rows_per_s"] / alone["rows_per_s"]
+                full["value_end_to_end_alone"] = alone["rows_per_s"]
+                full["scaling_vs_alone"] = e2e["scaling_vs_alone"]
             if e2e_reg:
                 if "rows_per_s" in e2e_reg and e2e.get("rows_per_s"):
                     # the registered scan beside the headline: this run's rate, and (1 GPU) what its CPU cost predicts for 8 GPUs on this quota,
@@ -909,6 +960,11 @@ def main():
                     p8 = (e2e_reg.get("host_cpu_cost") or {}).get("predicted_rows_per_s_at_8_gpus")
                     if p8 and world == 1:
                         e2e_reg["predicted_8_gpus_vs_staged_1_gpu"] = p8 / e2e["rows_per_s"]
+                    if alone_reg and alone_reg.get("rows_per_s"):
+                        e2e_reg["alone_rows_per_s"] = alone_reg["rows_per_s"]
+                        e2e_reg["scaling_vs_alone"] = e2e_reg["rows_per_s"] / alone_reg["rows_per_s"]
+                    if alone and alone.get("rows_per_s"):  # the opt-in path at N GPUs over the DROP-IN path at one: north_star's >= 6x is asked of that 1-GPU number
+                        e2e_reg["vs_staged_alone"] = e2e_reg["rows_per_s"] / alone["rows_per_s"]
                 full["end_to_end_registered"] = e2e_reg
         elif e2e_error:
             full["end_to_end"] = {"error": e2e_error}

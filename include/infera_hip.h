@@ -131,7 +131,9 @@ int32_t infera_hip_choose_slot(const int32_t *slot_numa, uintptr_t nslots, int32
  * CONTRACT: a registered range must stay mapped until it is unregistered.  The library never registers memory on its own -- a buffer
  * the caller frees behind a stale registration would fault the GPU.  Ranges must not overlap each other; they MAY share memory pages
  * (neighbours on the heap): the runtime pins whole pages, so ranges whose page spans touch share one registration, which lives until
- * the last of them is unregistered.  Unregistering waits for the zero-copy calls that are reading the pages it unmaps (a chunk's time).  0 / -1 (+ infera_last_error). */
+ * the last of them is unregistered.  Unregistering waits for the zero-copy calls that are reading the pages it unmaps (a chunk's time).  0 / -1 (+ infera_last_error).
+ * ONLY after a 0 may the memory be freed or unmapped: -1 with "host memory range still in use" means calls were still reading the range after
+ * 5 s (a wedged GPU) -- it is no longer served, but its pages stay pinned and may still be read; keep it mapped. */
 int32_t infera_hip_register_host_memory(const void *base, uint64_t bytes);
 int32_t infera_hip_unregister_host_memory(const void *base);
 /* infera_predict_columns calls served zero-copy so far (tests, bench) */

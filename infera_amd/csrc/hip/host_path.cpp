@@ -420,8 +420,17 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
   HostCall call(m, fill, dfill, h_out, rows, col_major, slot, *lease.c);
   g_slot_calls[size_t(slot) % 64].fetch_add(1, std::memory_order_relaxed);
   g_slot_rows[size_t(slot) % 64].fetch_add(uint64_t(rows), std::memory_order_relaxed);
-  if (call.is_big()) call.run_pipelined();
-  else call.run_chunks(t_leased - t_entry);
+  try {
+    if (call.is_big()) call.run_pipelined();
+    else call.run_chunks(t_leased - t_entry);
+  } catch (...) {
+    // Whatever threw (a launch error in exec_plan, a non-NotReady error from wait_stream, ...) may have left a copy, a 2-D copy or the pulling
+    // kernel of this chunk in flight: nothing may still read the caller's registered pages (the ZeroCopyPins taken in capi.cpp are released while
+    // unwinding -- an application may then unmap them) or this context's staging (the next lessee overwrites it) when the lease goes back
+    // (run_pipelined's own handler also drains the shared copy stream).
+    (void)hipStreamSynchronize(lease.c->stream);
+    throw;
+  }
   if (range.on) prof::note_call(t_entry, now_ns(), uint64_t(rows));
   return true;
 }

@@ -215,18 +215,10 @@ namespace {
 constexpr int64_t kTileKernelMaxRows = 32768;
 // ... and the shortest ones (a DataChunk is 2048 rows) as 16-row tiles on the 16x16x4 instruction (mlp3_tile16_kernel): twice the
 // workgroups, half the layer-1 chain, a quarter of the layer-2 time.  INFERA_MLP_TILE16_MAX_ROWS (measurement knob; default below; 0: never).
-constexpr int64_t kTile16MaxRows = 4096;
-int64_t tile16_max_rows() {
-  static const int64_t v = [] {
-    const char *e = std::getenv("INFERA_MLP_TILE16_MAX_ROWS");
-    return e ? int64_t(std::atoll(e)) : kTile16MaxRows;
-  }();
-  return v;
-}
 template <class C, bool XCM>
 void launch_tile(hipStream_t s, const float *X, const float *packed, float *Y, int64_t rows) {
   if constexpr (C::D1 % 64 == 0 && C::D2 <= 128) {
-    if (rows <= tile16_max_rows()) {
+    if (rows <= mlp3_tile16_max_rows()) {
       hipLaunchKernelGGL((mlp3_tile16_kernel<C, XCM>), dim3(unsigned((rows + 15) / 16)), dim3(256), 0, s, X, packed, Y, rows);
       return;
     }

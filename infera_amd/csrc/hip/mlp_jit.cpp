@@ -320,6 +320,13 @@ bool mlp3_jit_prepare(const Mlp3Shape &sh, std::string *why) {
 
 constexpr int64_t kTileKernelMaxRows = 32768;  // (as for the ahead-of-time configurations, mlp_fused.hip)
 constexpr int64_t kTile16MaxRows = 4096;
+int64_t mlp3_tile16_max_rows() {
+  static const int64_t v = [] {
+    const char *e = std::getenv("INFERA_MLP_TILE16_MAX_ROWS");
+    return e ? int64_t(std::atoll(e)) : kTile16MaxRows;
+  }();
+  return v;
+}
 
 int64_t mlp3_jit_colmajor_max_rows(const Mlp3Shape &sh) {
   std::unique_lock<std::mutex> lk;
@@ -341,9 +348,11 @@ bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const f
     }
     Variant &v = x_colmajor ? c.tile_xcm : c.tile;
     Variant &v16 = x_colmajor ? c.tile16_xcm : c.tile16;
-    if (rows <= kTile16MaxRows && v16.ok) {
-      tile = tile16 = true;
+    if (rows <= mlp3_tile16_max_rows() && v16.ok) {
       fn = function_on_device(v16.code, v16.lowered, v16.fn_by_device, 0, why);
+      tile = tile16 = fn != nullptr;  // (a 16-row module that does not load on this device: the 32-row tile variant below serves the chunk)
+    }
+    if (fn) {
     } else if (rows <= kTileKernelMaxRows && v.ok) {
       tile = true;
       fn = function_on_device(v.code, v.lowered, v.fn_by_device, 0, why);

@@ -24,6 +24,9 @@ bool mlp3_jit_prepare(const Mlp3Shape &sh, std::string *why);
 bool mlp3_jit_launch(hipStream_t s, const Mlp3Shape &sh, const float *X, const float *packed, float *Y, int64_t rows,
                      int num_cus, std::string *why, bool x_colmajor = false);
 int64_t mlp3_jit_colmajor_max_rows(const Mlp3Shape &sh);  // 0: no column-major kernel
+// Chunks of up to this many rows run on the 16-row tile kernel (INFERA_MLP_TILE16_MAX_ROWS; default 4096; 0: never): ONE knob for the
+// ahead-of-time configurations (mlp_fused.hip) and the hipRTC ones (mlp_jit.cpp), so the three-way bit-identity test covers both.
+int64_t mlp3_tile16_max_rows();
 std::string mlp3_jit_kernel_name(const Mlp3Shape &sh);
 
 }  // namespace infera_hip::kern

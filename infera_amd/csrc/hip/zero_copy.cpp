@@ -93,29 +93,37 @@ void busy_remove(uintptr_t pb, uintptr_t pe) {
 // wedged GPU must not block the application's allocator for ever -- after kUnmapWaitSeconds the pages stay pinned (leaked until the process
 // exits; registering them again fails and their chunks are staged) and the error is logged.  Called WITHOUT g_reg_mu; the spans are in g_busy.
 constexpr int kUnmapWaitSeconds = 5;
-void unmap_dead_blocks(const std::vector<std::shared_ptr<PageBlock>> &dead) {
-  if (dead.empty()) return;
-  {
-    UnsafeOpGuard guard;
-    for (const auto &blk : dead) {
-      const auto t0 = std::chrono::steady_clock::now();
-      bool drained = true;
-      for (int spin = 0; blk->readers.load(std::memory_order_acquire) > 0; spin++) {
-        if (spin < 64) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(20));
-        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kUnmapWaitSeconds)) {
-          drained = false;
-          break;
-        }
+// false: at least one block is still being read after the wait -- its pages stay pinned AND MAY STILL BE READ, the caller must be told
+// (the header's contract is "free once unregister returns 0").
+bool unmap_dead_blocks(const std::vector<std::shared_ptr<PageBlock>> &dead) {
+  if (dead.empty()) return true;
+  bool all_drained = true;
+  for (const auto &blk : dead) {
+    // the reader wait holds NOTHING (in hipGraph mode UnsafeOpGuard is the capture lock, exclusively: five seconds of it per stuck block would
+    // stall every capture and allocation of the process); only the unmap itself is an operation a capture must not see
+    const auto t0 = std::chrono::steady_clock::now();
+    bool drained = true;
+    for (int spin = 0; blk->readers.load(std::memory_order_acquire) > 0; spin++) {
+      if (spin < 64) std::this_thread::yield();
+      else std::this_thread::sleep_for(std::chrono::microseconds(20));
+      if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kUnmapWaitSeconds)) {
+        drained = false;
+        break;
       }
-      if (drained) (void)hipHostUnregister(reinterpret_cast<void *>(blk->pb));
-      else log_msg(0, "unregister_host_memory: calls still read a " + std::to_string((blk->pe - blk->pb) >> 10) + " KiB block after " +
-                          std::to_string(kUnmapWaitSeconds) + " s (GPU wedged?): its pages stay pinned");
+    }
+    if (drained) {
+      UnsafeOpGuard guard;
+      (void)hipHostUnregister(reinterpret_cast<void *>(blk->pb));
+    } else {
+      all_drained = false;
+      log_msg(0, "unregister_host_memory: calls still read a " + std::to_string((blk->pe - blk->pb) >> 10) + " KiB block after " +
+                     std::to_string(kUnmapWaitSeconds) + " s (GPU wedged?): its pages stay pinned");
     }
   }
   std::lock_guard<std::mutex> writer(g_reg_mu);
   for (const auto &blk : dead) busy_remove(blk->pb, blk->pe);
   g_reg_cv.notify_all();
+  return all_drained;
 }
 // (under g_reg_mu + g_index_mu) one reference less on every block under [pb, pe); blocks nobody refers to any more leave the index -> `dead`
 void release_blocks(uintptr_t pb, uintptr_t pe, std::vector<std::shared_ptr<PageBlock>> &dead) {
@@ -210,7 +218,7 @@ void register_host_memory(const void *base, size_t bytes) {
   }
   writer.unlock();
   g_reg_cv.notify_all();
-  unmap_dead_blocks(dead);
+  (void)unmap_dead_blocks(dead);  // (blocks of a FAILED registration: nobody was handed their addresses)
   if (failure) std::rethrow_exception(failure);
   if (!usable) log_msg(1, "registered host range is covered by blocks with different device addresses: its chunks take the staged path");
 }
@@ -230,7 +238,9 @@ bool unregister_host_memory(const void *base) {
   }
   // the dead blocks are out of the index; they are unmapped once the calls that pinned them have finished -- with no lock held: other
   // registrations and unregistrations proceed unless they touch these very pages
-  unmap_dead_blocks(dead);
+  if (!unmap_dead_blocks(dead))
+    throw InferaError::onnx("host memory range still in use: zero-copy calls were still reading it after " + std::to_string(kUnmapWaitSeconds) +
+                            " s; the range is no longer served but its pages stay pinned -- keep the memory mapped");
   return true;
 }
 
@@ -294,19 +304,20 @@ bool zero_copy_rect_enabled() { return Config::get().zero_copy_rect; }
 // 2-D copies a GPU has in flight (between a call's enqueue and its return).  The runtime executes them ONE AT A TIME however many streams
 // issue them (tools/ubench/chunk_pull_probe.hip: 28.6 us per MiB from 1 to 16 streams), which is what makes two or three callers alternate
 // nicely -- and what stops a GPU at 80 M rows/s.  The pulling kernel runs beside it on the shader cores.  So a chunk takes the 2-D copy while
-// fewer than INFERA_ZERO_COPY_RECT_INFLIGHT (default 2) are in flight on its GPU and the pulling kernel otherwise.
+// fewer than INFERA_ZERO_COPY_RECT_INFLIGHT (default 3) are in flight on its GPU and the pulling kernel otherwise.  Counted per PHYSICAL GPU, like
+// SubmitGate (host_path.cpp gate_for_slot): two device slots on one GPU (INFERA_DEVICES=0,0) share the runtime's one-at-a-time 2-D copy path.
 namespace {
 std::atomic<int> g_rect_inflight[64];
 }
 int rect_copy_acquire() {
   const int limit = Config::get().zero_copy_rect_inflight;
-  const int slot = rt::home_slot();
-  std::atomic<int> &n = g_rect_inflight[size_t(slot) % 64];
+  const int gpu = int(size_t(devices().ids[size_t(rt::home_slot())]) % 64);
+  std::atomic<int> &n = g_rect_inflight[gpu];
   if (limit > 0 && n.fetch_add(1, std::memory_order_relaxed) >= limit) {
     n.fetch_sub(1, std::memory_order_relaxed);
     return -1;
   }
-  return limit > 0 ? slot : 64;  // (64: no limit, nothing to give back)
+  return limit > 0 ? gpu : 64;  // (the ticket is the GPU's index; 64: no limit, nothing to give back)
 }
 void rect_copy_release(int ticket) {
   if (ticket >= 0 && ticket < 64) g_rect_inflight[size_t(ticket)].fetch_sub(1, std::memory_order_relaxed);

@@ -127,3 +127,26 @@ def test_balanced_slot_dealing_never_starves_the_other_socket():
     assert load == [4] * 8
     assert capi.choose_slot_balanced(topo, [3, 3, 3, 3, 0, 0, 0, 0], -1) == 4      # node unknown: least loaded
     assert capi.choose_slot_balanced([0], [5], 1) == 0 and capi.choose_slot_balanced([-1, -1], [1, 0], 0) == 1
+
+
+def test_bench_relaunches_itself_when_gpus_is_asked_without_a_launcher():
+    """`python bench.py --gpus 8` with no torch.distributed.run around it used to scan ONE shard and print "n_gpus": 1.
+    The decision is a pure function: N > 1 and no WORLD_SIZE / RANK in the environment -> the launcher command for N ranks on 127.0.0.1;
+    already a rank, N = 1 or --host-path (one process over N slots by definition) -> None."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    argv = ["--gpus", "8", "--steps", "3", "--share-device", "0"]
+    cmd = bench.relaunch_command(8, False, argv, {})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and cmd[-len(argv):] == argv
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536 and os.path.basename(cmd[-len(argv) - 1]) == "bench.py"
+    assert bench.relaunch_command(8, False, argv, {"WORLD_SIZE": "8", "RANK": "3"}) is None   # already a rank of a launch
+    assert bench.relaunch_command(1, False, ["--gpus", "1"], {}) is None
+    assert bench.relaunch_command(8, True, argv + ["--host-path"], {}) is None
+    # ... and a rank whose WORLD_SIZE disagrees with --gpus refuses to run (it used to pass silently when WORLD_SIZE was unset)
+    import subprocess
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in p.stderr

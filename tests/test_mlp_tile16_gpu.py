@@ -19,14 +19,15 @@ sys.path.insert(0, %(root)r)
 import numpy as np
 from infera_amd import capi, onnx_writer, synth
 out = {}
-for name, dims in (("c2", (128, 256, 64, 1)), ("c2x3", (128, 256, 64, 3))):
+# (the third shape has no ahead-of-time instantiation: hipRTC compiles its kernels at load -- mlp_jit.cpp reads the same knob, ADVICE r5)
+for name, dims in (("c2", (128, 256, 64, 1)), ("c2x3", (128, 256, 64, 3)), ("jit", (64, 128, 32, 2))):
     path = onnx_writer.write(os.path.join(%(tmp)r, name + ".onnx"), onnx_writer.mlp(dims))
     capi.load_model(name, path)
     h = hashlib.sha256()
     for rows in (1, 15, 16, 17, 31, 33, 2047, 2048, 4096, 4097, 6000):
-        x = synth.table(5, 0, rows, 128)
+        x = synth.table(5, 0, rows, dims[0])
         a = capi.predict(name, x)                                              # row-major staging
-        b = capi.predict_columns(name, [np.ascontiguousarray(x[:, c]) for c in range(128)])   # column-major staging
+        b = capi.predict_columns(name, [np.ascontiguousarray(x[:, c]) for c in range(dims[0])])   # column-major staging
         assert a.shape == (rows, dims[-1]) and np.array_equal(a, b), (name, rows)
         h.update(a.tobytes())
     out[name] = h.hexdigest()
@@ -47,7 +48,7 @@ def test_tile16_equals_tile32_bit_for_bit(built, tmp_path):
     with16 = run_child(tmp_path, 4096)   # the shipped limit: chunks up to 4096 rows on 16-row tiles
     never = run_child(tmp_path, 0)       # 32-row tiles only (round 4's path)
     always = run_child(tmp_path, 1 << 20)
-    assert with16["c2_exec"][0] == "mlp3_fused"
+    assert with16["c2_exec"][0] == "mlp3_fused" and with16["jit_exec"][0] == "mlp3_fused"
     assert with16 == never == always
 
 
