@@ -409,10 +409,13 @@ void launch(hipStream_t s, const float *X, const float *W, const float *bias, fl
 // row*(K/4) + (c ^ (row & 15)): conflict-free for the linear writes and for the fragment reads (16 lanes =
 // 16 rows at one column -> 16 distinct bank quads).  No barrier: the region belongs to one wave, whose LDS
 // operations execute in order; the next tile's K/8 loads are in flight (in registers) during the MFMAs.
-template <int K, int SM>
+template <int K, int SM, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void dense_narrow16s_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                     const float *__restrict__ bias, float *__restrict__ Y,
-                                                                    int64_t rows, int M, ActParam act) {
+                                                                    int64_t rows, int M, ActParam act, int mode) {
+  // mode (wave-uniform): bit 0 = a full tile's 32 x M results are parked in the wave's LDS tile and leave as ONE contiguous run of 16-byte
+  // pieces (Y 16-byte aligned).  NT: non-temporal table loads AND result stores (a select between a plain and a non-temporal load of one
+  // address folds into the plain one -- it has to be a template parameter)
   constexpr int G = K / 16, PR = K / 4, NL = K / 8;  // k groups, 16-byte pieces per row, load instructions per tile
   static_assert(PR % 16 == 0, "the XOR swizzle needs a multiple of 16 pieces per row");
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [G][64][4] weights, then WAVES x [32 rows][K] tiles
@@ -441,6 +444,11 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16s_kernel(const float
   const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X);
   auto fetch = [&](f32x4(&v)[NL], int64_t tile) {
     const int64_t base = tile * (32 * PR) + lane;
+    if ((tile + 1) * (32 * PR) <= total4) {  // a whole tile (wave-uniform): NL loads back to back, no per-load bounds branch
+#pragma unroll
+      for (int i = 0; i < NL; i++) v[i] = NT ? __builtin_nontemporal_load(x4 + base + i * 64) : x4[base + i * 64];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const int64_t p = base + i * 64;
@@ -465,6 +473,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16s_kernel(const float
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x1[j], acc[1], 0, 0, 0);
       }
     }
+    const bool park = SM != 3 && (mode & 1) && (tile << 5) + 32 <= rows;  // (a ragged last tile keeps the per-row stores)
+    float *ys = reinterpret_cast<float *>(xs);
+    if (park) asm volatile("" ::: "memory");  // the fragment reads above are done with the tile before results are parked over it
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const int64_t row = (tile << 5) + 16 * t + n;
@@ -500,17 +511,40 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16s_kernel(const float
 #pragma unroll
         for (int i = 0; i < 4; i++) v[i] = SM == 1 ? v[i] / sum : v[i] - ls;
       }
-      if (row < rows) {
+      if (park) {
+        float *yrow = ys + (16 * t + n) * M + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 * q + i < M) yrow[i] = v[i];
+      } else if (row < rows) {
         float *yrow = Y + row * M + 4 * q;
         if ((M & 1) == 0 && 4 * q + 3 < M) {  // row stride M*4 is 8-byte aligned: two 8-byte stores
-          *reinterpret_cast<f32x2 *>(yrow) = f32x2{v[0], v[1]};
-          *reinterpret_cast<f32x2 *>(yrow + 2) = f32x2{v[2], v[3]};
+          if (NT) {
+            __builtin_nontemporal_store(f32x2{v[0], v[1]}, reinterpret_cast<f32x2 *>(yrow));
+            __builtin_nontemporal_store(f32x2{v[2], v[3]}, reinterpret_cast<f32x2 *>(yrow + 2));
+          } else {
+            *reinterpret_cast<f32x2 *>(yrow) = f32x2{v[0], v[1]};
+            *reinterpret_cast<f32x2 *>(yrow + 2) = f32x2{v[2], v[3]};
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < 4; i++)
-            if (4 * q + i < M) yrow[i] = v[i];
+            if (4 * q + i < M) {
+              if (NT) __builtin_nontemporal_store(v[i], yrow + i);
+              else yrow[i] = v[i];
+            }
         }
       }
+    }
+    if (park) {  // 32 x M floats = 8M 16-byte pieces, consecutive in Y: lane l takes pieces l, l + 64
+      asm volatile("" ::: "memory");
+      f32x4 *y4 = reinterpret_cast<f32x4 *>(Y) + tile * (8 * M);
+      const f32x4 *ys4 = reinterpret_cast<const f32x4 *>(ys);
+      for (int p = lane; p < 8 * M; p += 64) {
+        if (NT) __builtin_nontemporal_store(ys4[p], y4 + p);
+        else y4[p] = ys4[p];
+      }
+      asm volatile("" ::: "memory");  // ... before the next tile is parked over the results
     }
   }
 }
@@ -523,14 +557,27 @@ static void launch_narrow16s(hipStream_t s, const float *X, const float *W, cons
   const int per_cu = int(std::max<size_t>(1, (160 * 1024) / lds));
   int64_t blocks = std::min<int64_t>((ntiles + WAVES - 1) / WAVES, 256 * per_cu);
   dim3 grid((unsigned)blocks), block(WAVES * 64);
+  // Round 6 (profiles/r06_c4_store_ab.txt, same process, same buffers, bit-identical): per-row 8-byte stores 5.13 ms per 50M rows; the tile's
+  // results parked and written as 16-byte pieces 5.17 (no gain by itself); non-temporal loads + per-row non-temporal stores 5.03; BOTH 4.87 ms =
+  // 5.67 TB/s.  INFERA_DENSE16S_MODE=0 / INFERA_DENSE16S_NT=0 (read per launch: measurement + bit-identity test) switch them off.
+  const int mode_env = getenv("INFERA_DENSE16S_MODE") ? atoi(getenv("INFERA_DENSE16S_MODE")) : 1;
+  const int mode = (reinterpret_cast<uintptr_t>(Y) & 15) == 0 ? mode_env : (mode_env & ~1);
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    hipLaunchKernelGGL(kernel, grid, block, lds, s, X, W, bias, Y, rows, M, act);
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, X, W, bias, Y, rows, M, act, mode);
   };
-  if (softmax_mode == 0) go(dense_narrow16s_kernel<K, 0>);
-  else if (softmax_mode == 1) go(dense_narrow16s_kernel<K, 1>);
-  else if (softmax_mode == 2) go(dense_narrow16s_kernel<K, 2>);
-  else go(dense_narrow16s_kernel<K, 3>);
+  const bool nt = !(getenv("INFERA_DENSE16S_NT") && atoi(getenv("INFERA_DENSE16S_NT")) == 0);
+  if (nt) {
+    if (softmax_mode == 0) go(dense_narrow16s_kernel<K, 0, true>);
+    else if (softmax_mode == 1) go(dense_narrow16s_kernel<K, 1, true>);
+    else if (softmax_mode == 2) go(dense_narrow16s_kernel<K, 2, true>);
+    else go(dense_narrow16s_kernel<K, 3, true>);
+  } else {
+    if (softmax_mode == 0) go(dense_narrow16s_kernel<K, 0, false>);
+    else if (softmax_mode == 1) go(dense_narrow16s_kernel<K, 1, false>);
+    else if (softmax_mode == 2) go(dense_narrow16s_kernel<K, 2, false>);
+    else go(dense_narrow16s_kernel<K, 3, false>);
+  }
 }
 
 // ---- any row length: the 16x16x4 kernel for tables whose rows are not 64/128/256 floats -------------------------
@@ -715,6 +762,11 @@ static void launch_narrow16g(hipStream_t s, const float *X, const float *W, cons
   const int64_t blocks = std::min<int64_t>((ntiles + WAVES - 1) / WAVES, 256 * per_cu);
   const int aligned = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 ? 1 : 0) | (x_colmajor ? 2 : 0);
   dim3 grid((unsigned)blocks), block(WAVES * 64);
+  // Round 6 (profiles/r06_c4_store_ab.txt, same process, same buffers, bit-identical): per-row 8-byte stores 5.13 ms per 50M rows; the tile's
+  // results parked and written as 16-byte pieces 5.17 (no gain by itself); non-temporal loads + per-row non-temporal stores 5.03; BOTH 4.87 ms =
+  // 5.67 TB/s.  INFERA_DENSE16S_MODE=0 / INFERA_DENSE16S_NT=0 (read per launch: measurement + bit-identity test) switch them off.
+  const int mode_env = getenv("INFERA_DENSE16S_MODE") ? atoi(getenv("INFERA_DENSE16S_MODE")) : 1;
+  const int mode = (reinterpret_cast<uintptr_t>(Y) & 15) == 0 ? mode_env : (mode_env & ~1);
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     hipLaunchKernelGGL(kernel, grid, block, lds, s, X, W, bias, Y, rows, K, M, act, aligned);
