@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # torch first: its bundled HIP runtime must be the one libinfera.so binds to (one runtime per process)
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -294,7 +295,7 @@ def bind_to_gpu_numa_node(numa_node: int) -> dict:
 
 
 def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, threads_arg: str, reps: int, budget: dict,
-               world: int, barrier, max_over_ranks, sweep_full: bool = True) -> dict:
+               world: int, barrier, max_over_ranks, sweep_full: bool = True, scan=None, probe_h2d: bool = True) -> dict:
     """rows/s through the SQL surface: wall time from the first chunk's gather to the last result
     element consumed; median of `reps` scans after one warm-up; thread count = best of a sweep.  With N ranks the sweep runs
     in lockstep (a barrier before every candidate, the slowest rank's time decides) over 1x / 2x / 3x the ranks' share of
@@ -303,6 +304,7 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
     is what bounds N GPUs fed from one CPU quota."""
     from infera_amd import capi, sqlharness
 
+    scan = scan or sqlharness.bench_scan_table  # (sqlharness.bench_scan_segments: the same scan over a table in DuckDB's segment shape)
     top = budget["usable"]
     if threads_arg:
         cands = [int(x) for x in threads_arg.split(",")]
@@ -313,13 +315,13 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
         cands = sorted({t for t in (4, 8, 12, 16, 24, 32, 48) if t <= max(8, 3 * top)})
     else:
         cands = [min(24, max(8, top))]
-    sqlharness.bench_scan_table(fn, model, table, min(rows, 60 * 2048 * 4), cols, cands[0], 1)  # contexts, pinned buffers, code objects
+    scan(fn, model, table, min(rows, 60 * 2048 * 4), cols, cands[0], 1)  # contexts, pinned buffers, code objects
     sweep = {}
     if len(cands) > 1:
         sweep_rows = rows if world == 1 else min(rows, 6_000_000)
         for t in cands:
             barrier()
-            secs, _ = sqlharness.bench_scan_table(fn, model, table, sweep_rows, cols, t, 1)
+            secs, _ = scan(fn, model, table, sweep_rows, cols, t, 1)
             sweep[str(t)] = sweep_rows * world / max_over_ranks(secs[0])
         top_rate = max(sweep.values())  # (identical on every rank: the rates are max-reduced)
         best_t = min(int(t) for t, v in sweep.items() if v >= 0.98 * top_rate)  # fewest threads within 2 % of the best: less CPU per chunk
@@ -335,11 +337,11 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
     dev0 = capi.device_ordinal(0)
     chunk_bytes = 2048 * cols * 4
     h2d_measured = max(capi.h2d_probe(dev0, chunk_bytes, 256, max(2, min(16, best_t))), capi.h2d_probe(dev0, 8 << 20, 48, 2),
-                       capi.h2d_probe(dev0, 8 << 20, 32, 4), capi.h2d_probe(dev0, 2 << 20, 96, 8))
+                       capi.h2d_probe(dev0, 8 << 20, 32, 4), capi.h2d_probe(dev0, 2 << 20, 96, 8)) if probe_h2d else None
     before = {d["slot"]: d["host_rows"] for d in capi.get_devices()["devices"]}
     barrier()
     t0 = time.perf_counter()
-    (secs, checksum), phases = sqlharness.phase_breakdown(sqlharness.bench_scan_table, fn, model, table, rows, cols, best_t, reps)
+    (secs, checksum), phases = sqlharness.phase_breakdown(scan, fn, model, table, rows, cols, best_t, reps)
     barrier()
     wall = max_over_ranks(time.perf_counter() - t0)
     secs_sorted = sorted(secs)
@@ -353,7 +355,7 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
     cost_rate = None
     if cost_t < best_t:
         barrier()
-        (secs_c, _), phases_c = sqlharness.phase_breakdown(sqlharness.bench_scan_table, fn, model, table, rows, cols, cost_t, max(2, reps // 2))
+        (secs_c, _), phases_c = sqlharness.phase_breakdown(scan, fn, model, table, rows, cols, cost_t, max(2, reps // 2))
         cost_rate = rows * world / max_over_ranks(sorted(secs_c)[len(secs_c) // 2])
         phases = dict(phases, **{k: phases_c[k] for k in ("cpu_us_per_chunk", "sys_us_per_chunk", "cpus_busy", "gather") if k in phases_c})
     cpu_us = max_over_ranks(phases.get("cpu_us_per_chunk", 0.0))
@@ -362,17 +364,39 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
             "rows_per_cpu_second": rows_per_cpu_s, "measured_at_threads": cost_t, "rows_per_s_at_those_threads": cost_rate or rate,
             "what": "process CPU time (getrusage: user + system, every thread incl. the HIP runtime's) per 2048-row chunk over the timed scans; "
                     "rows_per_cpu_second = 2048 / cpu_us_per_chunk -- the host-side capacity one CPU of the quota adds, whatever the link does"}
+    # the SECOND bound of the 8-GPU model: what the host's memory system delivers to staging buffers -- the staged path's own gather
+    # routine over the same table, nothing sent to a GPU, at the scan's caller count and at one thread per CPU of the quota (all ranks at once)
+    host_copy = None
+    if probe_h2d and isinstance(table, np.ndarray) and phases.get("gather", 0) > 1.0:  # (a staged scan: the registered scans gather nothing)
+        try:
+            host_copy = {}
+            for label, t in (("at_callers", best_t), ("at_quota", max(1, top // world))):
+                barrier()
+                g = sqlharness.bench_gather_only(table, rows, cols, t, 3)
+                sec = max_over_ranks(min(g["scan_seconds"]))
+                host_copy[label] = {"threads_per_rank": t, "gb_per_s": rows * world * cols * 4 / sec / 1e9, "cpu_us_per_chunk": g["cpu_us_per_chunk"]}
+            host["host_copy"] = host_copy
+            host["host_copy_gbs_at_threads"] = host_copy["at_quota"]["gb_per_s"]
+        except Exception as exc:
+            host["host_copy"] = {"error": f"{type(exc).__name__}: {exc}"}
+            host_copy = None
     if rows_per_cpu_s and world == 1:
         quota = budget["usable"]
         cap = quota * rows_per_cpu_s
+        copy_cap = host_copy["at_quota"]["gb_per_s"] * 1e9 / (cols * 4) if host_copy else None  # rows/s the quota's CPUs can gather, link or no link
+        p8 = min(8 * rate, cap, copy_cap) if copy_cap else min(8 * rate, cap)
         host.update({
             "cpu_quota_assumed": quota,
             "host_capacity_rows_per_s_on_quota": cap,
-            "predicted_rows_per_s_at_8_gpus": min(8 * rate, cap),
-            "predicted_scaling_at_8_gpus": min(8 * rate, cap) / rate,
+            "host_copy_capacity_rows_per_s_on_quota": copy_cap,
+            "predicted_rows_per_s_at_8_gpus": p8,
+            "predicted_scaling_at_8_gpus": p8 / rate,
+            "binding_bound": "8 x the 1-GPU rate" if p8 == 8 * rate else "cpu time per chunk" if p8 == cap else "host copy rate",
+            "bounds_in_gpus": {"cpu_time": cap / rate, "host_copy": copy_cap / rate if copy_cap else None},
             "cpus_needed_for_6x": 6 * rate / rows_per_cpu_s,
-            "prediction_note": f"8 GPUs fed from THIS box's quota of {quota} CPUs: min(8 x the 1-GPU rate, quota x rows_per_cpu_second) -- a prediction from the "
-                               f"measured CPU cost per chunk (the gather into pinned staging is {phases.get('gather', 0):.0f} us of it), not a measurement; "
+            "prediction_note": f"8 GPUs fed from THIS box's quota of {quota} CPUs: min(8 x the 1-GPU rate, quota x rows_per_cpu_second, what {quota} threads gather per second "
+                               f"with no GPU behind them) -- a prediction from the measured CPU cost per chunk (the gather into pinned staging is "
+                               f"{phases.get('gather', 0):.0f} us of it) and the measured host copy rate on the GPU's NUMA node, not a measurement; "
                                f">= 6x needs {6 * rate / rows_per_cpu_s:.1f} CPUs at this cost per chunk"})
     from infera_amd import shard
 
@@ -398,8 +422,54 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
             "device_slots": [{"slot": d["slot"], "ordinal": d["ordinal"], "rows_this_run": d["host_rows"] - before.get(d["slot"], 0)} for d in after]}
 
 
+def duckdb_blocks_scan(fn: str, model: str, rows: int, cols: int, out_cols: int, seed: int, budget: dict, world: int, barrier, max_over_ranks,
+                       all_ok=lambda ok: ok) -> dict:
+    """The registered scan on DuckDB's BLOCK LAYOUT (profiles/r06_duckdb_blocks.txt): the table as column segments in
+    separately allocated 256 KiB blocks from the extension's registering allocator (sqlharness.SegmentTable) -- 128 unrelated block addresses
+    per chunk, vectors 8 bytes past a 16-byte boundary, one straddling chunk per row group staged -- so EVERY chunk is the pulling kernel's; no
+    2-D copy applies.  This, not the contiguous registered table above it, is the row the 8-GPU prediction of the opt-in path is read from."""
+    from infera_amd import sqlharness
+
+    prev = os.environ.get("INFERA_ZERO_COPY_ALLOCATOR")
+    os.environ["INFERA_ZERO_COPY_ALLOCATOR"] = "1"
+    seg, why = None, ""
+    try:
+        seg = sqlharness.SegmentTable(rows, cols, seed, min(32, max(1, budget["usable"] // world)))
+        if not seg.registering_allocator:
+            why = "the registering allocator was not installed"
+    except Exception as exc:
+        why = f"{type(exc).__name__}: {exc}"
+    finally:
+        if prev is None:
+            os.environ.pop("INFERA_ZERO_COPY_ALLOCATOR", None)
+        else:
+            os.environ["INFERA_ZERO_COPY_ALLOCATOR"] = prev
+    if not all_ok(seg is not None and not why):
+        if seg is not None:
+            seg.close()
+        return {"error": why or "a peer rank could not build its segment table"}
+    out = {"rows": rows, "blocks": seg.blocks, "block_bytes": 262144, "header_bytes": 8, "values_per_segment": 65534, "create_seconds": seg.create_seconds,
+           "layout": "per (row group, column) two 256 KiB blocks from the extension's registering allocator; every chunk's 128 FLAT vectors point into "
+                     "128 unrelated blocks (first segment: 8 bytes past a 16-byte boundary); the chunk per row group that straddles two segments is staged",
+           "callers": {}}
+    try:
+        for t in ((2, 4, 8) if world == 1 else (4, 8)):
+            d = end_to_end(fn, model, seg, rows, cols, out_cols, str(t), 3, budget, world, barrier, max_over_ranks, scan=sqlharness.bench_scan_segments,
+                           probe_h2d=False)
+            out["callers"][str(t)] = {"rows_per_s": d["rows_per_s"], "cpu_us_per_chunk": d["host_cpu_cost"]["cpu_us_per_chunk"]}
+        out["assembled_chunks_per_scan_set"] = seg.assembled_chunks
+        if world == 1:  # 8 GPUs on this box's CPU quota, from this row: the best caller count under both bounds (8 x the per-GPU rate; CPUs / CPU time per chunk)
+            quota = budget["usable"]
+            best = max(((min(8 * v["rows_per_s"], quota * 2048e6 / v["cpu_us_per_chunk"]), int(t)) for t, v in out["callers"].items() if v["cpu_us_per_chunk"] > 0),
+                       default=(None, None))
+            out["predicted_rows_per_s_at_8_gpus"], out["predicted_at_callers_per_gpu"] = best
+    finally:
+        seg.close()
+    return out
+
+
 def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_cols: int, reps: int, budget: dict, world: int, barrier,
-                          max_over_ranks, threads_arg: str = "", all_ok=lambda ok: ok) -> dict:
+                          max_over_ranks, threads_arg: str = "", all_ok=lambda ok: ok, seed: int = 42) -> dict:
     """The same scan with the host table REGISTERED once (infera_hip_register_host_memory -- an opt-in for an application that owns
     long-lived column storage or opens DuckDB with the extension's registering allocator; NOT the drop-in path and never the headline).
     Every chunk is fetched in place (round 5: at most three 2-D copies in flight per GPU -- the runtime runs them one at a time -- and the
@@ -443,6 +513,12 @@ def end_to_end_registered(fn: str, model: str, table, rows: int, cols: int, out_
                         "frac_of_pcie": f["frac_of_pcie"], **{k: fh[k] for k in ("predicted_rows_per_s_at_8_gpus", "predicted_scaling_at_8_gpus", "cpus_needed_for_6x") if k in fh}}
     e["what"] = ("OPT-IN zero-copy path (include/infera_hip.h), not the drop-in path: no CPU gather, no pinned staging, no linear H2D copy -- "
                  "a third of the staged path's CPU time per chunk, which is what bounds 8 GPUs on one CPU quota")
+    e["table_shape"] = "ONE contiguous registered range (qualifies for 2-D copies: a numpy / Arrow table; NOT DuckDB's storage shape -- see duckdb_blocks)"
+    try:
+        e["duckdb_blocks"] = duckdb_blocks_scan(fn, model, rows if world == 1 else min(rows, 4_000_000), cols, out_cols, seed, budget, world, barrier,
+                                                max_over_ranks, all_ok)
+    except Exception as exc:
+        e["duckdb_blocks"] = {"error": f"{type(exc).__name__}: {exc}"}
     return e
 
 
@@ -593,9 +669,18 @@ def compact_e2e(e: dict) -> dict:
     if "threads_per_rank" in e or "threads" in e:
         out["threads"] = out["callers_per_gpu"] = e.get("threads_per_rank", e.get("threads"))
     h = e.get("host_cpu_cost") or {}
-    out.update(_pick(h, ("cpu_us_per_chunk", "measured_at_threads", "predicted_scaling_at_8_gpus", "cpus_needed_for_6x")))
+    out.update(_pick(h, ("cpu_us_per_chunk", "measured_at_threads", "predicted_scaling_at_8_gpus", "cpus_needed_for_6x", "host_copy_gbs_at_threads", "binding_bound")))
+    if h.get("bounds_in_gpus"):
+        out["bounds_in_gpus"] = {k: _r(v, 3) for k, v in h["bounds_in_gpus"].items() if v}
     if e.get("few_callers"):
         out["few_callers"] = _pick(e["few_callers"], ("threads_per_rank", "rows_per_s", "cpu_us_per_chunk", "predicted_scaling_at_8_gpus"))
+    blk = e.get("duckdb_blocks")
+    if isinstance(blk, dict):  # [M rows/s, CPU us per chunk] by callers per GPU, on DuckDB's block layout
+        out["duckdb_blocks"] = ({"error": str(blk["error"])[:80]} if "error" in blk else
+                                {**{t: [_r(v["rows_per_s"] / 1e6, 4), _r(v["cpu_us_per_chunk"], 3)] for t, v in blk.get("callers", {}).items()},
+                                 **({"vs_staged_alone": {t: _r(v, 3) for t, v in blk["vs_staged_alone"].items()}} if "vs_staged_alone" in blk else {})})
+    if e.get("prediction_from"):
+        out["prediction_from"] = e["prediction_from"].split(" ")[0]
     return out
 
 
@@ -869,7 +954,7 @@ def main():
                         alone = end_to_end(sql_fn, "bench", table, e2e_rows, cols, out_cols, args.e2e_threads, max(2, min(args.e2e_reps, 3)), budget, 1,
                                            lambda: None, lambda v: v, sweep_full=False)
                         if not args.no_registered:
-                            alone_reg = end_to_end_registered(sql_fn, "bench", table, e2e_rows, cols, out_cols, 2, budget, 1, lambda: None, lambda v: v)
+                            alone_reg = end_to_end_registered(sql_fn, "bench", table, e2e_rows, cols, out_cols, 2, budget, 1, lambda: None, lambda v: v, seed=42 + rank)
                     except Exception as exc:  # (the alone phase must never cost the collective one: the barrier below is reached either way)
                         alone_reg = {"error": f"{type(exc).__name__}: {exc}"}
                 try:
@@ -890,7 +975,7 @@ def main():
     if sql_fn and table is not None and not args.no_end_to_end and not args.no_registered and all_ok(e2e is not None):
         try:
             e2e_reg = end_to_end_registered(sql_fn, "bench", table, min(rows, 10_000_000) if args.workload != "mlp" else rows, cols, out_cols,
-                                            max(2, min(args.e2e_reps, 3)), budget, world, barrier, shard.max_over_ranks, all_ok=all_ok)
+                                            max(2, min(args.e2e_reps, 3)), budget, world, barrier, shard.max_over_ranks, all_ok=all_ok, seed=42 + rank)
         except Exception as exc:
             dist_broken = world > 1
             e2e_reg = {"error": f"{type(exc).__name__}: {exc}"}
@@ -958,8 +1043,14 @@ def main():
                     # both as multiples of the STAGED 1-GPU rate -- the >= 6x of north_star is asked of the drop-in path's 1-GPU number
                     e2e_reg["vs_staged"] = e2e_reg["rows_per_s"] / e2e["rows_per_s"]
                     p8 = (e2e_reg.get("host_cpu_cost") or {}).get("predicted_rows_per_s_at_8_gpus")
+                    blk = e2e_reg.get("duckdb_blocks") or {}
                     if p8 and world == 1:
-                        e2e_reg["predicted_8_gpus_vs_staged_1_gpu"] = p8 / e2e["rows_per_s"]
+                        e2e_reg["predicted_8_gpus_vs_staged_1_gpu_contiguous_table"] = p8 / e2e["rows_per_s"]
+                        # the figure to quote: from DuckDB's block layout (every chunk the pulling kernel's), not from the contiguous table
+                        e2e_reg["predicted_8_gpus_vs_staged_1_gpu"] = (blk["predicted_rows_per_s_at_8_gpus"] if blk.get("predicted_rows_per_s_at_8_gpus") else p8) / e2e["rows_per_s"]
+                        e2e_reg["prediction_from"] = "duckdb_blocks" if blk.get("predicted_rows_per_s_at_8_gpus") else "contiguous registered table (duckdb_blocks failed)"
+                    if world > 1 and alone and alone.get("rows_per_s") and blk.get("callers"):
+                        blk["vs_staged_alone"] = {t: v["rows_per_s"] / alone["rows_per_s"] for t, v in blk["callers"].items()}
                     if alone_reg and alone_reg.get("rows_per_s"):
                         e2e_reg["alone_rows_per_s"] = alone_reg["rows_per_s"]
                         e2e_reg["scaling_vs_alone"] = e2e_reg["rows_per_s"] / alone_reg["rows_per_s"]

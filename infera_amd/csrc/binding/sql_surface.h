@@ -108,6 +108,28 @@ void infera_sql_bench_last_cpu(double *cpu_seconds, double *sys_seconds, double 
 int32_t infera_sql_bench_scan_table(const char *function, const char *model, const float *table, uint64_t rows, uint32_t ncols,
                                     int32_t threads, int32_t reps, double *secs, double *checksum, char *err, uint64_t errlen);
 
+
+/* The host side of the staged scan ALONE: the same workers and chunk order over the same table, each chunk only gathered into the worker's own
+ * buffer (infera_gather_columns_colmajor), nothing sent to a GPU.  secs[rep] = wall seconds of scan `rep`; *cpu_seconds = process CPU time over
+ * all reps.  rows * ncols * 4 / secs = what the host's memory system delivers to staging buffers at `threads` threads.  0 / -1. */
+int32_t infera_sql_bench_gather_only(const float *table, uint64_t rows, uint32_t ncols, int32_t threads, int32_t reps, double *secs, double *cpu_seconds);
+
+/* The same table in DuckDB's SEGMENT shape (round 6): every (row group, column) in ceil(rows_in_group / seg_values) separately allocated
+ * blocks of `block_bytes` (256 KiB) whose first `header_bytes` (8) are the block header; seg_values = (block_bytes - header_bytes) / 4.
+ * Blocks come from `alloc_fn` (the stub's DBConfig::allocator -- the extension's REGISTERING allocator when INFERA_ZERO_COPY_ALLOCATOR=1) and
+ * go back through `free_fn`.  Values are those of infera_sql_synth_table for the same seed.  The scan points each chunk's FLAT vectors into
+ * the blocks; the one vector per row group that straddles two segments is assembled in the worker's own buffer (`assembled_chunks`). */
+typedef void *(*infera_sql_block_alloc_fn)(void *ctx, uint64_t bytes);
+typedef void (*infera_sql_block_free_fn)(void *ctx, void *block, uint64_t bytes);
+typedef struct InferaSqlSegmentTable InferaSqlSegmentTable;
+InferaSqlSegmentTable *infera_sql_segment_table_create(uint64_t rows, uint32_t ncols, uint64_t seed, int32_t threads, uint64_t block_bytes,
+                                                       uint64_t header_bytes, infera_sql_block_alloc_fn alloc_fn, infera_sql_block_free_fn free_fn,
+                                                       void *alloc_ctx);
+void infera_sql_segment_table_destroy(InferaSqlSegmentTable *t);
+uint64_t infera_sql_segment_table_blocks(const InferaSqlSegmentTable *t);
+int32_t infera_sql_bench_scan_segments(const char *function, const char *model, const InferaSqlSegmentTable *t, uint64_t rows, int32_t threads,
+                                       int32_t reps, double *secs, double *checksum, uint64_t *assembled_chunks, char *err, uint64_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -144,7 +144,7 @@ bool unregister_host_memory(const void *base);
 // Pins (reader counts) on the page blocks a zero-copy call reads: hold until the GPU has finished with them.
 struct ZeroCopyPins {
   static constexpr size_t kMax = 520;  // (kMaxZeroCopyCols runs, a few of them straddling a block border)
-  std::shared_ptr<void> blocks[kMax];
+  void *blocks[kMax];  // PageBlock * (raw: a pinned block's object outlives its last reader, zero_copy.cpp; nothing to construct per chunk)
   size_t count = 0;
   ZeroCopyPins() = default;
   ZeroCopyPins(const ZeroCopyPins &) = delete;

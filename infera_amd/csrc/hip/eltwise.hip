@@ -491,7 +491,7 @@ __device__ __forceinline__ void gather_run(const T *__restrict__ s, float *__res
     }
   }
 }
-__global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, int ncols, int64_t rows, float *__restrict__ dst) {
+__device__ __forceinline__ void gather_cols_wave(const ColumnTable &tab, int ncols, int64_t rows, float *__restrict__ dst) {
   const int c = int(blockIdx.x) * (kBlock / 64) + int(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= ncols) return;
   const int type = tab.type[c] & 7;
@@ -524,6 +524,31 @@ __global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, in
         if (lane + 64 * i < n4) d4[lane + 64 * i] = v[i];
       return;
     }
+    if ((reinterpret_cast<uintptr_t>(s) & 15) == 8 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && (n & 3) == 0) {
+      // A run that starts 8 bytes past a 16-byte boundary: what a FLAT vector inside a DuckDB buffer-manager block is (the block header is 8
+      // bytes; round 6).  Read as the n/4 + 1 ALIGNED 16-byte pieces that cover it -- the two floats in front of the run and the two behind it
+      // share their 16-byte unit, hence their page, with the run's own first / last floats: no access leaves the pages the run lies in -- and
+      // shifted by half a piece on the way out (the upper half of piece j + the lower half of piece j + 1, taken from the neighbouring lane).
+      // Same 1 KB wave instructions, all in flight before the first store, as the aligned path; element-wise 4-byte loads were 3x slower.
+      const f32x4 *a4 = reinterpret_cast<const f32x4 *>(s - 2);
+      f32x4 *d4 = reinterpret_cast<f32x4 *>(d);
+      const int n4 = n >> 2;  // (<= 512)
+      f32x4 v[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (lane + 64 * i <= n4) v[i] = a4[lane + 64 * i];
+      if (lane == 0 && n4 == 512) v[8] = a4[512];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        float nx = __shfl_down(v[i][0], 1), ny = __shfl_down(v[i][1], 1);
+        const float fx = __shfl(v[i + 1][0], 0), fy = __shfl(v[i + 1][1], 0);  // lane 63's neighbour: lane 0 of the next round
+        if (lane == 63) nx = fx, ny = fy;
+        if (lane + 64 * i < n4) d4[lane + 64 * i] = f32x4{v[i][2], v[i][3], nx, ny};
+      }
+      return;
+    }
     gather_run(s, d, n, lane, [](float x) { return x; });
   } else if (type == 1) {
     gather_run(reinterpret_cast<const double *>(src) + r0, d, n, lane, [](double x) { return float(x); });
@@ -534,11 +559,18 @@ __global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, in
   }
 }
 
+__global__ __launch_bounds__(kBlock) void gather_cols_kernel(ColumnTable tab, int ncols, int64_t rows, float *__restrict__ dst) {
+  gather_cols_wave(tab, ncols, rows, dst);
+}
+
 void gather_columns_device(hipStream_t s, const ColumnTable &tab, int ncols, int64_t rows, float *dst) {
   if (rows <= 0 || ncols <= 0) return;
   // (Also measured and dropped: the fused MLP's tile kernel reading the column runs ITSELF (each workgroup pulling its own 32 rows of
   // every column into LDS: one launch per chunk, bit-identical) -- 46 M rows/s against 82: 128-byte pieces per (column, tile) use the
-  // link far worse than this kernel's 1 KB wave instructions; more hardware queues (GPU_MAX_HW_QUEUES=8 / 16): worse.)
+  // link far worse than this kernel's 1 KB wave instructions; more hardware queues (GPU_MAX_HW_QUEUES=8 / 16): worse, fewer (1 / 2 / 3): worse;
+  // round 6: pulls of different callers taking TURNS on the link -- a per-GPU ticket in device memory, a pull's waves asleep until fewer than
+  // K = 1 / 2 pulls that started before it were unfinished (the idea: four callers' pulls that start together share the link, finish together
+  // and idle it together) -- bit-identical, within +-3 % at every caller count on DuckDB-shaped segments: profiles/r06_duckdb_blocks.txt.)
   hipLaunchKernelGGL(gather_cols_kernel, dim3(unsigned((ncols + kBlock / 64 - 1) / (kBlock / 64)), unsigned((rows + kGatherRowBlock - 1) / kGatherRowBlock)),
                      dim3(kBlock), 0, s, tab, ncols, rows, dst);
 }

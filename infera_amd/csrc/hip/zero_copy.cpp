@@ -37,6 +37,9 @@ std::shared_mutex g_index_mu;                                   // g_ranges / g_
 std::map<uintptr_t, HostRange> g_ranges;                        // by base; non-overlapping
 std::map<uintptr_t, std::shared_ptr<PageBlock>> g_blocks;       // by pb; non-overlapping
 std::atomic<size_t> g_nranges{0};
+// Bumped (with g_index_mu held exclusively) whenever a range or a block LEAVES the index: what a caller thread's cache of resolved runs is
+// valid against (additions never invalidate a hit).
+std::atomic<uint64_t> g_index_gen{0};
 
 // pins [pb, pe) and returns its device delta, the same on every selected GPU or an error
 // (un)registration is called from the APPLICATION's threads (an allocator hook): their current HIP device is put back afterwards
@@ -134,6 +137,7 @@ void release_blocks(uintptr_t pb, uintptr_t pe, std::vector<std::shared_ptr<Page
       dead.push_back(it->second);
       g_busy.emplace_back(it->second->pb, it->second->pe);
       it = g_blocks.erase(it);  // no later lookup can find it
+      g_index_gen.fetch_add(1, std::memory_order_release);
     } else {
       ++it;
     }
@@ -202,6 +206,7 @@ void register_host_memory(const void *base, size_t bytes) {
     for (auto &blk : fresh) busy_remove(blk->pb, blk->pe);
     if (failure) {
       g_ranges.erase(b);
+      g_index_gen.fetch_add(1, std::memory_order_release);
       g_nranges.store(g_ranges.size(), std::memory_order_release);
       release_blocks(pb, pe, dead);  // (the fresh blocks never entered the index: this drops the references taken on the existing ones)
     } else {
@@ -233,6 +238,7 @@ bool unregister_host_memory(const void *base) {
     if (rit == g_ranges.end() || rit->second.pending) return false;  // (a range still being registered by another thread is not there yet)
     const uintptr_t pb = b & ~uintptr_t(4095), pe = (rit->second.end + 4095) & ~uintptr_t(4095);
     g_ranges.erase(rit);
+    g_index_gen.fetch_add(1, std::memory_order_release);
     g_nranges.store(g_ranges.size(), std::memory_order_release);
     release_blocks(pb, pe, dead);
   }
@@ -247,17 +253,54 @@ bool unregister_host_memory(const void *base) {
 // Resolves n host runs to device-visible addresses; every run must lie inside ONE registered range.  The blocks under the runs are PINNED
 // (reader count) until the returned guard dies -- hold it until the GPU has finished reading.  O(log n) per run, one shared lock.
 ZeroCopyPins::~ZeroCopyPins() {
-  for (size_t i = 0; i < count; i++) static_cast<PageBlock *>(blocks[i].get())->readers.fetch_sub(1, std::memory_order_release);
+  // (the last access to each block: the unregistering thread that waits for readers == 0 holds the block object until then)
+  for (size_t i = 0; i < count; i++) static_cast<PageBlock *>(blocks[i])->readers.fetch_sub(1, std::memory_order_release);
 }
+
+namespace {
+// A caller thread's last resolution of run i of its chunks.  A table scan walks a column segment vector by vector: the next chunk's run i lies
+// in the SAME registered range and block as this one's 31 times out of 32 (DuckDB: 32 vectors per 256 KiB block) -- with 20,000 blocks of a
+// 10M x 128 table registered one by one, the two tree walks per run cost 13 us per chunk for a lone caller and 25 us at two or more (cache
+// misses on tree nodes every caller walks; round 6, tools/r06_segments_ranges.sh).  Valid while g_index_gen has not moved (nothing left the
+// index since) -- checked under the shared index lock, so nothing can leave while the hit is being pinned either.
+struct RunHit {
+  uintptr_t rb = 1, re = 0;  // the registered range
+  intptr_t delta = 0;
+  PageBlock *blk = nullptr;
+  std::shared_ptr<PageBlock> keep;  // (keeps the block OBJECT alive for the raw pointer above; not its registration)
+};
+struct RunCache {
+  uint64_t gen = ~uint64_t(0);
+  RunHit hit[kern::kMaxZeroCopyCols];
+};
+thread_local RunCache t_runs;
+}  // namespace
 
 bool lookup_host_memory_many(size_t n, const void *const *ptrs, const size_t *bytes, const void **out, ZeroCopyPins &pins) {
   if (g_nranges.load(std::memory_order_acquire) == 0) return false;
   std::shared_lock<std::shared_mutex> lk(g_index_mu);
+  RunCache &rc = t_runs;
+  const uint64_t gen = g_index_gen.load(std::memory_order_acquire);
+  if (rc.gen != gen) {
+    for (auto &h : rc.hit) h = RunHit();
+    rc.gen = gen;
+  }
   uintptr_t hb = 0, he = 0;  // the range the previous run lay in (columns of one table usually share it)
   intptr_t hd = 0;
   PageBlock *last = nullptr;  // the block pinned last (consecutive runs usually share it too)
   for (size_t i = 0; i < n; i++) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(ptrs[i]), ae = a + bytes[i];
+    RunHit *hit = i < size_t(kern::kMaxZeroCopyCols) ? &rc.hit[i] : nullptr;
+    if (hit && hit->blk && a >= hit->rb && ae <= hit->re && a >= hit->blk->pb && ae <= hit->blk->pe) {  // where run i was last time
+      out[i] = reinterpret_cast<const void *>(intptr_t(a) + hit->delta);
+      if (hit->blk != last) {
+        if (pins.count == ZeroCopyPins::kMax) return false;
+        hit->blk->readers.fetch_add(1, std::memory_order_acquire);
+        pins.blocks[pins.count++] = hit->blk;
+        last = hit->blk;
+      }
+      continue;
+    }
     if (!(a >= hb && ae <= he)) {
       auto it = g_ranges.upper_bound(a);
       if (it == g_ranges.begin()) return false;
@@ -280,8 +323,12 @@ bool lookup_host_memory_many(size_t n, const void *const *ptrs, const size_t *by
       if (at >= bit->second->pe) return false;  // (cannot happen for a registered range)
       if (pins.count == ZeroCopyPins::kMax) return false;  // more blocks than a chunk is expected to touch: take the staged path
       bit->second->readers.fetch_add(1, std::memory_order_acquire);
-      pins.blocks[pins.count++] = bit->second;
+      pins.blocks[pins.count++] = bit->second.get();
       last = bit->second.get();
+      if (hit && a >= last->pb && ae <= last->pe) {  // the whole run in one block: remember it for this thread's next chunk
+        hit->rb = hb, hit->re = he, hit->delta = hd, hit->blk = last;
+        hit->keep = bit->second;
+      }
       at = last->pe;
     }
   }

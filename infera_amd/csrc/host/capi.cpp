@@ -320,7 +320,7 @@ char *infera_hip_get_devices(void) {
          ",\"host_rows\":" + std::to_string(rows) + ",\"numa_node\":" + std::to_string(i < ds.numa.size() ? ds.numa[i] : -1) +
          ",\"ordinal\":" + std::to_string(ds.ids[i]) + ",\"pinned_staging_bytes\":" + std::to_string(slot_pinned_bytes(int(i))) + ",\"slot\":" + std::to_string(i) + "}";
   }
-  o += "],\"host_phases\":" + host_phase_json() + ",\"reason\":" + json_str(ds.why) + "}";
+  o += "],\"host_phases\":" + host_phase_json() + ",\"registered_host_ranges\":" + std::to_string(registered_host_ranges()) + ",\"reason\":" + json_str(ds.why) + "}";
   return dup_cstr(o);
 }
 

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import time
 import os
 from typing import Any
 
@@ -82,6 +83,19 @@ def lib() -> C.CDLL:
         L.infera_sql_bench_last_times.restype = None
         L.infera_sql_bench_last_cpu.argtypes = [C.POINTER(C.c_double)] * 3
         L.infera_sql_bench_last_cpu.restype = None
+        L.infera_sql_bench_gather_only.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.infera_sql_bench_gather_only.restype = C.c_int32
+        L.infera_stub_segment_table_create.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]
+        L.infera_stub_segment_table_create.restype = C.c_void_p
+        L.infera_stub_segment_table_get.argtypes = [C.c_void_p]
+        L.infera_stub_segment_table_get.restype = C.c_void_p
+        L.infera_stub_segment_table_destroy.argtypes = [C.c_void_p]
+        L.infera_stub_segment_table_destroy.restype = None
+        L.infera_sql_segment_table_blocks.argtypes = [C.c_void_p]
+        L.infera_sql_segment_table_blocks.restype = C.c_uint64
+        L.infera_sql_bench_scan_segments.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_double),
+                                                     C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+        L.infera_sql_bench_scan_segments.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -300,6 +314,61 @@ def bench_scan_table(function: str, model: str, table: np.ndarray, rows: int, nc
                                                  rows, ncols, threads, reps, secs, C.byref(cs), err, len(err))
     if rc != 0:
         raise SqlError(err.value.decode())
+    return list(secs), cs.value
+
+
+def bench_gather_only(table: np.ndarray, rows: int, ncols: int, threads: int, reps: int = 3) -> dict:
+    """The host side of the staged scan alone (no GPU): `threads` workers gather every 2048-row chunk of the table into their own buffers with the
+    staged path's own routine.  GB/s of gathered features (best rep) and process CPU microseconds per chunk."""
+    assert table.dtype == np.float32 and table.flags.c_contiguous and table.size >= rows * ncols
+    secs = (C.c_double * reps)()
+    cpu = C.c_double()
+    if lib().infera_sql_bench_gather_only(table.ctypes.data, rows, ncols, threads, reps, secs, C.byref(cpu)) != 0:
+        raise SqlError("gather-only scan failed")
+    best = min(secs)
+    return {"threads": threads, "gb_per_s": rows * ncols * 4 / best / 1e9, "rows_per_s": rows / best,
+            "cpu_us_per_chunk": cpu.value / reps / ((rows + 2047) // 2048) * 1e6, "scan_seconds": list(secs)}
+
+
+class SegmentTable:
+    """The table of synth_table() in DuckDB's SEGMENT shape (round 6): per (row group, column) two separately allocated 256 KiB blocks
+    (8-byte block header, 65,534 values each) taken from the DuckDB stand-in's DBConfig::allocator -- the extension's REGISTERING allocator
+    when INFERA_ZERO_COPY_ALLOCATOR=1 is set in the environment when the table is made (every block pinned where it lies as it is handed out),
+    malloc otherwise.  A chunk's 128 FLAT vectors point into 128 unrelated blocks; the one chunk per row group that straddles two segments is
+    assembled in ordinary memory (as DuckDB's scan does).  Blocks go back through the allocator on close()."""
+
+    def __init__(self, rows: int, ncols: int, seed: int = 42, threads: int = 8):
+        hooked = C.c_int32()
+        t0 = time.perf_counter()
+        self.handle = lib().infera_stub_segment_table_create(rows, ncols, seed, threads, C.byref(hooked))
+        if not self.handle:
+            raise SqlError("segment table: allocation failed")
+        self.create_seconds = time.perf_counter() - t0
+        self.rows, self.ncols, self.registering_allocator = rows, ncols, bool(hooked.value)
+        self.blocks = int(lib().infera_sql_segment_table_blocks(lib().infera_stub_segment_table_get(self.handle)))
+        self.assembled_chunks = 0
+
+    def close(self):
+        if self.handle:
+            lib().infera_stub_segment_table_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+def bench_scan_segments(function: str, model: str, table: SegmentTable, rows: int, ncols: int, threads: int, reps: int = 1):
+    """bench_scan_table() over a SegmentTable (same workers, same chunk order, same result consumer); returns ([seconds per scan], checksum)."""
+    assert table.handle and rows <= table.rows and ncols == table.ncols
+    secs = (C.c_double * reps)()
+    cs = C.c_double()
+    asm = C.c_uint64()
+    err = C.create_string_buffer(512)
+    rc = lib().infera_sql_bench_scan_segments(function.encode(), model.encode(), lib().infera_stub_segment_table_get(table.handle), rows, threads, reps,
+                                              secs, C.byref(cs), C.byref(asm), err, len(err))
+    if rc != 0:
+        raise SqlError(err.value.decode())
+    table.assembled_chunks = asm.value
     return list(secs), cs.value
 
 

@@ -394,4 +394,40 @@ double infera_stub_allocator_scan(const char *model, int32_t threads, double sec
   }
 }
 
+// A whole table in DuckDB's segment shape whose blocks come from DBConfig::allocator (round 6): the registering allocator of the extension when
+// INFERA_ZERO_COPY_ALLOCATOR=1 (every 256 KiB block pinned where it lies as it is handed out -- what `DuckDB db(path, &config)` would do for
+// the buffer manager's blocks), plain malloc otherwise.  The scans over it are csrc/binding/scan_driver.cpp's.  The allocator lives as long as
+// the table (`*hook_installed` says which one it is).
+namespace {
+struct StubSegmentTable {
+  DBConfig config;
+  InferaSqlSegmentTable *table = nullptr;
+};
+void *stub_block_alloc(void *ctx, uint64_t bytes) { return static_cast<StubSegmentTable *>(ctx)->config.allocator->AllocateData(bytes); }
+void stub_block_free(void *ctx, void *block, uint64_t bytes) {
+  static_cast<StubSegmentTable *>(ctx)->config.allocator->FreeData(static_cast<data_ptr_t>(block), bytes);
+}
+}  // namespace
+
+void *infera_stub_segment_table_create(uint64_t rows, uint32_t ncols, uint64_t seed, int32_t threads, int32_t *hook_installed) {
+  auto *st = new StubSegmentTable;
+  const bool hooked = infera_install_zero_copy_allocator(st->config);
+  if (!st->config.allocator) st->config.allocator = make_uniq<Allocator>();
+  if (hook_installed) *hook_installed = hooked ? 1 : 0;
+  // Storage::BLOCK_ALLOC_SIZE = 262144, Storage::BLOCK_HEADER_SIZE = sizeof(uint64_t) (duckdb/storage/storage_info.hpp, quoted from memory)
+  st->table = infera_sql_segment_table_create(rows, ncols, seed, threads, 262144, 8, stub_block_alloc, stub_block_free, st);
+  if (!st->table) {
+    delete st;
+    return nullptr;
+  }
+  return st;
+}
+const InferaSqlSegmentTable *infera_stub_segment_table_get(void *handle) { return handle ? static_cast<StubSegmentTable *>(handle)->table : nullptr; }
+void infera_stub_segment_table_destroy(void *handle) {
+  auto *st = static_cast<StubSegmentTable *>(handle);
+  if (!st) return;
+  infera_sql_segment_table_destroy(st->table);  // (frees every block through the allocator: the registering one unregisters it first)
+  delete st;
+}
+
 }  // extern "C"

@@ -28,8 +28,20 @@ def test_default_bench_line_is_small_and_has_contract_fields_and_other_workloads
     assert abs(e["vs_cpu_baseline"] - e["rows_per_s"] / best) / e["vs_cpu_baseline"] < 1e-3  # against the FASTEST of the three CPU legs
     assert e["vs_cpu_reference_shaped"] >= e["vs_cpu_baseline"]
     assert 5 < e["cpu_us_per_chunk"] < 2000 and 0 < e["predicted_scaling_at_8_gpus"] <= 8.0 and e["cpus_needed_for_6x"] > 0
+    # round 6: the SECOND bound of the 8-GPU model (what the quota's CPUs gather per second with no GPU behind them), and which bound binds
+    assert e["host_copy_gbs_at_threads"] > 1.0 and e["binding_bound"] in ("cpu time per chunk", "host copy rate", "8 x the 1-GPU rate")
+    bg = e["bounds_in_gpus"]
+    assert e["predicted_scaling_at_8_gpus"] == pytest.approx(min(8.0, bg["cpu_time"], bg["host_copy"]), rel=2e-2)
     g = d["end_to_end_registered"]
     assert "error" not in g and g["rows_per_s"] > 0 and g["zero_copy_calls"] > 0 and g["cpu_us_per_chunk"] > 0
+    # round 6: the registered scan on DuckDB's block layout (128 unrelated 256 KiB blocks per chunk: the pulling kernel only) at 2 / 4 / 8 callers,
+    # [M rows/s, CPU us per chunk]; the 8-GPU prediction of the opt-in path is read from THIS row
+    blk = g["duckdb_blocks"]
+    assert "error" not in blk and all(blk[t][0] > 1.0 and 1.0 < blk[t][1] < 500 for t in ("2", "4", "8")), blk
+    assert g["prediction_from"] == "duckdb_blocks" and g["predicted_8_gpus_vs_staged_1_gpu"] > 0
+    fb = full["end_to_end_registered"]["duckdb_blocks"]
+    assert fb["blocks"] > 20_000 and fb["assembled_chunks_per_scan_set"] > 0 and fb["predicted_at_callers_per_gpu"] in (2, 4, 8)
+    assert full["end_to_end_registered"]["predicted_8_gpus_vs_staged_1_gpu"] == pytest.approx(fb["predicted_rows_per_s_at_8_gpus"] / e["rows_per_s"], rel=1e-3)
     o = d["other_workloads"]
     c4, c5, c5f = o["C4"], o["C5"], o["C5_fp32"]
     assert c4["roofline"]["bound"] == "hbm" and c4["rows"] == 50_000_000 and 0.0 < c4["roofline"]["frac"] < 1.0, c4

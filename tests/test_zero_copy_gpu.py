@@ -243,3 +243,80 @@ def test_gpu_zero_copy_rect_copy_equals_pulling_kernel(gpu_api, tmp_path):
         out[rect] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
         assert out[rect]["zero_copy_calls"] == 5
     assert out["1"]["sha"] == out["0"]["sha"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [4, 252, 2044, 2048])
+def test_gpu_zero_copy_runs_eight_bytes_past_a_16_byte_boundary(gpu_api, tmp_path, rows):
+    """A FLAT vector inside a DuckDB buffer-manager block starts 8 bytes past a 16-byte boundary (the block header is 8 bytes): round 6 gave
+    such runs their own path in the pulling kernel (aligned 16-byte pieces, shifted by half a piece) -- bit-identical to the staged path, and
+    no access leaves the run's own pages: the first column starts 8 bytes into the FIRST registered page and the last column ends 8 bytes
+    before the end of the LAST one (a 16-byte read one piece further out would touch unregistered, possibly unmapped memory)."""
+    k = 128
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp((128, 256, 64, 1)))
+    x = synth.table(11, 0, rows, k)
+    # every column run in its own page-aligned slab, 8 bytes in; the last run placed so that it ENDS 8 bytes before its slab's end
+    slab_floats = (rows * 4 + 16 + 4095) // 4096 * 4096 // 4
+    big = _page_aligned((k, slab_floats), np.float32)
+    cols = []
+    for c in range(k):
+        start = 2 if c < k - 1 else slab_floats - 2 - rows
+        big[c, start:start + rows] = x[:, c]
+        cols.append(big[c, start:start + rows])
+        assert cols[-1].ctypes.data % 16 == 8
+    gpu_api.load_model("zc8", path)
+    try:
+        staged = gpu_api.predict_columns("zc8", cols)
+        before = gpu_api.zero_copy_calls()
+        gpu_api.register_host_memory(big)
+        try:
+            got = gpu_api.predict_columns("zc8", cols)
+            assert gpu_api.zero_copy_calls() == before + 1
+        finally:
+            gpu_api.unregister_host_memory(big)
+        assert np.array_equal(got, staged) and np.array_equal(got, gpu_api.predict("zc8", x))
+    finally:
+        gpu_api.unload_model("zc8")
+
+
+@pytest.mark.gpu
+def test_gpu_scan_over_duckdb_shaped_segments_equals_the_staged_scan(gpu_api, tmp_path, monkeypatch):
+    """the registered scan on DuckDB's block layout -- per (row group, column) two separately allocated 256 KiB blocks from the
+    extension's REGISTERING allocator (8-byte header, 65,534 values), 128 unrelated block addresses per chunk, the chunk that straddles two
+    segments assembled in ordinary memory.  Every chunk but those is fetched in place; the scan's checksum is the staged scan's over the
+    contiguous twin of the table (same values), and the allocator's blocks are all unregistered again when the table is closed."""
+    from infera_amd import sqlharness
+
+    rows, k = 122_880 * 2 + 70_000, 128
+    path = W.write(str(tmp_path / "m.onnx"), W.mlp((128, 256, 64, 1)))
+    gpu_api.load_model("seg", path)
+    try:
+        flat = sqlharness.synth_table(rows, k, 42, 8)
+        (secs, want) = sqlharness.bench_scan_table("infera_predict", "seg", flat, rows, k, 4, 1)
+        monkeypatch.setenv("INFERA_ZERO_COPY_ALLOCATOR", "1")
+        ranges0 = gpu_api.get_devices()["registered_host_ranges"]
+        t = sqlharness.SegmentTable(rows, k, 42, 8)
+        try:
+            assert t.registering_allocator and t.blocks == 128 * 6   # three row groups x two segments
+            assert gpu_api.get_devices()["registered_host_ranges"] == ranges0 + t.blocks
+            before = gpu_api.zero_copy_calls()
+            (secs, got) = sqlharness.bench_scan_segments("infera_predict", "seg", t, rows, k, 4, 1)
+            nchunks = (rows + 2047) // 2048
+            assert t.assembled_chunks == 3                                             # one straddling chunk per row group
+            assert gpu_api.zero_copy_calls() - before == nchunks - t.assembled_chunks    # every other chunk in place
+            assert abs(got - want) <= 1e-6 * rows, (got, want)                         # same fp32 results, summed in double in another order
+        finally:
+            t.close()
+        assert gpu_api.get_devices()["registered_host_ranges"] == ranges0
+        # ... and without the hook the same table is ordinary memory: every chunk staged, same checksum
+        monkeypatch.delenv("INFERA_ZERO_COPY_ALLOCATOR")
+        t = sqlharness.SegmentTable(rows, k, 42, 8)
+        try:
+            assert not t.registering_allocator
+            before = gpu_api.zero_copy_calls()
+            (secs, got2) = sqlharness.bench_scan_segments("infera_predict", "seg", t, rows, k, 4, 1)
+            assert gpu_api.zero_copy_calls() == before and abs(got2 - want) <= 1e-6 * rows
+        finally:
+            t.close()
+    finally:
+        gpu_api.unload_model("seg")
