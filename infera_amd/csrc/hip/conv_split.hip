@@ -551,9 +551,23 @@ void conv2d_split6(hipStream_t s, const float *X, const float *packed, const flo
     return;
   }
   const unsigned bx = unsigned((total_pix + 127) / 128);
+#ifdef INFERA_CONV_PROBES
+  // TIMING PROBE ONLY (wrong results): a stride-2 layer's lanes read CONSECUTIVE 16-byte pieces, as they would from an input stored
+  // de-interleaved by column phase -- the upper bound of what such a layout could buy (round 6, profiles/r06_stride2_probe.txt)
+  ConvGeom gp = g;
+  SecondInput x2p = x2;
+  if (getenv("INFERA_CONV_PROBE_SW1")) {
+    if (gp.sw == 2 && gp.kw == 3) gp.sw = 1;
+    if (x2p.X && x2p.sw == 2) x2p.sw = 1;
+  }
+  auto launch = [&](auto kernel, int features) {
+    hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / features)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, gp, act, x2p);
+  };
+#else
   auto launch = [&](auto kernel, int features) {
     hipLaunchKernelGGL(kernel, dim3(bx, unsigned(g.M / features)), dim3(kBlock), 0, s, X, packed, bias, residual, Y, total_pix, g, act, x2);
   };
+#endif
   if (g.M % 128 == 0) launch(conv2d_split6p_kernel, 128);
   else if (split6_tt(g) && !x2.X) launch(conv2d_split6_kernel<2, true>, 64);
   else launch(conv2d_split6_kernel<2, false>, 64);
