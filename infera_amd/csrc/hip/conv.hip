@@ -1480,7 +1480,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv2d_stem_split6_kernel(const fl
     // the two adjacent words of a lane into ds_read2_b64, which the LDS serves at a quarter of that rate (eight cycles per instruction: 32 banks,
     // 16-lane groups) -- sixteen of them per k-block and wave kept the LDS, not the matrix cores, busy (MI355X_MICROARCH.md, LDS table;
     // profiles/r04_stem_lds_ab.txt).  The counter wait is written by hand as well (wait_words), with the words as operands so that no use moves
-    // above it.
+    // above it.  What the constraints can and cannot promise (ADVICE r4 / VERDICT r5 item 7): the destinations are EARLY-CLOBBER ("=&v": never the
+    // address register of a read that is still to be issued) and every use of a word goes through wait_words' "+v" operand, so nothing can read a
+    // word before the wait; what C++-level asm cannot forbid is a register COPY of a word between its read and the wait (the copy would carry
+    // the old contents).  hipcc 7.2 (clang 20, the version the Makefile pins and __graft_entry__.build() prints) makes none -- the k loop has no
+    // spill and no v_mov of a word register before its wait -- and tests/test_stem_pool_gpu.py (fused stem == INFERA_STEM_SPLIT=0's exact-fp32
+    // kernels' plan within the split arithmetic's bound, and == itself across wave counts bit for bit) is the gate a toolchain bump has to pass.
     using u64w = unsigned long long;
     u64w w[PW][8];
     u32x4_t a3[2][3];
@@ -1489,8 +1494,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv2d_stem_split6_kernel(const fl
       const unsigned a0 = unsigned(size_t((const __attribute__((address_space(3))) void *)row)), a1 = a0 + unsigned(pg.HALF) * 8u;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w[p][e]) : "v"(a0), "n"(8 * e));
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w[p][4 + e]) : "v"(a1), "n"(8 * e));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(w[p][e]) : "v"(a0), "n"(8 * e));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(w[p][4 + e]) : "v"(a1), "n"(8 * e));
       }
     };
     // (the weight fragments the same way: a read the compiler counts would make it wait for "all but the last three" LDS reads before the matrix
@@ -1498,7 +1503,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv2d_stem_split6_kernel(const fl
     const unsigned wfrag_a = unsigned(size_t((const __attribute__((address_space(3))) void *)wfrag));
     auto fetch_weights = [&](int kb, int buf) {
 #pragma unroll
-      for (int k = 0; k < 3; k++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a3[buf][k]) : "v"(wfrag_a), "n"((kb * 3 + k) * 1024));
+      for (int k = 0; k < 3; k++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(a3[buf][k]) : "v"(wfrag_a), "n"((kb * 3 + k) * 1024));
     };
     auto wait_words = [&](int buf) {
       if constexpr (PW == 2)
