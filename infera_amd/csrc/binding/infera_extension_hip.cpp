@@ -481,12 +481,24 @@ data_ptr_t RegisteringAllocate(PrivateAllocatorData *pd, idx_t size) {
 #if defined(__GNUC__) && !defined(__clang__)
 #pragma GCC diagnostic pop
 #endif
+// Unregisters a block before it goes back to the heap (waits for the calls still reading it: a chunk's time).  false: calls were STILL reading it
+// after the library's bounded wait (a wedged GPU) -- the memory may not be freed or moved; the block is leaked instead (include/infera_hip.h:
+// only a 0 from infera_hip_unregister_host_memory says the range is no longer read).  "Was not registered" (no GPU, pinning limit) is fine.
+bool ReleasedForFree(data_ptr_t p) {
+  if (infera::infera_hip_unregister_host_memory(p) == 0) return true;
+  const char *e = infera::infera_last_error();
+  return !(e && std::strstr(e, "still in use"));
+}
 void RegisteringFree(PrivateAllocatorData *pd, data_ptr_t p, idx_t size) {
-  if (p && WorthRegistering(pd, size)) (void)infera::infera_hip_unregister_host_memory(p);  // waits for the calls still reading this block
+  if (p && WorthRegistering(pd, size) && !ReleasedForFree(p)) return;
   Allocator::DefaultFree(pd, p, size);
 }
 data_ptr_t RegisteringReallocate(PrivateAllocatorData *pd, data_ptr_t p, idx_t old_size, idx_t size) {
-  if (p && WorthRegistering(pd, old_size)) (void)infera::infera_hip_unregister_host_memory(p);
+  if (p && WorthRegistering(pd, old_size) && !ReleasedForFree(p)) {  // the old block stays where it is (leaked): copy out of it
+    const data_ptr_t fresh = RegisteringAllocate(pd, size);
+    if (fresh) std::memcpy(fresh, p, old_size < size ? old_size : size);
+    return fresh;
+  }
   const data_ptr_t q = Allocator::DefaultReallocate(pd, p, old_size, size);
   if (q && WorthRegistering(pd, size)) (void)infera::infera_hip_register_host_memory(q, size);
   return q;
