@@ -589,10 +589,12 @@ static void launch_narrow16s(hipStream_t s, const float *X, const float *W, cons
 // weights.  From there on it is the narrow16s kernel: B = X[row n][16g+4q+j], A = W fragment-major in LDS, two
 // independent 16-row accumulators per wave, next tile's loads in flight during the MFMAs, epilogue in registers.
 // NL = 16-byte loads per lane per tile (ceil(K/8)), a compile-time bucket so the prefetch registers are static.
-template <int SM, int NL>
+template <int SM, int NL, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void dense_narrow16g_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                     const float *__restrict__ bias, float *__restrict__ Y,
                                                                     int64_t rows, int K, int M, ActParam act, int xflags) {
+  // NT: non-temporal table loads + result stores (round 6: 52 -> 16 columns 5.34 -> 5.70 TB/s, other shapes unchanged; parking the results as in
+  // dense_narrow16s_kernel LOSES 5-20 % here -- these shapes are bound by their LDS traffic, not by HBM: profiles/r06_dense16g_ab.txt)
   // xflags: bit 0 = X is 16-byte aligned; bit 1 = X is ONE COLUMN-MAJOR chunk [K][rows] (the host path's staging layout: a DataChunk's
   // flat columns as they were copied) -- column k of a tile is 32 consecutive floats at X + k*rows + row0: quad p -> column p/8, rows
   // 4*(p%8)..+3, scattered down a column of the LDS tile; everything after the tile is the row-major kernel.
@@ -636,7 +638,10 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16g_kernel(const float
       const int64_t row0 = tile << 5;
       if (tile < full_tiles) {
 #pragma unroll
-        for (int i = 0; i < NL; i++) v[i] = *reinterpret_cast<const f32x4 *>(X + int64_t(pq[i] >> 3) * rows + row0 + 4 * (pq[i] & 7));
+        for (int i = 0; i < NL; i++) {
+          const f32x4 *p4 = reinterpret_cast<const f32x4 *>(X + int64_t(pq[i] >> 3) * rows + row0 + 4 * (pq[i] & 7));
+          v[i] = NT ? __builtin_nontemporal_load(p4) : *p4;
+        }
         return;
       }
 #pragma unroll
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16g_kernel(const float
     if (tile < full_tiles) {  // wave-uniform: straight-line loads, all in flight together
       const f32x4 *src = reinterpret_cast<const f32x4 *>(X + tile * 32 * K);
 #pragma unroll
-      for (int i = 0; i < NL; i++) v[i] = src[pq[i]];
+      for (int i = 0; i < NL; i++) v[i] = NT ? __builtin_nontemporal_load(src + pq[i]) : src[pq[i]];
       return;
     }
     const int64_t base = tile * 32 * K;  // ragged end of the table / unaligned base: element by element
@@ -734,12 +739,20 @@ __global__ __launch_bounds__(WAVES * 64) void dense_narrow16g_kernel(const float
       if (row < rows) {
         float *yrow = Y + row * M + 4 * q;
         if ((M & 1) == 0 && 4 * q + 3 < M) {  // row stride M*4 is 8-byte aligned: two 8-byte stores
-          *reinterpret_cast<f32x2 *>(yrow) = f32x2{v[0], v[1]};
-          *reinterpret_cast<f32x2 *>(yrow + 2) = f32x2{v[2], v[3]};
+          if (NT) {
+            __builtin_nontemporal_store(f32x2{v[0], v[1]}, reinterpret_cast<f32x2 *>(yrow));
+            __builtin_nontemporal_store(f32x2{v[2], v[3]}, reinterpret_cast<f32x2 *>(yrow + 2));
+          } else {
+            *reinterpret_cast<f32x2 *>(yrow) = f32x2{v[0], v[1]};
+            *reinterpret_cast<f32x2 *>(yrow + 2) = f32x2{v[2], v[3]};
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < 4; i++)
-            if (4 * q + i < M) yrow[i] = v[i];
+            if (4 * q + i < M) {
+              if (NT) __builtin_nontemporal_store(v[i], yrow + i);
+              else yrow[i] = v[i];
+            }
         }
       }
     }
@@ -762,20 +775,22 @@ static void launch_narrow16g(hipStream_t s, const float *X, const float *W, cons
   const int64_t blocks = std::min<int64_t>((ntiles + WAVES - 1) / WAVES, 256 * per_cu);
   const int aligned = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 ? 1 : 0) | (x_colmajor ? 2 : 0);
   dim3 grid((unsigned)blocks), block(WAVES * 64);
-  // Round 6 (profiles/r06_c4_store_ab.txt, same process, same buffers, bit-identical): per-row 8-byte stores 5.13 ms per 50M rows; the tile's
-  // results parked and written as 16-byte pieces 5.17 (no gain by itself); non-temporal loads + per-row non-temporal stores 5.03; BOTH 4.87 ms =
-  // 5.67 TB/s.  INFERA_DENSE16S_MODE=0 / INFERA_DENSE16S_NT=0 (read per launch: measurement + bit-identity test) switch them off.
-  const int mode_env = getenv("INFERA_DENSE16S_MODE") ? atoi(getenv("INFERA_DENSE16S_MODE")) : 1;
-  const int mode = (reinterpret_cast<uintptr_t>(Y) & 15) == 0 ? mode_env : (mode_env & ~1);
+  const bool nt = !(getenv("INFERA_DENSE16S_NT") && atoi(getenv("INFERA_DENSE16S_NT")) == 0);  // (non-temporal loads + stores, as launch_narrow16s; per launch: A/B)
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     hipLaunchKernelGGL(kernel, grid, block, lds, s, X, W, bias, Y, rows, K, M, act, aligned);
   };
   auto by_nl = [&](auto smt) {
     constexpr int SMv = decltype(smt)::value;
-    if (K <= 32) go(dense_narrow16g_kernel<SMv, 4>);
-    else if (K <= 64) go(dense_narrow16g_kernel<SMv, 8>);
-    else go(dense_narrow16g_kernel<SMv, 16>);
+    if (nt) {
+      if (K <= 32) go(dense_narrow16g_kernel<SMv, 4, true>);
+      else if (K <= 64) go(dense_narrow16g_kernel<SMv, 8, true>);
+      else go(dense_narrow16g_kernel<SMv, 16, true>);
+    } else {
+      if (K <= 32) go(dense_narrow16g_kernel<SMv, 4, false>);
+      else if (K <= 64) go(dense_narrow16g_kernel<SMv, 8, false>);
+      else go(dense_narrow16g_kernel<SMv, 16, false>);
+    }
   };
   if (softmax_mode == 0) by_nl(std::integral_constant<int, 0>{});
   else if (softmax_mode == 1) by_nl(std::integral_constant<int, 1>{});
