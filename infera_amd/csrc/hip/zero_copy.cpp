@@ -119,6 +119,14 @@ bool unmap_dead_blocks(const std::vector<std::shared_ptr<PageBlock>> &dead) {
       (void)hipHostUnregister(reinterpret_cast<void *>(blk->pb));
     } else {
       all_drained = false;
+      // the stuck readers hold RAW pointers to the block object (ZeroCopyPins) and will decrement its reader count if they ever return: the
+      // object must outlive them -> parked for the life of the process (a handful of bytes per wedged block)
+      static std::mutex graveyard_mu;
+      static std::vector<std::shared_ptr<PageBlock>> *graveyard = new std::vector<std::shared_ptr<PageBlock>>();
+      {
+        std::lock_guard<std::mutex> lk(graveyard_mu);
+        graveyard->push_back(blk);
+      }
       log_msg(0, "unregister_host_memory: calls still read a " + std::to_string((blk->pe - blk->pb) >> 10) + " KiB block after " +
                      std::to_string(kUnmapWaitSeconds) + " s (GPU wedged?): its pages stay pinned");
     }
