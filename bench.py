@@ -729,6 +729,19 @@ def compact_line(full: dict) -> dict:
     return line
 
 
+_LINE_OUT = None  # the process's ORIGINAL stdout (claim_stdout): where the one JSON line goes
+
+
+def claim_stdout() -> None:
+    """Keeps the driver's stdout for the ONE JSON line: file descriptor 1 is pointed at stderr for everything else this process and the
+    libraries in it print (gloo announces "[Gloo] Rank 0 is connected to 1 peer ranks" on stdout from C++, HIP runtime warnings, ...)."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
 def emit(full: dict, detail_path: str) -> None:
     """Full object -> stderr + the detail file; the compact line (<= LINE_LIMIT bytes) -> stdout, last."""
     text = json.dumps(full)
@@ -750,7 +763,7 @@ def emit(full: dict, detail_path: str) -> None:
             c = {k: (v[:60] if isinstance(v, str) else v) for k, v in c.items() if k in CONTRACT_FIELDS}
             c["config"] = {"workload": str(full["config"].get("workload", ""))[:60]}
             line = json.dumps(c, separators=(",", ":"))
-    print(line, flush=True)
+    print(line, file=_LINE_OUT or sys.stdout, flush=True)
 
 
 def relaunch_command(gpus: int, host_path: bool, argv: list, env: dict):
@@ -775,6 +788,7 @@ def main():
     if cmd:
         print(f"bench.py: --gpus {args.gpus} without a launcher: re-executing as {args.gpus} ranks under torch.distributed.run", file=sys.stderr, flush=True)
         os.execv(cmd[0], cmd)
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -96,6 +96,8 @@ def run_bench(args, env=None, launcher=None, timeout=1200):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    # ... and NOTHING else on stdout (round 6: gloo announced its peers there from C++; bench.py points fd 1 at stderr for everything but the line)
+    assert [l for l in p.stdout.splitlines() if l.strip()] == lines, p.stdout[-2000:]
     assert len(lines[0]) <= 4096, len(lines[0])
     try:
         with open(detail) as fh:
