@@ -6,6 +6,7 @@ OUT=${1:-gpurun_out/r06_c4_store_ab.txt}
 mkdir -p "$(dirname "$OUT")"
 {
   echo "== tools/ubench/hbm_stream 24 GiB =="
+  [ -x tools/ubench/hbm_stream ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/hbm_stream tools/ubench/hbm_stream.hip
   tools/ubench/hbm_stream 24
   echo "== parity: C4 tests under each mode =="
   for m in "0 1" "1 0" "1 1"; do
