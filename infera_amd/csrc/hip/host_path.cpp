@@ -239,6 +239,7 @@ void HostCall::enqueue_chunk(int64_t r0, int64_t nr, bool single_pass, bool dire
     // zero-copy: the GPU pulls the caller's (registered) column runs itself -- straight into the chunk the first kernel reads when it
     // reads column-major chunks, else into the transpose's source
     if (cm_direct) {
+      prof::Section sec(8, "enqueue: fetch launch");
       (*dfill)(ctx.stream, din, r0, nr);
     } else {
       ctx.ensure_dev(ctx.dev_cm, ctx.dev_cm_cap, h2d_bytes(nr));
@@ -247,7 +248,10 @@ void HostCall::enqueue_chunk(int64_t r0, int64_t nr, bool single_pass, bool dire
     }
   } else if (cm_direct) {
     if (small_in) kin = pin;
-    else HIP_TRY(hipMemcpyAsync(din, pin, h2d_bytes(nr), hipMemcpyHostToDevice, ctx.stream));
+    else {
+      prof::Section sec(8, "enqueue: H2D copy");
+      HIP_TRY(hipMemcpyAsync(din, pin, h2d_bytes(nr), hipMemcpyHostToDevice, ctx.stream));
+    }
   } else if (col_major && small_in) {
     kern::transpose_cm(ctx.stream, pin, din, nr, int64_t(in_row / 4));
   } else if (!col_major && small_in && m.in_single_reader) {
@@ -258,6 +262,7 @@ void HostCall::enqueue_chunk(int64_t r0, int64_t nr, bool single_pass, bool dire
   if (direct_out) {
     // the plan's only writer of the result stores it straight into the pinned (host-coherent) buffer: a few KB per
     // chunk over PCIe from the kernel's epilogue instead of one more enqueue + blit kernel + dependency per chunk
+    prof::Section sec(9, "enqueue: model launch");
     exec_plan(m, dm, ctx, kin, ctx.pin_out, nr, cm_direct);
   } else {
     exec_plan(m, dm, ctx, kin, ctx.dev_out, nr, cm_direct);
@@ -367,7 +372,9 @@ void HostCall::run_chunks(uint64_t lease_ns) {
     const uint64_t t_g = now_ns();
     // one device pass for the whole chunk?  (plans with activation scratch split long calls; may reallocate -- and drop graphs --
     // so before the lookup).  A column-major chunk is only handed to the first kernel as it lies when it is.
+    std::optional<prof::Section> sec_scratch(std::in_place, 7, "prepare scratch");
     const bool single_pass = prepare_scratch(m, ctx, nr) == nr;
+    sec_scratch.reset();
     bool done = false;
     {
       prof::Range range("infera:enqueue");
@@ -388,9 +395,11 @@ void HostCall::run_chunks(uint64_t lease_ns) {
     const uint64_t t_w = now_ns();
     {
       prof::Range range("infera:copy_out");
+      prof::Section sec(14, "copy out");
       std::memcpy(h_out + size_t(r0) * (out_row / 4), ctx.pin_out, size_t(nr) * out_row);
     }
     const uint64_t t_c = now_ns();
+    prof::Section sec_counters(15, "phase counters");
     if (r0 == 0) g_phase_ns[kPhLease].fetch_add(lease_ns, std::memory_order_relaxed);
     g_phase_ns[kPhGather].fetch_add(t_f1 - t_f0, std::memory_order_relaxed);
     g_phase_ns[kPhGate].fetch_add(t_g - t_f1, std::memory_order_relaxed);
@@ -413,11 +422,15 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
   prof::Range range("infera:chunk");
   const uint64_t t_entry = now_ns();
   std::optional<prof::Range> lease_range(std::in_place, "infera:lease");
+  std::optional<prof::Section> sec_lease(std::in_place, 5, "lease (+ hipSetDevice)");
   HostLease lease(slot);
+  sec_lease.reset();
   lease_range.reset();
   const uint64_t t_leased = now_ns();
   if (fault_injected(slot)) hip_fail(hipErrorLaunchFailure, "injected fault (INFERA_FAULT_INJECT)");
+  std::optional<prof::Section> sec_setup(std::in_place, 6, "call setup");
   HostCall call(m, fill, dfill, h_out, rows, col_major, slot, *lease.c);
+  sec_setup.reset();
   g_slot_calls[size_t(slot) % 64].fetch_add(1, std::memory_order_relaxed);
   g_slot_rows[size_t(slot) % 64].fetch_add(uint64_t(rows), std::memory_order_relaxed);
   try {
@@ -431,7 +444,7 @@ bool run_host_impl(const LoadedModel &m, const FillFn &fill, const DeviceFillFn 
     (void)hipStreamSynchronize(lease.c->stream);
     throw;
   }
-  if (range.on) prof::note_call(t_entry, now_ns(), uint64_t(rows));
+  if (range.on || prof::sections_enabled()) prof::note_call(t_entry, now_ns(), uint64_t(rows));
   return true;
 }
 

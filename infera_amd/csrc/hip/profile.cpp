@@ -40,8 +40,26 @@ void report_at_exit() {
   }
 }
 
+constexpr int kMaxSections = 48;
+std::atomic<uint64_t> g_sec_ns[kMaxSections], g_sec_n[kMaxSections];
+std::atomic<const char *> g_sec_name[kMaxSections];
+void report_sections_at_exit() {
+  const uint64_t calls = g_calls.load();
+  if (!calls) return;
+  std::fprintf(stderr, "[infera profile] sections, ns per host-ABI call (%llu calls; a section entered several times per call counts every time):\n", (unsigned long long)calls);
+  for (int i = 0; i < kMaxSections; i++)
+    if (const char *n = g_sec_name[i].load())
+      std::fprintf(stderr, "[infera profile]   %-28s %9.1f ns per call  (%.2f entries per call)\n", n, double(g_sec_ns[i].load()) / double(calls),
+                   double(g_sec_n[i].load()) / double(calls));
+}
+
 bool init() {
   const char *e = std::getenv("INFERA_PROFILE");
+  if (e && std::atoi(e) == 2) {  // sections only: no roctx ranges (the marker library serialises the callers that push them)
+    std::atexit(report_sections_at_exit);
+    std::atexit(report_at_exit);
+    return false;
+  }
   if (!e || std::atoi(e) != 1) return false;
   for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
     if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
@@ -62,6 +80,26 @@ bool init() {
 bool enabled() {
   static const bool on = init();
   return on;
+}
+bool sections_enabled() {
+  static const bool on = [] {
+    (void)enabled();  // (registers the exit reports)
+    const char *e = std::getenv("INFERA_PROFILE");
+    return e && std::atoi(e) == 2;
+  }();
+  return on;
+}
+void section_add(int id, const char *name, uint64_t ns) {
+  if (id < 0 || id >= kMaxSections) return;
+  g_sec_name[id].store(name, std::memory_order_relaxed);
+  g_sec_ns[id].fetch_add(ns, std::memory_order_relaxed);
+  g_sec_n[id].fetch_add(1, std::memory_order_relaxed);
+}
+Section::Section(int i, const char *n) : id(i), name(n) {
+  if (sections_enabled()) t0 = rt::now_ns();
+}
+Section::~Section() {
+  if (t0) section_add(id, name, rt::now_ns() - t0);
 }
 void push(const char *name) {
   if (g_push) (void)g_push(name);

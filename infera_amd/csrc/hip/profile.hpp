@@ -21,6 +21,21 @@ void push(const char *name);    // roctxRangePushA (no-op when the marker librar
 void pop();                     // roctxRangePop
 void note_call(uint64_t t_begin_ns, uint64_t t_end_ns, uint64_t rows);  // for the exit report's rows/s
 
+// INFERA_PROFILE=2 (round 6): additionally, fine-grained SECTIONS of a host-ABI call's CPU work (registry read, validation, run lookup, lease,
+// the two launches, event record, naps, queries, result copy ...) are clocked and reported at exit as ns per call: what the 18-20 us of CPU per
+// chunk of the registered path are made of.  Off: one relaxed load per section.
+bool sections_enabled();
+void section_add(int id, const char *name, uint64_t ns);
+struct Section {
+  const int id;
+  const char *const name;
+  uint64_t t0 = 0;
+  Section(int i, const char *n);
+  ~Section();
+  Section(const Section &) = delete;
+  Section &operator=(const Section &) = delete;
+};
+
 struct Range {
   const bool on;
   explicit Range(const char *name) : on(enabled()) {

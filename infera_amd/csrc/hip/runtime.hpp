@@ -20,7 +20,10 @@
 #include <vector>
 
 #include "../host/common.hpp"
+#include <optional>
+
 #include "backend.hpp"
+#include "profile.hpp"
 
 namespace infera_hip {
 namespace rt {
@@ -132,12 +135,22 @@ struct ThreadCtx {
     };
     const bool known = est.ema_ns > 0.0;
     {
+      std::optional<prof::Section> sec_slack(std::in_place, 13, "wait: timer slack set");
       TimerSlack slack;
-      if (known) nap(std::min({est.ema_ns * kPollFirst, est.min_ns * 0.9, 2.0e6}));
+      sec_slack.reset();
+      if (known) {
+        prof::Section sec(11, "wait: first nap (asleep)");
+        nap(std::min({est.ema_ns * kPollFirst, est.min_ns * 0.9, 2.0e6}));
+      }
       for (;;) {
-        const hipError_t e = query();
+        hipError_t e;
+        {
+          prof::Section sec(12, "wait: event queries");
+          e = query();
+        }
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) hip_fail(e, "hipEventQuery");
+        prof::Section sec(16, "wait: later naps (asleep)");
         nap(known ? std::max(3000.0, std::min(est.ema_ns * kPollNext, 50000.0)) : std::max(3000.0, std::min(waited_ns() * 0.25, 200000.0)));
       }
     }
@@ -154,7 +167,10 @@ struct ThreadCtx {
   // instead of a marker event -- no record call, no marker packet -- measured 20-45 % slower at 5-45 us more CPU per chunk: profiles/r05_wait_stream_query_ab.txt.)
   void wait_stream(uint64_t key = 0) {
     if (!poll_ev) HIP_TRY(hipEventCreateWithFlags(&poll_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(poll_ev, stream));
+    {
+      prof::Section sec(10, "wait: event record");
+      HIP_TRY(hipEventRecord(poll_ev, stream));
+    }
     poll_until([&] { return hipEventQuery(poll_ev); }, wait_est, key);
   }
   void drop_graphs() {

@@ -9,10 +9,12 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <optional>
 #include <string>
 
 #include "../../../include/infera_hip.h"
 #include "../hip/backend.hpp"
+#include "../hip/profile.hpp"
 #include "common.hpp"
 #include "engine.hpp"
 #include "remote.hpp"
@@ -490,6 +492,7 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
   InferaInferenceResult res = error_result();
   guarded([&] {
     if (!model_name || !columns) throw InferaError::null_pointer();
+    std::optional<prof::Section> sec_find(std::in_place, 0, "capi: registry read + validation");
     auto m = engine::find(checked_str(model_name));
     // A NULL cell or an unsupported type must fail before any model-level error, as ExtractFeatures
     // runs before the FFI call in the reference (infera_extension.cpp:267-270).
@@ -505,7 +508,10 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
       }
     }
     OutShape o = engine::validate_predict(*m, rows, ncols);
+    sec_find.reset();
+    std::optional<prof::Section> sec_alloc(std::in_place, 1, "capi: result allocation");
     float *out = alloc_out(o.len);
+    sec_alloc.reset();
     try {
       // Column-major staging: every column is converted / copied into pinned staging as the contiguous run it already is
       // (FLOAT: memcpy; DOUBLE / INTEGER: vectorised conversion of the run; constant vectors filled) and the GPU reads the
@@ -518,6 +524,7 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
       // what a chunk costs the host drops from ~78 us of CPU to the launch and the wait.
       bool served = false;
       if (ncols > 0 && ncols <= uintptr_t(kern::kMaxZeroCopyCols) && registered_host_ranges() > 0 && Config::get().host_zero_copy) {
+        std::optional<prof::Section> sec_lookup(std::in_place, 2, "capi: run table + lookup + pins");
         kern::ColumnTable tab;
         size_t esz[kern::kMaxZeroCopyCols], run_bytes[kern::kMaxZeroCopyCols];
         const void *host_ptr[kern::kMaxZeroCopyCols];
@@ -530,6 +537,7 @@ struct InferaInferenceResult infera_predict_columns(const char *model_name, cons
         }
         ZeroCopyPins pins;  // the page blocks under the runs stay mapped until this call has finished with them (unregistering waits for it)
         const bool all = lookup_host_memory_many(ncols, host_ptr, run_bytes, tab.ptr, pins);
+        sec_lookup.reset();
         // FLOAT runs at ONE stride (a [columns][rows] matrix: a numpy / Arrow table, a row group whose columns were allocated together): the
         // chunk is a pitched rectangle, and ONE 2-D copy on the copy engines moves it -- they read pinned host memory at the link's DMA rate
         // (~55 GB/s), where a kernel pulling the same runs reaches 42 (round 3).  Anything else (typed columns, constants, blocks of a
