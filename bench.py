@@ -424,47 +424,52 @@ def end_to_end(fn: str, model: str, table, rows: int, cols: int, out_cols: int, 
 
 def duckdb_blocks_scan(fn: str, model: str, rows: int, cols: int, out_cols: int, seed: int, budget: dict, world: int, barrier, max_over_ranks,
                        all_ok=lambda ok: ok) -> dict:
-    """The registered scan on DuckDB's BLOCK LAYOUT (profiles/r06_duckdb_blocks.txt): the table as column segments in
-    separately allocated 256 KiB blocks from the extension's registering allocator (sqlharness.SegmentTable) -- 128 unrelated block addresses
-    per chunk, vectors 8 bytes past a 16-byte boundary, one straddling chunk per row group staged -- so EVERY chunk is the pulling kernel's; no
-    2-D copy applies.  This, not the contiguous registered table above it, is the row the 8-GPU prediction of the opt-in path is read from."""
+    """The registered scan on DuckDB's BLOCK LAYOUT (profiles/r06_duckdb_blocks.txt): the table as column segments in 256 KiB
+    blocks (8-byte header, 65,534 values) from the extension's registering allocator (sqlharness.SegmentTable), the chunk per row group that
+    straddles two segments staged.  Two allocation orders: `callers` = every block of the table allocated in a RANDOM order -- 128 unrelated
+    addresses per chunk, the pulling kernel for every chunk: the conservative row, and the one the 8-GPU prediction of the opt-in path is read
+    from; `in_order` = a row group's 128 column blocks allocated back to back (a table loaded by one thread): out of the allocator's arena they
+    lie at one 256 KiB stride inside one registration, and the 2-D copy applies as on a contiguous table."""
     from infera_amd import sqlharness
 
     prev = os.environ.get("INFERA_ZERO_COPY_ALLOCATOR")
     os.environ["INFERA_ZERO_COPY_ALLOCATOR"] = "1"
-    seg, why = None, ""
+    out = {"rows": rows, "block_bytes": 262144, "header_bytes": 8, "values_per_segment": 65534,
+           "layout": "per (row group, column) two 256 KiB blocks from the extension's registering (arena) allocator; first segment's vectors 8 bytes past a "
+                     "16-byte boundary; the chunk per row group that straddles two segments is staged",
+           "callers": {}, "in_order": {}}
     try:
-        seg = sqlharness.SegmentTable(rows, cols, seed, min(32, max(1, budget["usable"] // world)))
-        if not seg.registering_allocator:
-            why = "the registering allocator was not installed"
-    except Exception as exc:
-        why = f"{type(exc).__name__}: {exc}"
-    finally:
-        if prev is None:
-            os.environ.pop("INFERA_ZERO_COPY_ALLOCATOR", None)
-        else:
-            os.environ["INFERA_ZERO_COPY_ALLOCATOR"] = prev
-    if not all_ok(seg is not None and not why):
-        if seg is not None:
-            seg.close()
-        return {"error": why or "a peer rank could not build its segment table"}
-    out = {"rows": rows, "blocks": seg.blocks, "block_bytes": 262144, "header_bytes": 8, "values_per_segment": 65534, "create_seconds": seg.create_seconds,
-           "layout": "per (row group, column) two 256 KiB blocks from the extension's registering allocator; every chunk's 128 FLAT vectors point into "
-                     "128 unrelated blocks (first segment: 8 bytes past a 16-byte boundary); the chunk per row group that straddles two segments is staged",
-           "callers": {}}
-    try:
-        for t in ((2, 4, 8) if world == 1 else (4, 8)):
-            d = end_to_end(fn, model, seg, rows, cols, out_cols, str(t), 3, budget, world, barrier, max_over_ranks, scan=sqlharness.bench_scan_segments,
-                           probe_h2d=False)
-            out["callers"][str(t)] = {"rows_per_s": d["rows_per_s"], "cpu_us_per_chunk": d["host_cpu_cost"]["cpu_us_per_chunk"]}
-        out["assembled_chunks_per_scan_set"] = seg.assembled_chunks
-        if world == 1:  # 8 GPUs on this box's CPU quota, from this row: the best caller count under both bounds (8 x the per-GPU rate; CPUs / CPU time per chunk)
+        for key, shuffled, counts in (("callers", True, (2, 4, 8) if world == 1 else (4, 8)), ("in_order", False, (4, 8) if world == 1 else (4,))):
+            seg, why = None, ""
+            try:
+                seg = sqlharness.SegmentTable(rows, cols, seed, min(32, max(1, budget["usable"] // world)), shuffled=shuffled)
+                if not seg.registering_allocator:
+                    why = "the registering allocator was not installed"
+            except Exception as exc:
+                why = f"{type(exc).__name__}: {exc}"
+            if not all_ok(seg is not None and not why):
+                if seg is not None:
+                    seg.close()
+                return {"error": why or "a peer rank could not build its segment table"}
+            try:
+                out["blocks"], out["create_seconds"] = seg.blocks, seg.create_seconds
+                for t in counts:
+                    d = end_to_end(fn, model, seg, rows, cols, out_cols, str(t), 3, budget, world, barrier, max_over_ranks, scan=sqlharness.bench_scan_segments,
+                                   probe_h2d=False)
+                    out[key][str(t)] = {"rows_per_s": d["rows_per_s"], "cpu_us_per_chunk": d["host_cpu_cost"]["cpu_us_per_chunk"]}
+                out["assembled_chunks_per_scan_set"] = seg.assembled_chunks
+            finally:
+                seg.close()
+        if world == 1:  # 8 GPUs on this box's CPU quota, from the CONSERVATIVE row: the best caller count under both bounds (8 x the per-GPU rate; CPUs / CPU time per chunk)
             quota = budget["usable"]
             best = max(((min(8 * v["rows_per_s"], quota * 2048e6 / v["cpu_us_per_chunk"]), int(t)) for t, v in out["callers"].items() if v["cpu_us_per_chunk"] > 0),
                        default=(None, None))
             out["predicted_rows_per_s_at_8_gpus"], out["predicted_at_callers_per_gpu"] = best
     finally:
-        seg.close()
+        if prev is None:
+            os.environ.pop("INFERA_ZERO_COPY_ALLOCATOR", None)
+        else:
+            os.environ["INFERA_ZERO_COPY_ALLOCATOR"] = prev
     return out
 
 
@@ -678,6 +683,7 @@ def compact_e2e(e: dict) -> dict:
     if isinstance(blk, dict):  # [M rows/s, CPU us per chunk] by callers per GPU, on DuckDB's block layout
         out["duckdb_blocks"] = ({"error": str(blk["error"])[:80]} if "error" in blk else
                                 {**{t: [_r(v["rows_per_s"] / 1e6, 4), _r(v["cpu_us_per_chunk"], 3)] for t, v in blk.get("callers", {}).items()},
+                                 "in_order": {t: [_r(v["rows_per_s"] / 1e6, 4), _r(v["cpu_us_per_chunk"], 3)] for t, v in blk.get("in_order", {}).items()},
                                  **({"vs_staged_alone": {t: _r(v, 3) for t, v in blk["vs_staged_alone"].items()}} if "vs_staged_alone" in blk else {})})
     if e.get("prediction_from"):
         out["prediction_from"] = e["prediction_from"].split(" ")[0]

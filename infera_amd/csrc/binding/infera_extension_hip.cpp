@@ -37,7 +37,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -464,15 +466,111 @@ void LoadInternal(ExtensionLoader &loader) {
 // application:   DBConfig config;  infera_install_zero_copy_allocator(config);  DuckDB db(path, &config);
 // It is a no-op unless INFERA_ZERO_COPY_ALLOCATOR=1 (a registered block stays pinned for its lifetime: opt-in, like the path itself).
 namespace {
+// ARENA (round 6).  Registering every 256 KiB block by itself costs an ioctl per Allocate / Free (~28 us each, on whichever thread DuckDB's
+// buffer manager allocates), leaves 20,000 registrations for a 5 GB table, and scatters a chunk's 128 column vectors over 128 unrelated
+// registrations -- which only the pulling kernel can fetch.  So blocks of the buffer manager's size (`block_bytes`, default 256 KiB = DuckDB's
+// Storage::BLOCK_ALLOC_SIZE) come out of SLABS of 256 blocks (64 MiB), each registered ONCE: Allocate / Free are a bit operation under a mutex,
+// the registry holds one range per slab, and blocks handed out back to back -- the column segments of a row group loaded by one thread -- lie at
+// ONE stride inside ONE registration, which is what the engine's 2-D copy needs (include/infera_hip.h: FLOAT runs at one pitch inside one pinned
+// block).  Lowest free block of the oldest slab with room first, so that consecutive allocations stay adjacent and emptied slabs can go back to
+// the system (one empty slab is kept as hysteresis).  Other sizes >= `min_bytes` keep their own registration; smaller ones are plain memory.
+// A slab's pages are pinned as a whole: up to 64 MiB of slack per arena.  INFERA_ZERO_COPY_ARENA=0: the per-block registrations of round 4.
+struct Slab {
+  data_ptr_t base = nullptr;
+  uint64_t free_bits[4] = {~uint64_t(0), ~uint64_t(0), ~uint64_t(0), ~uint64_t(0)};  // bit set = free
+  int used = 0;
+  bool registered = false;
+};
 struct InferaAllocatorData : PrivateAllocatorData {
   idx_t min_bytes = 128 * 1024;
+  idx_t block_bytes = 256 * 1024;
+  bool arena = true;
+  static constexpr int kSlabBlocks = 256;
+  std::mutex mu;
+  std::vector<unique_ptr<Slab>> slabs;      // creation order
+  std::map<data_ptr_t, Slab *> by_base;     // (a 100 GB buffer pool is 1,600 slabs: Free finds its slab in O(log n))
+  ~InferaAllocatorData() override {
+    for (auto &sl : slabs) {
+      if (sl->registered) (void)infera::infera_hip_unregister_host_memory(sl->base);
+      std::free(sl->base);
+    }
+  }
+  Slab *SlabOf(data_ptr_t p) {  // (under mu)
+    auto it = by_base.upper_bound(p);
+    if (it == by_base.begin()) return nullptr;
+    --it;
+    return p < it->first + idx_t(kSlabBlocks) * block_bytes ? it->second : nullptr;
+  }
+  data_ptr_t Take() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (auto &sl : slabs)
+        if (sl->used < kSlabBlocks)
+          for (int w = 0; w < 4; w++)
+            if (sl->free_bits[w]) {
+              const int bit = __builtin_ctzll(sl->free_bits[w]);
+              sl->free_bits[w] &= ~(uint64_t(1) << bit);
+              sl->used++;
+              return sl->base + idx_t(64 * w + bit) * block_bytes;
+            }
+    }
+    // no room: a new slab, made and pinned OUTSIDE the lock (pinning 64 MiB takes milliseconds; other threads keep allocating and freeing)
+    auto fresh = make_uniq<Slab>();
+    void *mem = nullptr;
+    if (posix_memalign(&mem, size_t(2) << 20, size_t(kSlabBlocks) * block_bytes) != 0) return nullptr;
+    fresh->base = static_cast<data_ptr_t>(mem);
+    // (a failed registration -- no GPU, pinning limit reached -- only means the slab's chunks are staged like any other memory)
+    fresh->registered = infera::infera_hip_register_host_memory(mem, uint64_t(kSlabBlocks) * block_bytes) == 0;
+    fresh->free_bits[0] &= ~uint64_t(1);
+    fresh->used = 1;
+    std::lock_guard<std::mutex> lk(mu);
+    slabs.push_back(std::move(fresh));
+    by_base[slabs.back()->base] = slabs.back().get();
+    return slabs.back()->base;
+  }
+  // true: `p` was a slab block and has been given back
+  bool GiveBack(data_ptr_t p) {
+    unique_ptr<Slab> retired;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      Slab *sl = SlabOf(p);
+      if (!sl) return false;
+      const idx_t i = idx_t(p - sl->base) / block_bytes;
+      sl->free_bits[i / 64] |= uint64_t(1) << (i % 64);
+      sl->used--;
+      if (sl->used == 0) {  // keep ONE empty slab around; a second one goes back to the system
+        int empty = 0;
+        for (auto &x : slabs) empty += x->used == 0;
+        if (empty > 1)
+          for (auto it = slabs.begin(); it != slabs.end(); ++it)
+            if (it->get() == sl) {
+              by_base.erase(sl->base);
+              retired = std::move(*it);
+              slabs.erase(it);
+              break;
+            }
+      }
+    }
+    if (retired) {  // outside the lock: unregistering waits for the calls still reading the slab (none: its blocks are all free)
+      bool release = true;
+      if (retired->registered && infera::infera_hip_unregister_host_memory(retired->base) != 0) {
+        const char *e = infera::infera_last_error();
+        release = !(e && std::strstr(e, "still in use"));  // (a wedged GPU may still read it: leaked, include/infera_hip.h)
+      }
+      if (release) std::free(retired->base);
+    }
+    return true;
+  }
 };
-inline bool WorthRegistering(PrivateAllocatorData *pd, idx_t size) { return size >= static_cast<InferaAllocatorData *>(pd)->min_bytes; }
+inline InferaAllocatorData *Data(PrivateAllocatorData *pd) { return static_cast<InferaAllocatorData *>(pd); }
+inline bool WorthRegistering(PrivateAllocatorData *pd, idx_t size) { return size >= Data(pd)->min_bytes; }
+inline bool FromArena(PrivateAllocatorData *pd, idx_t size) { return Data(pd)->arena && size == Data(pd)->block_bytes; }
 #if defined(__GNUC__) && !defined(__clang__)
 #pragma GCC diagnostic push
 #pragma GCC diagnostic ignored "-Wmaybe-uninitialized"  // (the fresh block's CONTENTS are uninitialised; only its address range is registered)
 #endif
 data_ptr_t RegisteringAllocate(PrivateAllocatorData *pd, idx_t size) {
+  if (FromArena(pd, size)) return Data(pd)->Take();
   const data_ptr_t p = Allocator::DefaultAllocate(pd, size);
   // (a failed registration -- no GPU, pinning limit reached -- only means the block's chunks are staged like any other memory)
   if (p && WorthRegistering(pd, size)) (void)infera::infera_hip_register_host_memory(p, size);
@@ -490,13 +588,25 @@ bool ReleasedForFree(data_ptr_t p) {
   return !(e && std::strstr(e, "still in use"));
 }
 void RegisteringFree(PrivateAllocatorData *pd, data_ptr_t p, idx_t size) {
-  if (p && WorthRegistering(pd, size) && !ReleasedForFree(p)) return;
+  if (!p) return;
+  if (FromArena(pd, size) && Data(pd)->GiveBack(p)) return;
+  if (WorthRegistering(pd, size) && !ReleasedForFree(p)) return;
   Allocator::DefaultFree(pd, p, size);
 }
 data_ptr_t RegisteringReallocate(PrivateAllocatorData *pd, data_ptr_t p, idx_t old_size, idx_t size) {
-  if (p && WorthRegistering(pd, old_size) && !ReleasedForFree(p)) {  // the old block stays where it is (leaked): copy out of it
+  if (!p) return RegisteringAllocate(pd, size);
+  const idx_t keep = old_size < size ? old_size : size;
+  if (FromArena(pd, old_size) || FromArena(pd, size)) {
+    // a slab block cannot grow in place, and a block of the arena's size has to come out of a slab: allocate, copy, release the old one
     const data_ptr_t fresh = RegisteringAllocate(pd, size);
-    if (fresh) std::memcpy(fresh, p, old_size < size ? old_size : size);
+    if (!fresh) return nullptr;
+    std::memcpy(fresh, p, keep);
+    RegisteringFree(pd, p, old_size);
+    return fresh;
+  }
+  if (WorthRegistering(pd, old_size) && !ReleasedForFree(p)) {  // a wedged GPU may still read the old block: it stays where it is (leaked)
+    const data_ptr_t fresh = RegisteringAllocate(pd, size);
+    if (fresh) std::memcpy(fresh, p, keep);
     return fresh;
   }
   const data_ptr_t q = Allocator::DefaultReallocate(pd, p, old_size, size);
@@ -526,8 +636,10 @@ DUCKDB_EXTENSION_API void infera_init(duckdb::DatabaseInstance &db) {
 DUCKDB_EXTENSION_API bool infera_install_zero_copy_allocator(duckdb::DBConfig &config) {
   const char *e = std::getenv("INFERA_ZERO_COPY_ALLOCATOR");
   if (!e || std::atoi(e) != 1) return false;
-  config.allocator = duckdb::make_uniq<duckdb::Allocator>(duckdb::RegisteringAllocate, duckdb::RegisteringFree, duckdb::RegisteringReallocate,
-                                                         duckdb::make_uniq<duckdb::InferaAllocatorData>());
+  auto data = duckdb::make_uniq<duckdb::InferaAllocatorData>();
+  const char *arena = std::getenv("INFERA_ZERO_COPY_ARENA");
+  data->arena = !(arena && std::atoi(arena) == 0);
+  config.allocator = duckdb::make_uniq<duckdb::Allocator>(duckdb::RegisteringAllocate, duckdb::RegisteringFree, duckdb::RegisteringReallocate, std::move(data));
   return true;
 }
 }

@@ -419,7 +419,7 @@ struct InferaSqlSegmentTable {
 
 InferaSqlSegmentTable *infera_sql_segment_table_create(uint64_t rows, uint32_t ncols, uint64_t seed, int32_t threads, uint64_t block_bytes,
                                                        uint64_t header_bytes, infera_sql_block_alloc_fn alloc_fn, infera_sql_block_free_fn free_fn,
-                                                       void *alloc_ctx) {
+                                                       void *alloc_ctx, uint64_t shuffle_seed) {
   if (!alloc_fn || !free_fn || block_bytes <= header_bytes + 4 || ncols == 0) return nullptr;
   if (threads < 1) threads = 1;
   auto *t = new InferaSqlSegmentTable;
@@ -429,19 +429,28 @@ InferaSqlSegmentTable *infera_sql_segment_table_create(uint64_t rows, uint32_t n
   t->segs_per_group = uint32_t((RG + t->seg_values - 1) / t->seg_values);
   t->free_fn = free_fn, t->alloc_ctx = alloc_ctx;
   t->blocks.assign(size_t(ngroups) * t->segs_per_group * ncols, nullptr);
-  // allocation in column-major order of a group's segments, single-threaded: neighbouring columns get unrelated addresses from the allocator
-  // (a checkpointing / appending DuckDB interleaves them with everything else it allocates)
-  bool ok = true;
-  for (uint64_t g = 0; g < ngroups && ok; g++) {
+  // ALLOCATION ORDER decides where a chunk's 128 blocks lie relative to each other, and with an arena allocator whether they lie at one
+  // stride: shuffle_seed = 0: a (row group, segment)'s columns back to back, group after group -- a table loaded by ONE thread; != 0: every
+  // block of the table in a random order -- parallel loads, evictions and reloads interleaved with everything else the allocator serves:
+  // 128 unrelated addresses per chunk whatever the allocator does (VERDICT r5 item 2's shape; the conservative row of every table).
+  std::vector<size_t> order;
+  for (uint64_t g = 0; g < ngroups; g++) {
     const uint64_t gr = std::min<uint64_t>(RG, rows - g * RG);
-    for (uint32_t k = 0; k < t->segs_per_group && ok; k++) {
+    for (uint32_t k = 0; k < t->segs_per_group; k++) {
       if (uint64_t(k) * t->seg_values >= gr) continue;
-      for (uint32_t c = 0; c < ncols && ok; c++) {
-        void *b = alloc_fn(alloc_ctx, block_bytes);
-        ok = b != nullptr;
-        t->blocks[(size_t(g) * t->segs_per_group + k) * ncols + c] = static_cast<uint8_t *>(b);
-      }
+      for (uint32_t c = 0; c < ncols; c++) order.push_back((size_t(g) * t->segs_per_group + k) * ncols + c);
     }
+  }
+  if (shuffle_seed)
+    for (size_t i = order.size(); i > 1; i--) std::swap(order[i - 1], order[size_t(splitmix64(shuffle_seed + i) % i)]);
+  bool ok = true;
+  for (size_t slot : order) {
+    void *b = alloc_fn(alloc_ctx, block_bytes);
+    if (!b) {
+      ok = false;
+      break;
+    }
+    t->blocks[slot] = static_cast<uint8_t *>(b);
   }
   if (!ok) {
     infera_sql_segment_table_destroy(t);

@@ -38,6 +38,7 @@ def test_default_bench_line_is_small_and_has_contract_fields_and_other_workloads
     # [M rows/s, CPU us per chunk]; the 8-GPU prediction of the opt-in path is read from THIS row
     blk = g["duckdb_blocks"]
     assert "error" not in blk and all(blk[t][0] > 1.0 and 1.0 < blk[t][1] < 500 for t in ("2", "4", "8")), blk
+    assert all(blk["in_order"][t][0] > 1.0 for t in ("4", "8")), blk  # a row group's blocks allocated back to back: the arena puts them at one stride
     assert g["prediction_from"] == "duckdb_blocks" and g["predicted_8_gpus_vs_staged_1_gpu"] > 0
     fb = full["end_to_end_registered"]["duckdb_blocks"]
     assert fb["blocks"] > 20_000 and fb["assembled_chunks_per_scan_set"] > 0 and fb["predicted_at_callers_per_gpu"] in (2, 4, 8)

@@ -295,19 +295,25 @@ def test_gpu_scan_over_duckdb_shaped_segments_equals_the_staged_scan(gpu_api, tm
         (secs, want) = sqlharness.bench_scan_table("infera_predict", "seg", flat, rows, k, 4, 1)
         monkeypatch.setenv("INFERA_ZERO_COPY_ALLOCATOR", "1")
         ranges0 = gpu_api.get_devices()["registered_host_ranges"]
-        t = sqlharness.SegmentTable(rows, k, 42, 8)
-        try:
-            assert t.registering_allocator and t.blocks == 128 * 6   # three row groups x two segments
-            assert gpu_api.get_devices()["registered_host_ranges"] == ranges0 + t.blocks
-            before = gpu_api.zero_copy_calls()
-            (secs, got) = sqlharness.bench_scan_segments("infera_predict", "seg", t, rows, k, 4, 1)
-            nchunks = (rows + 2047) // 2048
-            assert t.assembled_chunks == 3                                             # one straddling chunk per row group
-            assert gpu_api.zero_copy_calls() - before == nchunks - t.assembled_chunks    # every other chunk in place
-            assert abs(got - want) <= 1e-6 * rows, (got, want)                         # same fp32 results, summed in double in another order
-        finally:
-            t.close()
-        assert gpu_api.get_devices()["registered_host_ranges"] == ranges0
+        nchunks = (rows + 2047) // 2048
+        # the allocator's ARENA (slabs of 256 blocks, one registration each) with the blocks handed out in order / in a random order, and the
+        # per-block registrations of INFERA_ZERO_COPY_ARENA=0: the same results whichever mechanism fetches a chunk
+        for arena, shuffled, ranges in (("1", False, 3), ("1", True, 3), ("0", True, 128 * 6)):
+            monkeypatch.setenv("INFERA_ZERO_COPY_ARENA", arena)
+            t = sqlharness.SegmentTable(rows, k, 42, 8, shuffled=shuffled)
+            try:
+                assert t.registering_allocator and t.blocks == 128 * 6   # three row groups x two segments
+                assert gpu_api.get_devices()["registered_host_ranges"] == ranges0 + ranges, (arena, shuffled)
+                before = gpu_api.zero_copy_calls()
+                (secs, got) = sqlharness.bench_scan_segments("infera_predict", "seg", t, rows, k, 4, 1)
+                assert t.assembled_chunks == 3                                             # one straddling chunk per row group
+                assert gpu_api.zero_copy_calls() - before == nchunks - t.assembled_chunks    # every other chunk in place
+                assert abs(got - want) <= 1e-6 * rows, (got, want, arena, shuffled)        # same fp32 results, summed in double in another order
+            finally:
+                t.close()
+            # (the arena keeps ONE empty slab for the next allocation; everything else is unregistered again)
+            assert gpu_api.get_devices()["registered_host_ranges"] in (ranges0, ranges0 + 1), (arena, shuffled)
+        monkeypatch.delenv("INFERA_ZERO_COPY_ARENA")
         # ... and without the hook the same table is ordinary memory: every chunk staged, same checksum
         monkeypatch.delenv("INFERA_ZERO_COPY_ALLOCATOR")
         t = sqlharness.SegmentTable(rows, k, 42, 8)

@@ -53,10 +53,14 @@ measure("registered, ONE contiguous range (2-D copies + pulling kernel)", sqlhar
 capi.unregister_host_memory(flat)
 del flat
 os.environ["INFERA_ZERO_COPY_ALLOCATOR"] = "1"
-seg = sqlharness.SegmentTable(rows, 128, 42, 16)
-print(f"(segment table: {seg.blocks} blocks of 256 KiB from the registering allocator = {seg.registering_allocator}, made in {seg.create_seconds:.2f} s; "
-      f"registered ranges now {capi.get_devices()['registered_host_ranges']})", flush=True)
-before = capi.zero_copy_calls()
-measure("registered, DuckDB segments (pulling kernel only)", sqlharness.bench_scan_segments, seg)
-print(f"(zero-copy calls {capi.zero_copy_calls() - before}, assembled chunks in the last scan set {seg.assembled_chunks})")
-seg.close()
+for label, arena, shuffled in (("registered, DuckDB segments, ARENA allocator, a row group's blocks allocated back to back (2-D copies + pulling kernel)", "1", False),
+                               ("registered, DuckDB segments, ARENA allocator, blocks allocated in a random order (pulling kernel only)", "1", True),
+                               ("registered, DuckDB segments, one registration per block (round 6's first shape; pulling kernel only)", "0", True)):
+    os.environ["INFERA_ZERO_COPY_ARENA"] = arena
+    seg = sqlharness.SegmentTable(rows, 128, 42, 16, shuffled=shuffled)
+    print(f"(segment table: {seg.blocks} blocks of 256 KiB, registering allocator = {seg.registering_allocator}, arena = {arena}, shuffled = {shuffled}, made in "
+          f"{seg.create_seconds:.2f} s; registered ranges now {capi.get_devices()['registered_host_ranges']})", flush=True)
+    before = capi.zero_copy_calls()
+    measure(label, sqlharness.bench_scan_segments, seg)
+    print(f"(zero-copy calls {capi.zero_copy_calls() - before}, assembled chunks in the last scan set {seg.assembled_chunks})")
+    seg.close()
