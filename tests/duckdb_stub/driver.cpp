@@ -430,4 +430,20 @@ void infera_stub_segment_table_destroy(void *handle) {
   delete st;
 }
 
+// The allocator DBConfig::allocator holds after infera_install_zero_copy_allocator, driven call by call (tests/test_arena_allocator.py: runs
+// without a GPU too -- a registration that fails only means the memory is plain memory).  One allocator per handle.
+void *infera_stub_allocator_create(int32_t *hook_installed) {
+  auto *config = new DBConfig;
+  const bool hooked = infera_install_zero_copy_allocator(*config);
+  if (!config->allocator) config->allocator = make_uniq<Allocator>();
+  if (hook_installed) *hook_installed = hooked ? 1 : 0;
+  return config;
+}
+void infera_stub_allocator_destroy(void *h) { delete static_cast<DBConfig *>(h); }
+void *infera_stub_allocate(void *h, uint64_t size) { return static_cast<DBConfig *>(h)->allocator->AllocateData(size); }
+void infera_stub_free(void *h, void *p, uint64_t size) { static_cast<DBConfig *>(h)->allocator->FreeData(static_cast<data_ptr_t>(p), size); }
+void *infera_stub_reallocate(void *h, void *p, uint64_t old_size, uint64_t size) {
+  return static_cast<DBConfig *>(h)->allocator->ReallocateData(static_cast<data_ptr_t>(p), old_size, size);
+}
+
 }  // extern "C"
