@@ -419,7 +419,7 @@ struct InferaSqlSegmentTable {
 
 InferaSqlSegmentTable *infera_sql_segment_table_create(uint64_t rows, uint32_t ncols, uint64_t seed, int32_t threads, uint64_t block_bytes,
                                                        uint64_t header_bytes, infera_sql_block_alloc_fn alloc_fn, infera_sql_block_free_fn free_fn,
-                                                       void *alloc_ctx, uint64_t shuffle_seed) {
+                                                       void *alloc_ctx, uint64_t shuffle_seed, int32_t alloc_threads) {
   if (!alloc_fn || !free_fn || block_bytes <= header_bytes + 4 || ncols == 0) return nullptr;
   if (threads < 1) threads = 1;
   auto *t = new InferaSqlSegmentTable;
@@ -444,13 +444,39 @@ InferaSqlSegmentTable *infera_sql_segment_table_create(uint64_t rows, uint32_t n
   if (shuffle_seed)
     for (size_t i = order.size(); i > 1; i--) std::swap(order[i - 1], order[size_t(splitmix64(shuffle_seed + i) % i)]);
   bool ok = true;
-  for (size_t slot : order) {
-    void *b = alloc_fn(alloc_ctx, block_bytes);
-    if (!b) {
-      ok = false;
-      break;
+  if (alloc_threads > 1 && !shuffle_seed) {
+    // a PARALLEL load: `alloc_threads` workers each claim a (row group, segment) at a time and allocate its `ncols` blocks one after the other
+    // (DuckDB's parallel insert: every thread appends to row groups of its own) -- the allocator sees the threads' requests interleaved
+    std::atomic<size_t> next_set{0};
+    std::atomic<bool> failed{false};
+    const size_t nsets = order.size() / ncols;
+    std::vector<std::thread> workers;
+    for (int w = 0; w < alloc_threads; w++)
+      workers.emplace_back([&] {
+        for (;;) {
+          const size_t set = next_set.fetch_add(1);
+          if (set >= nsets || failed.load()) break;
+          for (uint32_t c = 0; c < ncols; c++) {
+            void *b = alloc_fn(alloc_ctx, block_bytes);
+            if (!b) {
+              failed = true;
+              break;
+            }
+            t->blocks[order[set * ncols + c]] = static_cast<uint8_t *>(b);
+          }
+        }
+      });
+    for (auto &x : workers) x.join();
+    ok = !failed.load();
+  } else {
+    for (size_t slot : order) {
+      void *b = alloc_fn(alloc_ctx, block_bytes);
+      if (!b) {
+        ok = false;
+        break;
+      }
+      t->blocks[slot] = static_cast<uint8_t *>(b);
     }
-    t->blocks[slot] = static_cast<uint8_t *>(b);
   }
   if (!ok) {
     infera_sql_segment_table_destroy(t);

@@ -124,7 +124,8 @@ typedef void (*infera_sql_block_free_fn)(void *ctx, void *block, uint64_t bytes)
 typedef struct InferaSqlSegmentTable InferaSqlSegmentTable;
 InferaSqlSegmentTable *infera_sql_segment_table_create(uint64_t rows, uint32_t ncols, uint64_t seed, int32_t threads, uint64_t block_bytes,
                                                        uint64_t header_bytes, infera_sql_block_alloc_fn alloc_fn, infera_sql_block_free_fn free_fn,
-                                                       void *alloc_ctx, uint64_t shuffle_seed /* 0: a row group's segments back to back; else: all blocks in a random order */);
+                                                       void *alloc_ctx, uint64_t shuffle_seed /* 0: a row group's segments back to back; else: all blocks in a random order */,
+                                                       int32_t alloc_threads /* > 1 (in-order only): that many threads allocate whole (row group, segment) sets concurrently */);
 void infera_sql_segment_table_destroy(InferaSqlSegmentTable *t);
 uint64_t infera_sql_segment_table_blocks(const InferaSqlSegmentTable *t);
 int32_t infera_sql_bench_scan_segments(const char *function, const char *model, const InferaSqlSegmentTable *t, uint64_t rows, int32_t threads,

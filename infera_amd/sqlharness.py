@@ -85,7 +85,7 @@ def lib() -> C.CDLL:
         L.infera_sql_bench_last_cpu.restype = None
         L.infera_sql_bench_gather_only.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.infera_sql_bench_gather_only.restype = C.c_int32
-        L.infera_stub_segment_table_create.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_int32), C.c_uint64]
+        L.infera_stub_segment_table_create.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_int32), C.c_uint64, C.c_int32]
         L.infera_stub_segment_table_create.restype = C.c_void_p
         L.infera_stub_segment_table_get.argtypes = [C.c_void_p]
         L.infera_stub_segment_table_get.restype = C.c_void_p
@@ -337,14 +337,15 @@ class SegmentTable:
     malloc otherwise.  A chunk's 128 FLAT vectors point into 128 unrelated blocks; the one chunk per row group that straddles two segments is
     assembled in ordinary memory (as DuckDB's scan does).  Blocks go back through the allocator on close()."""
 
-    def __init__(self, rows: int, ncols: int, seed: int = 42, threads: int = 8, shuffled: bool = False):
+    def __init__(self, rows: int, ncols: int, seed: int = 42, threads: int = 8, shuffled: bool = False, alloc_threads: int = 1):
         """shuffled: every block of the table allocated in a random order (unrelated addresses per chunk whatever the allocator does: parallel
         loads, evictions, reloads); default: a (row group, segment)'s 128 column blocks back to back (a table loaded by one thread -- with the
         extension's ARENA allocator they then lie at one 256 KiB stride inside one registration, which the engine's 2-D copy can fetch)."""
         hooked = C.c_int32()
         t0 = time.perf_counter()
         self.shuffled = shuffled
-        self.handle = lib().infera_stub_segment_table_create(rows, ncols, seed, threads, C.byref(hooked), 0x5EED if shuffled else 0)
+        # alloc_threads > 1 (not shuffled): that many threads allocate whole (row group, segment) sets concurrently -- a parallel load
+        self.handle = lib().infera_stub_segment_table_create(rows, ncols, seed, threads, C.byref(hooked), 0x5EED if shuffled else 0, alloc_threads)
         if not self.handle:
             raise SqlError("segment table: allocation failed")
         self.create_seconds = time.perf_counter() - t0

@@ -409,13 +409,14 @@ void stub_block_free(void *ctx, void *block, uint64_t bytes) {
 }
 }  // namespace
 
-void *infera_stub_segment_table_create(uint64_t rows, uint32_t ncols, uint64_t seed, int32_t threads, int32_t *hook_installed, uint64_t shuffle_seed) {
+void *infera_stub_segment_table_create(uint64_t rows, uint32_t ncols, uint64_t seed, int32_t threads, int32_t *hook_installed, uint64_t shuffle_seed,
+                                       int32_t alloc_threads) {
   auto *st = new StubSegmentTable;
   const bool hooked = infera_install_zero_copy_allocator(st->config);
   if (!st->config.allocator) st->config.allocator = make_uniq<Allocator>();
   if (hook_installed) *hook_installed = hooked ? 1 : 0;
   // Storage::BLOCK_ALLOC_SIZE = 262144, Storage::BLOCK_HEADER_SIZE = sizeof(uint64_t) (duckdb/storage/storage_info.hpp, quoted from memory)
-  st->table = infera_sql_segment_table_create(rows, ncols, seed, threads, 262144, 8, stub_block_alloc, stub_block_free, st, shuffle_seed);
+  st->table = infera_sql_segment_table_create(rows, ncols, seed, threads, 262144, 8, stub_block_alloc, stub_block_free, st, shuffle_seed, alloc_threads);
   if (!st->table) {
     delete st;
     return nullptr;

@@ -53,11 +53,13 @@ measure("registered, ONE contiguous range (2-D copies + pulling kernel)", sqlhar
 capi.unregister_host_memory(flat)
 del flat
 os.environ["INFERA_ZERO_COPY_ALLOCATOR"] = "1"
-for label, arena, shuffled in (("registered, DuckDB segments, ARENA allocator, a row group's blocks allocated back to back (2-D copies + pulling kernel)", "1", False),
-                               ("registered, DuckDB segments, ARENA allocator, blocks allocated in a random order (pulling kernel only)", "1", True),
-                               ("registered, DuckDB segments, one registration per block (round 6's first shape; pulling kernel only)", "0", True)):
+for label, arena, shuffled, alloc_threads in (
+        ("registered, DuckDB segments, ARENA allocator, a row group's blocks allocated back to back by ONE thread (2-D copies + pulling kernel)", "1", False, 1),
+        ("... by FOUR threads at once, each a row group's segment at a time (a parallel load)", "1", False, 4),
+        ("registered, DuckDB segments, ARENA allocator, blocks allocated in a random order (pulling kernel only)", "1", True, 1),
+        ("registered, DuckDB segments, one registration per block (round 6's first shape; pulling kernel only)", "0", True, 1)):
     os.environ["INFERA_ZERO_COPY_ARENA"] = arena
-    seg = sqlharness.SegmentTable(rows, 128, 42, 16, shuffled=shuffled)
+    seg = sqlharness.SegmentTable(rows, 128, 42, 16, shuffled=shuffled, alloc_threads=alloc_threads)
     print(f"(segment table: {seg.blocks} blocks of 256 KiB, registering allocator = {seg.registering_allocator}, arena = {arena}, shuffled = {shuffled}, made in "
           f"{seg.create_seconds:.2f} s; registered ranges now {capi.get_devices()['registered_host_ranges']})", flush=True)
     before = capi.zero_copy_calls()
